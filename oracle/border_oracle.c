@@ -1,0 +1,670 @@
+/*
+ * border_oracle.c -- CPU restatement of border's opt-step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under border_amd/ (the product) may link,
+ * import or call this file.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker.
+ *
+ * Every function cites the reference file:line (relative to /root/reference)
+ * whose behaviour it restates.  The arithmetic lives in third-party crates that
+ * are not vendored under /root/reference:
+ *   - rand = "=0.8.5" (Cargo.toml:53): StdRng = rand_chacha 0.3 ChaCha12Rng,
+ *     rand_core 0.6 SeedableRng::seed_from_u64 (PCG32 key expansion)
+ *   - tch = "0.16.0" (Cargo.toml:31) -> libtorch 2.3.0 ATen ops
+ *     (conv2d, linear, relu, gather, argmax, smooth_l1_loss, mse_loss, Adam)
+ * so this file restates their published algorithms.
+ *
+ * PARITY PINNING
+ *   RNG: pinned.  ChaCha12 core + word order + next_u64 + from_rng reproduce
+ *     rand 0.8.5's own known-answer test `test_stdrng_construction`
+ *     (rand/src/rngs/std.rs: seed [1,0,0,0,23,0,0,0,200,1,0,0,210,30,0,0,0..],
+ *     targets 10719222850664546238, 14064965282130556830) and the ChaCha20
+ *     zero-key vector (76b8e0ad...).  seed_from_u64's PCG32 expansion is restated
+ *     from rand_core 0.6 and has no upstream vector available offline.
+ *   Float math: the reference holds no golden vector for DQN/IQN/SAC
+ *      => "parity unpinned" at the libtorch boundary; the
+ *     stand-in pin is PyTorch 2.10 CPU (same ATen op set tch binds) via
+ *     oracle/torch_ref.py -> tests/golden/ (npz fixtures).
+ *
+ * Numerics: storage is f32 like the reference; dot products accumulate in
+ * double and round once to f32, so the oracle sits at the centre of the
+ * f32-roundoff cloud that ATen (any summation order) and the MFMA kernels
+ * (k-ordered fmaf chains) both live in.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* StdRng (ChaCha12) -- generic_replay_buffer/base.rs:353 (seed_from_u64),     */
+/* :386 (next_u32)                                                             */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    uint32_t key[8];
+    uint64_t word_pos; /* index of the next u32 word of the key stream */
+} orc_rng;
+
+static inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+
+#define QR(a, b, c, d)                                                                             \
+    do {                                                                                           \
+        a += b; d ^= a; d = rotl32(d, 16);                                                         \
+        c += d; b ^= c; b = rotl32(b, 12);                                                         \
+        a += b; d ^= a; d = rotl32(d, 8);                                                          \
+        c += d; b ^= c; b = rotl32(b, 7);                                                          \
+    } while (0)
+
+/* One ChaCha block (rand_chacha layout: 64-bit block counter in words 12,13,
+ * 64-bit stream id (=0) in words 14,15). */
+ORC_API void orc_chacha_block(const uint32_t key[8], uint64_t counter, int rounds, uint32_t out[16])
+{
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                      key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t w[16];
+    memcpy(w, s, sizeof w);
+    for (int r = 0; r < rounds; r += 2) {
+        QR(w[0], w[4], w[8], w[12]);  QR(w[1], w[5], w[9], w[13]);
+        QR(w[2], w[6], w[10], w[14]); QR(w[3], w[7], w[11], w[15]);
+        QR(w[0], w[5], w[10], w[15]); QR(w[1], w[6], w[11], w[12]);
+        QR(w[2], w[7], w[8], w[13]);  QR(w[3], w[4], w[9], w[14]);
+    }
+    for (int i = 0; i < 16; ++i) out[i] = w[i] + s[i];
+}
+
+/* StdRng::from_seed: 32 little-endian key bytes, counter 0, stream 0. */
+ORC_API void orc_rng_from_seed(orc_rng* g, const uint8_t seed[32])
+{
+    for (int i = 0; i < 8; ++i)
+        g->key[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) |
+                    ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
+    g->word_pos = 0;
+}
+
+/* rand_core 0.6 SeedableRng::seed_from_u64: PCG32 expands the u64 into the seed. */
+ORC_API void orc_seed_bytes_from_u64(uint64_t state, uint8_t seed[32])
+{
+    for (int i = 0; i < 8; ++i) {
+        state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+        uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+        uint32_t rot = (uint32_t)(state >> 59);
+        uint32_t x = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        seed[4 * i] = (uint8_t)x; seed[4 * i + 1] = (uint8_t)(x >> 8);
+        seed[4 * i + 2] = (uint8_t)(x >> 16); seed[4 * i + 3] = (uint8_t)(x >> 24);
+    }
+}
+
+ORC_API void orc_rng_seed_from_u64(orc_rng* g, uint64_t seed)
+{
+    uint8_t s[32];
+    orc_seed_bytes_from_u64(seed, s);
+    orc_rng_from_seed(g, s);
+}
+
+/* BlockRng::next_u32: words of block 0, then block 1, ... */
+ORC_API uint32_t orc_rng_next_u32(orc_rng* g)
+{
+    uint32_t blk[16];
+    orc_chacha_block(g->key, g->word_pos >> 4, 12, blk);
+    return blk[g->word_pos++ & 15];
+}
+
+/* BlockRng::next_u64: low word first. */
+ORC_API uint64_t orc_rng_next_u64(orc_rng* g)
+{
+    uint64_t lo = orc_rng_next_u32(g);
+    uint64_t hi = orc_rng_next_u32(g);
+    return lo | (hi << 32);
+}
+
+/* generic_replay_buffer/base.rs:384-390: ixs[k] = (next_u32() as usize) % size */
+ORC_API void orc_sample_indices(orc_rng* g, uint64_t size, int n, uint64_t* out)
+{
+    for (int k = 0; k < n; ++k) out[k] = (uint64_t)orc_rng_next_u32(g) % size;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SimpleReplayBuffer -- generic_replay_buffer/base.rs:86-123 (state),         */
+/* :295-316 (push), :376-402 (batch), :137-219 (reward/flag push + sample);    */
+/* storage rows follow TensorBatch (border-tch-agent/src/tensor_batch.rs:85-   */
+/* 120): push writes rows (i+k)%capacity, sample = index_select rows.          */
+/* Rows are opaque bytes here (u8 Atari frames, f32 vectors, i64 actions).     */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    uint64_t capacity, i, size;
+    uint64_t obs_bytes, act_bytes;
+    uint8_t *obs, *act, *next_obs;
+    float* reward;
+    int8_t *is_terminated, *is_truncated;
+    orc_rng rng;
+} orc_replay;
+
+ORC_API orc_replay* orc_replay_build(uint64_t capacity, uint64_t seed, uint64_t obs_bytes,
+                                     uint64_t act_bytes)
+{
+    orc_replay* r = (orc_replay*)calloc(1, sizeof *r);
+    r->capacity = capacity; r->obs_bytes = obs_bytes; r->act_bytes = act_bytes;
+    r->obs = (uint8_t*)calloc(capacity, obs_bytes);
+    r->next_obs = (uint8_t*)calloc(capacity, obs_bytes);
+    r->act = (uint8_t*)calloc(capacity, act_bytes);
+    r->reward = (float*)calloc(capacity, sizeof(float));
+    r->is_terminated = (int8_t*)calloc(capacity, 1);
+    r->is_truncated = (int8_t*)calloc(capacity, 1);
+    orc_rng_seed_from_u64(&r->rng, seed);
+    return r;
+}
+
+ORC_API void orc_replay_free(orc_replay* r)
+{
+    if (!r) return;
+    free(r->obs); free(r->next_obs); free(r->act); free(r->reward);
+    free(r->is_terminated); free(r->is_truncated); free(r);
+}
+
+ORC_API uint64_t orc_replay_len(const orc_replay* r) { return r->size; }
+ORC_API uint64_t orc_replay_head(const orc_replay* r) { return r->i; }
+
+/* base.rs:295-316 */
+ORC_API void orc_replay_push(orc_replay* r, uint64_t len, const uint8_t* obs, const uint8_t* act,
+                             const uint8_t* next_obs, const float* reward, const int8_t* term,
+                             const int8_t* trunc)
+{
+    for (uint64_t k = 0; k < len; ++k) {
+        uint64_t j = (r->i + k) % r->capacity;
+        memcpy(r->obs + j * r->obs_bytes, obs + k * r->obs_bytes, r->obs_bytes);
+        memcpy(r->act + j * r->act_bytes, act + k * r->act_bytes, r->act_bytes);
+        memcpy(r->next_obs + j * r->obs_bytes, next_obs + k * r->obs_bytes, r->obs_bytes);
+        r->reward[j] = reward[k];
+        r->is_terminated[j] = term[k];
+        r->is_truncated[j] = trunc[k];
+    }
+    r->i = (r->i + len) % r->capacity;
+    r->size += len;
+    if (r->size >= r->capacity) r->size = r->capacity;
+}
+
+/* base.rs:376-402, uniform branch.  Returns -1 on an empty buffer (the
+ * reference panics there: `% self.size` with size == 0). */
+ORC_API int orc_replay_batch(orc_replay* r, int n, uint64_t* ixs, uint8_t* obs, uint8_t* act,
+                             uint8_t* next_obs, float* reward, int8_t* term, int8_t* trunc)
+{
+    if (r->size == 0) return -1;
+    orc_sample_indices(&r->rng, r->size, n, ixs);
+    for (int k = 0; k < n; ++k) {
+        uint64_t j = ixs[k];
+        memcpy(obs + (uint64_t)k * r->obs_bytes, r->obs + j * r->obs_bytes, r->obs_bytes);
+        memcpy(act + (uint64_t)k * r->act_bytes, r->act + j * r->act_bytes, r->act_bytes);
+        memcpy(next_obs + (uint64_t)k * r->obs_bytes, r->next_obs + j * r->obs_bytes, r->obs_bytes);
+        reward[k] = r->reward[j];
+        term[k] = r->is_terminated[j];
+        trunc[k] = r->is_truncated[j];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Layers (libtorch semantics): conv2d = cross-correlation, no padding, OIHW;  */
+/* linear = x W^T + b with W [out,in]; relu.                                   */
+/* ------------------------------------------------------------------------- */
+
+static void conv2d_fwd(const float* x, const float* w, const float* b, float* y, int B, int C,
+                       int H, int W, int O, int K, int S, int relu)
+{
+    const int OH = (H - K) / S + 1, OW = (W - K) / S + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < B; ++n)
+        for (int o = 0; o < O; ++o)
+            for (int oh = 0; oh < OH; ++oh)
+                for (int ow = 0; ow < OW; ++ow) {
+                    double acc = 0.0;
+                    for (int c = 0; c < C; ++c)
+                        for (int kh = 0; kh < K; ++kh) {
+                            const float* xr = x + (((size_t)n * C + c) * H + oh * S + kh) * W + ow * S;
+                            const float* wr = w + (((size_t)o * C + c) * K + kh) * K;
+                            for (int kw = 0; kw < K; ++kw) acc += (double)xr[kw] * (double)wr[kw];
+                        }
+                    float v = (float)acc + b[o];
+                    if (relu && v < 0.f) v = 0.f;
+                    y[(((size_t)n * O + o) * OH + oh) * OW + ow] = v;
+                }
+}
+
+/* dy is the gradient w.r.t. the conv output (pre-activation). dx may be NULL. */
+static void conv2d_bwd(const float* x, const float* w, const float* dy, float* dw, float* db,
+                       float* dx, int B, int C, int H, int W, int O, int K, int S)
+{
+    const int OH = (H - K) / S + 1, OW = (W - K) / S + 1;
+#pragma omp parallel for schedule(static)
+    for (int o = 0; o < O; ++o) {
+        double bacc = 0.0;
+        for (int n = 0; n < B; ++n)
+            for (int p = 0; p < OH * OW; ++p) bacc += dy[((size_t)n * O + o) * OH * OW + p];
+        db[o] = (float)bacc;
+        for (int c = 0; c < C; ++c)
+            for (int kh = 0; kh < K; ++kh)
+                for (int kw = 0; kw < K; ++kw) {
+                    double acc = 0.0;
+                    for (int n = 0; n < B; ++n)
+                        for (int oh = 0; oh < OH; ++oh) {
+                            const float* dyr = dy + (((size_t)n * O + o) * OH + oh) * OW;
+                            const float* xr = x + (((size_t)n * C + c) * H + oh * S + kh) * W + kw;
+                            for (int ow = 0; ow < OW; ++ow) acc += (double)dyr[ow] * (double)xr[ow * S];
+                        }
+                    dw[(((size_t)o * C + c) * K + kh) * K + kw] = (float)acc;
+                }
+    }
+    if (!dx) return;
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < B; ++n)
+        for (int c = 0; c < C; ++c)
+            for (int ih = 0; ih < H; ++ih)
+                for (int iw = 0; iw < W; ++iw) {
+                    double acc = 0.0;
+                    for (int kh = 0; kh < K; ++kh) {
+                        int t = ih - kh;
+                        if (t < 0 || t % S) continue;
+                        int oh = t / S;
+                        if (oh >= OH) continue;
+                        for (int kw = 0; kw < K; ++kw) {
+                            int u = iw - kw;
+                            if (u < 0 || u % S) continue;
+                            int ow = u / S;
+                            if (ow >= OW) continue;
+                            for (int o = 0; o < O; ++o)
+                                acc += (double)dy[(((size_t)n * O + o) * OH + oh) * OW + ow] *
+                                       (double)w[(((size_t)o * C + c) * K + kh) * K + kw];
+                        }
+                    }
+                    dx[(((size_t)n * C + c) * H + ih) * W + iw] = (float)acc;
+                }
+}
+
+static void linear_fwd(const float* x, const float* w, const float* b, float* y, int B, int I,
+                       int O, int relu)
+{
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < B; ++n)
+        for (int o = 0; o < O; ++o) {
+            double acc = 0.0;
+            const float* xr = x + (size_t)n * I;
+            const float* wr = w + (size_t)o * I;
+            for (int i = 0; i < I; ++i) acc += (double)xr[i] * (double)wr[i];
+            float v = (float)acc + b[o];
+            if (relu && v < 0.f) v = 0.f;
+            y[(size_t)n * O + o] = v;
+        }
+}
+
+static void linear_bwd(const float* x, const float* w, const float* dy, float* dw, float* db,
+                       float* dx, int B, int I, int O)
+{
+#pragma omp parallel for schedule(static)
+    for (int o = 0; o < O; ++o) {
+        double bacc = 0.0;
+        for (int n = 0; n < B; ++n) bacc += dy[(size_t)n * O + o];
+        db[o] = (float)bacc;
+        for (int i = 0; i < I; ++i) {
+            double acc = 0.0;
+            for (int n = 0; n < B; ++n) acc += (double)dy[(size_t)n * O + o] * (double)x[(size_t)n * I + i];
+            dw[(size_t)o * I + i] = (float)acc;
+        }
+    }
+    if (!dx) return;
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < B; ++n)
+        for (int i = 0; i < I; ++i) {
+            double acc = 0.0;
+            for (int o = 0; o < O; ++o) acc += (double)dy[(size_t)n * O + o] * (double)w[(size_t)o * I + i];
+            dx[(size_t)n * I + i] = (float)acc;
+        }
+}
+
+/* multiply gradient by relu'(post-activation value) */
+static void relu_bwd(const float* y_post, float* dy, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!(y_post[i] > 0.f)) dy[i] = 0.f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Networks.                                                                   */
+/*  kind 0: AtariCnn  (border-tch-agent/src/cnn/base.rs:23-36): input u8       */
+/*          [B,n_stack,1,84,84]; x.squeeze(2).float()/255; c1(k8,s4)+relu;     */
+/*          c2(k4,s2)+relu; c3(k3,s1)+relu; flatten(C,H,W); l1+relu; l2.       */
+/*          Parameter order in the flat vector: c1.weight c1.bias c2.weight    */
+/*          c2.bias c3.weight c3.bias l1.weight l1.bias l2.weight l2.bias      */
+/*          (OIHW / [out,in], the libtorch layouts).                           */
+/*  kind 1: Mlp (border-tch-agent/src/mlp/base.rs:13-41): in->units..->out,    */
+/*          relu between, optional relu on the output; order mlp.ln{i}.weight, */
+/*          mlp.ln{i}.bias.  Input f32 [B,in_dim].                             */
+/* ------------------------------------------------------------------------- */
+
+#define ORC_MAX_UNITS 8
+typedef struct {
+    int32_t kind;      /* 0 AtariCnn, 1 Mlp */
+    int32_t n_stack;   /* cnn */
+    int32_t in_dim;    /* mlp */
+    int32_t n_units;   /* mlp */
+    int32_t units[ORC_MAX_UNITS];
+    int32_t out_dim;
+    int32_t activation_out; /* mlp */
+} orc_net_cfg;
+
+ORC_API int64_t orc_net_param_count(const orc_net_cfg* c)
+{
+    if (c->kind == 0) {
+        int64_t n = 32LL * c->n_stack * 64 + 32;
+        n += 64LL * 32 * 16 + 64;
+        n += 64LL * 64 * 9 + 64;
+        n += 512LL * 3136 + 512;
+        n += (int64_t)c->out_dim * 512 + c->out_dim;
+        return n;
+    }
+    int64_t n = 0; int in = c->in_dim;
+    for (int i = 0; i < c->n_units; ++i) { n += (int64_t)c->units[i] * in + c->units[i]; in = c->units[i]; }
+    n += (int64_t)c->out_dim * in + c->out_dim;
+    return n;
+}
+
+/* activation cache; sizes for the largest case are computed at alloc time */
+typedef struct {
+    int B;
+    float* x0;  /* cnn: normalised input [B,4,84,84]; mlp: copy of input */
+    float* a[ORC_MAX_UNITS + 2]; /* post-activation outputs of each layer; last = net output */
+    int n_layers;
+} orc_cache;
+
+static orc_cache* cache_alloc(const orc_net_cfg* c, int B)
+{
+    orc_cache* k = (orc_cache*)calloc(1, sizeof *k);
+    k->B = B;
+    if (c->kind == 0) {
+        k->n_layers = 5;
+        k->x0 = (float*)malloc(sizeof(float) * (size_t)B * c->n_stack * 84 * 84);
+        k->a[0] = (float*)malloc(sizeof(float) * (size_t)B * 32 * 20 * 20);
+        k->a[1] = (float*)malloc(sizeof(float) * (size_t)B * 64 * 9 * 9);
+        k->a[2] = (float*)malloc(sizeof(float) * (size_t)B * 64 * 7 * 7);
+        k->a[3] = (float*)malloc(sizeof(float) * (size_t)B * 512);
+        k->a[4] = (float*)malloc(sizeof(float) * (size_t)B * c->out_dim);
+    } else {
+        k->n_layers = c->n_units + 1;
+        k->x0 = (float*)malloc(sizeof(float) * (size_t)B * c->in_dim);
+        for (int i = 0; i < c->n_units; ++i) k->a[i] = (float*)malloc(sizeof(float) * (size_t)B * c->units[i]);
+        k->a[c->n_units] = (float*)malloc(sizeof(float) * (size_t)B * c->out_dim);
+    }
+    return k;
+}
+
+static void cache_free(orc_cache* k)
+{
+    if (!k) return;
+    free(k->x0);
+    for (int i = 0; i < k->n_layers; ++i) free(k->a[i]);
+    free(k);
+}
+
+static const float* net_out(const orc_cache* k) { return k->a[k->n_layers - 1]; }
+
+static void net_forward(const orc_net_cfg* c, const float* p, const void* input, orc_cache* k)
+{
+    const int B = k->B;
+    if (c->kind == 0) {
+        const uint8_t* u = (const uint8_t*)input;
+        const size_t n = (size_t)B * c->n_stack * 84 * 84;
+        /* cnn/base.rs:26  xs.squeeze_dim(2).internal_cast_float(true) / 255 */
+        for (size_t i = 0; i < n; ++i) k->x0[i] = (float)u[i] / 255.0f;
+        const float* w1 = p; const float* b1 = w1 + 32 * c->n_stack * 64;
+        const float* w2 = b1 + 32; const float* b2 = w2 + 64 * 32 * 16;
+        const float* w3 = b2 + 64; const float* b3 = w3 + 64 * 64 * 9;
+        const float* w4 = b3 + 64; const float* b4 = w4 + 512 * 3136;
+        const float* w5 = b4 + 512; const float* b5 = w5 + (size_t)c->out_dim * 512;
+        conv2d_fwd(k->x0, w1, b1, k->a[0], B, c->n_stack, 84, 84, 32, 8, 4, 1);
+        conv2d_fwd(k->a[0], w2, b2, k->a[1], B, 32, 20, 20, 64, 4, 2, 1);
+        conv2d_fwd(k->a[1], w3, b3, k->a[2], B, 64, 9, 9, 64, 3, 1, 1);
+        linear_fwd(k->a[2], w4, b4, k->a[3], B, 3136, 512, 1);
+        linear_fwd(k->a[3], w5, b5, k->a[4], B, 512, c->out_dim, 0);
+    } else {
+        memcpy(k->x0, input, sizeof(float) * (size_t)B * c->in_dim);
+        const float* x = k->x0; int in = c->in_dim; const float* q = p;
+        for (int i = 0; i < c->n_units; ++i) {
+            linear_fwd(x, q, q + (size_t)c->units[i] * in, k->a[i], B, in, c->units[i], 1);
+            q += (size_t)c->units[i] * in + c->units[i]; x = k->a[i]; in = c->units[i];
+        }
+        linear_fwd(x, q, q + (size_t)c->out_dim * in, k->a[c->n_units], B, in, c->out_dim, c->activation_out);
+    }
+}
+
+/* dout: gradient w.r.t. the network output (post activation_out).  grads gets
+ * the gradient of every parameter, same layout as p. */
+static void net_backward(const orc_net_cfg* c, const float* p, const orc_cache* k, const float* dout,
+                         float* g)
+{
+    const int B = k->B;
+    if (c->kind == 0) {
+        const size_t o1 = 0, ob1 = o1 + 32 * c->n_stack * 64, o2 = ob1 + 32, ob2 = o2 + 64 * 32 * 16,
+                     o3 = ob2 + 64, ob3 = o3 + 64 * 64 * 9, o4 = ob3 + 64, ob4 = o4 + 512 * 3136,
+                     o5 = ob4 + 512, ob5 = o5 + (size_t)c->out_dim * 512;
+        float* d4 = (float*)malloc(sizeof(float) * (size_t)B * 512);
+        float* d3 = (float*)malloc(sizeof(float) * (size_t)B * 3136);
+        float* d2 = (float*)malloc(sizeof(float) * (size_t)B * 64 * 81);
+        float* d1 = (float*)malloc(sizeof(float) * (size_t)B * 32 * 400);
+        linear_bwd(k->a[3], p + o5, dout, g + o5, g + ob5, d4, B, 512, c->out_dim);
+        relu_bwd(k->a[3], d4, (size_t)B * 512);
+        linear_bwd(k->a[2], p + o4, d4, g + o4, g + ob4, d3, B, 3136, 512);
+        relu_bwd(k->a[2], d3, (size_t)B * 3136);
+        conv2d_bwd(k->a[1], p + o3, d3, g + o3, g + ob3, d2, B, 64, 9, 9, 64, 3, 1);
+        relu_bwd(k->a[1], d2, (size_t)B * 64 * 81);
+        conv2d_bwd(k->a[0], p + o2, d2, g + o2, g + ob2, d1, B, 32, 20, 20, 64, 4, 2);
+        relu_bwd(k->a[0], d1, (size_t)B * 32 * 400);
+        conv2d_bwd(k->x0, p + o1, d1, g + o1, g + ob1, NULL, B, c->n_stack, 84, 84, 32, 8, 4);
+        free(d4); free(d3); free(d2); free(d1);
+    } else {
+        const int L = c->n_units + 1;
+        size_t off[ORC_MAX_UNITS + 2]; int ins[ORC_MAX_UNITS + 2] = {0}, outs[ORC_MAX_UNITS + 2] = {0};
+        size_t o = 0; int in = c->in_dim;
+        for (int i = 0; i < L; ++i) {
+            int out = i < c->n_units ? c->units[i] : c->out_dim;
+            off[i] = o; ins[i] = in; outs[i] = out; o += (size_t)out * in + out; in = out;
+        }
+        float* d = (float*)malloc(sizeof(float) * (size_t)B * outs[L - 1]);
+        memcpy(d, dout, sizeof(float) * (size_t)B * outs[L - 1]);
+        if (c->activation_out) relu_bwd(k->a[L - 1], d, (size_t)B * outs[L - 1]);
+        for (int i = L - 1; i >= 0; --i) {
+            const float* x = i == 0 ? k->x0 : k->a[i - 1];
+            float* dx = i == 0 ? NULL : (float*)malloc(sizeof(float) * (size_t)B * ins[i]);
+            linear_bwd(x, p + off[i], d, g + off[i], g + off[i] + (size_t)outs[i] * ins[i], dx, B, ins[i], outs[i]);
+            if (dx) relu_bwd(k->a[i - 1], dx, (size_t)B * ins[i]);
+            free(d); d = dx;
+        }
+    }
+}
+
+/* Q-values only (Policy::sample / tests).  out: [B,out_dim]. */
+ORC_API void orc_net_forward(const orc_net_cfg* c, const float* params, const void* input, int B,
+                             float* out)
+{
+    orc_cache* k = cache_alloc(c, B);
+    net_forward(c, params, input, k);
+    memcpy(out, net_out(k), sizeof(float) * (size_t)B * c->out_dim);
+    cache_free(k);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Adam -- opt.rs:35 (tch nn::Adam::default(): beta1 .9, beta2 .999, wd 0,     */
+/* eps 1e-8, amsgrad false) + libtorch torch/csrc/api/src/optim/adam.cpp:      */
+/*   exp_avg.mul_(b1).add_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2);   */
+/*   denom = (exp_avg_sq.sqrt() / sqrt(1-b2^t)).add_(eps);                     */
+/*   p.addcdiv_(exp_avg, denom, -(lr/(1-b1^t)))                                */
+/* Scalars are doubles on the host and enter the f32 element kernels as f32.   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    double lr, beta1, beta2, eps;
+    int64_t step;
+} orc_adam_cfg;
+
+ORC_API void orc_adam_step(orc_adam_cfg* a, float* p, const float* g, float* m, float* v, int64_t n)
+{
+    a->step += 1;
+    const double bc1 = 1.0 - pow(a->beta1, (double)a->step);
+    const double bc2 = 1.0 - pow(a->beta2, (double)a->step);
+    const float b1 = (float)a->beta1, omb1 = (float)(1.0 - a->beta1);
+    const float b2 = (float)a->beta2, omb2 = (float)(1.0 - a->beta2);
+    const float sbc2 = (float)sqrt(bc2), eps = (float)a->eps;
+    const float neg_step = (float)(-(a->lr / bc1));
+    for (int64_t i = 0; i < n; ++i) {
+        m[i] = m[i] * b1 + g[i] * omb1;
+        v[i] = v[i] * b2 + omb2 * g[i] * g[i];
+        float denom = sqrtf(v[i]) / sbc2 + eps;
+        p[i] = p[i] + neg_step * m[i] / denom;
+    }
+}
+
+/* util.rs:31-45  dest = tau*src + (1-tau)*dest, per variable (elementwise) */
+ORC_API void orc_track(float* dest, const float* src, double tau, int64_t n)
+{
+    const float t = (float)tau, omt = (float)(1.0 - tau);
+    for (int64_t i = 0; i < n; ++i) dest[i] = t * src[i] + omt * dest[i];
+}
+
+/* ------------------------------------------------------------------------- */
+/* Dqn::update_critic -- border-tch-agent/src/dqn/base.rs:60-160               */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    double discount_factor;
+    int32_t double_dqn;
+    int32_t critic_loss;  /* 0 = Mse, 1 = SmoothL1 (util.rs:17-23) */
+    int32_t has_clip_td_err;
+    double clip_min, clip_max;
+} orc_dqn_cfg;
+
+typedef struct {
+    float* q_pred_all; /* [B,A] online Q(obs)            or NULL */
+    float* q_next_all; /* [B,A] target-net Q(next_obs)   or NULL */
+    float* pred;       /* [B]                             or NULL */
+    float* tgt;        /* [B]                             or NULL */
+    float* grads;      /* [n_params] dLoss/dparams        or NULL */
+    float* td_abs;     /* [B] |pred-tgt| (PER priorities) or NULL */
+} orc_dqn_probe;
+
+/* argmax(-1): first maximal index, like at::argmax on CPU */
+static int argmax_row(const float* r, int A)
+{
+    int best = 0;
+    for (int a = 1; a < A; ++a)
+        if (r[a] > r[best]) best = a;
+    return best;
+}
+
+/* One critic update on a given minibatch.  act: int64 [B]; term: int8 [B];
+ * weight: PER importance weights [B] or NULL (base.rs:123-145 branch).
+ * Updates qnet params + Adam state in place; returns the loss. */
+ORC_API float orc_dqn_update(const orc_net_cfg* net, float* qnet, const float* qnet_tgt,
+                             orc_adam_cfg* adam, float* adam_m, float* adam_v,
+                             const orc_dqn_cfg* cfg, int B, const void* obs, const int64_t* act,
+                             const void* next_obs, const float* reward, const int8_t* term,
+                             const float* weight, orc_dqn_probe* probe)
+{
+    const int A = net->out_dim;
+    const int64_t np = orc_net_param_count(net);
+    orc_cache* k = cache_alloc(net, B);
+    orc_cache* kt = cache_alloc(net, B);
+    float* pred = (float*)malloc(sizeof(float) * B);
+    float* tgt = (float*)malloc(sizeof(float) * B);
+    float* dq = (float*)calloc((size_t)B * A, sizeof(float));
+    float* g = (float*)calloc((size_t)np, sizeof(float));
+
+    /* :71-74  pred = qnet(obs).gather(-1, act).squeeze() */
+    net_forward(net, qnet, obs, k);
+    const float* q = net_out(k);
+    for (int b = 0; b < B; ++b) pred[b] = q[(size_t)b * A + act[b]];
+    if (probe && probe->q_pred_all) memcpy(probe->q_pred_all, q, sizeof(float) * (size_t)B * A);
+
+    /* :91-105 target (no_grad) */
+    const float gamma = (float)cfg->discount_factor;
+    if (cfg->double_dqn) {
+        orc_cache* kn = cache_alloc(net, B);
+        net_forward(net, qnet, next_obs, kn);
+        net_forward(net, qnet_tgt, next_obs, kt);
+        for (int b = 0; b < B; ++b) {
+            int y = argmax_row(net_out(kn) + (size_t)b * A, A);
+            float qq = net_out(kt)[(size_t)b * A + y];
+            tgt[b] = reward[b] + ((float)(1 - term[b]) * gamma) * qq;
+        }
+        cache_free(kn);
+    } else {
+        net_forward(net, qnet_tgt, next_obs, kt);
+        for (int b = 0; b < B; ++b) {
+            const float* r = net_out(kt) + (size_t)b * A;
+            float qq = r[argmax_row(r, A)];
+            tgt[b] = reward[b] + ((float)(1 - term[b]) * gamma) * qq;
+        }
+    }
+    if (probe && probe->q_next_all) memcpy(probe->q_next_all, net_out(kt), sizeof(float) * (size_t)B * A);
+
+    /* :123-152 loss and dLoss/dpred */
+    double lsum = 0.0;
+    for (int b = 0; b < B; ++b) {
+        float d = pred[b] - tgt[b];
+        float dl; /* d loss_b / d pred_b before the 1/B of Reduction::Mean */
+        if (weight) {
+            /* loss_b = criterion(w * clip(|pred-tgt|), 0) */
+            float td = fabsf(d), s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            float dtd = 1.f;
+            if (cfg->has_clip_td_err) {
+                if (td < (float)cfg->clip_min) { td = (float)cfg->clip_min; dtd = 0.f; }
+                else if (td > (float)cfg->clip_max) { td = (float)cfg->clip_max; dtd = 0.f; }
+            }
+            if (probe && probe->td_abs) probe->td_abs[b] = td;
+            float l = weight[b] * td;
+            if (cfg->critic_loss == 1) {
+                float z = fabsf(l);
+                lsum += z < 1.f ? 0.5 * (double)z * z : (double)z - 0.5;
+                dl = (z < 1.f ? l : (l > 0.f ? 1.f : -1.f)) * weight[b] * dtd * s;
+            } else {
+                lsum += (double)l * l;
+                dl = 2.f * l * weight[b] * dtd * s;
+            }
+        } else {
+            if (probe && probe->td_abs) probe->td_abs[b] = fabsf(d);
+            if (cfg->critic_loss == 1) { /* smooth_l1_loss(beta = 1.0, Mean) */
+                float z = fabsf(d);
+                lsum += z < 1.f ? 0.5 * (double)z * z : (double)z - 0.5;
+                dl = z < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+            } else { /* mse_loss(Mean) */
+                lsum += (double)d * d;
+                dl = 2.f * d;
+            }
+        }
+        dq[(size_t)b * A + act[b]] = dl / (float)B;
+    }
+    const float loss = (float)(lsum / B);
+
+    /* :150 qnet.backward_step(loss) = zero_grad; backward; Adam step (opt.rs:74-83) */
+    net_backward(net, qnet, k, dq, g);
+    if (probe && probe->grads) memcpy(probe->grads, g, sizeof(float) * (size_t)np);
+    if (probe && probe->pred) memcpy(probe->pred, pred, sizeof(float) * B);
+    if (probe && probe->tgt) memcpy(probe->tgt, tgt, sizeof(float) * B);
+    orc_adam_step(adam, qnet, g, adam_m, adam_v, np);
+
+    cache_free(k); cache_free(kt);
+    free(pred); free(tgt); free(dq); free(g);
+    return loss;
+}
+
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

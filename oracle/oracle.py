@@ -1,0 +1,253 @@
+"""ctypes binding of the CPU oracle (oracle/border_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of border_oracle.c.  Importable from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never from border_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libborder_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    src = os.path.join(_HERE, "border_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class RngState(C.Structure):
+    _fields_ = [("key", C.c_uint32 * 8), ("word_pos", C.c_uint64)]
+
+
+class NetCfg(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("n_stack", C.c_int32),
+        ("in_dim", C.c_int32),
+        ("n_units", C.c_int32),
+        ("units", C.c_int32 * 8),
+        ("out_dim", C.c_int32),
+        ("activation_out", C.c_int32),
+    ]
+
+
+class AdamCfg(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double), ("step", C.c_int64)]
+
+
+class DqnCfg(C.Structure):
+    _fields_ = [("discount_factor", C.c_double), ("double_dqn", C.c_int32),
+                ("critic_loss", C.c_int32), ("has_clip_td_err", C.c_int32),
+                ("clip_min", C.c_double), ("clip_max", C.c_double)]
+
+
+class DqnProbe(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("q_pred_all", "q_next_all", "pred", "tgt", "grads", "td_abs")]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_rng_next_u32.restype = C.c_uint32
+        L.orc_rng_next_u64.restype = C.c_uint64
+        L.orc_replay_build.restype = C.c_void_p
+        L.orc_replay_build.argtypes = [C.c_uint64] * 4
+        L.orc_replay_free.argtypes = [C.c_void_p]
+        L.orc_replay_len.restype = C.c_uint64
+        L.orc_replay_len.argtypes = [C.c_void_p]
+        L.orc_replay_head.restype = C.c_uint64
+        L.orc_replay_head.argtypes = [C.c_void_p]
+        L.orc_replay_push.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
+        L.orc_replay_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        L.orc_net_param_count.restype = C.c_int64
+        L.orc_dqn_update.restype = C.c_float
+        L.orc_dqn_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_adam_step.argtypes = [C.c_void_p] * 5 + [C.c_int64]
+        L.orc_track.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int64]
+        L.orc_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------- RNG
+class StdRng:
+    """rand 0.8.5 StdRng (ChaCha12)."""
+
+    def __init__(self, state: RngState):
+        self.s = state
+
+    @classmethod
+    def seed_from_u64(cls, seed: int) -> "StdRng":
+        s = RngState()
+        lib().orc_rng_seed_from_u64(C.byref(s), C.c_uint64(seed))
+        return cls(s)
+
+    @classmethod
+    def from_seed(cls, seed_bytes: bytes) -> "StdRng":
+        assert len(seed_bytes) == 32
+        s = RngState()
+        lib().orc_rng_from_seed(C.byref(s), (C.c_uint8 * 32)(*seed_bytes))
+        return cls(s)
+
+    def next_u32(self) -> int:
+        return lib().orc_rng_next_u32(C.byref(self.s))
+
+    def next_u64(self) -> int:
+        return lib().orc_rng_next_u64(C.byref(self.s))
+
+    def sample_indices(self, size: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.uint64)
+        lib().orc_sample_indices(C.byref(self.s), C.c_uint64(size), C.c_int(n), _p(out))
+        return out
+
+
+def seed_bytes_from_u64(seed: int) -> bytes:
+    b = (C.c_uint8 * 32)()
+    lib().orc_seed_bytes_from_u64(C.c_uint64(seed), b)
+    return bytes(b)
+
+
+def chacha_block(key_words, counter: int, rounds: int) -> np.ndarray:
+    out = (C.c_uint32 * 16)()
+    lib().orc_chacha_block((C.c_uint32 * 8)(*key_words), C.c_uint64(counter), C.c_int(rounds), out)
+    return np.array(list(out), dtype=np.uint32)
+
+
+# ----------------------------------------------------------------------------- replay
+class Replay:
+    """SimpleReplayBuffer restatement over opaque byte rows."""
+
+    def __init__(self, capacity: int, seed: int, obs_bytes: int, act_bytes: int):
+        self.h = lib().orc_replay_build(capacity, seed, obs_bytes, act_bytes)
+        self.obs_bytes, self.act_bytes = obs_bytes, act_bytes
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_replay_free(self.h)
+            self.h = None
+
+    def __len__(self):
+        return int(lib().orc_replay_len(self.h))
+
+    @property
+    def head(self):
+        return int(lib().orc_replay_head(self.h))
+
+    def push(self, obs, act, next_obs, reward, term, trunc):
+        n = len(reward)
+        obs = np.ascontiguousarray(obs).view(np.uint8).reshape(n, self.obs_bytes)
+        next_obs = np.ascontiguousarray(next_obs).view(np.uint8).reshape(n, self.obs_bytes)
+        act = np.ascontiguousarray(act).view(np.uint8).reshape(n, self.act_bytes)
+        reward = np.ascontiguousarray(reward, dtype=np.float32)
+        term = np.ascontiguousarray(term, dtype=np.int8)
+        trunc = np.ascontiguousarray(trunc, dtype=np.int8)
+        lib().orc_replay_push(self.h, n, _p(obs), _p(act), _p(next_obs), _p(reward), _p(term), _p(trunc))
+
+    def batch(self, n: int):
+        ixs = np.empty(n, np.uint64)
+        obs = np.empty((n, self.obs_bytes), np.uint8)
+        nobs = np.empty((n, self.obs_bytes), np.uint8)
+        act = np.empty((n, self.act_bytes), np.uint8)
+        rew = np.empty(n, np.float32)
+        term = np.empty(n, np.int8)
+        trunc = np.empty(n, np.int8)
+        rc = lib().orc_replay_batch(self.h, n, _p(ixs), _p(obs), _p(act), _p(nobs), _p(rew), _p(term), _p(trunc))
+        if rc != 0:
+            raise RuntimeError("batch() on an empty buffer")
+        return dict(ixs=ixs, obs=obs, act=act, next_obs=nobs, reward=rew, is_terminated=term,
+                    is_truncated=trunc)
+
+
+# ----------------------------------------------------------------------------- nets / DQN
+def cnn_cfg(out_dim: int, n_stack: int = 4) -> NetCfg:
+    c = NetCfg()
+    c.kind, c.n_stack, c.out_dim = 0, n_stack, out_dim
+    return c
+
+
+def mlp_cfg(in_dim: int, units, out_dim: int, activation_out: bool = False) -> NetCfg:
+    c = NetCfg()
+    c.kind, c.in_dim, c.n_units, c.out_dim = 1, in_dim, len(units), out_dim
+    for i, u in enumerate(units):
+        c.units[i] = u
+    c.activation_out = int(activation_out)
+    return c
+
+
+def param_count(cfg: NetCfg) -> int:
+    return int(lib().orc_net_param_count(C.byref(cfg)))
+
+
+def net_forward(cfg: NetCfg, params: np.ndarray, x: np.ndarray) -> np.ndarray:
+    B = x.shape[0]
+    x = np.ascontiguousarray(x)
+    out = np.empty((B, cfg.out_dim), np.float32)
+    lib().orc_net_forward(C.byref(cfg), _p(params), _p(x), B, _p(out))
+    return out
+
+
+class DqnOracle:
+    """Dqn::opt_ restatement (dqn/base.rs:182-200) over explicit minibatches."""
+
+    def __init__(self, net: NetCfg, params: np.ndarray, *, lr: float, discount_factor=0.99,
+                 double_dqn=False, critic_loss="Mse", clip_td_err=None, tau=0.005,
+                 soft_update_interval=1):
+        self.net = net
+        self.q = np.array(params, dtype=np.float32, copy=True)
+        self.q_tgt = self.q.copy()  # DqnModel::clone (dqn/model/base.rs:94-115)
+        self.m = np.zeros_like(self.q)
+        self.v = np.zeros_like(self.q)
+        self.adam = AdamCfg(lr, 0.9, 0.999, 1e-8, 0)
+        self.cfg = DqnCfg(discount_factor, int(double_dqn), {"Mse": 0, "SmoothL1": 1}[critic_loss],
+                          int(clip_td_err is not None),
+                          *(clip_td_err if clip_td_err is not None else (0.0, 0.0)))
+        self.tau, self.soft_update_interval, self.soft_update_counter = tau, soft_update_interval, 0
+        self.n_opts = 0
+
+    def update(self, obs, act, next_obs, reward, term, weight=None, probe=False):
+        B = len(reward)
+        A = self.net.out_dim
+        obs, next_obs = np.ascontiguousarray(obs), np.ascontiguousarray(next_obs)
+        act = np.ascontiguousarray(act, dtype=np.int64).reshape(B)
+        reward = np.ascontiguousarray(reward, dtype=np.float32)
+        term = np.ascontiguousarray(term, dtype=np.int8)
+        w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float32)
+        pr, bufs = None, {}
+        if probe:
+            bufs = dict(q_pred_all=np.empty((B, A), np.float32), q_next_all=np.empty((B, A), np.float32),
+                        pred=np.empty(B, np.float32), tgt=np.empty(B, np.float32),
+                        grads=np.empty_like(self.q), td_abs=np.empty(B, np.float32))
+            pr = DqnProbe(*[bufs[n].ctypes.data for n, _ in DqnProbe._fields_])
+        loss = lib().orc_dqn_update(C.byref(self.net), _p(self.q), _p(self.q_tgt), C.byref(self.adam),
+                                    _p(self.m), _p(self.v), C.byref(self.cfg), B, _p(obs), _p(act),
+                                    _p(next_obs), _p(reward), _p(term), _p(w),
+                                    C.byref(pr) if pr is not None else None)
+        # dqn/base.rs:190-196
+        self.soft_update_counter += 1
+        if self.soft_update_counter == self.soft_update_interval:
+            self.soft_update_counter = 0
+            lib().orc_track(_p(self.q_tgt), _p(self.q), C.c_double(self.tau), self.q.size)
+        self.n_opts += 1
+        bufs["loss"] = float(loss)
+        return bufs

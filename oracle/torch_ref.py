@@ -1,0 +1,217 @@
+"""ATen (PyTorch CPU) restatement of border-tch-agent's DQN opt step, op for op.
+
+TEST INFRASTRUCTURE ONLY (same rule as border_oracle.c): used to generate the golden fixtures
+under tests/golden/ (tests/golden/make_golden.py), to cross-check the C oracle, and as
+bench.py's `cpu_baseline` (tch 0.16 is a thin FFI over these very ATen kernels, so this is the
+closest obtainable stand-in for "border-tch-agent's CPU path": BASELINE.md section 2).
+
+Each function cites the reference lines it follows.  Nothing here is imported by border_amd/.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+CNN_NAMES = ["c1.weight", "c1.bias", "c2.weight", "c2.bias", "c3.weight", "c3.bias",
+             "l1.weight", "l1.bias", "l2.weight", "l2.bias"]
+
+
+def cnn_shapes(out_dim: int, n_stack: int = 4):
+    """AtariCnn variable shapes (border-tch-agent/src/cnn/base.rs:23-36)."""
+    return [(32, n_stack, 8, 8), (32,), (64, 32, 4, 4), (64,), (64, 64, 3, 3), (64,),
+            (512, 3136), (512,), (out_dim, 512), (out_dim,)]
+
+
+def mlp_shapes(in_dim: int, units, out_dim: int):
+    """Mlp variable shapes (border-tch-agent/src/mlp/base.rs:13-41), order ln0.w ln0.b ..."""
+    shapes, i = [], in_dim
+    for u in list(units) + [out_dim]:
+        shapes += [(u, i), (u,)]
+        i = u
+    return shapes
+
+
+def init_params(shapes, seed: int) -> np.ndarray:
+    """Deterministic uniform(+-1/sqrt(fan_in)) init -> flat f32 vector in reference order.
+    (The init scheme is irrelevant to parity: fixtures carry the weights.)"""
+    rng = np.random.default_rng(seed)
+    out, fan_in = [], 1
+    for s in shapes:
+        if len(s) > 1:
+            fan_in = int(np.prod(s[1:]))
+        bound = 1.0 / math.sqrt(fan_in)
+        out.append(rng.uniform(-bound, bound, size=s).astype(np.float32).ravel())
+    return np.concatenate(out)
+
+
+def unflatten(flat: np.ndarray, shapes):
+    ts, o = [], 0
+    for s in shapes:
+        n = int(np.prod(s))
+        ts.append(torch.from_numpy(np.array(flat[o:o + n], copy=True)).reshape(s))
+        o += n
+    return ts
+
+
+def flatten(ts) -> np.ndarray:
+    return np.concatenate([t.detach().numpy().ravel() for t in ts]).astype(np.float32)
+
+
+def cnn_forward(p, x_u8: torch.Tensor) -> torch.Tensor:
+    """cnn/base.rs:23-36.  x_u8: [B,n_stack,1,84,84] holding integers 0..255."""
+    x = x_u8.squeeze(2).to(torch.float32) / 255  # :26
+    x = F.conv2d(x, p[0], p[1], stride=4).relu()  # :27-28
+    x = F.conv2d(x, p[2], p[3], stride=2).relu()  # :29-30
+    x = F.conv2d(x, p[4], p[5], stride=1).relu().flatten(1)  # :31-32
+    x = F.linear(x, p[6], p[7]).relu()  # :33-34
+    return F.linear(x, p[8], p[9])  # :35
+
+
+def mlp_forward(p, x: torch.Tensor, activation_out=False) -> torch.Tensor:
+    """mlp/base.rs:13-41."""
+    n = len(p) // 2
+    for i in range(n):
+        x = F.linear(x, p[2 * i], p[2 * i + 1])
+        if i < n - 1 or activation_out:
+            x = x.relu()
+    return x
+
+
+class TorchDqn:
+    """Dqn (dqn/base.rs) with DqnModel (dqn/model/base.rs) and tch's Adam (opt.rs:35)."""
+
+    def __init__(self, kind, shapes, params: np.ndarray, *, lr, discount_factor=0.99, double_dqn=False,
+                 critic_loss="Mse", clip_td_err=None, tau=0.005, soft_update_interval=1):
+        self.kind, self.shapes = kind, shapes
+        self.q = [t.requires_grad_(True) for t in unflatten(params, shapes)]
+        self.q_tgt = unflatten(params, shapes)  # DqnModel::clone, dqn/model/base.rs:94-115
+        self.m = [torch.zeros_like(t) for t in self.q]
+        self.v = [torch.zeros_like(t) for t in self.q]
+        self.lr, self.step = lr, 0
+        self.gamma, self.double_dqn, self.critic_loss = discount_factor, double_dqn, critic_loss
+        self.clip_td_err = clip_td_err
+        self.tau, self.soft_update_interval, self.soft_update_counter = tau, soft_update_interval, 0
+
+    def fwd(self, p, x):
+        return cnn_forward(p, x) if self.kind == "cnn" else mlp_forward(p, x)
+
+    def _adam(self):
+        """libtorch torch/csrc/api/src/optim/adam.cpp (Adam::step), defaults of opt.rs:35."""
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        self.step += 1
+        bc1 = 1 - b1 ** self.step
+        bc2 = 1 - b2 ** self.step
+        with torch.no_grad():
+            for p, m, v in zip(self.q, self.m, self.v):
+                g = p.grad
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+                p.addcdiv_(m, denom, value=-(self.lr / bc1))
+
+    def update(self, obs, act, next_obs, reward, term, weight=None):
+        """dqn/base.rs:60-160 followed by :190-196 (soft update)."""
+        obs = torch.from_numpy(np.ascontiguousarray(obs))
+        next_obs = torch.from_numpy(np.ascontiguousarray(next_obs))
+        act = torch.from_numpy(np.ascontiguousarray(act, dtype=np.int64)).reshape(-1, 1)
+        reward = torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32))
+        is_terminated = torch.from_numpy(np.ascontiguousarray(term, dtype=np.int8))
+
+        q_all = self.fwd(self.q, obs)
+        pred = q_all.gather(-1, act).squeeze()  # :71-74
+        with torch.no_grad():  # :91-105
+            if self.double_dqn:
+                x = self.fwd(self.q, next_obs)
+                y = x.argmax(-1).unsqueeze(-1)
+                qn_all = self.fwd(self.q_tgt, next_obs)
+                q = qn_all.gather(-1, y).squeeze()
+            else:
+                qn_all = self.fwd(self.q_tgt, next_obs)
+                y = qn_all.argmax(-1).unsqueeze(-1)
+                q = qn_all.gather(-1, y).squeeze()
+            tgt = reward + (1 - is_terminated) * self.gamma * q
+        td_abs = None
+        if weight is not None:  # :123-145
+            n = len(weight)
+            td = (pred - tgt).abs()
+            if self.clip_td_err is not None:
+                td = td.clip(*self.clip_td_err)
+            td_abs = td.detach().numpy().copy()
+            l = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float32)) * td
+            z = torch.zeros(n)
+            loss = F.smooth_l1_loss(l, z, reduction="mean", beta=1.0) if self.critic_loss == "SmoothL1" \
+                else F.mse_loss(l, z, reduction="mean")
+        else:  # :146-152
+            loss = F.smooth_l1_loss(pred, tgt, reduction="mean", beta=1.0) if self.critic_loss == "SmoothL1" \
+                else F.mse_loss(pred, tgt, reduction="mean")
+        # opt.rs:74-83 backward_step = zero_grad + backward + step
+        for p in self.q:
+            p.grad = None
+        loss.backward()
+        grads = flatten([p.grad for p in self.q])
+        self._adam()
+        # dqn/base.rs:190-196 + util.rs:31-45
+        self.soft_update_counter += 1
+        if self.soft_update_counter == self.soft_update_interval:
+            self.soft_update_counter = 0
+            with torch.no_grad():
+                for d, s in zip(self.q_tgt, self.q):
+                    d.copy_(self.tau * s + (1.0 - self.tau) * d)
+        return dict(loss=float(loss.detach()), q_pred_all=q_all.detach().numpy().copy(),
+                    q_next_all=qn_all.numpy().copy(), pred=pred.detach().numpy().copy(),
+                    tgt=tgt.numpy().copy(), grads=grads, td_abs=td_abs)
+
+    def params(self):
+        return flatten(self.q)
+
+    def tgt_params(self):
+        return flatten(self.q_tgt)
+
+
+def synthetic_atari_batch(B: int, A: int, seed: int):
+    """SURVEY.md section 8(d) synthetic inputs for a fixed minibatch."""
+    rng = np.random.default_rng(seed)
+    obs = rng.integers(0, 256, size=(B, 4, 1, 84, 84), dtype=np.uint8)
+    next_obs = rng.integers(0, 256, size=(B, 4, 1, 84, 84), dtype=np.uint8)
+    act = rng.integers(0, A, size=(B,), dtype=np.int64)
+    reward = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=B, p=[0.05, 0.9, 0.05]).astype(np.float32)
+    term = (rng.random(B) < 0.005).astype(np.int8)
+    return obs, act, next_obs, reward, term
+
+
+def time_dqn_atari(batch_size=256, n_actions=6, steps=5, warmup=1, threads=None, capacity=4096,
+                   critic_loss="SmoothL1"):
+    """CPU baseline: sample (RNG + 3x index_select on an f32 ring, as the reference stores it:
+    border-atari-env/src/obs.rs:45-52 + tensor_batch.rs:95-120) + update, timed like
+    Trainer::train_step (border-core/src/trainer.rs:213-225).  Returns opt-steps/sec."""
+    import time
+    if threads:
+        torch.set_num_threads(threads)
+    shapes = cnn_shapes(n_actions)
+    agent = TorchDqn("cnn", shapes, init_params(shapes, 0), lr=1e-4, critic_loss=critic_loss, tau=1.0,
+                     soft_update_interval=10000)
+    g = torch.Generator().manual_seed(0)
+    ring_obs = torch.randint(0, 256, (capacity, 4, 1, 84, 84), generator=g).to(torch.float32)
+    ring_next = torch.randint(0, 256, (capacity, 4, 1, 84, 84), generator=g).to(torch.float32)
+    ring_act = torch.randint(0, n_actions, (capacity, 1), generator=g)
+    ring_rew = torch.zeros(capacity)
+    ring_term = torch.zeros(capacity, dtype=torch.int8)
+    rng = np.random.default_rng(42)
+
+    def one():
+        ixs = torch.from_numpy(rng.integers(0, capacity, batch_size))
+        obs = ring_obs.index_select(0, ixs).numpy()
+        nobs = ring_next.index_select(0, ixs).numpy()
+        act = ring_act.index_select(0, ixs).numpy()
+        agent.update(obs, act, nobs, ring_rew[ixs].numpy(), ring_term[ixs].numpy())
+
+    for _ in range(warmup):
+        one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return steps / dt, torch.get_num_threads()

@@ -1,0 +1,167 @@
+"""Generates the golden fixtures in this directory.  Run once, in the build container:
+
+    python tests/golden/make_golden.py
+
+Sources of truth
+  * rng_kat.json   -- rand 0.8.5's own known-answer vector (test_stdrng_construction) and the
+                      ChaCha20 zero-key block, written out as literals; plus StdRng::seed_from_u64(42)
+                      words / index batches produced by an independent pure-Python ChaCha12 below
+                      (NOT by oracle/border_oracle.c, so the C oracle is checked against it).
+  * dqn_*.npz      -- PyTorch CPU (oracle/torch_ref.py: the ATen ops tch 0.16 binds) run on seeded
+                      inputs.  Large tensors (CNN weights, gradients, parameters) are stored as a
+                      seed + strided samples + per-variable norms to keep the fixtures small.
+The reference (Rust) cannot run here, and holds no golden vectors for this path.
+"""
+import hashlib
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+M = 0xFFFFFFFF
+
+
+def _rotl(x, n):
+    return ((x << n) & M) | (x >> (32 - n))
+
+
+def _qr(s, a, b, c, d):
+    s[a] = (s[a] + s[b]) & M; s[d] = _rotl(s[d] ^ s[a], 16)
+    s[c] = (s[c] + s[d]) & M; s[b] = _rotl(s[b] ^ s[c], 12)
+    s[a] = (s[a] + s[b]) & M; s[d] = _rotl(s[d] ^ s[a], 8)
+    s[c] = (s[c] + s[d]) & M; s[b] = _rotl(s[b] ^ s[c], 7)
+
+
+def chacha_block(key, counter, rounds):
+    st = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key) + [counter & M, (counter >> 32) & M, 0, 0]
+    w = list(st)
+    for _ in range(rounds // 2):
+        _qr(w, 0, 4, 8, 12); _qr(w, 1, 5, 9, 13); _qr(w, 2, 6, 10, 14); _qr(w, 3, 7, 11, 15)
+        _qr(w, 0, 5, 10, 15); _qr(w, 1, 6, 11, 12); _qr(w, 2, 7, 8, 13); _qr(w, 3, 4, 9, 14)
+    return [(w[i] + st[i]) & M for i in range(16)]
+
+
+class PyStdRng:
+    def __init__(self, seed32):
+        self.key = struct.unpack("<8I", bytes(seed32))
+        self.pos = 0
+        self._blk, self._blk_no = None, -1
+
+    def u32(self):
+        b = self.pos // 16
+        if b != self._blk_no:
+            self._blk, self._blk_no = chacha_block(self.key, b, 12), b
+        v = self._blk[self.pos % 16]
+        self.pos += 1
+        return v
+
+
+def seed_from_u64(state):
+    out = b""
+    for _ in range(8):
+        state = (state * 6364136223846793005 + 11634580027462260723) & 0xFFFFFFFFFFFFFFFF
+        xs = (((state >> 18) ^ state) >> 27) & M
+        rot = state >> 59
+        x = ((xs >> rot) | (xs << ((32 - rot) & 31))) & M
+        out += struct.pack("<I", x)
+    return out
+
+
+def make_rng():
+    kat = {
+        "chacha20_zero_key_block0_words": [0xADE0B876, 0x903DF1A0, 0xE56A5D40, 0x28BD8653],
+        "rand085_test_stdrng_construction": {
+            "seed": [1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16,
+            "x0_next_u64": 10719222850664546238,
+            "x1_next_u64_after_from_rng": 14064965282130556830,
+        },
+    }
+    sd = seed_from_u64(42)
+    r = PyStdRng(sd)
+    kat["seed_from_u64_42"] = {"seed_hex": sd.hex(), "first8_u32": [r.u32() for _ in range(8)]}
+    # index streams: base.rs:384-390 for three (size, batch) settings; first batch verbatim and a
+    # sha256 over the first 1000 batches (little-endian u64 each).
+    streams = []
+    for seed, size, batch in [(42, 1_000_000, 256), (42, 10_000, 32), (7, 65_537, 512), (42, 1, 4)]:
+        r = PyStdRng(seed_from_u64(seed))
+        h = hashlib.sha256()
+        first = None
+        for b in range(1000):
+            ixs = [r.u32() % size for _ in range(batch)]
+            if b == 0:
+                first = ixs
+            h.update(struct.pack("<%dQ" % batch, *ixs))
+        streams.append(dict(seed=seed, size=size, batch=batch, first_batch=first, sha256_1000_batches=h.hexdigest()))
+    kat["index_streams"] = streams
+    with open(os.path.join(HERE, "rng_kat.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+
+def sample_stride(n):
+    return max(1, n // 4096) | 1
+
+
+def make_dqn(name, kind, shapes, batch_fn, n_steps, **kw):
+    from oracle import torch_ref as T
+    import torch
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    p0 = T.init_params(shapes, seed=kw.pop("param_seed"))
+    agent = T.TorchDqn(kind, shapes, p0, **kw)
+    out = {}
+    for s in range(n_steps):
+        obs, act, nobs, rew, term = batch_fn(s)
+        r = agent.update(obs, act, nobs, rew, term)
+        out[f"s{s}_loss"] = np.float32(r["loss"])
+        out[f"s{s}_q_pred_all"] = r["q_pred_all"]
+        out[f"s{s}_q_next_all"] = r["q_next_all"]
+        out[f"s{s}_pred"], out[f"s{s}_tgt"] = r["pred"], r["tgt"]
+        st = sample_stride(r["grads"].size)
+        out[f"s{s}_grads_sample"] = r["grads"][::st]
+        out[f"s{s}_params_sample"] = agent.params()[::st]
+        out[f"s{s}_tgt_params_sample"] = agent.tgt_params()[::st]
+        # per-variable L2 norms
+        o, gn, pn = 0, [], []
+        P = agent.params()
+        for sh in shapes:
+            n = int(np.prod(sh))
+            gn.append(np.linalg.norm(r["grads"][o:o + n].astype(np.float64)))
+            pn.append(np.linalg.norm(P[o:o + n].astype(np.float64)))
+            o += n
+        out[f"s{s}_grad_norms"], out[f"s{s}_param_norms"] = np.array(gn), np.array(pn)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def main():
+    make_rng()
+    from oracle import torch_ref as T
+
+    # (1) Nature-CNN, B=4, A=6, SmoothL1, 3 steps, tau=1 sync every 2 steps
+    make_dqn("dqn_cnn_b4_huber.npz", "cnn", T.cnn_shapes(6), lambda s: T.synthetic_atari_batch(4, 6, 100 + s), 3,
+             param_seed=1, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=2)
+    # (2) Nature-CNN, B=8, A=6, Mse + double DQN (the Atari example's loss), 2 steps
+    make_dqn("dqn_cnn_b8_mse_ddqn.npz", "cnn", T.cnn_shapes(6), lambda s: T.synthetic_atari_batch(8, 6, 200 + s), 2,
+             param_seed=2, lr=1e-4, critic_loss="Mse", double_dqn=True, tau=0.005, soft_update_interval=1)
+
+    # (3) CartPole-shaped MLP[64,64], B=32 (BASELINE config 1), 5 steps, tau=.01 every step
+    def cart(s):
+        rng = np.random.default_rng(300 + s)
+        obs = rng.standard_normal((32, 4)).astype(np.float32)
+        nobs = rng.standard_normal((32, 4)).astype(np.float32)
+        act = rng.integers(0, 2, 32)
+        rew = np.ones(32, np.float32)
+        term = (rng.random(32) < 0.1).astype(np.int8)
+        return obs, act, nobs, rew, term
+
+    make_dqn("dqn_mlp_cartpole.npz", "mlp", T.mlp_shapes(4, [64, 64], 2), cart, 5,
+             param_seed=3, lr=1e-3, critic_loss="Mse", tau=0.01, soft_update_interval=1)
+    print("fixtures:", sorted(os.listdir(HERE)))
+
+
+if __name__ == "__main__":
+    main()

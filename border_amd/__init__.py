@@ -1,0 +1,8 @@
+"""border_amd -- MI355X-native opt-step engine behind border's Agent / ReplayBufferBase traits.
+
+Only what the hot path needs lives here: csrc/ (HIP kernels + the C ABI of include/border_amd.h)
+and the host-side mirror of the reference interfaces (replay.py, dqn.py, trainer.py).
+"""
+from ._lib import BdrError, device_count  # noqa: F401
+from .replay import GenericTransitionBatch, SimpleReplayBuffer, SimpleReplayBufferConfig  # noqa: F401
+from .dqn import AtariCnnConfig, Dqn, DqnConfig, DqnModelConfig, MlpConfig, OptimizerConfig  # noqa: F401

@@ -1,0 +1,142 @@
+"""ctypes loader for libborder_amd.so (the C ABI declared in include/border_amd.h).
+
+The product path has no CPU fallback: if the HIP extension is missing or no MI355X is visible,
+constructors raise.  `import torch` happens first on purpose: PyTorch-ROCm bundles its own
+libamdhip64.so.7 / librccl.so.1, and loading it first makes this library bind to that same
+runtime by soname instead of pulling a second HIP runtime into the process.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libborder_amd.so")
+
+BDR_MAX_UNITS = 8
+BDR_UNIQUE_ID_BYTES = 128
+
+
+class BdrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"border_amd error {code}: {msg}")
+        self.code = code
+
+
+class ReplayConfig(C.Structure):
+    _fields_ = [("capacity", C.c_uint64), ("seed", C.c_uint64), ("obs_row_bytes", C.c_uint64),
+                ("act_row_bytes", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NetConfig(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_stack", C.c_int32), ("in_dim", C.c_int32), ("n_units", C.c_int32),
+                ("units", C.c_int32 * BDR_MAX_UNITS), ("out_dim", C.c_int32), ("activation_out", C.c_int32)]
+
+
+class DqnConfigC(C.Structure):
+    _fields_ = [("net", NetConfig), ("opt_kind", C.c_int32), ("lr", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("weight_decay", C.c_double), ("eps", C.c_double),
+                ("soft_update_interval", C.c_uint64), ("n_updates_per_opt", C.c_uint64),
+                ("batch_size", C.c_uint64), ("discount_factor", C.c_double), ("tau", C.c_double),
+                ("train", C.c_int32), ("double_dqn", C.c_int32), ("critic_loss", C.c_int32),
+                ("has_clip_td_err", C.c_int32), ("clip_td_err_min", C.c_double), ("clip_td_err_max", C.c_double),
+                ("record_verbose_level", C.c_int32), ("device", C.c_int32), ("param_seed", C.c_uint64)]
+
+
+class DqnRecordC(C.Structure):
+    _fields_ = [("loss", C.c_float), ("pred_mean", C.c_float), ("reward_mean", C.c_float),
+                ("tgt_mean", C.c_float), ("tgt_minus_pred_mean", C.c_float), ("has_verbose", C.c_int32)]
+
+
+class DeviceBatch(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("obs", C.c_void_p), ("next_obs", C.c_void_p), ("act", C.c_void_p),
+                ("reward", C.c_void_p), ("is_terminated", C.c_void_p), ("is_truncated", C.c_void_p),
+                ("ixs", C.c_void_p)]
+
+
+# every symbol include/border_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "bdr_last_error", "bdr_device_count", "bdr_version",
+    "bdr_replay_create", "bdr_replay_destroy", "bdr_replay_push", "bdr_replay_len", "bdr_replay_head",
+    "bdr_replay_sample_indices", "bdr_replay_batch", "bdr_replay_last_batch", "bdr_replay_fill_synthetic",
+    "bdr_replay_read_rows",
+    "bdr_dqn_config_default", "bdr_dqn_create", "bdr_agent_destroy", "bdr_agent_set_train", "bdr_agent_is_train",
+    "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
+    "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
+    "bdr_agent_set_params", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_dqn_probe",
+    "bdr_agent_profile_enable", "bdr_agent_profile_read",
+    "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_agent_allreduce_params",
+    "bdr_agent_broadcast_params",
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP extension; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BdrError(2, f"{LIB_PATH} is missing: run `python -m border_amd.build` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401  (see module docstring: one HIP runtime per process)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.bdr_last_error.restype = C.c_char_p
+    L.bdr_version.restype = C.c_char_p
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)  # AttributeError here == ABI drift
+        if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default"):
+            fn.restype = C.c_int32
+    L.bdr_dqn_config_default.restype = None
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+    L.bdr_replay_create.argtypes = [C.POINTER(ReplayConfig), C.POINTER(vp)]
+    L.bdr_replay_destroy.argtypes = [vp]
+    L.bdr_replay_push.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
+    L.bdr_replay_len.argtypes = [vp, C.POINTER(u64)]
+    L.bdr_replay_head.argtypes = [vp, C.POINTER(u64)]
+    L.bdr_replay_sample_indices.argtypes = [vp, u64, vp]
+    L.bdr_replay_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]
+    L.bdr_replay_last_batch.argtypes = [vp, C.POINTER(DeviceBatch)]
+    L.bdr_replay_fill_synthetic.argtypes = [vp, u64, u64, i32, i32]
+    L.bdr_replay_read_rows.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp, vp]
+    L.bdr_dqn_config_default.argtypes = [C.POINTER(DqnConfigC)]
+    L.bdr_dqn_create.argtypes = [C.POINTER(DqnConfigC), C.POINTER(vp)]
+    L.bdr_agent_destroy.argtypes = [vp]
+    L.bdr_agent_set_train.argtypes = [vp, i32]
+    L.bdr_agent_is_train.argtypes = [vp, C.POINTER(i32)]
+    L.bdr_agent_opt.argtypes = [vp, vp]
+    L.bdr_agent_opt_with_record.argtypes = [vp, vp, C.POINTER(DqnRecordC)]
+    L.bdr_dqn_update_on_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, C.POINTER(DqnRecordC)]
+    L.bdr_agent_qvalues.argtypes = [vp, u64, vp, vp, vp]
+    L.bdr_agent_sync.argtypes = [vp]
+    L.bdr_agent_n_opts.argtypes = [vp, C.POINTER(u64)]
+    L.bdr_agent_param_count.argtypes = [vp, C.POINTER(u64)]
+    L.bdr_agent_get_params.argtypes = [vp, i32, vp, u64]
+    L.bdr_agent_set_params.argtypes = [vp, i32, vp, u64]
+    L.bdr_agent_save_params.argtypes = [vp, C.c_char_p]
+    L.bdr_agent_load_params.argtypes = [vp, C.c_char_p]
+    L.bdr_dqn_probe.argtypes = [vp, i32, vp, u64]
+    L.bdr_agent_profile_enable.argtypes = [vp, i32]
+    L.bdr_agent_profile_read.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
+    L.bdr_comm_get_unique_id.argtypes = [vp]
+    L.bdr_comm_init_rank.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.bdr_comm_destroy.argtypes = [vp]
+    L.bdr_agent_allreduce_params.argtypes = [vp, vp, i32]
+    L.bdr_agent_broadcast_params.argtypes = [vp, vp, i32, i32]
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise BdrError(status, lib().bdr_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    lib().bdr_device_count(C.byref(n))
+    return n.value

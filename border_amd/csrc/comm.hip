@@ -1,0 +1,121 @@
+// Multi-GPU parameter exchange over RCCL/xGMI: one process per GPU, the flat f32 parameter arena
+// is all-reduced (north_star: periodic averaging) or broadcast from a root (the faithful
+// learner->actors sync of border-async-trainer/src/async_trainer/base.rs:268-272, which ships
+// NamedTensors over a crossbeam channel).  librccl is resolved lazily with dlopen so that
+// single-GPU users never load it, and so that inside a PyTorch process the already-loaded
+// librccl.so.1 (same soname) is reused.
+#include <dlfcn.h>
+
+#include "common.hpp"
+
+using namespace bdr;
+
+namespace bdr {
+float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* stream, int* device);
+int32_t agent_scale(bdr_agent* a, float* p, float s);
+}
+
+namespace {
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef void* rcclComm_t;
+// ncclDataType_t: ncclFloat32 = 7; ncclRedOp_t: ncclSum = 0
+constexpr int kNcclFloat = 7, kNcclSum = 0;
+
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(rcclUniqueId*) = nullptr;
+    int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int32_t load_rccl()
+{
+    if (g_rccl.h) return BDR_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(BDR_ERR_COMM, "cannot load librccl: %s", dlerror());
+    Rccl r; r.h = h;
+#define SYM(field, name) *(void**)(&r.field) = dlsym(h, name); if (!r.field) return fail(BDR_ERR_COMM, "librccl lacks %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce"); SYM(Broadcast, "ncclBroadcast"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl = r;
+    return BDR_OK;
+}
+#define BDR_NCCL(expr)                                                                                             \
+    do {                                                                                                           \
+        int e__ = (expr);                                                                                          \
+        if (e__ != 0) return fail(BDR_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(e__));               \
+    } while (0)
+}  // namespace
+
+struct bdr_comm { rcclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; };
+
+extern "C" {
+
+int32_t bdr_comm_get_unique_id(uint8_t id[BDR_UNIQUE_ID_BYTES])
+{
+    BDR_REQUIRE(id, "null argument");
+    BDR_TRY(load_rccl());
+    rcclUniqueId u;
+    BDR_NCCL(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, BDR_UNIQUE_ID_BYTES);
+    return BDR_OK;
+}
+
+int32_t bdr_comm_init_rank(const uint8_t id[BDR_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank, int32_t device, bdr_comm** out)
+{
+    BDR_REQUIRE(id && out, "null argument");
+    BDR_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+    BDR_TRY(ensure_device(device));
+    BDR_TRY(load_rccl());
+    rcclUniqueId u;
+    memcpy(u.internal, id, BDR_UNIQUE_ID_BYTES);
+    bdr_comm* c = new bdr_comm();
+    c->nranks = nranks; c->rank = rank; c->device = device;
+    int e = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+    if (e != 0) { delete c; return fail(BDR_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(e)); }
+    *out = c;
+    return BDR_OK;
+}
+
+int32_t bdr_comm_destroy(bdr_comm* c)
+{
+    if (!c) return BDR_OK;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    return BDR_OK;
+}
+
+int32_t bdr_agent_allreduce_params(bdr_agent* a, bdr_comm* c, int32_t which)
+{
+    BDR_REQUIRE(a && c, "null argument");
+    size_t n = 0; hipStream_t s = nullptr; int dev = 0;
+    float* p = agent_arena(a, which, &n, &s, &dev);
+    BDR_REQUIRE(p, "which must be 0..4");
+    BDR_REQUIRE(dev == c->device, "agent and communicator live on different devices");
+    BDR_HIP(hipSetDevice(dev));
+    if (c->nranks == 1) return BDR_OK;
+    BDR_NCCL(g_rccl.AllReduce(p, p, n, kNcclFloat, kNcclSum, c->comm, s));
+    return agent_scale(a, p, 1.0f / (float)c->nranks);
+}
+
+int32_t bdr_agent_broadcast_params(bdr_agent* a, bdr_comm* c, int32_t which, int32_t root)
+{
+    BDR_REQUIRE(a && c, "null argument");
+    BDR_REQUIRE(root >= 0 && root < c->nranks, "bad root");
+    size_t n = 0; hipStream_t s = nullptr; int dev = 0;
+    float* p = agent_arena(a, which, &n, &s, &dev);
+    BDR_REQUIRE(p, "which must be 0..4");
+    BDR_HIP(hipSetDevice(dev));
+    if (c->nranks == 1) return BDR_OK;
+    BDR_NCCL(g_rccl.Broadcast(p, p, n, kNcclFloat, root, c->comm, s));
+    return BDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// Shared host-side plumbing of libborder_amd.so: error reporting, HIP call checking,
+// the opaque handle layouts.  gfx950 only; no CPU fallback anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/border_amd.h"
+
+namespace bdr {
+
+extern thread_local char g_err[512];
+
+inline int32_t fail(int32_t code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define BDR_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return ::bdr::fail(BDR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                               __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define BDR_TRY(expr)                                                                              \
+    do {                                                                                           \
+        int32_t s__ = (expr);                                                                      \
+        if (s__ != BDR_OK) return s__;                                                             \
+    } while (0)
+
+#define BDR_REQUIRE(cond, ...)                                                                     \
+    do {                                                                                           \
+        if (!(cond)) return ::bdr::fail(BDR_ERR_INVALID, __VA_ARGS__);                             \
+    } while (0)
+
+inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+int32_t ensure_device(int32_t device);
+
+}  // namespace bdr
+
+// ---------------------------------------------------------------------------------------------
+// Replay ring: one fused record per transition, record_stride bytes apart (multiple of 128):
+//   [0, obs_bytes)                       obs
+//   [obs_off2, obs_off2 + obs_bytes)     next_obs      (obs_off2 = round_up(obs_bytes, 16))
+//   [act_off, act_off + act_bytes)       act
+//   [tail_off + 0]  f32 reward, [+4] i8 is_terminated, [+5] i8 is_truncated
+// ---------------------------------------------------------------------------------------------
+struct bdr_replay {
+    int32_t device = 0;
+    uint64_t capacity = 0, i = 0, size = 0;
+    uint64_t obs_bytes = 0, act_bytes = 0;
+    uint64_t next_off = 0, act_off = 0, tail_off = 0, stride = 0;
+    uint32_t key[8] = {0};     // ChaCha12 key = seed_from_u64(seed)
+    uint64_t word_pos = 0;     // next u32 word of the key stream (host-tracked, passed by value)
+    uint8_t* ring = nullptr;   // capacity * stride bytes in HBM
+    hipStream_t stream = nullptr;
+    hipEvent_t written = nullptr;  // recorded after the last push/fill on `stream`
+    hipEvent_t read = nullptr;     // recorded by the consumer after the last gather
+    bool read_pending = false;
+    // pinned staging for push
+    uint8_t* stage = nullptr;
+    uint64_t stage_records = 0;
+    // device batch buffers (lazily sized)
+    uint64_t batch_cap = 0, batch_n = 0;
+    uint8_t *b_obs = nullptr, *b_next = nullptr, *b_act = nullptr;
+    float* b_reward = nullptr;
+    int8_t *b_term = nullptr, *b_trunc = nullptr;
+    uint64_t* b_ixs = nullptr;
+};
+
+namespace bdr {
+// Enqueue "draw n indices + gather" on `stream` (the consumer's stream).  Handles the
+// cross-stream ordering against pushes.  Advances the RNG like one batch(n).
+int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream);
+int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n);
+}  // namespace bdr

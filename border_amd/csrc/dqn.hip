@@ -1,0 +1,1123 @@
+// DQN agent on MI355X: Dqn::update_critic / opt_ (border-tch-agent/src/dqn/base.rs:60-200) for the
+// AtariCnn Q-network (border-tch-agent/src/cnn/base.rs:23-36), as hand-written gfx950 kernels.
+//
+// One opt step enqueues, on the agent's stream (no host sync; dqn/base.rs:154-157's per-step loss
+// read-back happens only in opt_with_record):
+//   replay: ChaCha12 indices + row gather                       (replay.hip)
+//   fwd   : conv1..conv3, l1 (split-K) for {online(obs), target(next_obs)[, online(next_obs)]}
+//           in ONE launch per layer (blockIdx.z = network instance), FP32 MFMA implicit GEMM
+//   head  : l1 finish (+bias, relu) + l2 (wave dot products)     -> Q-values
+//   td    : gather Q(s,a), max/argmax target, r + (1-term)*gamma*q', Huber/MSE, dL/dQ, dL/dh1
+//   bwd   : l2 grads, l1 dW/dX, conv3 dW/dX, conv2 dW/dX, conv1 dW   (FP32 MFMA)
+//   adam  : fused p,g,m,v pass over the flat parameter arena (libtorch Adam::step formula)
+//   track : tau*src + (1-tau)*dst every soft_update_interval opts (util.rs:31-45)
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+#include "common.hpp"
+#include "igemm.hpp"
+
+using namespace bdr;
+
+namespace {
+
+constexpr int MAXZ = 3;       // network instances per forward launch
+constexpr int L1_SPLIT = 7;   // split-K of the 3136-deep l1 contraction (98 k-tiles = 7 * 14)
+constexpr float INV255 = 1.0f / 255.0f;
+
+// ---- flat parameter arena (internal layouts; every segment 16-byte aligned) ----------------------
+//   W1 [256][32]  k=(c,kh,kw)      b1[32]
+//   W2 [512][64]  k=(kh,kw,c)      b2[64]
+//   W3 [576][64]  k=(kh,kw,c)      b3[64]
+//   W4 [3136][512] k=(h,w,c)       b4[512]      (NHWC flatten of conv3's output)
+//   W5 [512][A]                    b5[A]
+struct Arena {
+    size_t w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, total;  // offsets in floats
+    int A;
+};
+Arena make_arena(int A)
+{
+    Arena a{};
+    size_t o = 0;
+    auto seg = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
+    a.w1 = seg(256 * 32); a.b1 = seg(32);
+    a.w2 = seg(512 * 64); a.b2 = seg(64);
+    a.w3 = seg(576 * 64); a.b3 = seg(64);
+    a.w4 = seg((size_t)3136 * 512); a.b4 = seg(512);
+    a.w5 = seg((size_t)512 * A); a.b5 = seg(A);
+    a.total = o; a.A = A;
+    return a;
+}
+
+// ================================================================================================
+// forward policies
+// ================================================================================================
+struct FwdArgs {
+    const void* x[MAXZ];     // layer input per instance
+    const float* w[MAXZ];    // weights [K][N]
+    const float* bias[MAXZ];
+    float* out[MAXZ];        // [M][N] (or split-K partials [S][M][N])
+    int M;
+    int nkt_per_split;
+};
+
+template <class G, class APolicy, int WM_, int WN_, bool U8SCALE>
+struct FwdP {
+    using A = APolicy;
+    using Args = FwdArgs;
+    static constexpr int WM = WM_, WN = WN_, TM = 1, TN = 1;
+    static constexpr int N = G::COUT;
+    static constexpr bool B_TR = false;
+    static constexpr int KP = 32;
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static auto a_src(const Args& a, int z)
+    {
+        if constexpr (U8SCALE) return reinterpret_cast<const uint8_t*>(a.x[z]);
+        else return reinterpret_cast<const float*>(a.x[z]);
+    }
+    __device__ static const float* w(const Args& a, int z, int) { return a.w[z]; }
+    __device__ static int tap_index(int, int t) { return t; }
+    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
+    __device__ static void store(const Args& a, int z, int, int m, int n, float v)
+    {
+        if constexpr (U8SCALE) v *= INV255;   // cnn/base.rs:26 "/ 255", folded into the epilogue
+        v += a.bias[z][n];
+        a.out[z][(size_t)m * N + n] = v > 0.f ? v : 0.f;   // relu (cnn/base.rs:28,30,32)
+    }
+};
+using FwdC1 = FwdP<GeomC1, AFwdU8<GeomC1>, 4, 1, true>;    // 128x32 tiles, M = B*400
+using FwdC2 = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false>;     // 64x64,  M = B*81
+using FwdC3 = FwdP<GeomC3, AFwd<GeomC3>, 2, 2, false>;     // 64x64,  M = B*49
+
+// l1: [B][3136] x [3136][512], split-K over blockIdx.y, raw partials (bias/relu in the head kernel)
+struct FwdL1 {
+    using A = AFwd<GeomL1>;
+    using Args = FwdArgs;
+    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int N = 512;
+    static constexpr bool B_TR = false;
+    static constexpr int KP = 32;
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static const float* a_src(const Args& a, int z) { return reinterpret_cast<const float*>(a.x[z]); }
+    __device__ static const float* w(const Args& a, int z, int) { return a.w[z]; }
+    __device__ static int tap_index(int, int t) { return t; }
+    __device__ static void kt_range(const Args& a, int y, int& k0, int& k1)
+    {
+        k0 = y * a.nkt_per_split; k1 = min(A::NKT, k0 + a.nkt_per_split);
+    }
+    __device__ static void store(const Args& a, int z, int y, int m, int n, float v)
+    {
+        a.out[z][((size_t)y * a.M + m) * N + n] = v;
+    }
+};
+
+// ================================================================================================
+// input-gradient policies (transposed conv as gather; epilogue applies relu'(previous activation))
+// ================================================================================================
+struct DxArgs {
+    const float* dy;     // gradient w.r.t. this layer's pre-activation output
+    const float* w;      // this layer's weights [K][N]
+    const float* mask;   // previous layer's post-relu activation (same shape as out)
+    float* out;          // gradient w.r.t. the previous layer's pre-activation
+    int M;               // rows (per parity class for stride 2)
+};
+
+// l1: dh0[b][k] = sum_n dh1[b][n] W4[k][n];  treated as 1x1 "conv" with CIN=512 -> N'=3136
+struct DxL1 {
+    using G = Geom<1, 1, 512, 1, 1, 1, 1, 1, 3136>;
+    using A = AFwd<G>;     // dense rows of dh1
+    using Args = DxArgs;
+    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int N = 3136;     // N' (columns of the result)
+    static constexpr int KP = 512;     // K' per tap (contiguous in memory)
+    static constexpr bool B_TR = true;
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
+    __device__ static const float* w(const Args& a, int, int) { return a.w; }
+    __device__ static int tap_index(int, int t) { return t; }
+    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
+    __device__ static void store(const Args& a, int, int, int m, int n, float v)
+    {
+        const size_t o = (size_t)m * N + n;
+        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
+    }
+};
+
+// conv3 (3x3, stride 1): rows over the 9x9 input grid, K' = 9 taps * 64, N' = 64
+struct DxC3 {
+    using G = GeomC3;
+    using A = ADxS1<G>;
+    using Args = DxArgs;
+    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int N = G::CIN, KP = G::COUT;
+    static constexpr bool B_TR = true;
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
+    __device__ static const float* w(const Args& a, int, int) { return a.w; }
+    __device__ static int tap_index(int, int t) { return t; }
+    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
+    __device__ static void store(const Args& a, int, int, int m, int n, float v)
+    {
+        const size_t o = (size_t)m * N + n;
+        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
+    }
+};
+
+// conv2 (4x4, stride 2): blockIdx.y = parity class (ph,pw); rows (b, ih/2, iw/2); K' = 4 taps * 64
+struct DxC2 {
+    using G = GeomC2;
+    using A = ADxS2<G>;
+    using Args = DxArgs;
+    static constexpr int WM = 4, WN = 1, TM = 1, TN = 1;
+    static constexpr int N = G::CIN, KP = G::COUT;
+    static constexpr bool B_TR = true;
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
+    __device__ static const float* w(const Args& a, int, int) { return a.w; }
+    // class y=(ph,pw), tap t=(a,b2) -> (kh,kw) = (ph+2a, pw+2*b2) -> kh*4+kw
+    __device__ static int tap_index(int y, int t) { return ((y >> 1) + 2 * (t >> 1)) * 4 + (y & 1) + 2 * (t & 1); }
+    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
+    __device__ static void store(const Args& a, int, int y, int m, int n, float v)
+    {
+        constexpr int HH = G::IH / 2, WH = G::IW / 2;
+        const int b = m / (HH * WH), rem = m % (HH * WH);
+        const int ih = 2 * (rem / WH) + (y >> 1), iw = 2 * (rem % WH) + (y & 1);
+        const size_t o = ((size_t)(b * G::IH + ih) * G::IW + iw) * N + n;
+        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
+    }
+};
+
+// ================================================================================================
+// weight-gradient policies
+// ================================================================================================
+struct DwArgs {
+    const void* x;      // layer input (activation of the previous layer)
+    const float* dy;    // [M][N]
+    float* part;        // partials: [chunks][K*N + N]
+    size_t part_stride; // floats between chunks
+    int M;
+};
+template <class G, class APolicy, int WM_, int WN_, bool U8>
+struct DwP {
+    using A = APolicy;
+    using Args = DwArgs;
+    static constexpr int WM = WM_, WN = WN_, TM = 1, TN = 1;
+    static constexpr int K = G::K, N = G::COUT;
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static auto a_src(const Args& a)
+    {
+        if constexpr (U8) return reinterpret_cast<const uint8_t*>(a.x);
+        else return reinterpret_cast<const float*>(a.x);
+    }
+    __device__ static const float* y_src(const Args& a) { return a.dy; }
+    __device__ static float* part(const Args& a, int chunk) { return a.part + (size_t)chunk * a.part_stride; }
+};
+using DwC1 = DwP<GeomC1, AFwdU8<GeomC1>, 4, 1, true>;    // 128(k) x 32(n) tiles: 2 ko-tiles
+using DwC2 = DwP<GeomC2, AFwd<GeomC2>, 2, 2, false>;     // 64 x 64: 8 ko-tiles
+using DwC3 = DwP<GeomC3, AFwd<GeomC3>, 2, 2, false>;     // 64 x 64: 9 ko-tiles
+using DwL1 = DwP<GeomL1, AFwd<GeomL1>, 2, 2, false>;     // 64 x 64: 49 x 8 tiles, single chunk
+
+// g[i] = scale * sum_c part[c][i]
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, size_t stride, int chunks,
+                                                          float* __restrict__ g, int n, int n_weights, float wscale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * stride + i];
+    g[i] = i < n_weights ? s * wscale : s;
+}
+
+// ================================================================================================
+// head: l1 finish + l2, one wave per (row, instance)
+// ================================================================================================
+struct HeadArgs {
+    const float* p1[MAXZ];   // l1 split-K partials [S][B][512]
+    const float* b4[MAXZ];
+    const float* w5[MAXZ];   // [512][A]
+    const float* b5[MAXZ];
+    float* h1[MAXZ];         // [B][512] post-relu
+    float* q[MAXZ];          // [B][A]
+    int B, A, S;
+};
+
+__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave, z = blockIdx.y;
+    if (row >= a.B) return;
+    // lane owns columns [lane*8, lane*8+8)
+    f32x4 h[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    for (int s = 0; s < a.S; ++s) {
+        const float* p = a.p1[z] + ((size_t)s * a.B + row) * 512 + lane * 8;
+        h[0] += *reinterpret_cast<const f32x4*>(p);
+        h[1] += *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    float hv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = h[j >> 2][j & 3] + a.b4[z][lane * 8 + j];
+        hv[j] = v > 0.f ? v : 0.f;   // cnn/base.rs:34 relu
+    }
+    float* ho = a.h1[z] + (size_t)row * 512 + lane * 8;
+    *reinterpret_cast<f32x4*>(ho) = f32x4{hv[0], hv[1], hv[2], hv[3]};
+    *reinterpret_cast<f32x4*>(ho + 4) = f32x4{hv[4], hv[5], hv[6], hv[7]};
+    for (int act = 0; act < a.A; ++act) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(hv[j], a.w5[z][(size_t)(lane * 8 + j) * a.A + act], s);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) a.q[z][(size_t)row * a.A + act] = s + a.b5[z][act];
+    }
+}
+
+// ================================================================================================
+// TD: dqn/base.rs:71-74 (pred), :91-105 (target), :146-152 (loss), plus dL/dQ and dL/dh1.
+// One wave per batch row.
+// ================================================================================================
+struct TdArgs {
+    const float* q_on;     // [B][A]  qnet(obs)
+    const float* q_tg;     // [B][A]  qnet_tgt(next_obs)
+    const float* q_on_next;  // [B][A] qnet(next_obs) (double DQN) or nullptr
+    const uint8_t* act;    // [B] rows of act_bytes; first 8 bytes = i64 action
+    int act_bytes;
+    const float* reward;
+    const int8_t* term;
+    const float* h1;       // [B][512] online net, post-relu
+    const float* w5;       // [512][A] online
+    float* dh1;            // [B][512]
+    float* dq;             // [B]   dL/dQ(s,a) (already divided by B)
+    float* pred;           // [B]
+    float* tgt;            // [B]
+    float* loss_row;       // [B]
+    int B, A;
+    float gamma;
+    int loss_kind;         // 0 mse, 1 smooth-l1
+};
+
+__global__ __launch_bounds__(256) void k_td_rows(TdArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= a.B) return;
+    const long long act = *reinterpret_cast<const long long*>(a.act + (size_t)row * a.act_bytes);
+    // argmax over actions: first maximal index (at::argmax), lanes >= A hold -inf
+    const float* sel = a.q_on_next ? a.q_on_next : a.q_tg;
+    float v = lane < a.A ? sel[(size_t)row * a.A + lane] : -INFINITY;
+    int idx = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    const float qn = a.q_tg[(size_t)row * a.A + idx];
+    const float pred = a.q_on[(size_t)row * a.A + act];
+    // reward + (1 - is_terminated) * discount_factor * q   (dqn/base.rs:104)
+    const float tgt = a.reward[row] + ((float)(1 - (int)a.term[row]) * a.gamma) * qn;
+    const float d = pred - tgt;
+    float lossb, dl;
+    if (a.loss_kind == 1) {   // smooth_l1_loss(beta=1.0)
+        const float zabs = fabsf(d);
+        lossb = zabs < 1.f ? 0.5f * zabs * zabs : zabs - 0.5f;
+        dl = zabs < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+    } else {                  // mse_loss
+        lossb = d * d;
+        dl = 2.f * d;
+    }
+    const float dq = dl / (float)a.B;   // Reduction::Mean
+    if (lane == 0) { a.dq[row] = dq; a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb; }
+    // dL/dh1[row][j] = relu'(h1) * dq * W5[j][act]
+    const float* hr = a.h1 + (size_t)row * 512 + lane * 8;
+    float out[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = hr[j] > 0.f ? dq * a.w5[(size_t)(lane * 8 + j) * a.A + act] : 0.f;
+    float* o = a.dh1 + (size_t)row * 512 + lane * 8;
+    *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+}
+
+// l2 gradients + loss mean.  thread per (j, a): gW5[j][a] = sum_b h1[b][j] * dq[b] * [act[b]==a]
+struct HeadBwdArgs {
+    const float* h1; const float* dq; const uint8_t* act; int act_bytes;
+    const float* loss_row;
+    float* gw5; float* gb5; float* loss;   // loss: [1]
+    int B, A;
+};
+__global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int n = 512 * a.A;
+    if (t < n) {
+        const int j = t / a.A, ac = t % a.A;
+        float s = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            const long long ab = *reinterpret_cast<const long long*>(a.act + (size_t)b * a.act_bytes);
+            if (ab == ac) s = fmaf(a.h1[(size_t)b * 512 + j], a.dq[b], s);
+        }
+        a.gw5[t] = s;
+    } else if (t < n + a.A) {
+        const int ac = t - n;
+        float s = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            const long long ab = *reinterpret_cast<const long long*>(a.act + (size_t)b * a.act_bytes);
+            if (ab == ac) s += a.dq[b];
+        }
+        a.gb5[ac] = s;
+    } else if (t == n + a.A) {
+        float s = 0.f;
+        for (int b = 0; b < a.B; ++b) s += a.loss_row[b];
+        a.loss[0] = s / (float)a.B;
+    }
+}
+
+// ================================================================================================
+// Adam (opt.rs:35 -> libtorch Adam::step) and track (util.rs:31-45) over the flat arena
+// ================================================================================================
+struct AdamScalars { float b1, omb1, b2, omb2, sqrt_bc2, eps, neg_step, wd_mul; };
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, size_t n4, AdamScalars s)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pp[j] *= s.wd_mul;                                 // AdamW decoupled decay (1 for Adam)
+        mm[j] = mm[j] * s.b1 + gg[j] * s.omb1;             // exp_avg.mul_(b1).add_(g, 1-b1)
+        vv[j] = vv[j] * s.b2 + s.omb2 * gg[j] * gg[j];     // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+        const float denom = __fsqrt_rn(vv[j]) / s.sqrt_bc2 + s.eps;
+        pp[j] = pp[j] + s.neg_step * mm[j] / denom;        // addcdiv_(exp_avg, denom, -step_size)
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+}
+
+__global__ __launch_bounds__(256) void k_track(float* __restrict__ dst, const float* __restrict__ src, size_t n4, float tau,
+                                               float omt)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 d = reinterpret_cast<f32x4*>(dst)[i], s = reinterpret_cast<const f32x4*>(src)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = tau * s[j] + omt * d[j];
+    reinterpret_cast<f32x4*>(dst)[i] = d;
+}
+
+__global__ __launch_bounds__(256) void k_scale(float* __restrict__ p, size_t n4, float s)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 d = reinterpret_cast<f32x4*>(p)[i];
+    d *= s;
+    reinterpret_cast<f32x4*>(p)[i] = d;
+}
+
+}  // namespace
+
+// ================================================================================================
+// agent handle
+// ================================================================================================
+struct ProfSlot { std::string name; hipEvent_t e0, e1; double ms = 0; uint64_t count = 0; };
+
+struct bdr_agent {
+    bdr_dqn_config cfg;
+    int32_t device = 0;
+    hipStream_t stream = nullptr;
+    Arena ar;
+    int B = 0;          // activation buffers are sized for this batch
+    // parameter arenas
+    float *q = nullptr, *q_tgt = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
+    // activations [instance]
+    float* a1[MAXZ] = {nullptr}; float* a2[MAXZ] = {nullptr}; float* a3[MAXZ] = {nullptr};
+    float* p1[MAXZ] = {nullptr}; float* h1[MAXZ] = {nullptr}; float* qv[MAXZ] = {nullptr};
+    // backward
+    float *dh1 = nullptr, *dy3 = nullptr, *dy2 = nullptr, *dy1 = nullptr;
+    float *dq = nullptr, *pred = nullptr, *tgt = nullptr, *loss_row = nullptr, *loss = nullptr;
+    float *part = nullptr; size_t part_floats = 0;
+    // update_on_batch staging
+    uint8_t *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr; float* u_rew = nullptr; int8_t* u_term = nullptr;
+    uint64_t u_cap = 0;
+    // bookkeeping (dqn/base.rs:26-48)
+    uint64_t adam_step = 0, soft_update_counter = 0, n_opts = 0;
+    bool train = false;
+    // profiling
+    bool prof = false;
+    std::vector<ProfSlot> slots;
+    size_t slot_cursor = 0;
+};
+
+namespace {
+
+int32_t alloc_f(float** p, size_t n) { BDR_HIP(hipMalloc((void**)p, std::max<size_t>(n, 4) * sizeof(float))); return BDR_OK; }
+
+void free_batch_buffers(bdr_agent* a)
+{
+    for (int z = 0; z < MAXZ; ++z) {
+        (void)hipFree(a->a1[z]); (void)hipFree(a->a2[z]); (void)hipFree(a->a3[z]);
+        (void)hipFree(a->p1[z]); (void)hipFree(a->h1[z]); (void)hipFree(a->qv[z]);
+        a->a1[z] = a->a2[z] = a->a3[z] = a->p1[z] = a->h1[z] = a->qv[z] = nullptr;
+    }
+    (void)hipFree(a->dh1); (void)hipFree(a->dy3); (void)hipFree(a->dy2); (void)hipFree(a->dy1);
+    (void)hipFree(a->dq); (void)hipFree(a->pred); (void)hipFree(a->tgt); (void)hipFree(a->loss_row);
+    (void)hipFree(a->part);
+    a->dh1 = a->dy3 = a->dy2 = a->dy1 = a->dq = a->pred = a->tgt = a->loss_row = a->part = nullptr;
+}
+
+// chunk counts of the weight-gradient reductions (rows M split across workgroups)
+struct DwPlan { int chunks_c1, chunks_c2, chunks_c3; size_t stride_c1, stride_c2, stride_c3, off_c1, off_c2, off_c3, total; };
+DwPlan dw_plan(int B)
+{
+    DwPlan p{};
+    auto mt = [](int M) { return (M + 31) / 32; };
+    p.chunks_c1 = std::min(128, mt(B * 400));
+    p.chunks_c2 = std::min(32, mt(B * 81));
+    p.chunks_c3 = std::min(28, mt(B * 49));
+    p.stride_c1 = 256 * 32 + 32; p.stride_c2 = 512 * 64 + 64; p.stride_c3 = 576 * 64 + 64;
+    p.off_c1 = 0;
+    p.off_c2 = p.off_c1 + p.chunks_c1 * p.stride_c1;
+    p.off_c3 = p.off_c2 + p.chunks_c2 * p.stride_c2;
+    p.total = p.off_c3 + p.chunks_c3 * p.stride_c3;
+    return p;
+}
+
+int32_t ensure_batch(bdr_agent* a, int B)
+{
+    if (B <= a->B) return BDR_OK;
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    free_batch_buffers(a);
+    const int A = a->ar.A;
+    for (int z = 0; z < MAXZ; ++z) {
+        BDR_TRY(alloc_f(&a->a1[z], (size_t)B * 400 * 32));
+        BDR_TRY(alloc_f(&a->a2[z], (size_t)B * 81 * 64));
+        BDR_TRY(alloc_f(&a->a3[z], (size_t)B * 49 * 64));
+        BDR_TRY(alloc_f(&a->p1[z], (size_t)L1_SPLIT * B * 512));
+        BDR_TRY(alloc_f(&a->h1[z], (size_t)B * 512));
+        BDR_TRY(alloc_f(&a->qv[z], (size_t)B * A));
+    }
+    BDR_TRY(alloc_f(&a->dh1, (size_t)B * 512));
+    BDR_TRY(alloc_f(&a->dy3, (size_t)B * 49 * 64));
+    BDR_TRY(alloc_f(&a->dy2, (size_t)B * 81 * 64));
+    BDR_TRY(alloc_f(&a->dy1, (size_t)B * 400 * 32));
+    BDR_TRY(alloc_f(&a->dq, B)); BDR_TRY(alloc_f(&a->pred, B)); BDR_TRY(alloc_f(&a->tgt, B));
+    BDR_TRY(alloc_f(&a->loss_row, B));
+    const DwPlan p = dw_plan(B);
+    BDR_TRY(alloc_f(&a->part, p.total));
+    a->part_floats = p.total;
+    a->B = B;
+    return BDR_OK;
+}
+
+// ---- profiling brackets --------------------------------------------------------------------------
+struct Bracket {
+    bdr_agent* a; ProfSlot* s = nullptr;
+    Bracket(bdr_agent* ag, const char* name) : a(ag)
+    {
+        if (!a->prof) return;
+        if (a->slot_cursor >= a->slots.size()) {
+            ProfSlot ns; ns.name = name;
+            (void)hipEventCreate(&ns.e0); (void)hipEventCreate(&ns.e1);
+            a->slots.push_back(ns);
+        }
+        s = &a->slots[a->slot_cursor++];
+        (void)hipEventRecord(s->e0, a->stream);
+    }
+    ~Bracket()
+    {
+        if (!s) return;
+        (void)hipEventRecord(s->e1, a->stream);
+    }
+};
+void prof_collect(bdr_agent* a)
+{
+    if (!a->prof) return;
+    (void)hipStreamSynchronize(a->stream);
+    for (size_t i = 0; i < a->slot_cursor; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a->slots[i].e0, a->slots[i].e1) == hipSuccess) { a->slots[i].ms += ms; a->slots[i].count++; }
+    }
+    a->slot_cursor = 0;
+}
+
+#define LAUNCH(kernel, grid, args)                                                                  \
+    do {                                                                                           \
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, a->stream, args);                            \
+        BDR_HIP(hipGetLastError());                                                                \
+    } while (0)
+
+// ---- the forward pass of nz network instances ------------------------------------------------------
+struct NetInst { const uint8_t* x; const float* params; int slot; };
+
+int32_t forward(bdr_agent* a, const NetInst* inst, int nz, int B)
+{
+    const Arena& ar = a->ar;
+    FwdArgs f{};
+    f.M = B * 400;
+    for (int z = 0; z < nz; ++z) { f.x[z] = inst[z].x; f.w[z] = inst[z].params + ar.w1; f.bias[z] = inst[z].params + ar.b1; f.out[z] = a->a1[inst[z].slot]; }
+    { Bracket br(a, "fwd_conv1"); LAUNCH(k_igemm<FwdC1>, dim3((f.M + 127) / 128, 1, nz), f); }
+    f.M = B * 81;
+    for (int z = 0; z < nz; ++z) { f.x[z] = a->a1[inst[z].slot]; f.w[z] = inst[z].params + ar.w2; f.bias[z] = inst[z].params + ar.b2; f.out[z] = a->a2[inst[z].slot]; }
+    { Bracket br(a, "fwd_conv2"); LAUNCH(k_igemm<FwdC2>, dim3((f.M + 63) / 64, 1, nz), f); }
+    f.M = B * 49;
+    for (int z = 0; z < nz; ++z) { f.x[z] = a->a2[inst[z].slot]; f.w[z] = inst[z].params + ar.w3; f.bias[z] = inst[z].params + ar.b3; f.out[z] = a->a3[inst[z].slot]; }
+    { Bracket br(a, "fwd_conv3"); LAUNCH(k_igemm<FwdC3>, dim3((f.M + 63) / 64, 1, nz), f); }
+    f.M = B; f.nkt_per_split = (98 + L1_SPLIT - 1) / L1_SPLIT;
+    for (int z = 0; z < nz; ++z) { f.x[z] = a->a3[inst[z].slot]; f.w[z] = inst[z].params + ar.w4; f.bias[z] = nullptr; f.out[z] = a->p1[inst[z].slot]; }
+    { Bracket br(a, "fwd_l1"); LAUNCH(k_igemm<FwdL1>, dim3(((B + 63) / 64) * 8, L1_SPLIT, nz), f); }
+    HeadArgs h{};
+    h.B = B; h.A = ar.A; h.S = L1_SPLIT;
+    for (int z = 0; z < nz; ++z) {
+        h.p1[z] = a->p1[inst[z].slot]; h.b4[z] = inst[z].params + ar.b4; h.w5[z] = inst[z].params + ar.w5;
+        h.b5[z] = inst[z].params + ar.b5; h.h1[z] = a->h1[inst[z].slot]; h.q[z] = a->qv[inst[z].slot];
+    }
+    { Bracket br(a, "head_fwd"); LAUNCH(k_head_fwd, dim3((B + 3) / 4, nz), h); }
+    return BDR_OK;
+}
+
+AdamScalars adam_scalars(const bdr_dqn_config& c, uint64_t step)
+{
+    // opt.rs:35: tch nn::Adam::default() -> beta1 .9, beta2 .999, wd 0, eps 1e-8; AdamW: opt.rs:38-55
+    const bool w = c.opt_kind == BDR_OPT_ADAMW;
+    const double b1 = w ? c.beta1 : 0.9, b2 = w ? c.beta2 : 0.999, eps = w ? c.eps : 1e-8, wd = w ? c.weight_decay : 0.0;
+    const double bc1 = 1.0 - std::pow(b1, (double)step), bc2 = 1.0 - std::pow(b2, (double)step);
+    AdamScalars s;
+    s.b1 = (float)b1; s.omb1 = (float)(1.0 - b1); s.b2 = (float)b2; s.omb2 = (float)(1.0 - b2);
+    s.sqrt_bc2 = (float)std::sqrt(bc2); s.eps = (float)eps; s.neg_step = (float)(-(c.lr / bc1));
+    s.wd_mul = (float)(1.0 - c.lr * wd);
+    return s;
+}
+
+// Dqn::update_critic on a device-resident batch (dqn/base.rs:60-160)
+int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
+                      const float* reward, const int8_t* term)
+{
+    BDR_TRY(ensure_batch(a, B));
+    const Arena& ar = a->ar;
+    const bdr_dqn_config& c = a->cfg;
+    // :71-74 + :91-103  slot 0 = qnet(obs), slot 1 = qnet_tgt(next_obs), slot 2 = qnet(next_obs) for double DQN
+    NetInst inst[3] = {{obs, a->q, 0}, {next_obs, a->q_tgt, 1}, {next_obs, a->q, 2}};
+    BDR_TRY(forward(a, inst, c.double_dqn ? 3 : 2, B));
+
+    TdArgs t{};
+    t.q_on = a->qv[0]; t.q_tg = a->qv[1]; t.q_on_next = c.double_dqn ? a->qv[2] : nullptr;
+    t.act = act; t.act_bytes = act_bytes; t.reward = reward; t.term = term;
+    t.h1 = a->h1[0]; t.w5 = a->q + ar.w5; t.dh1 = a->dh1; t.dq = a->dq; t.pred = a->pred; t.tgt = a->tgt;
+    t.loss_row = a->loss_row; t.B = B; t.A = ar.A; t.gamma = (float)c.discount_factor; t.loss_kind = c.critic_loss;
+    { Bracket br(a, "td_rows"); LAUNCH(k_td_rows, dim3((B + 3) / 4), t); }
+
+    HeadBwdArgs hb{a->h1[0], a->dq, act, act_bytes, a->loss_row, a->grad + ar.w5, a->grad + ar.b5, a->loss, B, ar.A};
+    { Bracket br(a, "head_bwd"); LAUNCH(k_head_bwd, dim3((512 * ar.A + ar.A + 1 + 255) / 256), hb); }
+
+    const DwPlan pl = dw_plan(a->B);   // buffer layout follows the allocated batch capacity
+    // l1: dW (+db) straight into the gradient arena, then dX with relu' of a3
+    {
+        DwArgs d{a->a3[0], a->dh1, a->grad + ar.w4, 0, B};
+        Bracket br(a, "bwd_l1_dw");
+        LAUNCH(k_igemm_red<DwL1>, dim3(49 * 8, 1), d);
+    }
+    {
+        DxArgs d{a->dh1, a->q + ar.w4, a->a3[0], a->dy3, B};
+        Bracket br(a, "bwd_l1_dx");
+        LAUNCH(k_igemm<DxL1>, dim3(((B + 63) / 64) * 49, 1, 1), d);
+    }
+    // conv3
+    {
+        const int M = B * 49, chunks = std::min(pl.chunks_c3, (M + 31) / 32);
+        DwArgs d{a->a2[0], a->dy3, a->part + pl.off_c3, pl.stride_c3, M};
+        { Bracket br(a, "bwd_conv3_dw"); LAUNCH(k_igemm_red<DwC3>, dim3(9, chunks), d); }
+        const int n = 576 * 64 + 64;
+        Bracket br(a, "bwd_conv3_red");
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, a->stream, a->part + pl.off_c3, pl.stride_c3,
+                           chunks, a->grad + ar.w3, n, 576 * 64, 1.0f);
+        BDR_HIP(hipGetLastError());
+    }
+    {
+        DxArgs d{a->dy3, a->q + ar.w3, a->a2[0], a->dy2, B * 81};
+        Bracket br(a, "bwd_conv3_dx");
+        LAUNCH(k_igemm<DxC3>, dim3((d.M + 63) / 64, 1, 1), d);
+    }
+    // conv2
+    {
+        const int M = B * 81, chunks = std::min(pl.chunks_c2, (M + 31) / 32);
+        DwArgs d{a->a1[0], a->dy2, a->part + pl.off_c2, pl.stride_c2, M};
+        { Bracket br(a, "bwd_conv2_dw"); LAUNCH(k_igemm_red<DwC2>, dim3(8, chunks), d); }
+        const int n = 512 * 64 + 64;
+        Bracket br(a, "bwd_conv2_red");
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, a->stream, a->part + pl.off_c2, pl.stride_c2,
+                           chunks, a->grad + ar.w2, n, 512 * 64, 1.0f);
+        BDR_HIP(hipGetLastError());
+    }
+    {
+        DxArgs d{a->dy2, a->q + ar.w2, a->a1[0], a->dy1, B * 100};
+        Bracket br(a, "bwd_conv2_dx");
+        LAUNCH(k_igemm<DxC2>, dim3((d.M + 127) / 128, 4, 1), d);
+    }
+    // conv1 (no input gradient)
+    {
+        const int M = B * 400, chunks = std::min(pl.chunks_c1, (M + 31) / 32);
+        DwArgs d{obs, a->dy1, a->part + pl.off_c1, pl.stride_c1, M};
+        { Bracket br(a, "bwd_conv1_dw"); LAUNCH(k_igemm_red<DwC1>, dim3(2, chunks), d); }
+        const int n = 256 * 32 + 32;
+        Bracket br(a, "bwd_conv1_red");
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, a->stream, a->part + pl.off_c1, pl.stride_c1,
+                           chunks, a->grad + ar.w1, n, 256 * 32, INV255);
+        BDR_HIP(hipGetLastError());
+    }
+    // :150 backward_step -> Adam
+    a->adam_step += 1;
+    const AdamScalars s = adam_scalars(c, a->adam_step);
+    const size_t n4 = ar.total / 4;
+    {
+        Bracket br(a, "adam");
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q, a->grad, a->m, a->v, n4, s);
+        BDR_HIP(hipGetLastError());
+    }
+    return BDR_OK;
+}
+
+int32_t soft_update(bdr_agent* a)
+{
+    const size_t n4 = a->ar.total / 4;
+    const float tau = (float)a->cfg.tau, omt = (float)(1.0 - a->cfg.tau);
+    Bracket br(a, "track");
+    hipLaunchKernelGGL(k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q_tgt, a->q, n4, tau, omt);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+
+// dqn/base.rs:182-200 bookkeeping after the n_updates_per_opt updates
+int32_t after_updates(bdr_agent* a)
+{
+    a->soft_update_counter += 1;
+    if (a->soft_update_counter == a->cfg.soft_update_interval) {
+        a->soft_update_counter = 0;
+        BDR_TRY(soft_update(a));
+    }
+    a->n_opts += 1;
+    return BDR_OK;
+}
+
+int32_t opt_inner(bdr_agent* a, bdr_replay* r)
+{
+    BDR_REQUIRE(r->obs_bytes == (uint64_t)a->cfg.net.n_stack * 84 * 84, "replay obs rows (%llu B) do not match the AtariCnn input",
+                (unsigned long long)r->obs_bytes);
+    BDR_REQUIRE(r->act_bytes >= 8, "discrete actions are stored as i64");
+    BDR_REQUIRE(r->device == a->device, "agent and replay buffer live on different devices");
+    for (uint64_t u = 0; u < a->cfg.n_updates_per_opt; ++u) {
+        { Bracket br(a, "sample"); BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->stream)); }
+        BDR_TRY(update_critic(a, (int)a->cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term));
+    }
+    return after_updates(a);
+}
+
+int32_t fill_record(bdr_agent* a, int B, const float* reward_dev, bdr_dqn_record* rec)
+{
+    BDR_HIP(hipMemcpyAsync(&rec->loss, a->loss, 4, hipMemcpyDeviceToHost, a->stream));
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    rec->has_verbose = 0;
+    if (a->cfg.record_verbose_level >= 2) {
+        std::vector<float> p(B), t(B), rw(B);
+        BDR_HIP(hipMemcpy(p.data(), a->pred, B * 4, hipMemcpyDeviceToHost));
+        BDR_HIP(hipMemcpy(t.data(), a->tgt, B * 4, hipMemcpyDeviceToHost));
+        BDR_HIP(hipMemcpy(rw.data(), reward_dev, B * 4, hipMemcpyDeviceToHost));
+        double sp = 0, st = 0, sr = 0, sd = 0;
+        for (int i = 0; i < B; ++i) { sp += p[i]; st += t[i]; sr += rw[i]; sd += (double)t[i] - p[i]; }
+        rec->pred_mean = (float)(sp / B); rec->tgt_mean = (float)(st / B); rec->reward_mean = (float)(sr / B);
+        rec->tgt_minus_pred_mean = (float)(sd / B);
+        rec->has_verbose = 1;
+    }
+    return BDR_OK;
+}
+
+// ---- reference <-> internal parameter layouts ------------------------------------------------------
+// reference order: c1.weight[32][4][8][8] c1.bias c2.weight[64][32][4][4] c2.bias c3.weight[64][64][3][3]
+// c3.bias l1.weight[512][3136 (c,h,w)] l1.bias l2.weight[A][512] l2.bias   (cnn/base.rs:23-36)
+size_t ref_param_count(int A) { return 8192 + 32 + 32768 + 64 + 36864 + 64 + (size_t)512 * 3136 + 512 + (size_t)A * 512 + A; }
+
+void to_internal(const Arena& ar, const float* ref, float* in)
+{
+    std::fill(in, in + ar.total, 0.f);
+    const float* p = ref;
+    for (int o = 0; o < 32; ++o) for (int k = 0; k < 256; ++k) in[ar.w1 + (size_t)k * 32 + o] = p[(size_t)o * 256 + k];
+    p += 8192; std::copy(p, p + 32, in + ar.b1); p += 32;
+    for (int o = 0; o < 64; ++o) for (int c = 0; c < 32; ++c) for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw)
+        in[ar.w2 + (size_t)((kh * 4 + kw) * 32 + c) * 64 + o] = p[((size_t)(o * 32 + c) * 4 + kh) * 4 + kw];
+    p += 32768; std::copy(p, p + 64, in + ar.b2); p += 64;
+    for (int o = 0; o < 64; ++o) for (int c = 0; c < 64; ++c) for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw)
+        in[ar.w3 + (size_t)((kh * 3 + kw) * 64 + c) * 64 + o] = p[((size_t)(o * 64 + c) * 3 + kh) * 3 + kw];
+    p += 36864; std::copy(p, p + 64, in + ar.b3); p += 64;
+    for (int o = 0; o < 512; ++o) for (int c = 0; c < 64; ++c) for (int hw = 0; hw < 49; ++hw)
+        in[ar.w4 + (size_t)(hw * 64 + c) * 512 + o] = p[(size_t)o * 3136 + c * 49 + hw];
+    p += (size_t)512 * 3136; std::copy(p, p + 512, in + ar.b4); p += 512;
+    for (int o = 0; o < ar.A; ++o) for (int k = 0; k < 512; ++k) in[ar.w5 + (size_t)k * ar.A + o] = p[(size_t)o * 512 + k];
+    p += (size_t)ar.A * 512; std::copy(p, p + ar.A, in + ar.b5);
+}
+
+void to_reference(const Arena& ar, const float* in, float* ref)
+{
+    float* p = ref;
+    for (int o = 0; o < 32; ++o) for (int k = 0; k < 256; ++k) p[(size_t)o * 256 + k] = in[ar.w1 + (size_t)k * 32 + o];
+    p += 8192; std::copy(in + ar.b1, in + ar.b1 + 32, p); p += 32;
+    for (int o = 0; o < 64; ++o) for (int c = 0; c < 32; ++c) for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw)
+        p[((size_t)(o * 32 + c) * 4 + kh) * 4 + kw] = in[ar.w2 + (size_t)((kh * 4 + kw) * 32 + c) * 64 + o];
+    p += 32768; std::copy(in + ar.b2, in + ar.b2 + 64, p); p += 64;
+    for (int o = 0; o < 64; ++o) for (int c = 0; c < 64; ++c) for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw)
+        p[((size_t)(o * 64 + c) * 3 + kh) * 3 + kw] = in[ar.w3 + (size_t)((kh * 3 + kw) * 64 + c) * 64 + o];
+    p += 36864; std::copy(in + ar.b3, in + ar.b3 + 64, p); p += 64;
+    for (int o = 0; o < 512; ++o) for (int c = 0; c < 64; ++c) for (int hw = 0; hw < 49; ++hw)
+        p[(size_t)o * 3136 + c * 49 + hw] = in[ar.w4 + (size_t)(hw * 64 + c) * 512 + o];
+    p += (size_t)512 * 3136; std::copy(in + ar.b4, in + ar.b4 + 512, p); p += 512;
+    for (int o = 0; o < ar.A; ++o) for (int k = 0; k < 512; ++k) p[(size_t)o * 512 + k] = in[ar.w5 + (size_t)k * ar.A + o];
+    p += (size_t)ar.A * 512; std::copy(in + ar.b5, in + ar.b5 + ar.A, p);
+}
+
+float* arena_ptr(bdr_agent* a, int which)
+{
+    switch (which) {
+        case 0: return a->q; case 1: return a->q_tgt; case 2: return a->m; case 3: return a->v; case 4: return a->grad;
+        default: return nullptr;
+    }
+}
+
+// the library's own initialiser: uniform(+-1/sqrt(fan_in)) from splitmix64 (init scheme is irrelevant to
+// parity: tests inject weights through bdr_agent_set_params)
+void init_reference_params(int A, uint64_t seed, std::vector<float>& ref)
+{
+    ref.resize(ref_param_count(A));
+    const size_t sizes[10] = {8192, 32, 32768, 64, 36864, 64, (size_t)512 * 3136, 512, (size_t)A * 512, (size_t)A};
+    const int fan[10] = {256, 256, 512, 512, 576, 576, 3136, 3136, 512, 512};
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    size_t o = 0;
+    for (int t = 0; t < 10; ++t) {
+        const float bound = 1.0f / std::sqrt((float)fan[t]);
+        for (size_t i = 0; i < sizes[t]; ++i) {
+            s += 0x9E3779B97F4A7C15ull;
+            uint64_t x = s; x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+            ref[o + i] = ((float)(x >> 40) * (2.0f / 16777216.0f) - 1.0f) * bound;
+        }
+        o += sizes[t];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void bdr_dqn_config_default(bdr_dqn_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    // dqn/config.rs:82-102
+    c->net.kind = BDR_NET_ATARI_CNN; c->net.n_stack = 4; c->net.out_dim = 0;
+    c->opt_kind = BDR_OPT_ADAM; c->lr = 0.0;
+    c->beta1 = 0.9; c->beta2 = 0.999; c->weight_decay = 0.0; c->eps = 1e-8;
+    c->soft_update_interval = 1; c->n_updates_per_opt = 1; c->batch_size = 1;
+    c->discount_factor = 0.99; c->tau = 0.005; c->train = 0; c->double_dqn = 0;
+    c->critic_loss = BDR_LOSS_MSE; c->has_clip_td_err = 0; c->record_verbose_level = 0;
+    c->device = -1; c->param_seed = 0;
+}
+
+int32_t bdr_dqn_create(const bdr_dqn_config* cfg, bdr_agent** out)
+{
+    BDR_REQUIRE(cfg && out, "null argument");
+    BDR_REQUIRE(cfg->device >= 0, "No device is given for DQN agent");   // dqn/base.rs:256-259
+    BDR_REQUIRE(cfg->net.kind == BDR_NET_ATARI_CNN, "only the AtariCnn Q-network is built in this round (Mlp: see DESIGN.md)");
+    BDR_REQUIRE(cfg->net.n_stack == 4, "AtariCnn kernels are specialised for n_stack = 4");
+    BDR_REQUIRE(cfg->net.out_dim >= 1 && cfg->net.out_dim <= 64, "out_dim must be in [1,64]");
+    BDR_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= 65536, "batch_size out of range");
+    BDR_REQUIRE(cfg->soft_update_interval >= 1 && cfg->n_updates_per_opt >= 1, "intervals must be >= 1");
+    BDR_REQUIRE(cfg->critic_loss == BDR_LOSS_MSE || cfg->critic_loss == BDR_LOSS_SMOOTH_L1, "unknown critic_loss");
+    BDR_REQUIRE(cfg->opt_kind == BDR_OPT_ADAM || cfg->opt_kind == BDR_OPT_ADAMW, "unknown optimizer");
+    BDR_TRY(ensure_device(cfg->device));
+    bdr_agent* a = new bdr_agent();
+    a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
+    a->ar = make_arena(cfg->net.out_dim);
+    BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
+    for (auto p : arenas) {
+        BDR_TRY(alloc_f(p, a->ar.total));
+        BDR_HIP(hipMemsetAsync(*p, 0, a->ar.total * 4, a->stream));
+    }
+    BDR_TRY(alloc_f(&a->loss, 4));
+    std::vector<float> ref, in(a->ar.total);
+    init_reference_params(a->ar.A, cfg->param_seed, ref);
+    to_internal(a->ar, ref.data(), in.data());
+    BDR_HIP(hipMemcpyAsync(a->q, in.data(), a->ar.total * 4, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->q_tgt, in.data(), a->ar.total * 4, hipMemcpyHostToDevice, a->stream));  // DqnModel::clone
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    BDR_TRY(ensure_batch(a, (int)cfg->batch_size));
+    *out = a;
+    return BDR_OK;
+}
+
+int32_t bdr_agent_destroy(bdr_agent* a)
+{
+    if (!a) return BDR_OK;
+    (void)hipSetDevice(a->device);
+    (void)hipStreamSynchronize(a->stream);
+    free_batch_buffers(a);
+    (void)hipFree(a->q); (void)hipFree(a->q_tgt); (void)hipFree(a->grad); (void)hipFree(a->m); (void)hipFree(a->v);
+    (void)hipFree(a->loss);
+    (void)hipFree(a->u_obs); (void)hipFree(a->u_next); (void)hipFree(a->u_act); (void)hipFree(a->u_rew); (void)hipFree(a->u_term);
+    for (auto& s : a->slots) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
+    (void)hipStreamDestroy(a->stream);
+    delete a;
+    return BDR_OK;
+}
+
+int32_t bdr_agent_set_train(bdr_agent* a, int32_t train) { BDR_REQUIRE(a, "null agent"); a->train = train != 0; return BDR_OK; }
+int32_t bdr_agent_is_train(const bdr_agent* a, int32_t* out) { BDR_REQUIRE(a && out, "null argument"); *out = a->train; return BDR_OK; }
+int32_t bdr_agent_n_opts(const bdr_agent* a, uint64_t* n) { BDR_REQUIRE(a && n, "null argument"); *n = a->n_opts; return BDR_OK; }
+
+int32_t bdr_agent_sync(bdr_agent* a)
+{
+    BDR_REQUIRE(a, "null agent");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    return BDR_OK;
+}
+
+int32_t bdr_agent_opt(bdr_agent* a, bdr_replay* r)
+{
+    BDR_REQUIRE(a && r, "null argument");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(opt_inner(a, r));
+    prof_collect(a);
+    return BDR_OK;
+}
+
+int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* r, bdr_dqn_record* rec)
+{
+    BDR_REQUIRE(a && r && rec, "null argument");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(opt_inner(a, r));
+    prof_collect(a);
+    return fill_record(a, (int)a->cfg.batch_size, r->b_reward, rec);
+}
+
+int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
+                                const float* reward, const int8_t* term, bdr_dqn_record* rec)
+{
+    BDR_REQUIRE(a && obs && act && next_obs && reward && term, "null argument");
+    BDR_REQUIRE(n >= 1 && n <= 65536, "batch size out of range");
+    BDR_HIP(hipSetDevice(a->device));
+    const size_t ob = (size_t)a->cfg.net.n_stack * 84 * 84;
+    if (n > a->u_cap) {
+        BDR_HIP(hipStreamSynchronize(a->stream));
+        (void)hipFree(a->u_obs); (void)hipFree(a->u_next); (void)hipFree(a->u_act); (void)hipFree(a->u_rew); (void)hipFree(a->u_term);
+        BDR_HIP(hipMalloc((void**)&a->u_obs, n * ob)); BDR_HIP(hipMalloc((void**)&a->u_next, n * ob));
+        BDR_HIP(hipMalloc((void**)&a->u_act, n * 8)); BDR_HIP(hipMalloc((void**)&a->u_rew, n * 4));
+        BDR_HIP(hipMalloc((void**)&a->u_term, round_up(n, 16)));
+        a->u_cap = n;
+    }
+    BDR_HIP(hipMemcpyAsync(a->u_obs, obs, n * ob, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->u_next, next_obs, n * ob, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->u_act, act, n * 8, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->u_rew, reward, n * 4, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, a->stream));
+    BDR_TRY(update_critic(a, (int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term));
+    BDR_TRY(after_updates(a));
+    prof_collect(a);
+    if (rec) return fill_record(a, (int)n, a->u_rew, rec);
+    BDR_HIP(hipStreamSynchronize(a->stream));   // host buffers may be reused by the caller
+    return BDR_OK;
+}
+
+int32_t bdr_agent_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out, int64_t* argmax_out)
+{
+    BDR_REQUIRE(a && obs, "null argument");
+    BDR_REQUIRE(n >= 1 && n <= 65536, "batch size out of range");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(ensure_batch(a, (int)n));
+    const size_t ob = (size_t)a->cfg.net.n_stack * 84 * 84;
+    uint8_t* d = nullptr;
+    BDR_HIP(hipMalloc((void**)&d, n * ob));
+    BDR_HIP(hipMemcpyAsync(d, obs, n * ob, hipMemcpyHostToDevice, a->stream));
+    NetInst inst[1] = {{d, a->q, 0}};
+    int32_t st = forward(a, inst, 1, (int)n);
+    std::vector<float> q(n * a->ar.A);
+    if (st == BDR_OK) {
+        hipError_t e = hipMemcpyAsync(q.data(), a->qv[0], q.size() * 4, hipMemcpyDeviceToHost, a->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+        if (e != hipSuccess) st = fail(BDR_ERR_HIP, "qvalues copy failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    a->slot_cursor = 0;
+    BDR_TRY(st);
+    if (q_out) memcpy(q_out, q.data(), q.size() * 4);
+    if (argmax_out)
+        for (uint64_t i = 0; i < n; ++i) {
+            int best = 0;
+            for (int k = 1; k < a->ar.A; ++k) if (q[i * a->ar.A + k] > q[i * a->ar.A + best]) best = k;
+            argmax_out[i] = best;
+        }
+    return BDR_OK;
+}
+
+int32_t bdr_agent_param_count(const bdr_agent* a, uint64_t* n)
+{
+    BDR_REQUIRE(a && n, "null argument");
+    *n = ref_param_count(a->ar.A);
+    return BDR_OK;
+}
+
+int32_t bdr_agent_get_params(bdr_agent* a, int32_t which, float* out, uint64_t n)
+{
+    BDR_REQUIRE(a && out, "null argument");
+    float* src = arena_ptr(a, which);
+    BDR_REQUIRE(src, "which must be 0..4");
+    BDR_REQUIRE(n == ref_param_count(a->ar.A), "parameter count mismatch (%llu vs %llu)", (unsigned long long)n,
+                (unsigned long long)ref_param_count(a->ar.A));
+    BDR_HIP(hipSetDevice(a->device));
+    std::vector<float> in(a->ar.total);
+    BDR_HIP(hipMemcpyAsync(in.data(), src, a->ar.total * 4, hipMemcpyDeviceToHost, a->stream));
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    to_reference(a->ar, in.data(), out);
+    return BDR_OK;
+}
+
+int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* inp, uint64_t n)
+{
+    BDR_REQUIRE(a && inp, "null argument");
+    float* dst = arena_ptr(a, which);
+    BDR_REQUIRE(dst, "which must be 0..4");
+    BDR_REQUIRE(n == ref_param_count(a->ar.A), "parameter count mismatch");
+    BDR_HIP(hipSetDevice(a->device));
+    std::vector<float> in(a->ar.total);
+    to_internal(a->ar, inp, in.data());
+    BDR_HIP(hipMemcpyAsync(dst, in.data(), a->ar.total * 4, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    return BDR_OK;
+}
+
+// named-tensor dump: "BDRP" u32 version, u32 count, then per tensor: u32 name_len, name, u32 ndim, u64 dims[], f32 data
+static int32_t save_arena(bdr_agent* a, int which, const std::string& path)
+{
+    std::vector<float> ref(ref_param_count(a->ar.A));
+    BDR_TRY(bdr_agent_get_params(a, which, ref.data(), ref.size()));
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return fail(BDR_ERR_IO, "cannot open %s for writing", path.c_str());
+    const int A = a->ar.A;
+    const char* names[10] = {"c1.weight", "c1.bias", "c2.weight", "c2.bias", "c3.weight", "c3.bias", "l1.weight", "l1.bias", "l2.weight", "l2.bias"};
+    const std::vector<std::vector<uint64_t>> dims = {{32, 4, 8, 8}, {32}, {64, 32, 4, 4}, {64}, {64, 64, 3, 3}, {64},
+                                                     {512, 3136}, {512}, {(uint64_t)A, 512}, {(uint64_t)A}};
+    uint32_t ver = 1, cnt = 10;
+    fwrite("BDRP", 1, 4, f); fwrite(&ver, 4, 1, f); fwrite(&cnt, 4, 1, f);
+    size_t o = 0;
+    for (int t = 0; t < 10; ++t) {
+        uint32_t nl = (uint32_t)strlen(names[t]), nd = (uint32_t)dims[t].size();
+        fwrite(&nl, 4, 1, f); fwrite(names[t], 1, nl, f); fwrite(&nd, 4, 1, f);
+        size_t n = 1;
+        for (auto d : dims[t]) { fwrite(&d, 8, 1, f); n *= d; }
+        fwrite(ref.data() + o, 4, n, f);
+        o += n;
+    }
+    const bool ok = fflush(f) == 0;
+    fclose(f);
+    return ok ? BDR_OK : fail(BDR_ERR_IO, "write to %s failed", path.c_str());
+}
+
+static int32_t load_arena(bdr_agent* a, int which, const std::string& path)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return fail(BDR_ERR_IO, "cannot open %s", path.c_str());
+    std::vector<float> ref(ref_param_count(a->ar.A));
+    char magic[4]; uint32_t ver = 0, cnt = 0;
+    bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "BDRP", 4) == 0 && fread(&ver, 4, 1, f) == 1 && fread(&cnt, 4, 1, f) == 1 && cnt == 10;
+    size_t o = 0;
+    for (uint32_t t = 0; ok && t < cnt; ++t) {
+        uint32_t nl = 0, nd = 0; char name[64];
+        ok = fread(&nl, 4, 1, f) == 1 && nl < 64 && fread(name, 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 4;
+        size_t n = 1;
+        for (uint32_t d = 0; ok && d < nd; ++d) { uint64_t x = 0; ok = fread(&x, 8, 1, f) == 1; n *= x; }
+        ok = ok && o + n <= ref.size() && fread(ref.data() + o, 4, n, f) == n;
+        o += n;
+    }
+    fclose(f);
+    if (!ok || o != ref.size()) return fail(BDR_ERR_IO, "%s is not a matching parameter file", path.c_str());
+    return bdr_agent_set_params(a, which, ref.data(), ref.size());
+}
+
+int32_t bdr_agent_save_params(bdr_agent* a, const char* dir)
+{
+    BDR_REQUIRE(a && dir, "null argument");
+    // dqn/base.rs:348-356: qnet.pt.tch, qnet_tgt.pt.tch  (here: same stems, own container)
+    BDR_TRY(save_arena(a, 0, std::string(dir) + "/qnet.bdr"));
+    return save_arena(a, 1, std::string(dir) + "/qnet_tgt.bdr");
+}
+
+int32_t bdr_agent_load_params(bdr_agent* a, const char* dir)
+{
+    BDR_REQUIRE(a && dir, "null argument");
+    BDR_TRY(load_arena(a, 0, std::string(dir) + "/qnet.bdr"));
+    return load_arena(a, 1, std::string(dir) + "/qnet_tgt.bdr");
+}
+
+int32_t bdr_dqn_probe(bdr_agent* a, int32_t what, float* out, uint64_t n)
+{
+    BDR_REQUIRE(a && out, "null argument");
+    BDR_HIP(hipSetDevice(a->device));
+    const float* src = nullptr;
+    switch (what) {
+        case 0: src = a->qv[0]; break;
+        case 1: src = a->qv[1]; break;
+        case 2: src = a->pred; break;
+        case 3: src = a->tgt; break;
+        case 4: src = a->loss; break;
+        default: return fail(BDR_ERR_INVALID, "unknown probe %d", what);
+    }
+    BDR_HIP(hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToHost, a->stream));
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    return BDR_OK;
+}
+
+int32_t bdr_agent_profile_enable(bdr_agent* a, int32_t on)
+{
+    BDR_REQUIRE(a, "null agent");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    a->prof = on != 0;
+    a->slot_cursor = 0;
+    for (auto& s : a->slots) { s.ms = 0; s.count = 0; }
+    return BDR_OK;
+}
+
+int32_t bdr_agent_profile_read(bdr_agent* a, char* names_out, uint64_t names_cap, float* ms_out, uint64_t* count_inout)
+{
+    BDR_REQUIRE(a && count_inout, "null argument");
+    std::string names;
+    uint64_t k = 0;
+    for (auto& s : a->slots) {
+        if (k < *count_inout && ms_out) ms_out[k] = s.count ? (float)(s.ms / (double)s.count) : 0.f;
+        names += s.name; names += '\n';
+        ++k;
+    }
+    if (names_out && names_cap) { strncpy(names_out, names.c_str(), names_cap - 1); names_out[names_cap - 1] = 0; }
+    *count_inout = k;
+    return BDR_OK;
+}
+
+}  // extern "C"
+
+// used by comm.hip
+namespace bdr {
+float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* stream, int* device)
+{
+    if (n_floats) *n_floats = a->ar.total;
+    if (stream) *stream = a->stream;
+    if (device) *device = a->device;
+    return arena_ptr(a, which);
+}
+int32_t agent_scale(bdr_agent* a, float* p, float s)
+{
+    const size_t n4 = a->ar.total / 4;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, p, n4, s);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+}  // namespace bdr

@@ -1,0 +1,457 @@
+// FP32-MFMA implicit-GEMM building blocks for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, bitwise a
+// k-ordered fmaf chain, 157 TFLOP/s chip peak).
+//
+// Two kernel shapes cover every contraction of the Nature-CNN step:
+//   k_igemm      C[m][n]  = sum_k A(m,k) * B(k,n)      forward convs / linears and the
+//                                                       input-gradient (transposed conv as gather)
+//   k_igemm_red  G[k][n]  = sum_m A(m,k) * Y(m,n)      weight gradients (reduction over rows,
+//                                                       split across workgroups, partials summed
+//                                                       by k_reduce_partials)
+// A(m,k) is never materialised: policies compute im2col addresses from compile-time geometry.
+// Activations are NHWC ([B][H][W][C] == the row-major GEMM C matrix), weights are [K][N] with
+// K ordered (kh,kw,cin) (conv1: (cin,kh,kw), matching its NCHW u8 input).
+//
+// MFMA operand maps (cdna_hip_programming.md section 3):
+//   A: lane l holds A[i=l&31][k=l>>5];  B: lane l holds B[k=l>>5][j=l&31];
+//   D: acc[r] = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+// The k-slot an element lands in is free as long as A and B agree, so a lane reads 4 consecutive
+// k of its row with one ds_read_b128 (half h takes k = 8u+4h+s) and feeds 4 MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace bdr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;        // k-tile
+constexpr int LDA = BK + 4;   // A tile row stride (floats): conflict-free ds_read_b128, 16B aligned
+
+template <int IH_, int IW_, int CIN_, int KH_, int KW_, int S_, int OH_, int OW_, int COUT_>
+struct Geom {
+    static constexpr int IH = IH_, IW = IW_, CIN = CIN_, KH = KH_, KW = KW_, S = S_, OH = OH_, OW = OW_,
+                         COUT = COUT_;
+    static constexpr int K = KH * KW * CIN;
+};
+using GeomC1 = Geom<84, 84, 4, 8, 8, 4, 20, 20, 32>;
+using GeomC2 = Geom<20, 20, 32, 4, 4, 2, 9, 9, 64>;
+using GeomC3 = Geom<9, 9, 64, 3, 3, 1, 7, 7, 64>;
+using GeomL1 = Geom<1, 1, 3136, 1, 1, 1, 1, 1, 512>;
+
+// ------------------------------------------------------------------------------------------------
+// A-operand policies.  Interface:
+//   VEC            k elements one thread stages per load (4: one f32x4; 8: 8 bytes of u8 pixels)
+//   Row            per-thread row context, row(x, m, M)
+//   load(row, kt, q, v[VEC/4])   q = which VEC-group of the 32-wide k-tile
+// ------------------------------------------------------------------------------------------------
+
+// NHWC f32 input, forward patches: m=(b,oh,ow), k=(kh,kw,c).
+template <class G>
+struct AFwd {
+    static constexpr int VEC = 4;
+    static constexpr int NKT = G::K / BK;
+    struct Row { const float* p; bool ok; };
+    __device__ static Row row(const float* x, int m, int M)
+    {
+        Row r;
+        r.ok = m < M;
+        const int mm = r.ok ? m : 0;
+        const int b = mm / (G::OH * G::OW), rem = mm % (G::OH * G::OW);
+        const int oh = rem / G::OW, ow = rem % G::OW;
+        r.p = x + ((size_t)(b * G::IH + oh * G::S) * G::IW + ow * G::S) * G::CIN;
+        return r;
+    }
+    __device__ static void load(const Row& r, int kt, int q, f32x4* v)
+    {
+        constexpr int TPT = G::CIN / BK;  // k-tiles per tap
+        const int tap = kt / TPT, c0 = (kt % TPT) * BK;
+        const int kh = tap / G::KW, kw = tap % G::KW;
+        const float* p = r.p + (kh * G::IW + kw) * G::CIN + c0 + q * 4;
+        v[0] = r.ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// conv1: NCHW u8 input [B][4][84][84], k=(c,kh,kw); one load = the 8 contiguous pixels of one
+// patch row.  Values stay integers 0..255 (exact in f32); the 1/255 of cnn/base.rs:26 is applied in
+// the epilogue.
+template <class G>
+struct AFwdU8 {
+    static constexpr int VEC = 8;
+    static constexpr int NKT = G::K / BK;
+    struct Row { const uint8_t* p; bool ok; };
+    __device__ static Row row(const uint8_t* x, int m, int M)
+    {
+        Row r;
+        r.ok = m < M;
+        const int mm = r.ok ? m : 0;
+        const int b = mm / (G::OH * G::OW), rem = mm % (G::OH * G::OW);
+        const int oh = rem / G::OW, ow = rem % G::OW;
+        r.p = x + (size_t)b * (G::CIN * G::IH * G::IW) + (oh * G::S) * G::IW + ow * G::S;
+        return r;
+    }
+    __device__ static void load(const Row& r, int kt, int q, f32x4* v)
+    {
+        static_assert(G::KW == 8 && G::KH == 8, "conv1 geometry");
+        const int c = kt >> 1, kh = ((kt & 1) << 2) + q;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(r.p + c * (G::IH * G::IW) + kh * G::IW);
+        uint32_t lo = 0, hi = 0;
+        if (r.ok) { lo = p[0]; hi = p[1]; }
+        v[0] = f32x4{(float)(lo & 255u), (float)((lo >> 8) & 255u), (float)((lo >> 16) & 255u), (float)(lo >> 24)};
+        v[1] = f32x4{(float)(hi & 255u), (float)((hi >> 8) & 255u), (float)((hi >> 16) & 255u), (float)(hi >> 24)};
+    }
+};
+
+// Input gradient of a stride-1 conv as a gather: rows m'=(b,ih,iw) over the conv INPUT grid,
+// k'=(kh,kw,cout) over dY [B][OH][OW][COUT]; out-of-range taps read zero.
+template <class G>
+struct ADxS1 {
+    static constexpr int VEC = 4;
+    static constexpr int NKT = G::KH * G::KW * G::COUT / BK;
+    struct Row { const float* dy; int b, ih, iw; bool ok; };
+    __device__ static Row row(const float* dy, int m, int M)
+    {
+        Row r;
+        r.ok = m < M; r.dy = dy;
+        const int mm = r.ok ? m : 0;
+        r.b = mm / (G::IH * G::IW);
+        const int rem = mm % (G::IH * G::IW);
+        r.ih = rem / G::IW; r.iw = rem % G::IW;
+        return r;
+    }
+    __device__ static void load(const Row& r, int kt, int q, f32x4* v)
+    {
+        constexpr int TPT = G::COUT / BK;
+        const int tap = kt / TPT, c0 = (kt % TPT) * BK;
+        const int oh = r.ih - tap / G::KW, ow = r.iw - tap % G::KW;
+        const bool ok = r.ok && oh >= 0 && oh < G::OH && ow >= 0 && ow < G::OW;
+        const float* p = r.dy + ((size_t)(r.b * G::OH + oh) * G::OW + ow) * G::COUT + c0 + q * 4;
+        v[0] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// Input gradient of a stride-2, 4x4 conv: the input grid splits into 4 parity classes (ih%2, iw%2);
+// class (ph,pw) only sees taps kh in {ph, ph+2}, kw in {pw, pw+2}, so K' = 4*COUT per class and no
+// MFMA work is spent on structurally-zero taps.  rows m' = (b, ih/2, iw/2) within a class.
+template <class G>
+struct ADxS2 {
+    static constexpr int VEC = 4;
+    static constexpr int NKT = 4 * G::COUT / BK;
+    static constexpr int HH = G::IH / 2, WH = G::IW / 2;
+    struct Row { const float* dy; int b, ihh, iwh; bool ok; };
+    __device__ static Row row(const float* dy, int m, int M)
+    {
+        static_assert(G::S == 2 && G::KH == 4 && G::KW == 4 && G::IH % 2 == 0 && G::IW % 2 == 0, "c2 geometry");
+        Row r;
+        r.ok = m < M; r.dy = dy;
+        const int mm = r.ok ? m : 0;
+        r.b = mm / (HH * WH);
+        const int rem = mm % (HH * WH);
+        r.ihh = rem / WH; r.iwh = rem % WH;
+        return r;
+    }
+    // tap t=(a,b2): kh = ph+2a, kw = pw+2*b2, oh = ihh-a, ow = iwh-b2
+    __device__ static void load(const Row& r, int kt, int q, f32x4* v)
+    {
+        constexpr int TPT = G::COUT / BK;
+        const int tap = kt / TPT, c0 = (kt % TPT) * BK;
+        const int oh = r.ihh - (tap >> 1), ow = r.iwh - (tap & 1);
+        const bool ok = r.ok && oh >= 0 && oh < G::OH && ow >= 0 && ow < G::OW;
+        const float* p = r.dy + ((size_t)(r.b * G::OH + oh) * G::OW + ow) * G::COUT + c0 + q * 4;
+        v[0] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The MFMA core shared by both kernels: one k-tile (32 deep) from LDS.
+//   As: [rows][LDA] f32, k contiguous.  Bs: [32][LDB] f32, n contiguous.
+// ------------------------------------------------------------------------------------------------
+template <int TM, int TN, int LDB>
+__device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const float* __restrict__ Bs, int arow0,
+                                           int bcol0, int lane, f32x16 (&acc)[TM][TN])
+{
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < BK / 8; ++u) {
+        f32x4 a[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            a[tm] = *reinterpret_cast<const f32x4*>(&As[(arow0 + tm * 32 + i) * LDA + 8 * u + 4 * h]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float b[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[(8 * u + 4 * h + s) * LDB + bcol0 + tn * 32 + i];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_igemm: C = A(m,k) * B(k,n) with a policy P:
+//   P::A (A-operand policy), P::WM, P::WN, P::TM, P::TN   (4 waves: WM*WN == 4)
+//   P::B_TR    false: B(k,n) = w[k*ldw + n]  (vector loads along n)
+//              true : B(k',n') = w[(tap*NP + n')*KP + c]  (transposed weights for dX; vector along k')
+//   P::Args    kernel arguments;  device hooks:
+//     a_src(args,z) -> input pointer;  M(args);  w(args,z,cls) -> weight pointer
+//     kt_range(args, &kt0, &kt1)  (split-K over blockIdx.y when P::SPLITK)
+//     store(args, z, cls/split, m, n, value)
+// grid: x = m-tiles * n-tiles (n fastest), y = split or parity class, z = problem instance.
+// ------------------------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
+{
+    using A = typename P::A;
+    constexpr int BM = P::WM * P::TM * 32, BN = P::WN * P::TN * 32;
+    constexpr int LDB = P::B_TR ? BN + 1 : BN;
+    constexpr int ROWS_PER_PASS = 256 * A::VEC / BK;   // rows of the A tile staged per pass
+    constexpr int A_PASSES = BM / ROWS_PER_PASS;
+    constexpr int AV = A::VEC / 4;
+    constexpr int B_VECS = BK * BN / 4 / 256;          // f32x4 per thread for the B tile
+    static_assert(P::WM * P::WN == 4, "4 waves");
+    static_assert(A_PASSES >= 1 && B_VECS >= 1, "tile too small for 256 threads");
+
+    __shared__ __attribute__((aligned(16))) float smem[BM * LDA + BK * LDB];
+    float* As = smem;
+    float* Bs = smem + BM * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / P::WN, wn = wave % P::WN;
+    constexpr int NT_N = P::N / BN;
+    const int mt = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.z, y = blockIdx.y;
+    const int M = P::M(args);
+
+    // per-thread staging coordinates
+    const int a_q = tid % (BK / A::VEC), a_r = tid / (BK / A::VEC);
+    typename A::Row rows[A_PASSES];
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) rows[p] = A::row(P::a_src(args, z), m0 + p * ROWS_PER_PASS + a_r, M);
+    const float* w = P::w(args, z, y);
+
+    int kt0, kt1;
+    P::kt_range(args, y, kt0, kt1);
+
+    f32x4 ra[A_PASSES][AV];
+    f32x4 rb[B_VECS];
+    auto prefetch = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) A::load(rows[p], kt, a_q, ra[p]);
+#pragma unroll
+        for (int v = 0; v < B_VECS; ++v) {
+            const int e = tid + v * 256;
+            if constexpr (!P::B_TR) {
+                const int kr = e / (BN / 4), n4 = e % (BN / 4);
+                rb[v] = *reinterpret_cast<const f32x4*>(w + (size_t)(kt * BK + kr) * P::N + n0 + n4 * 4);
+            } else {
+                // k-tile kt = (tap, c0); element (k'=c0+kq*4.., n') = w[(tap*NP + n0+n')*KP + c0 + kq*4]
+                constexpr int TPT = P::KP / BK;
+                const int tap = kt / TPT, c0 = (kt % TPT) * BK;
+                const int kq = e % 8, np = e / 8;
+                rb[v] = *reinterpret_cast<const f32x4*>(w + ((size_t)P::tap_index(y, tap) * P::N + n0 + np) * P::KP + c0 + kq * 4);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p)
+#pragma unroll
+            for (int j = 0; j < AV; ++j)
+                *reinterpret_cast<f32x4*>(&As[(p * ROWS_PER_PASS + a_r) * LDA + a_q * A::VEC + j * 4]) = ra[p][j];
+#pragma unroll
+        for (int v = 0; v < B_VECS; ++v) {
+            const int e = tid + v * 256;
+            if constexpr (!P::B_TR) {
+                const int kr = e / (BN / 4), n4 = e % (BN / 4);
+                *reinterpret_cast<f32x4*>(&Bs[kr * LDB + n4 * 4]) = rb[v];
+            } else {
+                const int kq = e % 8, np = e / 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(kq * 4 + j) * LDB + np] = rb[v][j];
+            }
+        }
+    };
+
+    f32x16 acc[P::TM][P::TN];
+#pragma unroll
+    for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < P::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    if (kt0 < kt1) prefetch(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        commit();
+        __syncthreads();
+        if (kt + 1 < kt1) prefetch(kt + 1);
+        mfma_ktile<P::TM, P::TN, LDB>(As, Bs, wm * P::TM * 32, wn * P::TN * 32, lane, acc);
+        __syncthreads();
+    }
+
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < P::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * P::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int n = n0 + (wn * P::TN + tn) * 32 + j;
+                if (m < M) P::store(args, z, y, m, n, acc[tm][tn][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_igemm_red: G[k][n] = sum_{m in chunk} A(m,k) * Y(m,n).
+//   P::A, P::WM, P::WN, P::TM, P::TN; KO_T = WM*TM*32 output rows, N_T = WN*TN*32 columns.
+//   P::K (total output rows), P::N (columns, == N_T * n-tiles)
+//   hooks: a_src(args), y_src(args), M(args), part(args, chunk) -> float* partial [K*N + N]
+// grid: x = ko-tiles * n-tiles, y = m-chunk.  The bias gradient (column sums of Y) is accumulated
+// by the ko-tile-0 workgroups from the very Y tiles they stage.
+// LDS: As[32 rows][KO_T (+4)] (read with lane = output row: consecutive floats), Ys[32][N_T].
+// ------------------------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
+{
+    using A = typename P::A;
+    constexpr int KO_T = P::WM * P::TM * 32, N_T = P::WN * P::TN * 32;
+    constexpr int LDAR = KO_T + 4, LDY = N_T;
+    constexpr int KSUB = KO_T / BK;                      // 32-wide k groups per tile row
+    constexpr int ROWS_PER_PASS = 256 * A::VEC / BK;     // rows per staging pass for one k group
+    constexpr int A_PASSES = (32 * KSUB) / ROWS_PER_PASS;  // (row, ksub) pairs / pass rows
+    constexpr int AV = A::VEC / 4;
+    constexpr int Y_VECS = 32 * N_T / 4 / 256;
+    static_assert(P::WM * P::WN == 4, "4 waves");
+    static_assert(A_PASSES >= 1, "A tile too small");
+    static_assert(Y_VECS >= 1, "Y tile too small");
+
+    __shared__ __attribute__((aligned(16))) float smem[32 * LDAR + 32 * LDY];
+    float* As = smem;
+    float* Ys = smem + 32 * LDAR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / P::WN, wn = wave % P::WN;
+    constexpr int NT_N = P::N / N_T;
+    const int kot = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
+    const int ko0 = kot * KO_T, n0 = nt * N_T;
+    const int chunk = blockIdx.y, nchunks = gridDim.y;
+    const int M = P::M(args);
+    const int n_mt = (M + 31) / 32;
+    const int per = (n_mt + nchunks - 1) / nchunks;
+    const int mt0 = chunk * per, mt1 = min(n_mt, mt0 + per);
+
+    const int a_q = tid % (BK / A::VEC), a_r = tid / (BK / A::VEC);  // a_r in [0, ROWS_PER_PASS)
+    const float* ysrc = P::y_src(args);
+
+    f32x4 ra[A_PASSES][AV];
+    f32x4 ry[Y_VECS];
+    f32x4 bsum[Y_VECS];
+#pragma unroll
+    for (int v = 0; v < Y_VECS; ++v) bsum[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // pass p covers (row, ksub) pairs: idx = p*ROWS_PER_PASS + a_r; row = idx % 32, ksub = idx / 32
+    auto prefetch = [&](int mt) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) {
+            const int idx = p * ROWS_PER_PASS + a_r;
+            const int row = idx % 32, ksub = idx / 32;
+            typename A::Row r = A::row(P::a_src(args), mt * 32 + row, M);
+            A::load(r, ko0 / BK + ksub, a_q, ra[p]);
+        }
+#pragma unroll
+        for (int v = 0; v < Y_VECS; ++v) {
+            const int e = tid + v * 256;
+            const int row = e / (N_T / 4), n4 = e % (N_T / 4);
+            const int m = mt * 32 + row;
+            ry[v] = m < M ? *reinterpret_cast<const f32x4*>(ysrc + (size_t)m * P::N + n0 + n4 * 4)
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) {
+            const int idx = p * ROWS_PER_PASS + a_r;
+            const int row = idx % 32, ksub = idx / 32;
+#pragma unroll
+            for (int j = 0; j < AV; ++j)
+                *reinterpret_cast<f32x4*>(&As[row * LDAR + ksub * BK + a_q * A::VEC + j * 4]) = ra[p][j];
+        }
+#pragma unroll
+        for (int v = 0; v < Y_VECS; ++v) {
+            const int e = tid + v * 256;
+            const int row = e / (N_T / 4), n4 = e % (N_T / 4);
+            *reinterpret_cast<f32x4*>(&Ys[row * LDY + n4 * 4]) = ry[v];
+            bsum[v] += ry[v];
+        }
+    };
+
+    f32x16 acc[P::TM][P::TN];
+#pragma unroll
+    for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < P::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int i = lane & 31, h = lane >> 5;
+    if (mt0 < mt1) prefetch(mt0);
+    for (int mt = mt0; mt < mt1; ++mt) {
+        commit();
+        __syncthreads();
+        if (mt + 1 < mt1) prefetch(mt + 1);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int red = 2 * t + h;
+            float a[P::TM], b[P::TN];
+#pragma unroll
+            for (int tm = 0; tm < P::TM; ++tm) a[tm] = As[red * LDAR + (wm * P::TM + tm) * 32 + i];
+#pragma unroll
+            for (int tn = 0; tn < P::TN; ++tn) b[tn] = Ys[red * LDY + (wn * P::TN + tn) * 32 + i];
+#pragma unroll
+            for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < P::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* part = P::part(args, chunk);
+#pragma unroll
+    for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < P::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ko = ko0 + (wm * P::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int n = n0 + (wn * P::TN + tn) * 32 + i;
+                part[(size_t)ko * P::N + n] = acc[tm][tn][r];
+            }
+
+    // bias gradient: column sums of the Y rows this chunk staged (ko-tile 0 only)
+    if (kot == 0) {
+        float* red = smem;  // reuse: [32 rows][N_T]
+#pragma unroll
+        for (int v = 0; v < Y_VECS; ++v) {
+            const int e = tid + v * 256;
+            const int row = e / (N_T / 4), n4 = e % (N_T / 4);
+            *reinterpret_cast<f32x4*>(&red[row * N_T + n4 * 4]) = bsum[v];
+        }
+        __syncthreads();
+        if (tid < N_T) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int row = 0; row < 32; ++row) s += red[row * N_T + tid];
+            part[(size_t)P::K * P::N + n0 + tid] = s;
+        }
+    }
+}
+
+}  // namespace bdr

@@ -1,0 +1,158 @@
+"""Host-side mirror of border-core's SimpleReplayBuffer over the C ABI.
+
+Same names and argument meaning as the reference traits:
+  ExperienceBufferBase::{push, len}   border-core/src/base/replay_buffer.rs:38-62
+  ReplayBufferBase::{build, batch}    border-core/src/base/replay_buffer.rs:74-127
+  SimpleReplayBufferConfig            border-core/src/generic_replay_buffer/config.rs:185-210
+The ring, the StdRng (ChaCha12) index draw and the gather all run on the MI355X.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class SimpleReplayBufferConfig:
+    """generic_replay_buffer/config.rs:185-210 (defaults: capacity 10000, seed 42, per None)."""
+    capacity: int = 10000
+    seed: int = 42
+    per_config: Optional[object] = None
+
+    def capacity_(self, v):  # builder-style setters like the reference's
+        self.capacity = v
+        return self
+
+    def seed_(self, v):
+        self.seed = v
+        return self
+
+
+@dataclass
+class GenericTransitionBatch:
+    """generic_replay_buffer/batch.rs:89-162 (host copy of a sampled batch)."""
+    obs: np.ndarray
+    act: np.ndarray
+    next_obs: np.ndarray
+    reward: np.ndarray
+    is_terminated: np.ndarray
+    is_truncated: np.ndarray
+    ix_sample: Optional[np.ndarray]
+    weight: Optional[np.ndarray] = None
+
+    def unpack(self):
+        return (self.obs, self.act, self.next_obs, self.reward, self.is_terminated, self.is_truncated,
+                self.ix_sample, self.weight)
+
+    def __len__(self):
+        return len(self.reward)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class SimpleReplayBuffer:
+    """SimpleReplayBuffer<O, A> with rows typed by (obs_shape, obs_dtype) / (act_shape, act_dtype)."""
+
+    def __init__(self, config: SimpleReplayBufferConfig, obs_shape, obs_dtype, act_shape=(1,), act_dtype=np.int64,
+                 device: int = 0):
+        if config.per_config is not None:
+            raise NotImplementedError("prioritized replay is not built yet (SURVEY.md section 8(f) rank 2)")
+        self.config = config
+        self.obs_shape, self.obs_dtype = tuple(obs_shape), np.dtype(obs_dtype)
+        self.act_shape, self.act_dtype = tuple(act_shape), np.dtype(act_dtype)
+        self.obs_bytes = int(np.prod(self.obs_shape)) * self.obs_dtype.itemsize
+        self.act_bytes = int(np.prod(self.act_shape)) * self.act_dtype.itemsize
+        cfg = _lib.ReplayConfig(config.capacity, config.seed, self.obs_bytes, self.act_bytes, device, 0)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().bdr_replay_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def build(cls, config: SimpleReplayBufferConfig, **kw) -> "SimpleReplayBuffer":
+        return cls(config, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().bdr_replay_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ExperienceBufferBase -------------------------------------------------------------------
+    def push(self, obs, act, next_obs, reward, is_terminated, is_truncated) -> None:
+        reward = np.ascontiguousarray(reward, dtype=np.float32).reshape(-1)
+        n = reward.shape[0]
+        obs = np.ascontiguousarray(obs, dtype=self.obs_dtype).reshape(n, -1)
+        next_obs = np.ascontiguousarray(next_obs, dtype=self.obs_dtype).reshape(n, -1)
+        act = np.ascontiguousarray(act, dtype=self.act_dtype).reshape(n, -1)
+        term = np.ascontiguousarray(is_terminated, dtype=np.int8).reshape(n)
+        trunc = np.ascontiguousarray(is_truncated, dtype=np.int8).reshape(n)
+        assert obs.nbytes == n * self.obs_bytes and act.nbytes == n * self.act_bytes
+        _lib.check(_lib.lib().bdr_replay_push(self._h, n, _p(obs), _p(act), _p(next_obs), _p(reward), _p(term),
+                                              _p(trunc)))
+
+    def len(self) -> int:
+        n = C.c_uint64()
+        _lib.check(_lib.lib().bdr_replay_len(self._h, C.byref(n)))
+        return n.value
+
+    __len__ = len
+
+    @property
+    def head(self) -> int:
+        n = C.c_uint64()
+        _lib.check(_lib.lib().bdr_replay_head(self._h, C.byref(n)))
+        return n.value
+
+    # ReplayBufferBase -----------------------------------------------------------------------
+    def batch(self, size: int) -> GenericTransitionBatch:
+        ixs = np.empty(size, np.uint64)
+        obs = np.empty((size,) + self.obs_shape, self.obs_dtype)
+        nobs = np.empty((size,) + self.obs_shape, self.obs_dtype)
+        act = np.empty((size,) + self.act_shape, self.act_dtype)
+        rew = np.empty(size, np.float32)
+        term = np.empty(size, np.int8)
+        trunc = np.empty(size, np.int8)
+        _lib.check(_lib.lib().bdr_replay_batch(self._h, size, _p(ixs), _p(obs), _p(act), _p(nobs), _p(rew), _p(term),
+                                               _p(trunc)))
+        return GenericTransitionBatch(obs, act, nobs, rew, term, trunc, ixs, None)
+
+    def sample_indices(self, size: int) -> np.ndarray:
+        """The index draw of batch() alone (advances the RNG like batch(size))."""
+        ixs = np.empty(size, np.uint64)
+        _lib.check(_lib.lib().bdr_replay_sample_indices(self._h, size, _p(ixs)))
+        return ixs
+
+    def update_priority(self, ixs, td_errs) -> None:
+        """base.rs:413-426: a no-op without PER, like the reference."""
+        return None
+
+    # benchmark / test helpers ---------------------------------------------------------------
+    def fill_synthetic(self, n: int, seed: int = 0, kind: int = 0, n_actions: int = 6) -> None:
+        _lib.check(_lib.lib().bdr_replay_fill_synthetic(self._h, n, seed, kind, n_actions))
+
+    def read_rows(self, first: int, n: int):
+        obs = np.empty((n,) + self.obs_shape, self.obs_dtype)
+        nobs = np.empty((n,) + self.obs_shape, self.obs_dtype)
+        act = np.empty((n,) + self.act_shape, self.act_dtype)
+        rew = np.empty(n, np.float32)
+        term = np.empty(n, np.int8)
+        trunc = np.empty(n, np.int8)
+        _lib.check(_lib.lib().bdr_replay_read_rows(self._h, first, n, _p(obs), _p(act), _p(nobs), _p(rew), _p(term),
+                                                   _p(trunc)))
+        return obs, act, nobs, rew, term, trunc

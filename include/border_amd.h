@@ -1,0 +1,243 @@
+/*
+ * border_amd.h -- C ABI of the MI355X-native opt-step engine that sits behind border-core's
+ * Agent / ReplayBufferBase / ExperienceBufferBase / SyncModel traits.
+ *
+ * The reference has no FFI of its own on this path (its only native boundary is
+ * tch -> torch-sys -> libtorch, which this library replaces), so every entry point below is
+ * shaped 1:1 after the Rust trait method it implements; the file:line of that method
+ * (relative to the reference tree) is cited next to each declaration.  INTEGRATION.md shows
+ * the Rust shim (`impl Agent for AmdDqn`, `impl ReplayBufferBase for AmdReplayBuffer`) a
+ * maintainer would add on top of these symbols.
+ *
+ * Conventions
+ *   - plain C types only; every function returns int32 status (BDR_OK == 0);
+ *     bdr_last_error() returns a thread-local message for the last failure.
+ *   - handles are opaque, heap allocated, NOT thread-safe but movable between threads
+ *     (Rust `Send`, not `Sync`), one HIP stream per handle, hipSetDevice on every entry.
+ *   - host pointers passed in are copied before the call returns unless stated otherwise.
+ *   - there is no CPU fallback: without a HIP device every constructor fails with
+ *     BDR_ERR_NO_DEVICE.
+ */
+#ifndef BORDER_AMD_H
+#define BORDER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDR_API __attribute__((visibility("default")))
+
+enum {
+    BDR_OK = 0,
+    BDR_ERR_INVALID = 1,    /* bad argument / config (anyhow::Error in the shim)     */
+    BDR_ERR_NO_DEVICE = 2,  /* no HIP device / extension cannot run                  */
+    BDR_ERR_HIP = 3,        /* a HIP runtime call failed                             */
+    BDR_ERR_EMPTY = 4,      /* batch() on an empty buffer (the reference panics)     */
+    BDR_ERR_IO = 5,         /* save/load failure                                     */
+    BDR_ERR_COMM = 6        /* RCCL failure                                          */
+};
+
+typedef struct bdr_replay bdr_replay;
+typedef struct bdr_agent bdr_agent;
+typedef struct bdr_comm bdr_comm;
+
+BDR_API const char* bdr_last_error(void);
+BDR_API int32_t bdr_device_count(int32_t* count);
+BDR_API const char* bdr_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * SimpleReplayBuffer  (border-core/src/generic_replay_buffer/base.rs:86-123)
+ * ---------------------------------------------------------------------------------------- */
+
+/* SimpleReplayBufferConfig (generic_replay_buffer/config.rs:185-210): capacity, seed,
+ * per_config (None only in this round; PER is SURVEY.md section 8(f) rank 2). */
+typedef struct {
+    uint64_t capacity;
+    uint64_t seed;
+    uint64_t obs_row_bytes; /* bytes of one observation row (Atari: 4*1*84*84 u8 = 28224)  */
+    uint64_t act_row_bytes; /* bytes of one action row (discrete: 8, one i64)              */
+    int32_t device;         /* HIP device ordinal                                          */
+    int32_t reserved;
+} bdr_replay_config;
+
+/* ReplayBufferBase::build (base.rs:336-356).  The ring lives in HBM as one fused record per
+ * transition: [obs | next_obs | act | reward f32 | is_terminated i8 | is_truncated i8 | pad]. */
+BDR_API int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out);
+BDR_API int32_t bdr_replay_destroy(bdr_replay* r);
+
+/* ExperienceBufferBase::push (base.rs:295-316): n transitions, rows written at
+ * (i+k) % capacity, i = (i+n) % capacity, size = min(size+n, capacity). Host pointers. */
+BDR_API int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, const void* act,
+                                const void* next_obs, const float* reward,
+                                const int8_t* is_terminated, const int8_t* is_truncated);
+
+/* ExperienceBufferBase::len (base.rs:318-320) and the write cursor `i`. */
+BDR_API int32_t bdr_replay_len(const bdr_replay* r, uint64_t* len);
+BDR_API int32_t bdr_replay_head(const bdr_replay* r, uint64_t* head);
+
+/* The index draw of ReplayBufferBase::batch (base.rs:384-390):
+ * ixs[k] = (StdRng::next_u32() as usize) % size, generated ON DEVICE by the ChaCha12 kernel
+ * and copied back; advances the RNG exactly as one batch(n) call does. */
+BDR_API int32_t bdr_replay_sample_indices(bdr_replay* r, uint64_t n, uint64_t* ixs_out);
+
+/* ReplayBufferBase::batch (base.rs:376-402): draws indices and gathers the batch into
+ * device-resident batch buffers owned by the replay handle (valid until the next batch()).
+ * Any *_out host pointer may be NULL; non-NULL ones receive a copy (synchronises).
+ * GenericTransitionBatch fields (generic_replay_buffer/batch.rs:89-162): obs, act, next_obs,
+ * reward, is_terminated, is_truncated, ix_sample; weight is None (uniform sampling). */
+BDR_API int32_t bdr_replay_batch(bdr_replay* r, uint64_t n, uint64_t* ixs_out, void* obs_out,
+                                 void* act_out, void* next_obs_out, float* reward_out,
+                                 int8_t* is_terminated_out, int8_t* is_truncated_out);
+
+/* Device pointers of the last gathered batch (for callers that keep the batch on device). */
+typedef struct {
+    uint64_t n;
+    const void* obs;      /* [n][obs_row_bytes] */
+    const void* next_obs; /* [n][obs_row_bytes] */
+    const void* act;      /* [n][act_row_bytes] */
+    const float* reward;  /* [n] */
+    const int8_t* is_terminated;
+    const int8_t* is_truncated;
+    const uint64_t* ixs;
+} bdr_device_batch;
+BDR_API int32_t bdr_replay_last_batch(const bdr_replay* r, bdr_device_batch* out);
+
+/* Benchmark helper (SURVEY.md section 8(d) synthetic inputs): fills transitions [0,n) on the
+ * device from a counter-based generator (seed, transition index) and sets size=min(n,capacity),
+ * i = n % capacity.  kind 0: Atari-like (u8 frames uniform 0..255, act uniform i64 in
+ * [0,n_actions), reward in {-1,0,1} with P=(.05,.9,.05), P(term)=.005, trunc 0);
+ * kind 1: f32 rows ~ N(0,1) approx (obs), act f32 ~ U(-1,1) (n_actions==0) or i64 uniform. */
+BDR_API int32_t bdr_replay_fill_synthetic(bdr_replay* r, uint64_t n, uint64_t seed, int32_t kind,
+                                          int32_t n_actions);
+/* Test helper: copy ring rows [first, first+n) back to the host (any pointer may be NULL). */
+BDR_API int32_t bdr_replay_read_rows(bdr_replay* r, uint64_t first, uint64_t n, void* obs, void* act,
+                                     void* next_obs, float* reward, int8_t* term, int8_t* trunc);
+
+/* ------------------------------------------------------------------------------------------
+ * DQN agent  (border-tch-agent/src/dqn/base.rs, dqn/config.rs:26-48, dqn/model/base.rs)
+ * ---------------------------------------------------------------------------------------- */
+
+enum { BDR_NET_ATARI_CNN = 0, BDR_NET_MLP = 1 };
+enum { BDR_LOSS_MSE = 0, BDR_LOSS_SMOOTH_L1 = 1 };        /* util.rs:17-23 CriticLoss      */
+enum { BDR_OPT_ADAM = 0, BDR_OPT_ADAMW = 1 };             /* opt.rs:13-28 OptimizerConfig  */
+#define BDR_MAX_UNITS 8
+
+/* AtariCnnConfig (cnn/config.rs:13-18) / MlpConfig (mlp/config.rs:7-12) */
+typedef struct {
+    int32_t kind;    /* BDR_NET_* */
+    int32_t n_stack; /* cnn */
+    int32_t in_dim;  /* mlp */
+    int32_t n_units; /* mlp */
+    int32_t units[BDR_MAX_UNITS];
+    int32_t out_dim; /* number of actions */
+    int32_t activation_out;
+} bdr_net_config;
+
+/* DqnConfig (dqn/config.rs:26-48; defaults :82-102) + DqnModelConfig.opt_config. */
+typedef struct {
+    bdr_net_config net;
+    int32_t opt_kind; /* BDR_OPT_ADAM: lr only (tch nn::Adam::default(): .9,.999,1e-8,wd 0) */
+    double lr;
+    double beta1, beta2, weight_decay, eps; /* AdamW variant only */
+    uint64_t soft_update_interval;
+    uint64_t n_updates_per_opt;
+    uint64_t batch_size;
+    double discount_factor;
+    double tau;
+    int32_t train;
+    int32_t double_dqn;
+    int32_t critic_loss; /* BDR_LOSS_* */
+    int32_t has_clip_td_err;
+    double clip_td_err_min, clip_td_err_max;
+    int32_t record_verbose_level;
+    int32_t device; /* HIP device ordinal ("No device is given for DQN agent": dqn/base.rs:256) */
+    uint64_t param_seed; /* seed of the library's own uniform(+-1/sqrt(fan_in)) initialiser */
+} bdr_dqn_config;
+
+BDR_API void bdr_dqn_config_default(bdr_dqn_config* cfg); /* dqn/config.rs:82-102 */
+
+/* Configurable::build (dqn/base.rs:252-286). */
+BDR_API int32_t bdr_dqn_create(const bdr_dqn_config* cfg, bdr_agent** out);
+BDR_API int32_t bdr_agent_destroy(bdr_agent* a);
+
+/* Agent::train / eval / is_train (dqn/base.rs:289-299). */
+BDR_API int32_t bdr_agent_set_train(bdr_agent* a, int32_t train);
+BDR_API int32_t bdr_agent_is_train(const bdr_agent* a, int32_t* out);
+
+/* Agent::opt (border-core/src/base/agent.rs:62-64 -> dqn/base.rs:301-309 -> opt_ :182-200):
+ * n_updates_per_opt x update_critic, soft-update bookkeeping, n_opts += 1.
+ * Enqueues on the agent's stream and returns WITHOUT synchronising. */
+BDR_API int32_t bdr_agent_opt(bdr_agent* a, bdr_replay* buffer);
+
+/* Agent::opt_with_record (dqn/base.rs:311-343): same step, then synchronises and returns
+ * the Record scalars.  keys: "loss" (always); verbose>=2 adds pred_mean, reward_mean,
+ * tgt_mean, tgt_minus_pred_mean. */
+typedef struct {
+    float loss;
+    float pred_mean, reward_mean, tgt_mean, tgt_minus_pred_mean;
+    int32_t has_verbose;
+} bdr_dqn_record;
+BDR_API int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* buffer, bdr_dqn_record* rec);
+
+/* One update_critic on a caller-supplied host minibatch (parity tests: "fixed minibatch").
+ * act: int64 [n]; obs/next_obs rows as in the replay buffer. */
+BDR_API int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act,
+                                        const void* next_obs, const float* reward,
+                                        const int8_t* is_terminated, bdr_dqn_record* rec);
+
+/* Policy::sample (dqn/base.rs:211-242), greedy part: Q(obs) for n observations -> q_out[n][A]
+ * and argmax actions (either pointer may be NULL).  Exploration (eps-greedy / softmax) uses
+ * host RNG in the reference (fastrand, unseeded) and stays in the caller. */
+BDR_API int32_t bdr_agent_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out,
+                                  int64_t* argmax_out);
+
+/* Block until everything enqueued on the agent's stream has finished. */
+BDR_API int32_t bdr_agent_sync(bdr_agent* a);
+BDR_API int32_t bdr_agent_n_opts(const bdr_agent* a, uint64_t* n);
+
+/* SyncModel::model_info / sync_model (border-async-trainer/src/sync_model.rs:2-13,
+ * dqn/base.rs:377-402) and checkpoint access.  Parameters cross the boundary in the
+ * reference's variable order and layouts (c1.weight OIHW, c1.bias, ... l2.bias / mlp.ln{i}.*).
+ * which: 0 = qnet, 1 = qnet_tgt, 2 = Adam exp_avg, 3 = Adam exp_avg_sq, 4 = last gradient. */
+BDR_API int32_t bdr_agent_param_count(const bdr_agent* a, uint64_t* n);
+BDR_API int32_t bdr_agent_get_params(bdr_agent* a, int32_t which, float* out, uint64_t n);
+BDR_API int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* in, uint64_t n);
+
+/* Agent::save_params / load_params (dqn/base.rs:345-371): writes/reads `qnet.bdr` and
+ * `qnet_tgt.bdr` (named f32 tensors, reference variable names) under dir. */
+BDR_API int32_t bdr_agent_save_params(bdr_agent* a, const char* dir);
+BDR_API int32_t bdr_agent_load_params(bdr_agent* a, const char* dir);
+
+/* Parity probes: copy intermediates of the LAST update to the host.
+ * what: 0 q_pred_all [B][A], 1 q_next_all [B][A], 2 pred [B], 3 tgt [B], 4 loss [1]. */
+BDR_API int32_t bdr_dqn_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
+
+/* Per-kernel device timing of the opt step (bench.py roofline leg): when enabled the step is
+ * bracketed kernel by kernel with HIP events on the agent's stream. */
+BDR_API int32_t bdr_agent_profile_enable(bdr_agent* a, int32_t on);
+/* names_out: '\n'-separated kernel labels; ms_out[i] = mean ms per launch since enable. */
+BDR_API int32_t bdr_agent_profile_read(bdr_agent* a, char* names_out, uint64_t names_cap,
+                                       float* ms_out, uint64_t* count_inout);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU parameter exchange (replaces the learner->actors NamedTensors channel of
+ * border-async-trainer/src/async_trainer/base.rs:268-272 with RCCL over xGMI).
+ * ---------------------------------------------------------------------------------------- */
+#define BDR_UNIQUE_ID_BYTES 128
+BDR_API int32_t bdr_comm_get_unique_id(uint8_t id[BDR_UNIQUE_ID_BYTES]);
+BDR_API int32_t bdr_comm_init_rank(const uint8_t id[BDR_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank,
+                                   int32_t device, bdr_comm** out);
+BDR_API int32_t bdr_comm_destroy(bdr_comm* c);
+/* params <- mean over ranks (ncclAllReduce sum on the flat arena, then 1/nranks), on the
+ * agent's stream; which as in bdr_agent_get_params (0 qnet, 1 qnet_tgt, 2/3 Adam moments). */
+BDR_API int32_t bdr_agent_allreduce_params(bdr_agent* a, bdr_comm* c, int32_t which);
+/* params <- root's (ncclBroadcast): the faithful learner->actor sync. */
+BDR_API int32_t bdr_agent_broadcast_params(bdr_agent* a, bdr_comm* c, int32_t which, int32_t root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BORDER_AMD_H */

@@ -1,0 +1,172 @@
+"""HIP DQN step (through the C ABI) vs the CPU oracle and the committed PyTorch goldens.
+
+Bar (BASELINE.json north_star): Q-values within 1e-4 relative for a fixed seed and fixed minibatch.
+Gradients / parameters are held to the same class of tolerance (f32 summation-order noise)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+QTOL = 1e-4  # relative, on Q-values (north_star)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def B():
+    import border_amd
+    if border_amd.device_count() == 0:
+        pytest.fail("no MI355X visible: the HIP path must run on the GPU box")
+    return border_amd
+
+
+def make_agent(B, A=6, **kw):
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=A),
+                                                    opt_config=B.OptimizerConfig.Adam(kw.pop("lr", 1e-4))),
+                      device=0, **kw)
+    return B.Dqn.build(cfg)
+
+
+def test_param_roundtrip_and_layout(B):
+    from oracle import torch_ref as T
+    a = make_agent(B, batch_size=4)
+    p = T.init_params(T.cnn_shapes(6), 11)
+    a.set_params(p, "qnet")
+    assert (a.get_params("qnet") == p).all()
+    assert a.param_count() == 1687206
+    a.close()
+
+
+def test_qvalues_match_oracle(B):
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    a = make_agent(B, batch_size=8)
+    p = T.init_params(T.cnn_shapes(6), 5)
+    a.set_params(p, "qnet")
+    obs = np.random.default_rng(0).integers(0, 256, (13, 4, 1, 84, 84), dtype=np.uint8)  # ragged M tails
+    q = a.qvalues(obs)
+    qo = O.net_forward(O.cnn_cfg(6), p, obs)
+    assert rel(q, qo) < QTOL, rel(q, qo)
+    assert (a.sample_greedy(obs) == qo.argmax(-1)).all()
+    a.close()
+
+
+def _run_golden(B, fix, batch_fn, n_steps, param_seed, Bsz, **kw):
+    from oracle import torch_ref as T
+    g = np.load(fix)
+    shapes = T.cnn_shapes(6)
+    a = make_agent(B, batch_size=Bsz, **kw)
+    p0 = T.init_params(shapes, param_seed)
+    a.set_params(p0, "qnet")
+    a.set_params(p0, "qnet_tgt")
+    lr = kw.get("lr", 1e-4)
+    for s in range(n_steps):
+        obs, act, nobs, rew, term = batch_fn(s)
+        rec = a.update_on_batch(obs, act, nobs, rew, term)
+        assert rel(a.probe("q_pred_all", Bsz * 6), g[f"s{s}_q_pred_all"].ravel()) < QTOL, s
+        assert rel(a.probe("q_next_all", Bsz * 6), g[f"s{s}_q_next_all"].ravel()) < QTOL, s
+        assert rel(a.probe("tgt", Bsz), g[f"s{s}_tgt"]) < QTOL
+        assert abs(rec["loss"] - g[f"s{s}_loss"]) <= QTOL * abs(g[f"s{s}_loss"]) + 1e-9
+        grads = a.get_params("grad")
+        st = max(1, grads.size // 4096) | 1
+        assert rel(grads[::st], g[f"s{s}_grads_sample"]) < 2e-4, (s, rel(grads[::st], g[f"s{s}_grads_sample"]))
+        o = 0
+        for i, sh in enumerate(shapes):
+            n = int(np.prod(sh))
+            gn = np.linalg.norm(grads[o:o + n].astype(np.float64))
+            assert abs(gn - g[f"s{s}_grad_norms"][i]) <= 2e-4 * g[f"s{s}_grad_norms"][i] + 1e-12, (s, i)
+            o += n
+        d = np.abs(a.get_params("qnet")[::st].astype(np.float64) - g[f"s{s}_params_sample"])
+        assert d.max() < 0.05 * lr, (s, d.max())
+        assert rel(a.get_params("qnet_tgt")[::st], g[f"s{s}_tgt_params_sample"]) < 1e-5
+    a.close()
+
+
+def test_golden_cnn_b4_huber(B, golden_dir):
+    from oracle import torch_ref as T
+    _run_golden(B, os.path.join(golden_dir, "dqn_cnn_b4_huber.npz"), lambda s: T.synthetic_atari_batch(4, 6, 100 + s), 3, 1, 4,
+                lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=2)
+
+
+def test_golden_cnn_b8_mse_double_dqn(B, golden_dir):
+    from oracle import torch_ref as T
+    _run_golden(B, os.path.join(golden_dir, "dqn_cnn_b8_mse_ddqn.npz"), lambda s: T.synthetic_atari_batch(8, 6, 200 + s), 2, 2, 8,
+                lr=1e-4, critic_loss="Mse", double_dqn=True, tau=0.005, soft_update_interval=1)
+
+
+def test_full_batch_256_vs_oracle(B):
+    """BASELINE config: B=256, A=6, SmoothL1.  One step against the C oracle (fixed minibatch)."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    shapes = T.cnn_shapes(6)
+    p0 = T.init_params(shapes, 7)
+    obs, act, nobs, rew, term = T.synthetic_atari_batch(256, 6, 77)
+    term[:8] = 1  # make sure the (1 - is_terminated) branch is exercised
+    a = make_agent(B, batch_size=256, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    ref = O.DqnOracle(O.cnn_cfg(6), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000)
+    rec = a.update_on_batch(obs, act, nobs, rew, term)
+    r = ref.update(obs, act, nobs, rew, term, probe=True)
+    assert rel(a.probe("q_pred_all", 256 * 6), r["q_pred_all"].ravel()) < QTOL
+    assert rel(a.probe("q_next_all", 256 * 6), r["q_next_all"].ravel()) < QTOL
+    assert rel(a.probe("pred", 256), r["pred"]) < QTOL and rel(a.probe("tgt", 256), r["tgt"]) < QTOL
+    assert abs(rec["loss"] - r["loss"]) <= QTOL * abs(r["loss"])
+    grads = a.get_params("grad")
+    o = 0
+    for sh in shapes:
+        n = int(np.prod(sh))
+        assert rel(grads[o:o + n], r["grads"][o:o + n]) < 2e-4, (sh, rel(grads[o:o + n], r["grads"][o:o + n]))
+        o += n
+    assert np.abs(a.get_params("qnet").astype(np.float64) - ref.q).max() < 0.05 * 1e-4
+    a.close()
+
+
+def test_opt_over_replay_matches_oracle_pipeline(B):
+    """Agent::opt over the HBM ring == oracle replay + oracle update on the same transitions:
+    sampled indices bit-identical, Q-values within tolerance, n_opts / soft-update bookkeeping."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    from tests import synth
+    cap, Bsz = 512, 32
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (4, 1, 84, 84), np.uint8)
+    rb.fill_synthetic(cap, seed=3, kind=0, n_actions=6)
+    rows = synth.atari_rows(3, 0, cap)
+    oref = O.Replay(cap, 42, 28224, 8)
+    oref.push(rows[0], rows[1].reshape(-1, 1), rows[2], rows[3], rows[4], rows[5])
+    p0 = T.init_params(T.cnn_shapes(6), 9)
+    a = make_agent(B, batch_size=Bsz, critic_loss="SmoothL1", tau=1.0, soft_update_interval=2, record_verbose_level=2)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    ref = O.DqnOracle(O.cnn_cfg(6), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=2)
+    for step in range(3):
+        rec = a.opt_with_record(rb)
+        b = oref.batch(Bsz)
+        r = ref.update(b["obs"].reshape(Bsz, 4, 1, 84, 84), b["act"].view(np.int64).ravel(),
+                       b["next_obs"].reshape(Bsz, 4, 1, 84, 84), b["reward"], b["is_terminated"], probe=True)
+        assert rel(a.probe("q_pred_all", Bsz * 6), r["q_pred_all"].ravel()) < 3e-4, step
+        assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-7
+        assert abs(rec["reward_mean"] - b["reward"].mean()) < 1e-6
+    assert a.n_opts == 3
+    assert rel(a.get_params("qnet_tgt"), ref.q_tgt) < 1e-3
+    a.close(); rb.close()
+
+
+def test_save_load_roundtrip(B, tmp_path):
+    a = make_agent(B, batch_size=4, param_seed=3)
+    p = a.get_params("qnet")
+    files = a.save_params(str(tmp_path))
+    assert all(os.path.exists(f) for f in files)
+    b = make_agent(B, batch_size=4, param_seed=99)
+    assert not (b.get_params("qnet") == p).all()
+    b.load_params(str(tmp_path))
+    assert (b.get_params("qnet") == p).all() and (b.get_params("qnet_tgt") == p).all()
+    a.close(); b.close()
+
+
+def test_missing_device_config_is_an_error(B):
+    with pytest.raises(B.BdrError):
+        B.Dqn.build(B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(out_dim=6))))

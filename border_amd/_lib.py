@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "bdr_dqn_config_default", "bdr_dqn_create", "bdr_agent_destroy", "bdr_agent_set_train", "bdr_agent_is_train",
     "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
-    "bdr_agent_set_params", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_dqn_probe",
+    "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_dqn_probe",
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
     "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_agent_allreduce_params",
     "bdr_agent_broadcast_params",
@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
     L.bdr_agent_param_count.argtypes = [vp, C.POINTER(u64)]
     L.bdr_agent_get_params.argtypes = [vp, i32, vp, u64]
     L.bdr_agent_set_params.argtypes = [vp, i32, vp, u64]
+    L.bdr_agent_arena_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u64)]
     L.bdr_agent_save_params.argtypes = [vp, C.c_char_p]
     L.bdr_agent_load_params.argtypes = [vp, C.c_char_p]
     L.bdr_dqn_probe.argtypes = [vp, i32, vp, u64]

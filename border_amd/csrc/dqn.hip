@@ -995,6 +995,15 @@ int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* inp, uint
     return BDR_OK;
 }
 
+int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint64_t* n_floats)
+{
+    BDR_REQUIRE(a && ptr && n_floats, "null argument");
+    float* p = arena_ptr(a, which);
+    BDR_REQUIRE(p, "which must be 0..4");
+    *ptr = p; *n_floats = a->ar.total;
+    return BDR_OK;
+}
+
 // named-tensor dump: "BDRP" u32 version, u32 count, then per tensor: u32 name_len, name, u32 ndim, u64 dims[], f32 data
 static int32_t save_arena(bdr_agent* a, int which, const std::string& path)
 {

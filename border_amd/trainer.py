@@ -1,0 +1,149 @@
+"""Host-side mirror of the opt-step loops that call the hot path.
+
+  Trainer.train_offline   border-core/src/trainer.rs:330-384 (pre-filled buffer, back-to-back
+                          Agent::opt; warmup_period = 0, opt_interval = 1) and the gating / timing
+                          of Trainer::train_step (:197-228): every record_agent_info_interval-th
+                          step is opt_with_record, the timer wraps opt*() only.
+  ParamExchange           the N>1 replacement of border-async-trainer's learner->actors model
+                          channel (async_trainer/base.rs:268-272): one replica per GPU, local replay
+                          shard, parameter averaging every sync_interval opt steps over RCCL.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class TrainerConfig:
+    """border-core/src/trainer/config.rs:30-87 (fields used by the offline loop)."""
+    max_opts: int = 0
+    opt_interval: int = 1
+    record_agent_info_interval: int = 0   # 0: never (the reference default is usize::MAX-like "0 => unset")
+    record_compute_cost_interval: int = 0
+    warmup_period: int = 0
+
+
+class Trainer:
+    def __init__(self, config: TrainerConfig):
+        self.config = config
+        self.env_steps = 0
+        self.opt_steps = 0
+        self.timer_for_opt_steps = 0.0
+        self.opt_steps_counter = 0
+        self.records = []
+
+    def train_step(self, agent, buffer):
+        """trainer.rs:197-228."""
+        c = self.config
+        if self.env_steps < c.warmup_period or self.env_steps % c.opt_interval != 0:
+            return None, False
+        t0 = time.perf_counter()
+        if c.record_agent_info_interval and (self.opt_steps + 1) % c.record_agent_info_interval == 0:
+            rec = agent.opt_with_record(buffer)
+        else:
+            agent.opt(buffer)
+            rec = None
+        self.opt_steps += 1
+        self.timer_for_opt_steps += time.perf_counter() - t0
+        self.opt_steps_counter += 1
+        return rec, True
+
+    def average_opt_time_ms(self):
+        """trainer.rs:164-174 (host-side enqueue time unless the step synchronised)."""
+        return 1000.0 * self.timer_for_opt_steps / max(1, self.opt_steps_counter)
+
+    def train_offline(self, agent, buffer, exchange=None):
+        """trainer.rs:330-384 without recorder / evaluator sinks (out of scope: SURVEY.md 2.1 #4)."""
+        self.config.warmup_period = 0
+        self.config.opt_interval = 1
+        agent.train()
+        while True:
+            self.env_steps += 1
+            rec, is_opt = self.train_step(agent, buffer)
+            if rec is not None:
+                self.records.append((self.opt_steps, rec))
+            if is_opt and exchange is not None:
+                exchange.after_opt(agent, self.opt_steps)
+            if self.opt_steps == self.config.max_opts:
+                return
+
+
+class ParamExchange:
+    """Parameter averaging across one-replica-per-GPU ranks.
+
+    backend "rccl": the library's own communicator (ncclAllReduce on the flat f32 arena + 1/N
+    scale, enqueued on the agent's stream; no host sync).  The unique id is created on rank 0
+    and handed to the other ranks by `bcast_bytes` (a callable(bytes|None) -> bytes, e.g. a
+    torch.distributed broadcast).
+    backend "torch": torch.distributed all_reduce on a tensor (CPU gloo path used by the
+    world_size-2 tests; params cross the C ABI as host vectors).
+    """
+
+    def __init__(self, world_size: int, rank: int, sync_interval: int, backend: str = "rccl", device: int = 0,
+                 bcast_bytes=None, which=("qnet",)):
+        self.world_size, self.rank, self.sync_interval, self.backend = world_size, rank, sync_interval, backend
+        self.which = tuple(which)
+        self._comm = None
+        if world_size > 1 and backend == "rccl":
+            L = _lib.lib()
+            uid = (C.c_uint8 * _lib.BDR_UNIQUE_ID_BYTES)()
+            if rank == 0:
+                _lib.check(L.bdr_comm_get_unique_id(uid))
+            raw = bcast_bytes(bytes(uid) if rank == 0 else None)
+            uid = (C.c_uint8 * _lib.BDR_UNIQUE_ID_BYTES)(*raw)
+            h = C.c_void_p()
+            _lib.check(L.bdr_comm_init_rank(uid, world_size, rank, device, C.byref(h)))
+            self._comm = h
+
+    def close(self):
+        if self._comm:
+            _lib.lib().bdr_comm_destroy(self._comm)
+            self._comm = None
+
+    def after_opt(self, agent, opt_steps: int) -> bool:
+        """Called after every opt step; averages every sync_interval-th step."""
+        if self.world_size == 1 or self.sync_interval <= 0 or opt_steps % self.sync_interval != 0:
+            return False
+        self.average(agent)
+        return True
+
+    def average(self, agent) -> None:
+        if self.world_size == 1:
+            return
+        if self.backend == "rccl":
+            for w in self.which:
+                _lib.check(_lib.lib().bdr_agent_allreduce_params(agent.handle, self._comm, agent.WHICH[w]))
+        else:
+            import torch
+            import torch.distributed as dist
+            for w in self.which:
+                t = torch.from_numpy(np.array(agent.get_params(w), copy=True))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t /= self.world_size
+                agent.set_params(t.numpy(), w)
+
+    def broadcast(self, agent, root: int = 0) -> None:
+        """The faithful learner->actors sync (SyncModel::sync_model on every actor)."""
+        if self.world_size == 1:
+            return
+        if self.backend == "rccl":
+            for w in self.which:
+                _lib.check(_lib.lib().bdr_agent_broadcast_params(agent.handle, self._comm, agent.WHICH[w], root))
+        else:
+            import torch
+            import torch.distributed as dist
+            for w in self.which:
+                t = torch.from_numpy(np.array(agent.get_params(w), copy=True))
+                dist.broadcast(t, src=root)
+                agent.set_params(t.numpy(), w)
+
+
+def shard_seed(base_seed: int, rank: int) -> int:
+    """Replay shard g draws from its own StdRng stream: seed + rank."""
+    return base_seed + rank

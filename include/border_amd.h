@@ -206,6 +206,10 @@ BDR_API int32_t bdr_agent_param_count(const bdr_agent* a, uint64_t* n);
 BDR_API int32_t bdr_agent_get_params(bdr_agent* a, int32_t which, float* out, uint64_t n);
 BDR_API int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* in, uint64_t n);
 
+/* Device address of a flat parameter arena (internal kernel layout, identical on every rank) so a
+ * host that already owns a communicator (e.g. torch.distributed) can reduce it in place. */
+BDR_API int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint64_t* n_floats);
+
 /* Agent::save_params / load_params (dqn/base.rs:345-371): writes/reads `qnet.bdr` and
  * `qnet_tgt.bdr` (named f32 tensors, reference variable names) under dir. */
 BDR_API int32_t bdr_agent_save_params(bdr_agent* a, const char* dir);

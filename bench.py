@@ -125,6 +125,8 @@ def main():
         agent.profile_enable(False)
         nz = 3 if args.double_dqn else 2
         fl = kernel_flops(args.batch, nz)
+        if not any(k in fl for k in prof):
+            sys.exit("bench.py needs --profile-steps >= 1 for the roofline leg")
         dom = max((k for k in prof if k in fl), key=lambda k: prof[k])
         achieved = fl[dom] / (prof[dom] * 1e-3) / 1e12
         step_flops = sum(fl.values()) + 2 * nz * args.batch * 512 * N_ACTIONS

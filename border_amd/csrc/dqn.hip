@@ -218,15 +218,30 @@ using DwC2 = DwP<GeomC2, AFwd<GeomC2>, 2, 2, false>;     // 64 x 64: 8 ko-tiles
 using DwC3 = DwP<GeomC3, AFwd<GeomC3>, 2, 2, false>;     // 64 x 64: 9 ko-tiles
 using DwL1 = DwP<GeomL1, AFwd<GeomL1>, 2, 2, false>;     // 64 x 64: 49 x 8 tiles, single chunk
 
-// g[i] = scale * sum_c part[c][i]
+// g[i] = scale * sum_c part[c][i].  64 outputs per workgroup, 4 chunk groups per output (chunk c goes
+// to group c % 4), fixed-order combine through LDS => deterministic.
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, size_t stride, int chunks,
                                                           float* __restrict__ g, int n, int n_weights, float wscale)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * stride + i];
-    g[i] = i < n_weights ? s * wscale : s;
+    if (i < n) {
+        int c = grp;
+        for (; c + 12 < chunks; c += 16) {
+            const float v0 = part[(size_t)c * stride + i], v1 = part[(size_t)(c + 4) * stride + i];
+            const float v2 = part[(size_t)(c + 8) * stride + i], v3 = part[(size_t)(c + 12) * stride + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < chunks; c += 4) s += part[(size_t)c * stride + i];
+    }
+    red[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const float t = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+        g[i] = i < n_weights ? t * wscale : t;
+    }
 }
 
 // ================================================================================================
@@ -339,7 +354,9 @@ __global__ __launch_bounds__(256) void k_td_rows(TdArgs a)
     *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
 }
 
-// l2 gradients + loss mean.  thread per (j, a): gW5[j][a] = sum_b h1[b][j] * dq[b] * [act[b]==a]
+// l2 gradients + loss mean.  Workgroup (a, half): gW5[j][a] = sum_{b: act[b]==a} h1[b][j] * dq[b] for 256 j.
+// Matching rows are compacted (in batch order) into LDS first so the row loop carries no branch and
+// its loads pipeline; the extra workgroup (blockIdx.x == 2*A) reduces the per-row losses to the mean.
 struct HeadBwdArgs {
     const float* h1; const float* dq; const uint8_t* act; int act_bytes;
     const float* loss_row;
@@ -348,29 +365,53 @@ struct HeadBwdArgs {
 };
 __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int n = 512 * a.A;
-    if (t < n) {
-        const int j = t / a.A, ac = t % a.A;
+    __shared__ int s_rows[256];
+    __shared__ float s_dq[256];
+    __shared__ int s_wcnt[4];
+    __shared__ float s_red[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x == 2 * a.A) {   // loss = mean over rows, fixed-order tree
         float s = 0.f;
-        for (int b = 0; b < a.B; ++b) {
-            const long long ab = *reinterpret_cast<const long long*>(a.act + (size_t)b * a.act_bytes);
-            if (ab == ac) s = fmaf(a.h1[(size_t)b * 512 + j], a.dq[b], s);
+        for (int b = tid; b < a.B; b += 256) s += a.loss_row[b];
+        s_red[tid] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) s_red[tid] += s_red[tid + w];
+            __syncthreads();
         }
-        a.gw5[t] = s;
-    } else if (t < n + a.A) {
-        const int ac = t - n;
-        float s = 0.f;
-        for (int b = 0; b < a.B; ++b) {
-            const long long ab = *reinterpret_cast<const long long*>(a.act + (size_t)b * a.act_bytes);
-            if (ab == ac) s += a.dq[b];
-        }
-        a.gb5[ac] = s;
-    } else if (t == n + a.A) {
-        float s = 0.f;
-        for (int b = 0; b < a.B; ++b) s += a.loss_row[b];
-        a.loss[0] = s / (float)a.B;
+        if (tid == 0) a.loss[0] = s_red[0] / (float)a.B;
+        return;
     }
+    const int ac = blockIdx.x >> 1, j = (blockIdx.x & 1) * 256 + tid;
+    float acc = 0.f, bacc = 0.f;
+    for (int b0 = 0; b0 < a.B; b0 += 256) {
+        const int b = b0 + tid;
+        bool match = false;
+        if (b < a.B) match = *reinterpret_cast<const long long*>(a.act + (size_t)b * a.act_bytes) == ac;
+        const unsigned long long m = __ballot(match);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (match) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            s_rows[pos] = b; s_dq[pos] = a.dq[b];
+        }
+        __syncthreads();
+        int k = 0;
+        for (; k + 4 <= total; k += 4) {
+            const float h0 = a.h1[(size_t)s_rows[k] * 512 + j], h1v = a.h1[(size_t)s_rows[k + 1] * 512 + j];
+            const float h2 = a.h1[(size_t)s_rows[k + 2] * 512 + j], h3 = a.h1[(size_t)s_rows[k + 3] * 512 + j];
+            acc = fmaf(h0, s_dq[k], acc); acc = fmaf(h1v, s_dq[k + 1], acc);
+            acc = fmaf(h2, s_dq[k + 2], acc); acc = fmaf(h3, s_dq[k + 3], acc);
+        }
+        for (; k < total; ++k) acc = fmaf(a.h1[(size_t)s_rows[k] * 512 + j], s_dq[k], acc);
+        if (tid == 0) for (int q = 0; q < total; ++q) bacc += s_dq[q];
+        __syncthreads();
+    }
+    a.gw5[(size_t)j * a.A + ac] = acc;
+    if (tid == 0 && (blockIdx.x & 1) == 0) a.gb5[ac] = bacc;
 }
 
 // ================================================================================================
@@ -611,7 +652,7 @@ int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* ne
     { Bracket br(a, "td_rows"); LAUNCH(k_td_rows, dim3((B + 3) / 4), t); }
 
     HeadBwdArgs hb{a->h1[0], a->dq, act, act_bytes, a->loss_row, a->grad + ar.w5, a->grad + ar.b5, a->loss, B, ar.A};
-    { Bracket br(a, "head_bwd"); LAUNCH(k_head_bwd, dim3((512 * ar.A + ar.A + 1 + 255) / 256), hb); }
+    { Bracket br(a, "head_bwd"); LAUNCH(k_head_bwd, dim3(2 * ar.A + 1), hb); }
 
     const DwPlan pl = dw_plan(a->B);   // buffer layout follows the allocated batch capacity
     // l1: dW (+db) straight into the gradient arena, then dX with relu' of a3
@@ -632,7 +673,7 @@ int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* ne
         { Bracket br(a, "bwd_conv3_dw"); LAUNCH(k_igemm_red<DwC3>, dim3(9, chunks), d); }
         const int n = 576 * 64 + 64;
         Bracket br(a, "bwd_conv3_red");
-        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, a->stream, a->part + pl.off_c3, pl.stride_c3,
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, a->stream, a->part + pl.off_c3, pl.stride_c3,
                            chunks, a->grad + ar.w3, n, 576 * 64, 1.0f);
         BDR_HIP(hipGetLastError());
     }
@@ -648,7 +689,7 @@ int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* ne
         { Bracket br(a, "bwd_conv2_dw"); LAUNCH(k_igemm_red<DwC2>, dim3(8, chunks), d); }
         const int n = 512 * 64 + 64;
         Bracket br(a, "bwd_conv2_red");
-        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, a->stream, a->part + pl.off_c2, pl.stride_c2,
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, a->stream, a->part + pl.off_c2, pl.stride_c2,
                            chunks, a->grad + ar.w2, n, 512 * 64, 1.0f);
         BDR_HIP(hipGetLastError());
     }
@@ -664,7 +705,7 @@ int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* ne
         { Bracket br(a, "bwd_conv1_dw"); LAUNCH(k_igemm_red<DwC1>, dim3(2, chunks), d); }
         const int n = 256 * 32 + 32;
         Bracket br(a, "bwd_conv1_red");
-        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, a->stream, a->part + pl.off_c1, pl.stride_c1,
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, a->stream, a->part + pl.off_c1, pl.stride_c1,
                            chunks, a->grad + ar.w1, n, 256 * 32, INV255);
         BDR_HIP(hipGetLastError());
     }

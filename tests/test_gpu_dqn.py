@@ -170,3 +170,22 @@ def test_save_load_roundtrip(B, tmp_path):
 def test_missing_device_config_is_an_error(B):
     with pytest.raises(B.BdrError):
         B.Dqn.build(B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(out_dim=6))))
+
+
+def test_rccl_comm_single_rank(B):
+    """The native RCCL path end to end on one GPU: unique id, ncclCommInitRank(nranks=1), and the
+    all-reduce / broadcast entry points (identity at nranks == 1)."""
+    import ctypes as C
+    L = B._lib.lib()
+    uid = (C.c_uint8 * B._lib.BDR_UNIQUE_ID_BYTES)()
+    B._lib.check(L.bdr_comm_get_unique_id(uid))
+    h = C.c_void_p()
+    B._lib.check(L.bdr_comm_init_rank(uid, 1, 0, 0, C.byref(h)))
+    a = make_agent(B, batch_size=4, param_seed=5)
+    p = a.get_params("qnet")
+    B._lib.check(L.bdr_agent_allreduce_params(a.handle, h, 0))
+    B._lib.check(L.bdr_agent_broadcast_params(a.handle, h, 0, 0))
+    a.sync()
+    assert (a.get_params("qnet") == p).all()
+    B._lib.check(L.bdr_comm_destroy(h))
+    a.close()

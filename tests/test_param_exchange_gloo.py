@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 gloo processes drive border_amd.ParamExchange (backend "torch")
+and the shard/seed logic with an oracle-backed stand-in agent (no GPU in this container).
+Properties: averaging identical replicas is the identity; the average is
+the arithmetic mean of the ranks' parameters; broadcast makes every rank equal to the root;
+shards draw from distinct StdRng streams."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeAgent:
+    """Implements the slice of the Dqn mirror that ParamExchange uses (get/set_params, WHICH)."""
+    WHICH = {"qnet": 0, "qnet_tgt": 1}
+
+    def __init__(self, p):
+        self.p = {"qnet": np.array(p, np.float32), "qnet_tgt": np.array(p, np.float32)}
+        self.handle = None
+
+    def get_params(self, which="qnet"):
+        return self.p[which]
+
+    def set_params(self, v, which="qnet"):
+        self.p[which] = np.array(v, np.float32)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from border_amd.trainer import ParamExchange, shard_seed
+    from oracle import oracle as O
+    ex = ParamExchange(world, rank, sync_interval=3, backend="torch")
+    base = np.linspace(-1, 1, 1000).astype(np.float32)
+    # (i) identical replicas: averaging is the identity
+    a = FakeAgent(base)
+    ex.average(a)
+    ok_identity = bool((a.get_params() == base).all())
+    # (ii) mean of different replicas; only every sync_interval-th step exchanges
+    b = FakeAgent(base * (rank + 1))
+    fired = [ex.after_opt(b, s) for s in (1, 2, 3)]
+    expect = base * np.float32(sum(range(1, world + 1))) / np.float32(world)
+    ok_mean = bool(np.allclose(b.get_params(), expect, rtol=1e-6, atol=1e-7)) and fired == [False, False, True]
+    # (iii) broadcast from the root
+    c = FakeAgent(base + rank)
+    ex.broadcast(c, root=0)
+    ok_bcast = bool((c.get_params() == base).all())
+    # (iv) distinct replay streams per shard
+    ix = O.StdRng.seed_from_u64(shard_seed(42, rank)).sample_indices(1_000_000, 8).tolist()
+    out.put((rank, ok_identity, ok_mean, ok_bcast, ix))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_identity, ok_mean, ok_bcast, ix in res:
+        assert ok_identity and ok_mean and ok_bcast, (rank, ok_identity, ok_mean, ok_bcast)
+    assert res[0][4] != res[1][4]

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libborder_amd.so")
+LIB_PATH = os.environ.get("BORDER_AMD_LIB") or os.path.join(HERE, "libborder_amd.so")  # override: kernel A/B probes
 
 BDR_MAX_UNITS = 8
 BDR_UNIQUE_ID_BYTES = 128

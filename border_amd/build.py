@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libborder_amd.so")
 SOURCES = ["replay.hip", "dqn.hip", "comm.hip"]  # missing files are skipped
-HEADERS = ["common.hpp", "igemm.hpp", "../../include/border_amd.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))) + ["../../include/border_amd.h"]
 
 
 def _stale() -> bool:

@@ -100,7 +100,6 @@ int32_t bdr_agent_allreduce_params(bdr_agent* a, bdr_comm* c, int32_t which)
     BDR_REQUIRE(p, "which must be 0..4");
     BDR_REQUIRE(dev == c->device, "agent and communicator live on different devices");
     BDR_HIP(hipSetDevice(dev));
-    if (c->nranks == 1) return BDR_OK;
     BDR_NCCL(g_rccl.AllReduce(p, p, n, kNcclFloat, kNcclSum, c->comm, s));
     return agent_scale(a, p, 1.0f / (float)c->nranks);
 }
@@ -113,7 +112,6 @@ int32_t bdr_agent_broadcast_params(bdr_agent* a, bdr_comm* c, int32_t which, int
     float* p = agent_arena(a, which, &n, &s, &dev);
     BDR_REQUIRE(p, "which must be 0..4");
     BDR_HIP(hipSetDevice(dev));
-    if (c->nranks == 1) return BDR_OK;
     BDR_NCCL(g_rccl.Broadcast(p, p, n, kNcclFloat, root, c->comm, s));
     return BDR_OK;
 }

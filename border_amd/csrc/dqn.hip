@@ -17,6 +17,7 @@
 
 #include "common.hpp"
 #include "igemm.hpp"
+#include "conv1_bf16.hpp"
 
 using namespace bdr;
 
@@ -470,6 +471,9 @@ struct bdr_agent {
     bdr_dqn_config cfg;
     int32_t device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;          // weight-gradient kernels run here, concurrently with the dX chain
+    hipEvent_t ev_fork[4] = {nullptr}, ev_join = nullptr;
+    bool overlap = true;
     Arena ar;
     int B = 0;          // activation buffers are sized for this batch
     // parameter arenas
@@ -516,9 +520,9 @@ DwPlan dw_plan(int B)
 {
     DwPlan p{};
     auto mt = [](int M) { return (M + 31) / 32; };
-    p.chunks_c1 = std::min(128, mt(B * 400));
-    p.chunks_c2 = std::min(32, mt(B * 81));
-    p.chunks_c3 = std::min(28, mt(B * 49));
+    p.chunks_c1 = std::min(256, mt(B * 400));
+    p.chunks_c2 = std::min(64, mt(B * 81));
+    p.chunks_c3 = std::min(56, mt(B * 49));
     p.stride_c1 = 256 * 32 + 32; p.stride_c2 = 512 * 64 + 64; p.stride_c3 = 576 * 64 + 64;
     p.off_c1 = 0;
     p.off_c2 = p.off_c1 + p.chunks_c1 * p.stride_c1;
@@ -585,11 +589,12 @@ void prof_collect(bdr_agent* a)
     a->slot_cursor = 0;
 }
 
-#define LAUNCH(kernel, grid, args)                                                                  \
+#define LAUNCH_ON(st, kernel, grid, args)                                                           \
     do {                                                                                           \
-        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, a->stream, args);                            \
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, args);                                   \
         BDR_HIP(hipGetLastError());                                                                \
     } while (0)
+#define LAUNCH(kernel, grid, args) LAUNCH_ON(a->stream, kernel, grid, args)
 
 // ---- the forward pass of nz network instances ------------------------------------------------------
 struct NetInst { const uint8_t* x; const float* params; int slot; };
@@ -598,9 +603,19 @@ int32_t forward(bdr_agent* a, const NetInst* inst, int nz, int B)
 {
     const Arena& ar = a->ar;
     FwdArgs f{};
-    f.M = B * 400;
-    for (int z = 0; z < nz; ++z) { f.x[z] = inst[z].x; f.w[z] = inst[z].params + ar.w1; f.bias[z] = inst[z].params + ar.b1; f.out[z] = a->a1[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv1"); LAUNCH(k_igemm<FwdC1>, dim3((f.M + 127) / 128, 1, nz), f); }
+    {
+        // conv1 on the bf16 matrix cores with exact operands (conv1_bf16.hpp)
+        Conv1Args c{};
+        c.M = B * 400; c.nz = nz;
+        for (int z = 0; z < nz; ++z) {
+            c.x[z] = inst[z].x; c.w1[z] = inst[z].params + ar.w1; c.bias[z] = inst[z].params + ar.b1; c.out[z] = a->a1[inst[z].slot];
+        }
+        const int items = (c.M + 31) / 32;
+        const int g = std::max(1, std::min(512 / nz, (items + 7) / 8));
+        Bracket br(a, "fwd_conv1");
+        hipLaunchKernelGGL(k_conv1_bf16, dim3(g * nz), dim3(512), 0, a->stream, c);
+        BDR_HIP(hipGetLastError());
+    }
     f.M = B * 81;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a1[inst[z].slot]; f.w[z] = inst[z].params + ar.w2; f.bias[z] = inst[z].params + ar.b2; f.out[z] = a->a2[inst[z].slot]; }
     { Bracket br(a, "fwd_conv2"); LAUNCH(k_igemm<FwdC2>, dim3((f.M + 63) / 64, 1, nz), f); }
@@ -651,29 +666,40 @@ int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* ne
     t.loss_row = a->loss_row; t.B = B; t.A = ar.A; t.gamma = (float)c.discount_factor; t.loss_kind = c.critic_loss;
     { Bracket br(a, "td_rows"); LAUNCH(k_td_rows, dim3((B + 3) / 4), t); }
 
-    HeadBwdArgs hb{a->h1[0], a->dq, act, act_bytes, a->loss_row, a->grad + ar.w5, a->grad + ar.b5, a->loss, B, ar.A};
-    { Bracket br(a, "head_bwd"); LAUNCH(k_head_bwd, dim3(2 * ar.A + 1), hb); }
-
+    // Backward.  The input-gradient chain (dX of l1 -> conv3 -> conv2) is the critical path; every
+    // weight-gradient kernel only needs the dY produced one link earlier, so those run on a second
+    // stream, forked/joined with events (each of these launches fills only part of the chip).
+    // With per-kernel profiling on, everything stays on the main stream.
+    const bool ov = a->overlap && !a->prof;
+    hipStream_t sd = ov ? a->side : a->stream;
+    auto fork = [&](int k) -> int32_t {
+        if (!ov) return BDR_OK;
+        BDR_HIP(hipEventRecord(a->ev_fork[k], a->stream));
+        BDR_HIP(hipStreamWaitEvent(a->side, a->ev_fork[k], 0));
+        return BDR_OK;
+    };
     const DwPlan pl = dw_plan(a->B);   // buffer layout follows the allocated batch capacity
-    // l1: dW (+db) straight into the gradient arena, then dX with relu' of a3
+    BDR_TRY(fork(0));                  // dh1, dq ready
+    HeadBwdArgs hb{a->h1[0], a->dq, act, act_bytes, a->loss_row, a->grad + ar.w5, a->grad + ar.b5, a->loss, B, ar.A};
+    { Bracket br(a, "head_bwd"); LAUNCH_ON(sd, k_head_bwd, dim3(2 * ar.A + 1), hb); }
     {
         DwArgs d{a->a3[0], a->dh1, a->grad + ar.w4, 0, B};
         Bracket br(a, "bwd_l1_dw");
-        LAUNCH(k_igemm_red<DwL1>, dim3(49 * 8, 1), d);
+        LAUNCH_ON(sd, k_igemm_red<DwL1>, dim3(49 * 8), d);
     }
     {
         DxArgs d{a->dh1, a->q + ar.w4, a->a3[0], a->dy3, B};
         Bracket br(a, "bwd_l1_dx");
         LAUNCH(k_igemm<DxL1>, dim3(((B + 63) / 64) * 49, 1, 1), d);
     }
-    // conv3
+    BDR_TRY(fork(1));                  // dy3 ready
     {
         const int M = B * 49, chunks = std::min(pl.chunks_c3, (M + 31) / 32);
         DwArgs d{a->a2[0], a->dy3, a->part + pl.off_c3, pl.stride_c3, M};
-        { Bracket br(a, "bwd_conv3_dw"); LAUNCH(k_igemm_red<DwC3>, dim3(9, chunks), d); }
+        { Bracket br(a, "bwd_conv3_dw"); LAUNCH_ON(sd, k_igemm_red<DwC3>, dim3(9 * chunks), d); }
         const int n = 576 * 64 + 64;
         Bracket br(a, "bwd_conv3_red");
-        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, a->stream, a->part + pl.off_c3, pl.stride_c3,
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, sd, a->part + pl.off_c3, pl.stride_c3,
                            chunks, a->grad + ar.w3, n, 576 * 64, 1.0f);
         BDR_HIP(hipGetLastError());
     }
@@ -682,14 +708,14 @@ int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* ne
         Bracket br(a, "bwd_conv3_dx");
         LAUNCH(k_igemm<DxC3>, dim3((d.M + 63) / 64, 1, 1), d);
     }
-    // conv2
+    BDR_TRY(fork(2));                  // dy2 ready
     {
         const int M = B * 81, chunks = std::min(pl.chunks_c2, (M + 31) / 32);
         DwArgs d{a->a1[0], a->dy2, a->part + pl.off_c2, pl.stride_c2, M};
-        { Bracket br(a, "bwd_conv2_dw"); LAUNCH(k_igemm_red<DwC2>, dim3(8, chunks), d); }
+        { Bracket br(a, "bwd_conv2_dw"); LAUNCH_ON(sd, k_igemm_red<DwC2>, dim3(8 * chunks), d); }
         const int n = 512 * 64 + 64;
         Bracket br(a, "bwd_conv2_red");
-        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, a->stream, a->part + pl.off_c2, pl.stride_c2,
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, sd, a->part + pl.off_c2, pl.stride_c2,
                            chunks, a->grad + ar.w2, n, 512 * 64, 1.0f);
         BDR_HIP(hipGetLastError());
     }
@@ -698,16 +724,20 @@ int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* ne
         Bracket br(a, "bwd_conv2_dx");
         LAUNCH(k_igemm<DxC2>, dim3((d.M + 127) / 128, 4, 1), d);
     }
-    // conv1 (no input gradient)
+    // conv1 (no input gradient) stays on the main stream
     {
         const int M = B * 400, chunks = std::min(pl.chunks_c1, (M + 31) / 32);
         DwArgs d{obs, a->dy1, a->part + pl.off_c1, pl.stride_c1, M};
-        { Bracket br(a, "bwd_conv1_dw"); LAUNCH(k_igemm_red<DwC1>, dim3(2, chunks), d); }
+        { Bracket br(a, "bwd_conv1_dw"); LAUNCH(k_igemm_red<DwC1>, dim3(2 * chunks), d); }
         const int n = 256 * 32 + 32;
         Bracket br(a, "bwd_conv1_red");
         hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, a->stream, a->part + pl.off_c1, pl.stride_c1,
                            chunks, a->grad + ar.w1, n, 256 * 32, INV255);
         BDR_HIP(hipGetLastError());
+    }
+    if (ov) {                          // join: all gradients complete before Adam
+        BDR_HIP(hipEventRecord(a->ev_join, a->side));
+        BDR_HIP(hipStreamWaitEvent(a->stream, a->ev_join, 0));
     }
     // :150 backward_step -> Adam
     a->adam_step += 1;
@@ -879,6 +909,10 @@ int32_t bdr_dqn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
     a->ar = make_arena(cfg->net.out_dim);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    BDR_HIP(hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking));
+    for (auto& e : a->ev_fork) BDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    BDR_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
+    a->overlap = getenv("BDR_NO_OVERLAP") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->ar.total));
@@ -906,6 +940,9 @@ int32_t bdr_agent_destroy(bdr_agent* a)
     (void)hipFree(a->loss);
     (void)hipFree(a->u_obs); (void)hipFree(a->u_next); (void)hipFree(a->u_act); (void)hipFree(a->u_rew); (void)hipFree(a->u_term);
     for (auto& s : a->slots) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
+    for (auto& e : a->ev_fork) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(a->ev_join);
+    (void)hipStreamDestroy(a->side);
     (void)hipStreamDestroy(a->stream);
     delete a;
     return BDR_OK;

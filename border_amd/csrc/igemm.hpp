@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
     static_assert(P::WM * P::WN == 4, "4 waves");
     static_assert(A_PASSES >= 1 && B_VECS >= 1, "tile too small for 256 threads");
 
-    __shared__ __attribute__((aligned(16))) float smem[BM * LDA + BK * LDB];
-    float* As = smem;
-    float* Bs = smem + BM * LDA;
+    // two LDS stages: tile t+1 is written while tile t feeds the matrix pipe (one barrier per k-tile)
+    constexpr int STAGE = BM * LDA + BK * LDB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / P::WN, wn = wave % P::WN;
@@ -241,6 +241,9 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
     f32x4 ra[A_PASSES][AV];
     f32x4 rb[B_VECS];
     auto prefetch = [&](int kt) {
+#ifdef BDR_ABL_NOLOAD
+        if (kt > kt0) return;
+#endif
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) A::load(rows[p], kt, a_q, ra[p]);
 #pragma unroll
@@ -258,7 +261,12 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int stage) {
+#ifdef BDR_ABL_NOCOMMIT
+        if (stage) return;
+#endif
+        float* As = smem + stage * STAGE;
+        float* Bs = As + BM * LDA;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p)
 #pragma unroll
@@ -286,13 +294,20 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    if (kt0 < kt1) prefetch(kt0);
+    if (kt0 < kt1) {
+        prefetch(kt0);
+        commit(0);
+        if (kt0 + 1 < kt1) prefetch(kt0 + 1);
+    }
+    __syncthreads();
+    int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        commit();
+        if (kt + 1 < kt1) commit(cur ^ 1);          // regs hold tile kt+1
+        if (kt + 2 < kt1) prefetch(kt + 2);         // in flight during the MFMAs below
+        const float* As = smem + cur * STAGE;
+        mfma_ktile<P::TM, P::TN, LDB>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc);
         __syncthreads();
-        if (kt + 1 < kt1) prefetch(kt + 1);
-        mfma_ktile<P::TM, P::TN, LDB>(As, Bs, wm * P::TM * 32, wn * P::TN * 32, lane, acc);
-        __syncthreads();
+        cur ^= 1;
     }
 
     const int j = lane & 31, h = lane >> 5;
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
 //   P::A, P::WM, P::WN, P::TM, P::TN; KO_T = WM*TM*32 output rows, N_T = WN*TN*32 columns.
 //   P::K (total output rows), P::N (columns, == N_T * n-tiles)
 //   hooks: a_src(args), y_src(args), M(args), part(args, chunk) -> float* partial [K*N + N]
-// grid: x = ko-tiles * n-tiles, y = m-chunk.  The bias gradient (column sums of Y) is accumulated
+// grid: 1-D (see the XCD-aware map in the kernel).  The bias gradient (column sums of Y) is accumulated
 // by the ko-tile-0 workgroups from the very Y tiles they stage.
 // LDS: As[32 rows][KO_T (+4)] (read with lane = output row: consecutive floats), Ys[32][N_T].
 // ------------------------------------------------------------------------------------------------
@@ -332,16 +347,29 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
     static_assert(A_PASSES >= 1, "A tile too small");
     static_assert(Y_VECS >= 1, "Y tile too small");
 
-    __shared__ __attribute__((aligned(16))) float smem[32 * LDAR + 32 * LDY];
-    float* As = smem;
-    float* Ys = smem + 32 * LDAR;
+    constexpr int STAGE = 32 * LDAR + 32 * LDY;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / P::WN, wn = wave % P::WN;
+    // XCD-aware block -> (tile, chunk) map.  Workgroup b is dispatched to XCD b % 8 and every XCD
+    // has its own L2: all output tiles of one row chunk read the same A/Y rows, so they are given
+    // to the same XCD (chunk c lives on XCD c % 8) and each XCD's L2 only ever sees 1/8 of the rows.
+    // grid: 1-D, TILES * nchunks workgroups with nchunks % 8 == 0 (else the identity map).
     constexpr int NT_N = P::N / N_T;
-    const int kot = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
+    constexpr int TILES = (P::K / KO_T) * NT_N;
+    const int nchunks = gridDim.x / TILES;
+    int tile, chunk;
+    if (nchunks % 8 == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        chunk = (j / TILES) * 8 + xcd;
+        tile = j % TILES;
+    } else {
+        chunk = blockIdx.x / TILES;
+        tile = blockIdx.x % TILES;
+    }
+    const int kot = tile / NT_N, nt = tile % NT_N;
     const int ko0 = kot * KO_T, n0 = nt * N_T;
-    const int chunk = blockIdx.y, nchunks = gridDim.y;
     const int M = P::M(args);
     const int n_mt = (M + 31) / 32;
     const int per = (n_mt + nchunks - 1) / nchunks;
@@ -358,6 +386,9 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
 
     // pass p covers (row, ksub) pairs: idx = p*ROWS_PER_PASS + a_r; row = idx % 32, ksub = idx / 32
     auto prefetch = [&](int mt) {
+#ifdef BDR_ABL_NOLOAD
+        if (mt > mt0) return;
+#endif
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
             const int idx = p * ROWS_PER_PASS + a_r;
@@ -374,7 +405,12 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
                           : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int stage) {
+#ifdef BDR_ABL_NOCOMMIT
+        if (stage) return;
+#endif
+        float* As = smem + stage * STAGE;
+        float* Ys = As + 32 * LDAR;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
             const int idx = p * ROWS_PER_PASS + a_r;
@@ -401,11 +437,18 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int i = lane & 31, h = lane >> 5;
-    if (mt0 < mt1) prefetch(mt0);
+    if (mt0 < mt1) {
+        prefetch(mt0);
+        commit(0);
+        if (mt0 + 1 < mt1) prefetch(mt0 + 1);
+    }
+    __syncthreads();
+    int cur = 0;
     for (int mt = mt0; mt < mt1; ++mt) {
-        commit();
-        __syncthreads();
-        if (mt + 1 < mt1) prefetch(mt + 1);
+        if (mt + 1 < mt1) commit(cur ^ 1);
+        if (mt + 2 < mt1) prefetch(mt + 2);
+        const float* As = smem + cur * STAGE;
+        const float* Ys = As + 32 * LDAR;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int red = 2 * t + h;
@@ -421,6 +464,7 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
         __syncthreads();
+        cur ^= 1;
     }
 
     float* part = P::part(args, chunk);

@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "bdr_replay_sample_indices", "bdr_replay_batch", "bdr_replay_last_batch", "bdr_replay_fill_synthetic",
     "bdr_replay_read_rows",
     "bdr_dqn_config_default", "bdr_dqn_create", "bdr_agent_destroy", "bdr_agent_set_train", "bdr_agent_is_train",
-    "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
+    "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_agent_opt_with_scalars", "bdr_agent_param_count_of", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
     "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_dqn_probe",
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
@@ -110,6 +110,8 @@ def lib() -> C.CDLL:
     L.bdr_agent_is_train.argtypes = [vp, C.POINTER(i32)]
     L.bdr_agent_opt.argtypes = [vp, vp]
     L.bdr_agent_opt_with_record.argtypes = [vp, vp, C.POINTER(DqnRecordC)]
+    L.bdr_agent_opt_with_scalars.argtypes = [vp, vp, vp, i32, C.POINTER(i32)]
+    L.bdr_agent_param_count_of.argtypes = [vp, i32, C.POINTER(u64)]
     L.bdr_dqn_update_on_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, C.POINTER(DqnRecordC)]
     L.bdr_agent_qvalues.argtypes = [vp, u64, vp, vp, vp]
     L.bdr_agent_sync.argtypes = [vp]

@@ -1,0 +1,173 @@
+// Common agent plumbing of libborder_amd.so: the polymorphic handle behind `bdr_agent*`, per-kernel
+// HIP-event profiling brackets, launch macros, and the optimizer kernels every agent shares.
+#pragma once
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "igemm.hpp"
+
+struct ProfSlot { std::string name; hipEvent_t e0, e1; double ms = 0; uint64_t count = 0; };
+
+// The opaque `bdr_agent` of include/border_amd.h.  Concrete agents: DqnCnn (dqn.hip), DqnMlp / Sac
+// (mlp_agents.hip), Iqn (iqn.hip).
+struct bdr_agent {
+    int32_t device = 0;
+    hipStream_t stream = nullptr;
+    bool train = false;
+    uint64_t n_opts = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfSlot> slots;
+    size_t slot_cursor = 0;
+
+    virtual ~bdr_agent() {}
+    virtual const char* kind() const = 0;
+    virtual int32_t opt(bdr_replay* r) = 0;                       // Agent::opt, asynchronous
+    virtual int32_t record(float* out, int cap, int* n) = 0;      // scalars of the last update (syncs)
+    virtual uint64_t param_count(int which) = 0;                  // reference-layout element count
+    virtual int32_t get_params(int which, float* out, uint64_t n) = 0;
+    virtual int32_t set_params(int which, const float* in, uint64_t n) = 0;
+    virtual float* arena(int which, size_t* n) = 0;               // flat device arena (kernel layout)
+    virtual int32_t save(const char* dir) = 0;
+    virtual int32_t load(const char* dir) = 0;
+};
+
+namespace bdr {
+
+struct Bracket {
+    bdr_agent* a; ProfSlot* s = nullptr;
+    Bracket(bdr_agent* ag, const char* name) : a(ag)
+    {
+        if (!a->prof) return;
+        if (a->slot_cursor >= a->slots.size()) {
+            ProfSlot ns; ns.name = name;
+            (void)hipEventCreate(&ns.e0); (void)hipEventCreate(&ns.e1);
+            a->slots.push_back(ns);
+        }
+        s = &a->slots[a->slot_cursor++];
+        (void)hipEventRecord(s->e0, a->stream);
+    }
+    ~Bracket()
+    {
+        if (!s) return;
+        (void)hipEventRecord(s->e1, a->stream);
+    }
+};
+
+inline void prof_collect(bdr_agent* a)
+{
+    if (!a->prof) return;
+    (void)hipStreamSynchronize(a->stream);
+    for (size_t i = 0; i < a->slot_cursor; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a->slots[i].e0, a->slots[i].e1) == hipSuccess) { a->slots[i].ms += ms; a->slots[i].count++; }
+    }
+    a->slot_cursor = 0;
+}
+
+inline int32_t alloc_f(float** p, size_t n)
+{
+    BDR_HIP(hipMalloc((void**)p, (n < 4 ? 4 : n) * sizeof(float)));
+    return BDR_OK;
+}
+
+// named f32 tensor container used by every agent's save/load (reference variable names)
+struct NamedTensor { std::string name; std::vector<uint64_t> dims; };
+int32_t save_named(const std::string& path, const std::vector<NamedTensor>& meta, const float* data, size_t n);
+int32_t load_named(const std::string& path, const std::vector<NamedTensor>& meta, float* data, size_t n);
+
+}  // namespace bdr
+
+#define LAUNCH_ON(st, kernel, grid, args)                                                           \
+    do {                                                                                           \
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, args);                                   \
+        BDR_HIP(hipGetLastError());                                                                \
+    } while (0)
+#define LAUNCH(kernel, grid, args) LAUNCH_ON(a->stream, kernel, grid, args)
+
+namespace {
+using namespace bdr;
+
+// ================================================================================================
+// Adam (opt.rs:35 -> libtorch Adam::step) and track (util.rs:31-45) over the flat arena
+// ================================================================================================
+struct AdamScalars { float b1, omb1, b2, omb2, sqrt_bc2, eps, neg_step, wd_mul; };
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, size_t n4, AdamScalars s)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pp[j] *= s.wd_mul;                                 // AdamW decoupled decay (1 for Adam)
+        mm[j] = mm[j] * s.b1 + gg[j] * s.omb1;             // exp_avg.mul_(b1).add_(g, 1-b1)
+        vv[j] = vv[j] * s.b2 + s.omb2 * gg[j] * gg[j];     // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+        const float denom = __fsqrt_rn(vv[j]) / s.sqrt_bc2 + s.eps;
+        pp[j] = pp[j] + s.neg_step * mm[j] / denom;        // addcdiv_(exp_avg, denom, -step_size)
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+}
+
+__global__ __launch_bounds__(256) void k_track(float* __restrict__ dst, const float* __restrict__ src, size_t n4, float tau,
+                                               float omt)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 d = reinterpret_cast<f32x4*>(dst)[i], s = reinterpret_cast<const f32x4*>(src)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = tau * s[j] + omt * d[j];
+    reinterpret_cast<f32x4*>(dst)[i] = d;
+}
+
+__global__ __launch_bounds__(256) void k_scale(float* __restrict__ p, size_t n4, float s)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 d = reinterpret_cast<f32x4*>(p)[i];
+    d *= s;
+    reinterpret_cast<f32x4*>(p)[i] = d;
+}
+
+
+// Adam scalars on the host in double, entering the f32 element kernel as f32 (libtorch Adam::step)
+inline AdamScalars adam_scalars_for(bool adamw, double lr, double beta1, double beta2, double eps, double wd, uint64_t step)
+{
+    // opt.rs:35: tch nn::Adam::default() -> beta1 .9, beta2 .999, wd 0, eps 1e-8; AdamW: opt.rs:38-55
+    const double b1 = adamw ? beta1 : 0.9, b2 = adamw ? beta2 : 0.999, e = adamw ? eps : 1e-8, w = adamw ? wd : 0.0;
+    const double bc1 = 1.0 - std::pow(b1, (double)step), bc2 = 1.0 - std::pow(b2, (double)step);
+    AdamScalars s;
+    s.b1 = (float)b1; s.omb1 = (float)(1.0 - b1); s.b2 = (float)b2; s.omb2 = (float)(1.0 - b2);
+    s.sqrt_bc2 = (float)std::sqrt(bc2); s.eps = (float)e; s.neg_step = (float)(-(lr / bc1));
+    s.wd_mul = (float)(1.0 - lr * w);
+    return s;
+}
+
+inline int32_t launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n_floats, const AdamScalars& s)
+{
+    const size_t n4 = n_floats / 4;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p, g, m, v, n4, s);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+inline int32_t launch_track(hipStream_t st, float* dst, const float* src, size_t n_floats, double tau)
+{
+    const size_t n4 = n_floats / 4;
+    hipLaunchKernelGGL(k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dst, src, n4, (float)tau, (float)(1.0 - tau));
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+inline int32_t launch_scale(hipStream_t st, float* p, size_t n_floats, float sc)
+{
+    const size_t n4 = n_floats / 4;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p, n4, sc);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+}  // namespace

@@ -12,7 +12,7 @@ using namespace bdr;
 
 namespace bdr {
 float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* stream, int* device);
-int32_t agent_scale(bdr_agent* a, float* p, float s);
+int32_t agent_scale(bdr_agent* a, float* p, size_t n, float s);
 }
 
 namespace {
@@ -97,11 +97,11 @@ int32_t bdr_agent_allreduce_params(bdr_agent* a, bdr_comm* c, int32_t which)
     BDR_REQUIRE(a && c, "null argument");
     size_t n = 0; hipStream_t s = nullptr; int dev = 0;
     float* p = agent_arena(a, which, &n, &s, &dev);
-    BDR_REQUIRE(p, "which must be 0..4");
+    BDR_REQUIRE(p, "unknown arena");
     BDR_REQUIRE(dev == c->device, "agent and communicator live on different devices");
     BDR_HIP(hipSetDevice(dev));
     BDR_NCCL(g_rccl.AllReduce(p, p, n, kNcclFloat, kNcclSum, c->comm, s));
-    return agent_scale(a, p, 1.0f / (float)c->nranks);
+    return agent_scale(a, p, n, 1.0f / (float)c->nranks);
 }
 
 int32_t bdr_agent_broadcast_params(bdr_agent* a, bdr_comm* c, int32_t which, int32_t root)
@@ -110,7 +110,7 @@ int32_t bdr_agent_broadcast_params(bdr_agent* a, bdr_comm* c, int32_t which, int
     BDR_REQUIRE(root >= 0 && root < c->nranks, "bad root");
     size_t n = 0; hipStream_t s = nullptr; int dev = 0;
     float* p = agent_arena(a, which, &n, &s, &dev);
-    BDR_REQUIRE(p, "which must be 0..4");
+    BDR_REQUIRE(p, "unknown arena");
     BDR_HIP(hipSetDevice(dev));
     BDR_NCCL(g_rccl.Broadcast(p, p, n, kNcclFloat, root, c->comm, s));
     return BDR_OK;

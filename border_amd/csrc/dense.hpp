@@ -1,0 +1,239 @@
+// Dense (fully connected) layers for the Mlp-based agents (border-tch-agent/src/mlp/base.rs:13-41,
+// mlp/mlp2.rs:7-50): the same FP32-MFMA kernels as the CNN path (igemm.hpp) driven by runtime
+// dimensions.  Every dimension is zero-padded to a multiple of 64 inside the library, so a layer is
+//   W [Kp][Np] (k-major, like the conv weights)   followed by   bias [Np]
+// and an activation / gradient buffer is [B][Np].  Padding rows/columns of W and bias stay exactly
+// zero under Adam (their gradients are exactly zero), so padded activations are zero as well.
+#pragma once
+#include <vector>
+
+#include "agent_base.hpp"
+
+namespace bdr {
+
+struct DenseLayer {
+    int in, out;       // logical sizes
+    int Kp, Np;        // padded sizes
+    size_t w, b;       // offsets (floats) into the flat arena
+    int relu;          // ReLU after this layer
+};
+
+struct MlpLayout {
+    std::vector<DenseLayer> L;
+    size_t total = 0;          // arena floats
+    size_t ref_total = 0;      // reference-layout floats
+    int in_dim = 0, out_dim = 0;
+};
+
+inline int pad64(int x) { return (x + 63) / 64 * 64; }
+
+// Mlp (mlp/base.rs:13-41): in -> units[0] -> ... -> out, ReLU between, optional ReLU on the output.
+// `base` lets several nets share one arena.
+inline MlpLayout make_mlp(int in_dim, const int* units, int n_units, int out_dim, bool activation_out, size_t base = 0)
+{
+    MlpLayout m;
+    m.in_dim = in_dim; m.out_dim = out_dim;
+    size_t o = base;
+    int in = in_dim;
+    for (int i = 0; i <= n_units; ++i) {
+        DenseLayer l;
+        l.in = in; l.out = i < n_units ? units[i] : out_dim;
+        l.Kp = pad64(l.in); l.Np = pad64(l.out);
+        l.w = o; o += (size_t)l.Kp * l.Np;
+        l.b = o; o += l.Np;
+        l.relu = i < n_units ? 1 : (activation_out ? 1 : 0);
+        m.ref_total += (size_t)l.out * l.in + l.out;
+        m.L.push_back(l);
+        in = l.out;
+    }
+    m.total = o - base;
+    return m;
+}
+
+// reference order: ln{i}.weight [out][in], ln{i}.bias [out]   <->   internal W[k][n], b[n] (padded)
+inline void mlp_to_internal(const MlpLayout& m, size_t base, const float* ref, float* in)
+{
+    const float* p = ref;
+    for (const auto& l : m.L) {
+        for (int o = 0; o < l.out; ++o)
+            for (int k = 0; k < l.in; ++k) in[l.w - base + (size_t)k * l.Np + o] = p[(size_t)o * l.in + k];
+        p += (size_t)l.out * l.in;
+        for (int o = 0; o < l.out; ++o) in[l.b - base + o] = p[o];
+        p += l.out;
+    }
+}
+inline void mlp_to_reference(const MlpLayout& m, size_t base, const float* in, float* ref)
+{
+    float* p = ref;
+    for (const auto& l : m.L) {
+        for (int o = 0; o < l.out; ++o)
+            for (int k = 0; k < l.in; ++k) p[(size_t)o * l.in + k] = in[l.w - base + (size_t)k * l.Np + o];
+        p += (size_t)l.out * l.in;
+        for (int o = 0; o < l.out; ++o) p[o] = in[l.b - base + o];
+        p += l.out;
+    }
+}
+
+// the library's own initialiser: uniform(+-1/sqrt(fan_in)) (tests inject weights through set_params)
+inline void mlp_init_reference(const MlpLayout& m, uint64_t seed, float* ref)
+{
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x7654321ull;
+    float* p = ref;
+    for (const auto& l : m.L) {
+        const float bound = 1.0f / std::sqrt((float)l.in);
+        const size_t n = (size_t)l.out * l.in + l.out;
+        for (size_t i = 0; i < n; ++i) {
+            s += 0x9E3779B97F4A7C15ull;
+            uint64_t x = s; x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+            p[i] = ((float)(x >> 40) * (2.0f / 16777216.0f) - 1.0f) * bound;
+        }
+        p += n;
+    }
+}
+
+}  // namespace bdr
+
+namespace {
+using namespace bdr;
+
+// ---- kernel policies ---------------------------------------------------------------------------------
+struct DenseArgs {
+    DenseSrc x;          // A operand rows
+    const float* w;      // layer weights [Kp][Np]
+    const float* bias;   // fwd only
+    float* out; int ldo;
+    const float* mask; int ldm;   // dx: ReLU' mask = post-activation of the previous layer (or null)
+    int M, ncols, kred, relu;
+    int w_ld;            // row stride of W (= Np of the layer)
+};
+
+struct DenseFwd {
+    using A = ADense;
+    using Args = DenseArgs;
+    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr bool B_TR = false;
+    __device__ static int N(const Args& a) { return a.ncols; }
+    __device__ static int KP(const Args&) { return 32; }
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static DenseSrc a_src(const Args& a, int) { return a.x; }
+    __device__ static const float* w(const Args& a, int, int) { return a.w; }
+    __device__ static int tap_index(int, int t) { return t; }
+    __device__ static void kt_range(const Args& a, int, int& k0, int& k1) { k0 = 0; k1 = a.kred / BK; }
+    __device__ static void store(const Args& a, int, int, int m, int n, float v)
+    {
+        v += a.bias[n];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        a.out[(size_t)m * a.ldo + n] = v;
+    }
+};
+
+// dX[M][Kp] = dY[M][Np] * W[Kp][Np]^T, optional ReLU' mask
+struct DenseDx {
+    using A = ADense;
+    using Args = DenseArgs;
+    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr bool B_TR = true;
+    __device__ static int N(const Args& a) { return a.ncols; }     // = Kp of the layer
+    __device__ static int KP(const Args& a) { return a.w_ld; }     // = Np of the layer (contiguous)
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static DenseSrc a_src(const Args& a, int) { return a.x; }
+    __device__ static const float* w(const Args& a, int, int) { return a.w; }
+    __device__ static int tap_index(int, int t) { return t; }
+    __device__ static void kt_range(const Args& a, int, int& k0, int& k1) { k0 = 0; k1 = a.kred / BK; }
+    __device__ static void store(const Args& a, int, int, int m, int n, float v)
+    {
+        if (a.mask && !(a.mask[(size_t)m * a.ldm + n] > 0.f)) v = 0.f;
+        a.out[(size_t)m * a.ldo + n] = v;
+    }
+};
+
+struct DenseDwArgs {
+    DenseSrc x;          // layer input rows [M][Kp]
+    const float* dy;     // [M][Np]
+    float* part; size_t part_stride;
+    int M, Kp, Np;
+};
+struct DenseDw {
+    using A = ADense;
+    using Args = DenseDwArgs;
+    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    __device__ static int K(const Args& a) { return a.Kp; }
+    __device__ static int N(const Args& a) { return a.Np; }
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static DenseSrc a_src(const Args& a) { return a.x; }
+    __device__ static const float* y_src(const Args& a) { return a.dy; }
+    __device__ static float* part(const Args& a, int chunk) { return a.part + (size_t)chunk * a.part_stride; }
+};
+
+// g[i] = sum_c part[c][i]  (same deterministic scheme as the conv path)
+__global__ __launch_bounds__(256) void k_dense_reduce(const float* __restrict__ part, size_t stride, int chunks,
+                                                       float* __restrict__ g, int n)
+{
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    float s = 0.f;
+    if (i < n) for (int c = grp; c < chunks; c += 4) s += part[(size_t)c * stride + i];
+    red[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) g[i] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+}
+
+// copy the logical columns of row-major host-layout rows into a zero-padded [B][ld] matrix:
+// dst[b][col0 + c] = src[b*src_ld + c], c < cols
+__global__ void k_pack_rows(const float* __restrict__ src, int src_ld, int cols, float* __restrict__ dst, int ld, int col0, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * cols) return;
+    const int b = i / cols, c = i % cols;
+    dst[(size_t)b * ld + col0 + c] = src[(size_t)b * src_ld + c];
+}
+
+// ---- host-side layer launches ------------------------------------------------------------------------
+inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, const float* params_base, DenseSrc x, float* out, int M)
+{
+    DenseArgs d{};
+    d.x = x; d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
+    d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
+    hipLaunchKernelGGL(k_igemm<DenseFwd>, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), dim3(256), 0, st, d);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+
+// dX (masked by the ReLU of the producing layer's post-activation `mask`, may be null)
+inline int32_t dense_dx(hipStream_t st, const DenseLayer& l, const float* params_base, const float* dy, float* dx,
+                        const float* mask, int M)
+{
+    DenseArgs d{};
+    d.x = DenseSrc{dy, l.Np}; d.w = params_base + l.w; d.out = dx; d.ldo = l.Kp; d.mask = mask; d.ldm = l.Kp;
+    d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np;
+    hipLaunchKernelGGL(k_igemm<DenseDx>, dim3(((M + 63) / 64) * (l.Kp / 64), 1, 1), dim3(256), 0, st, d);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+
+// dW, db straight into the gradient arena (single row chunk), or through `part` (chunks > 1)
+inline int32_t dense_dw(hipStream_t st, const DenseLayer& l, float* grad_base, DenseSrc x, const float* dy, int M,
+                        float* part = nullptr, int chunks = 1)
+{
+    const int tiles = (l.Kp / 64) * (l.Np / 64);
+    const int n = l.Kp * l.Np + l.Np;
+    DenseDwArgs d{x, dy, chunks > 1 ? part : grad_base + l.w, chunks > 1 ? (size_t)n : 0, M, l.Kp, l.Np};
+    hipLaunchKernelGGL(k_igemm_red<DenseDw>, dim3(tiles * chunks), dim3(256), 0, st, d);
+    BDR_HIP(hipGetLastError());
+    if (chunks > 1) {
+        hipLaunchKernelGGL(k_dense_reduce, dim3((n + 63) / 64), dim3(256), 0, st, part, (size_t)n, chunks, grad_base + l.w, n);
+        BDR_HIP(hipGetLastError());
+    }
+    return BDR_OK;
+}
+
+inline int32_t pack_rows(hipStream_t st, const float* src, int src_ld, int cols, float* dst, int ld, int col0, int B)
+{
+    const int n = B * cols;
+    hipLaunchKernelGGL(k_pack_rows, dim3((n + 255) / 256), dim3(256), 0, st, src, src_ld, cols, dst, ld, col0, B);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+
+}  // namespace

@@ -16,6 +16,7 @@
 #include <string>
 
 #include "common.hpp"
+#include "agent_base.hpp"
 #include "igemm.hpp"
 #include "conv1_bf16.hpp"
 
@@ -68,9 +69,10 @@ struct FwdP {
     using A = APolicy;
     using Args = FwdArgs;
     static constexpr int WM = WM_, WN = WN_, TM = 1, TN = 1;
-    static constexpr int N = G::COUT;
+    static constexpr int NC = G::COUT;
     static constexpr bool B_TR = false;
-    static constexpr int KP = 32;
+    __device__ static constexpr int N(const Args&) { return NC; }
+    __device__ static constexpr int KP(const Args&) { return 32; }
     __device__ static int M(const Args& a) { return a.M; }
     __device__ static auto a_src(const Args& a, int z)
     {
@@ -84,7 +86,7 @@ struct FwdP {
     {
         if constexpr (U8SCALE) v *= INV255;   // cnn/base.rs:26 "/ 255", folded into the epilogue
         v += a.bias[z][n];
-        a.out[z][(size_t)m * N + n] = v > 0.f ? v : 0.f;   // relu (cnn/base.rs:28,30,32)
+        a.out[z][(size_t)m * NC + n] = v > 0.f ? v : 0.f;   // relu (cnn/base.rs:28,30,32)
     }
 };
 using FwdC1 = FwdP<GeomC1, AFwdU8<GeomC1>, 4, 1, true>;    // 128x32 tiles, M = B*400
@@ -96,9 +98,10 @@ struct FwdL1 {
     using A = AFwd<GeomL1>;
     using Args = FwdArgs;
     static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
-    static constexpr int N = 512;
+    static constexpr int NC = 512;
     static constexpr bool B_TR = false;
-    static constexpr int KP = 32;
+    __device__ static constexpr int N(const Args&) { return NC; }
+    __device__ static constexpr int KP(const Args&) { return 32; }
     __device__ static int M(const Args& a) { return a.M; }
     __device__ static const float* a_src(const Args& a, int z) { return reinterpret_cast<const float*>(a.x[z]); }
     __device__ static const float* w(const Args& a, int z, int) { return a.w[z]; }
@@ -109,7 +112,7 @@ struct FwdL1 {
     }
     __device__ static void store(const Args& a, int z, int y, int m, int n, float v)
     {
-        a.out[z][((size_t)y * a.M + m) * N + n] = v;
+        a.out[z][((size_t)y * a.M + m) * NC + n] = v;
     }
 };
 
@@ -130,9 +133,10 @@ struct DxL1 {
     using A = AFwd<G>;     // dense rows of dh1
     using Args = DxArgs;
     static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
-    static constexpr int N = 3136;     // N' (columns of the result)
-    static constexpr int KP = 512;     // K' per tap (contiguous in memory)
+    static constexpr int NC = 3136;    // N' (columns of the result)
     static constexpr bool B_TR = true;
+    __device__ static constexpr int N(const Args&) { return NC; }
+    __device__ static constexpr int KP(const Args&) { return 512; }   // K' per tap (contiguous in memory)
     __device__ static int M(const Args& a) { return a.M; }
     __device__ static const float* a_src(const Args& a, int) { return a.dy; }
     __device__ static const float* w(const Args& a, int, int) { return a.w; }
@@ -140,7 +144,7 @@ struct DxL1 {
     __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
     __device__ static void store(const Args& a, int, int, int m, int n, float v)
     {
-        const size_t o = (size_t)m * N + n;
+        const size_t o = (size_t)m * NC + n;
         a.out[o] = a.mask[o] > 0.f ? v : 0.f;
     }
 };
@@ -151,8 +155,10 @@ struct DxC3 {
     using A = ADxS1<G>;
     using Args = DxArgs;
     static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
-    static constexpr int N = G::CIN, KP = G::COUT;
+    static constexpr int NC = G::CIN;
     static constexpr bool B_TR = true;
+    __device__ static constexpr int N(const Args&) { return NC; }
+    __device__ static constexpr int KP(const Args&) { return G::COUT; }
     __device__ static int M(const Args& a) { return a.M; }
     __device__ static const float* a_src(const Args& a, int) { return a.dy; }
     __device__ static const float* w(const Args& a, int, int) { return a.w; }
@@ -160,7 +166,7 @@ struct DxC3 {
     __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
     __device__ static void store(const Args& a, int, int, int m, int n, float v)
     {
-        const size_t o = (size_t)m * N + n;
+        const size_t o = (size_t)m * NC + n;
         a.out[o] = a.mask[o] > 0.f ? v : 0.f;
     }
 };
@@ -171,8 +177,10 @@ struct DxC2 {
     using A = ADxS2<G>;
     using Args = DxArgs;
     static constexpr int WM = 4, WN = 1, TM = 1, TN = 1;
-    static constexpr int N = G::CIN, KP = G::COUT;
+    static constexpr int NC = G::CIN;
     static constexpr bool B_TR = true;
+    __device__ static constexpr int N(const Args&) { return NC; }
+    __device__ static constexpr int KP(const Args&) { return G::COUT; }
     __device__ static int M(const Args& a) { return a.M; }
     __device__ static const float* a_src(const Args& a, int) { return a.dy; }
     __device__ static const float* w(const Args& a, int, int) { return a.w; }
@@ -184,7 +192,7 @@ struct DxC2 {
         constexpr int HH = G::IH / 2, WH = G::IW / 2;
         const int b = m / (HH * WH), rem = m % (HH * WH);
         const int ih = 2 * (rem / WH) + (y >> 1), iw = 2 * (rem % WH) + (y & 1);
-        const size_t o = ((size_t)(b * G::IH + ih) * G::IW + iw) * N + n;
+        const size_t o = ((size_t)(b * G::IH + ih) * G::IW + iw) * NC + n;
         a.out[o] = a.mask[o] > 0.f ? v : 0.f;
     }
 };
@@ -204,7 +212,8 @@ struct DwP {
     using A = APolicy;
     using Args = DwArgs;
     static constexpr int WM = WM_, WN = WN_, TM = 1, TN = 1;
-    static constexpr int K = G::K, N = G::COUT;
+    __device__ static constexpr int K(const Args&) { return G::K; }
+    __device__ static constexpr int N(const Args&) { return G::COUT; }
     __device__ static int M(const Args& a) { return a.M; }
     __device__ static auto a_src(const Args& a)
     {
@@ -415,62 +424,13 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
     if (tid == 0 && (blockIdx.x & 1) == 0) a.gb5[ac] = bacc;
 }
 
-// ================================================================================================
-// Adam (opt.rs:35 -> libtorch Adam::step) and track (util.rs:31-45) over the flat arena
-// ================================================================================================
-struct AdamScalars { float b1, omb1, b2, omb2, sqrt_bc2, eps, neg_step, wd_mul; };
-
-__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, size_t n4, AdamScalars s)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        pp[j] *= s.wd_mul;                                 // AdamW decoupled decay (1 for Adam)
-        mm[j] = mm[j] * s.b1 + gg[j] * s.omb1;             // exp_avg.mul_(b1).add_(g, 1-b1)
-        vv[j] = vv[j] * s.b2 + s.omb2 * gg[j] * gg[j];     // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
-        const float denom = __fsqrt_rn(vv[j]) / s.sqrt_bc2 + s.eps;
-        pp[j] = pp[j] + s.neg_step * mm[j] / denom;        // addcdiv_(exp_avg, denom, -step_size)
-    }
-    reinterpret_cast<f32x4*>(p)[i] = pp;
-    reinterpret_cast<f32x4*>(m)[i] = mm;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
-}
-
-__global__ __launch_bounds__(256) void k_track(float* __restrict__ dst, const float* __restrict__ src, size_t n4, float tau,
-                                               float omt)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 d = reinterpret_cast<f32x4*>(dst)[i], s = reinterpret_cast<const f32x4*>(src)[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) d[j] = tau * s[j] + omt * d[j];
-    reinterpret_cast<f32x4*>(dst)[i] = d;
-}
-
-__global__ __launch_bounds__(256) void k_scale(float* __restrict__ p, size_t n4, float s)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 d = reinterpret_cast<f32x4*>(p)[i];
-    d *= s;
-    reinterpret_cast<f32x4*>(p)[i] = d;
-}
-
 }  // namespace
 
 // ================================================================================================
-// agent handle
+// agent handle: Dqn<E, AtariCnn, R>
 // ================================================================================================
-struct ProfSlot { std::string name; hipEvent_t e0, e1; double ms = 0; uint64_t count = 0; };
-
-struct bdr_agent {
+struct DqnCnn : bdr_agent {
     bdr_dqn_config cfg;
-    int32_t device = 0;
-    hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // weight-gradient kernels run here, concurrently with the dX chain
     hipEvent_t ev_fork[4] = {nullptr}, ev_join = nullptr;
     bool overlap = true;
@@ -488,20 +448,26 @@ struct bdr_agent {
     // update_on_batch staging
     uint8_t *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr; float* u_rew = nullptr; int8_t* u_term = nullptr;
     uint64_t u_cap = 0;
+    const float* last_reward = nullptr; int last_B = 0;
     // bookkeeping (dqn/base.rs:26-48)
-    uint64_t adam_step = 0, soft_update_counter = 0, n_opts = 0;
-    bool train = false;
-    // profiling
-    bool prof = false;
-    std::vector<ProfSlot> slots;
-    size_t slot_cursor = 0;
+    uint64_t adam_step = 0, soft_update_counter = 0;
+
+    ~DqnCnn() override;
+    const char* kind() const override { return "dqn_cnn"; }
+    int32_t opt(bdr_replay* r) override;
+    int32_t record(float* out, int cap, int* n) override;
+    uint64_t param_count(int which) override;
+    int32_t get_params(int which, float* out, uint64_t n) override;
+    int32_t set_params(int which, const float* in, uint64_t n) override;
+    float* arena(int which, size_t* n) override;
+    int32_t save(const char* dir) override;
+    int32_t load(const char* dir) override;
 };
 
 namespace {
 
-int32_t alloc_f(float** p, size_t n) { BDR_HIP(hipMalloc((void**)p, std::max<size_t>(n, 4) * sizeof(float))); return BDR_OK; }
 
-void free_batch_buffers(bdr_agent* a)
+void free_batch_buffers(DqnCnn* a)
 {
     for (int z = 0; z < MAXZ; ++z) {
         (void)hipFree(a->a1[z]); (void)hipFree(a->a2[z]); (void)hipFree(a->a3[z]);
@@ -531,7 +497,7 @@ DwPlan dw_plan(int B)
     return p;
 }
 
-int32_t ensure_batch(bdr_agent* a, int B)
+int32_t ensure_batch(DqnCnn* a, int B)
 {
     if (B <= a->B) return BDR_OK;
     BDR_HIP(hipStreamSynchronize(a->stream));
@@ -558,48 +524,10 @@ int32_t ensure_batch(bdr_agent* a, int B)
     return BDR_OK;
 }
 
-// ---- profiling brackets --------------------------------------------------------------------------
-struct Bracket {
-    bdr_agent* a; ProfSlot* s = nullptr;
-    Bracket(bdr_agent* ag, const char* name) : a(ag)
-    {
-        if (!a->prof) return;
-        if (a->slot_cursor >= a->slots.size()) {
-            ProfSlot ns; ns.name = name;
-            (void)hipEventCreate(&ns.e0); (void)hipEventCreate(&ns.e1);
-            a->slots.push_back(ns);
-        }
-        s = &a->slots[a->slot_cursor++];
-        (void)hipEventRecord(s->e0, a->stream);
-    }
-    ~Bracket()
-    {
-        if (!s) return;
-        (void)hipEventRecord(s->e1, a->stream);
-    }
-};
-void prof_collect(bdr_agent* a)
-{
-    if (!a->prof) return;
-    (void)hipStreamSynchronize(a->stream);
-    for (size_t i = 0; i < a->slot_cursor; ++i) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, a->slots[i].e0, a->slots[i].e1) == hipSuccess) { a->slots[i].ms += ms; a->slots[i].count++; }
-    }
-    a->slot_cursor = 0;
-}
-
-#define LAUNCH_ON(st, kernel, grid, args)                                                           \
-    do {                                                                                           \
-        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, args);                                   \
-        BDR_HIP(hipGetLastError());                                                                \
-    } while (0)
-#define LAUNCH(kernel, grid, args) LAUNCH_ON(a->stream, kernel, grid, args)
-
 // ---- the forward pass of nz network instances ------------------------------------------------------
 struct NetInst { const uint8_t* x; const float* params; int slot; };
 
-int32_t forward(bdr_agent* a, const NetInst* inst, int nz, int B)
+int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B)
 {
     const Arena& ar = a->ar;
     FwdArgs f{};
@@ -637,22 +565,15 @@ int32_t forward(bdr_agent* a, const NetInst* inst, int nz, int B)
 
 AdamScalars adam_scalars(const bdr_dqn_config& c, uint64_t step)
 {
-    // opt.rs:35: tch nn::Adam::default() -> beta1 .9, beta2 .999, wd 0, eps 1e-8; AdamW: opt.rs:38-55
-    const bool w = c.opt_kind == BDR_OPT_ADAMW;
-    const double b1 = w ? c.beta1 : 0.9, b2 = w ? c.beta2 : 0.999, eps = w ? c.eps : 1e-8, wd = w ? c.weight_decay : 0.0;
-    const double bc1 = 1.0 - std::pow(b1, (double)step), bc2 = 1.0 - std::pow(b2, (double)step);
-    AdamScalars s;
-    s.b1 = (float)b1; s.omb1 = (float)(1.0 - b1); s.b2 = (float)b2; s.omb2 = (float)(1.0 - b2);
-    s.sqrt_bc2 = (float)std::sqrt(bc2); s.eps = (float)eps; s.neg_step = (float)(-(c.lr / bc1));
-    s.wd_mul = (float)(1.0 - c.lr * wd);
-    return s;
+    return adam_scalars_for(c.opt_kind == BDR_OPT_ADAMW, c.lr, c.beta1, c.beta2, c.eps, c.weight_decay, step);
 }
 
 // Dqn::update_critic on a device-resident batch (dqn/base.rs:60-160)
-int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
+int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
                       const float* reward, const int8_t* term)
 {
     BDR_TRY(ensure_batch(a, B));
+    a->last_reward = reward; a->last_B = B;
     const Arena& ar = a->ar;
     const bdr_dqn_config& c = a->cfg;
     // :71-74 + :91-103  slot 0 = qnet(obs), slot 1 = qnet_tgt(next_obs), slot 2 = qnet(next_obs) for double DQN
@@ -751,7 +672,7 @@ int32_t update_critic(bdr_agent* a, int B, const uint8_t* obs, const uint8_t* ne
     return BDR_OK;
 }
 
-int32_t soft_update(bdr_agent* a)
+int32_t soft_update(DqnCnn* a)
 {
     const size_t n4 = a->ar.total / 4;
     const float tau = (float)a->cfg.tau, omt = (float)(1.0 - a->cfg.tau);
@@ -762,7 +683,7 @@ int32_t soft_update(bdr_agent* a)
 }
 
 // dqn/base.rs:182-200 bookkeeping after the n_updates_per_opt updates
-int32_t after_updates(bdr_agent* a)
+int32_t after_updates(DqnCnn* a)
 {
     a->soft_update_counter += 1;
     if (a->soft_update_counter == a->cfg.soft_update_interval) {
@@ -773,7 +694,7 @@ int32_t after_updates(bdr_agent* a)
     return BDR_OK;
 }
 
-int32_t opt_inner(bdr_agent* a, bdr_replay* r)
+int32_t opt_inner(DqnCnn* a, bdr_replay* r)
 {
     BDR_REQUIRE(r->obs_bytes == (uint64_t)a->cfg.net.n_stack * 84 * 84, "replay obs rows (%llu B) do not match the AtariCnn input",
                 (unsigned long long)r->obs_bytes);
@@ -786,7 +707,7 @@ int32_t opt_inner(bdr_agent* a, bdr_replay* r)
     return after_updates(a);
 }
 
-int32_t fill_record(bdr_agent* a, int B, const float* reward_dev, bdr_dqn_record* rec)
+int32_t fill_record(DqnCnn* a, int B, const float* reward_dev, bdr_dqn_record* rec)
 {
     BDR_HIP(hipMemcpyAsync(&rec->loss, a->loss, 4, hipMemcpyDeviceToHost, a->stream));
     BDR_HIP(hipStreamSynchronize(a->stream));
@@ -847,7 +768,7 @@ void to_reference(const Arena& ar, const float* in, float* ref)
     p += (size_t)ar.A * 512; std::copy(in + ar.b5, in + ar.b5 + ar.A, p);
 }
 
-float* arena_ptr(bdr_agent* a, int which)
+float* arena_ptr(DqnCnn* a, int which)
 {
     switch (which) {
         case 0: return a->q; case 1: return a->q_tgt; case 2: return a->m; case 3: return a->v; case 4: return a->grad;
@@ -877,35 +798,100 @@ void init_reference_params(int A, uint64_t seed, std::vector<float>& ref)
 
 }  // namespace
 
-extern "C" {
 
-void bdr_dqn_config_default(bdr_dqn_config* c)
+// ---- virtual interface -----------------------------------------------------------------------------
+DqnCnn::~DqnCnn()
 {
-    if (!c) return;
-    memset(c, 0, sizeof *c);
-    // dqn/config.rs:82-102
-    c->net.kind = BDR_NET_ATARI_CNN; c->net.n_stack = 4; c->net.out_dim = 0;
-    c->opt_kind = BDR_OPT_ADAM; c->lr = 0.0;
-    c->beta1 = 0.9; c->beta2 = 0.999; c->weight_decay = 0.0; c->eps = 1e-8;
-    c->soft_update_interval = 1; c->n_updates_per_opt = 1; c->batch_size = 1;
-    c->discount_factor = 0.99; c->tau = 0.005; c->train = 0; c->double_dqn = 0;
-    c->critic_loss = BDR_LOSS_MSE; c->has_clip_td_err = 0; c->record_verbose_level = 0;
-    c->device = -1; c->param_seed = 0;
+    (void)hipSetDevice(device);
+    (void)hipStreamSynchronize(stream);
+    if (side) (void)hipStreamSynchronize(side);
+    free_batch_buffers(this);
+    (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v);
+    (void)hipFree(loss);
+    (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
+    for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
 }
 
-int32_t bdr_dqn_create(const bdr_dqn_config* cfg, bdr_agent** out)
+int32_t DqnCnn::opt(bdr_replay* r) { return opt_inner(this, r); }
+
+int32_t DqnCnn::record(float* out, int cap, int* n)
 {
-    BDR_REQUIRE(cfg && out, "null argument");
-    BDR_REQUIRE(cfg->device >= 0, "No device is given for DQN agent");   // dqn/base.rs:256-259
-    BDR_REQUIRE(cfg->net.kind == BDR_NET_ATARI_CNN, "only the AtariCnn Q-network is built in this round (Mlp: see DESIGN.md)");
+    bdr_dqn_record rec{};
+    BDR_TRY(fill_record(this, last_B, last_reward, &rec));
+    const float v[5] = {rec.loss, rec.pred_mean, rec.reward_mean, rec.tgt_mean, rec.tgt_minus_pred_mean};
+    const int k = rec.has_verbose ? 5 : 1;
+    for (int i = 0; i < k && i < cap; ++i) out[i] = v[i];
+    *n = k;
+    return BDR_OK;
+}
+
+uint64_t DqnCnn::param_count(int which) { return which == -1 ? (uint64_t)ar.A : ref_param_count(ar.A); }
+
+int32_t DqnCnn::get_params(int which, float* out, uint64_t n)
+{
+    float* src = arena_ptr(this, which);
+    BDR_REQUIRE(src, "which must be 0..4");
+    BDR_REQUIRE(n == ref_param_count(ar.A), "parameter count mismatch (%llu vs %llu)", (unsigned long long)n,
+                (unsigned long long)ref_param_count(ar.A));
+    std::vector<float> in(ar.total);
+    BDR_HIP(hipMemcpyAsync(in.data(), src, ar.total * 4, hipMemcpyDeviceToHost, stream));
+    BDR_HIP(hipStreamSynchronize(stream));
+    to_reference(ar, in.data(), out);
+    return BDR_OK;
+}
+
+int32_t DqnCnn::set_params(int which, const float* inp, uint64_t n)
+{
+    float* dst = arena_ptr(this, which);
+    BDR_REQUIRE(dst, "which must be 0..4");
+    BDR_REQUIRE(n == ref_param_count(ar.A), "parameter count mismatch");
+    std::vector<float> in(ar.total);
+    to_internal(ar, inp, in.data());
+    BDR_HIP(hipMemcpyAsync(dst, in.data(), ar.total * 4, hipMemcpyHostToDevice, stream));
+    BDR_HIP(hipStreamSynchronize(stream));
+    return BDR_OK;
+}
+
+float* DqnCnn::arena(int which, size_t* n)
+{
+    if (n) *n = ar.total;
+    return arena_ptr(this, which);
+}
+
+static std::vector<NamedTensor> cnn_meta(int A)
+{
+    return {{"c1.weight", {32, 4, 8, 8}}, {"c1.bias", {32}}, {"c2.weight", {64, 32, 4, 4}}, {"c2.bias", {64}},
+            {"c3.weight", {64, 64, 3, 3}}, {"c3.bias", {64}}, {"l1.weight", {512, 3136}}, {"l1.bias", {512}},
+            {"l2.weight", {(uint64_t)A, 512}}, {"l2.bias", {(uint64_t)A}}};
+}
+
+int32_t DqnCnn::save(const char* dir)
+{
+    // dqn/base.rs:348-356: qnet.pt.tch, qnet_tgt.pt.tch  (here: same stems, own container)
+    std::vector<float> ref(ref_param_count(ar.A));
+    BDR_TRY(get_params(0, ref.data(), ref.size()));
+    BDR_TRY(save_named(std::string(dir) + "/qnet.bdr", cnn_meta(ar.A), ref.data(), ref.size()));
+    BDR_TRY(get_params(1, ref.data(), ref.size()));
+    return save_named(std::string(dir) + "/qnet_tgt.bdr", cnn_meta(ar.A), ref.data(), ref.size());
+}
+
+int32_t DqnCnn::load(const char* dir)
+{
+    std::vector<float> ref(ref_param_count(ar.A));
+    BDR_TRY(load_named(std::string(dir) + "/qnet.bdr", cnn_meta(ar.A), ref.data(), ref.size()));
+    BDR_TRY(set_params(0, ref.data(), ref.size()));
+    BDR_TRY(load_named(std::string(dir) + "/qnet_tgt.bdr", cnn_meta(ar.A), ref.data(), ref.size()));
+    return set_params(1, ref.data(), ref.size());
+}
+
+namespace bdr {
+int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
+{
     BDR_REQUIRE(cfg->net.n_stack == 4, "AtariCnn kernels are specialised for n_stack = 4");
     BDR_REQUIRE(cfg->net.out_dim >= 1 && cfg->net.out_dim <= 64, "out_dim must be in [1,64]");
-    BDR_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= 65536, "batch_size out of range");
-    BDR_REQUIRE(cfg->soft_update_interval >= 1 && cfg->n_updates_per_opt >= 1, "intervals must be >= 1");
-    BDR_REQUIRE(cfg->critic_loss == BDR_LOSS_MSE || cfg->critic_loss == BDR_LOSS_SMOOTH_L1, "unknown critic_loss");
-    BDR_REQUIRE(cfg->opt_kind == BDR_OPT_ADAM || cfg->opt_kind == BDR_OPT_ADAMW, "unknown optimizer");
-    BDR_TRY(ensure_device(cfg->device));
-    bdr_agent* a = new bdr_agent();
+    DqnCnn* a = new DqnCnn();
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
     a->ar = make_arena(cfg->net.out_dim);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
@@ -930,60 +916,10 @@ int32_t bdr_dqn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     return BDR_OK;
 }
 
-int32_t bdr_agent_destroy(bdr_agent* a)
+int32_t dqn_cnn_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
+                                const float* reward, const int8_t* term)
 {
-    if (!a) return BDR_OK;
-    (void)hipSetDevice(a->device);
-    (void)hipStreamSynchronize(a->stream);
-    free_batch_buffers(a);
-    (void)hipFree(a->q); (void)hipFree(a->q_tgt); (void)hipFree(a->grad); (void)hipFree(a->m); (void)hipFree(a->v);
-    (void)hipFree(a->loss);
-    (void)hipFree(a->u_obs); (void)hipFree(a->u_next); (void)hipFree(a->u_act); (void)hipFree(a->u_rew); (void)hipFree(a->u_term);
-    for (auto& s : a->slots) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
-    for (auto& e : a->ev_fork) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(a->ev_join);
-    (void)hipStreamDestroy(a->side);
-    (void)hipStreamDestroy(a->stream);
-    delete a;
-    return BDR_OK;
-}
-
-int32_t bdr_agent_set_train(bdr_agent* a, int32_t train) { BDR_REQUIRE(a, "null agent"); a->train = train != 0; return BDR_OK; }
-int32_t bdr_agent_is_train(const bdr_agent* a, int32_t* out) { BDR_REQUIRE(a && out, "null argument"); *out = a->train; return BDR_OK; }
-int32_t bdr_agent_n_opts(const bdr_agent* a, uint64_t* n) { BDR_REQUIRE(a && n, "null argument"); *n = a->n_opts; return BDR_OK; }
-
-int32_t bdr_agent_sync(bdr_agent* a)
-{
-    BDR_REQUIRE(a, "null agent");
-    BDR_HIP(hipSetDevice(a->device));
-    BDR_HIP(hipStreamSynchronize(a->stream));
-    return BDR_OK;
-}
-
-int32_t bdr_agent_opt(bdr_agent* a, bdr_replay* r)
-{
-    BDR_REQUIRE(a && r, "null argument");
-    BDR_HIP(hipSetDevice(a->device));
-    BDR_TRY(opt_inner(a, r));
-    prof_collect(a);
-    return BDR_OK;
-}
-
-int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* r, bdr_dqn_record* rec)
-{
-    BDR_REQUIRE(a && r && rec, "null argument");
-    BDR_HIP(hipSetDevice(a->device));
-    BDR_TRY(opt_inner(a, r));
-    prof_collect(a);
-    return fill_record(a, (int)a->cfg.batch_size, r->b_reward, rec);
-}
-
-int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
-                                const float* reward, const int8_t* term, bdr_dqn_record* rec)
-{
-    BDR_REQUIRE(a && obs && act && next_obs && reward && term, "null argument");
-    BDR_REQUIRE(n >= 1 && n <= 65536, "batch size out of range");
-    BDR_HIP(hipSetDevice(a->device));
+    DqnCnn* a = static_cast<DqnCnn*>(base);
     const size_t ob = (size_t)a->cfg.net.n_stack * 84 * 84;
     if (n > a->u_cap) {
         BDR_HIP(hipStreamSynchronize(a->stream));
@@ -1000,17 +936,13 @@ int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const
     BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, a->stream));
     BDR_TRY(update_critic(a, (int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term));
     BDR_TRY(after_updates(a));
-    prof_collect(a);
-    if (rec) return fill_record(a, (int)n, a->u_rew, rec);
     BDR_HIP(hipStreamSynchronize(a->stream));   // host buffers may be reused by the caller
     return BDR_OK;
 }
 
-int32_t bdr_agent_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out, int64_t* argmax_out)
+int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_out)
 {
-    BDR_REQUIRE(a && obs, "null argument");
-    BDR_REQUIRE(n >= 1 && n <= 65536, "batch size out of range");
-    BDR_HIP(hipSetDevice(a->device));
+    DqnCnn* a = static_cast<DqnCnn*>(base);
     BDR_TRY(ensure_batch(a, (int)n));
     const size_t ob = (size_t)a->cfg.net.n_stack * 84 * 84;
     uint8_t* d = nullptr;
@@ -1018,137 +950,19 @@ int32_t bdr_agent_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_ou
     BDR_HIP(hipMemcpyAsync(d, obs, n * ob, hipMemcpyHostToDevice, a->stream));
     NetInst inst[1] = {{d, a->q, 0}};
     int32_t st = forward(a, inst, 1, (int)n);
-    std::vector<float> q(n * a->ar.A);
     if (st == BDR_OK) {
-        hipError_t e = hipMemcpyAsync(q.data(), a->qv[0], q.size() * 4, hipMemcpyDeviceToHost, a->stream);
+        hipError_t e = hipMemcpyAsync(q_out, a->qv[0], n * a->ar.A * 4, hipMemcpyDeviceToHost, a->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
         if (e != hipSuccess) st = fail(BDR_ERR_HIP, "qvalues copy failed: %s", hipGetErrorString(e));
     }
     (void)hipFree(d);
     a->slot_cursor = 0;
-    BDR_TRY(st);
-    if (q_out) memcpy(q_out, q.data(), q.size() * 4);
-    if (argmax_out)
-        for (uint64_t i = 0; i < n; ++i) {
-            int best = 0;
-            for (int k = 1; k < a->ar.A; ++k) if (q[i * a->ar.A + k] > q[i * a->ar.A + best]) best = k;
-            argmax_out[i] = best;
-        }
-    return BDR_OK;
+    return st;
 }
 
-int32_t bdr_agent_param_count(const bdr_agent* a, uint64_t* n)
+int32_t dqn_cnn_probe(bdr_agent* base, int32_t what, float* out, uint64_t n)
 {
-    BDR_REQUIRE(a && n, "null argument");
-    *n = ref_param_count(a->ar.A);
-    return BDR_OK;
-}
-
-int32_t bdr_agent_get_params(bdr_agent* a, int32_t which, float* out, uint64_t n)
-{
-    BDR_REQUIRE(a && out, "null argument");
-    float* src = arena_ptr(a, which);
-    BDR_REQUIRE(src, "which must be 0..4");
-    BDR_REQUIRE(n == ref_param_count(a->ar.A), "parameter count mismatch (%llu vs %llu)", (unsigned long long)n,
-                (unsigned long long)ref_param_count(a->ar.A));
-    BDR_HIP(hipSetDevice(a->device));
-    std::vector<float> in(a->ar.total);
-    BDR_HIP(hipMemcpyAsync(in.data(), src, a->ar.total * 4, hipMemcpyDeviceToHost, a->stream));
-    BDR_HIP(hipStreamSynchronize(a->stream));
-    to_reference(a->ar, in.data(), out);
-    return BDR_OK;
-}
-
-int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* inp, uint64_t n)
-{
-    BDR_REQUIRE(a && inp, "null argument");
-    float* dst = arena_ptr(a, which);
-    BDR_REQUIRE(dst, "which must be 0..4");
-    BDR_REQUIRE(n == ref_param_count(a->ar.A), "parameter count mismatch");
-    BDR_HIP(hipSetDevice(a->device));
-    std::vector<float> in(a->ar.total);
-    to_internal(a->ar, inp, in.data());
-    BDR_HIP(hipMemcpyAsync(dst, in.data(), a->ar.total * 4, hipMemcpyHostToDevice, a->stream));
-    BDR_HIP(hipStreamSynchronize(a->stream));
-    return BDR_OK;
-}
-
-int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint64_t* n_floats)
-{
-    BDR_REQUIRE(a && ptr && n_floats, "null argument");
-    float* p = arena_ptr(a, which);
-    BDR_REQUIRE(p, "which must be 0..4");
-    *ptr = p; *n_floats = a->ar.total;
-    return BDR_OK;
-}
-
-// named-tensor dump: "BDRP" u32 version, u32 count, then per tensor: u32 name_len, name, u32 ndim, u64 dims[], f32 data
-static int32_t save_arena(bdr_agent* a, int which, const std::string& path)
-{
-    std::vector<float> ref(ref_param_count(a->ar.A));
-    BDR_TRY(bdr_agent_get_params(a, which, ref.data(), ref.size()));
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) return fail(BDR_ERR_IO, "cannot open %s for writing", path.c_str());
-    const int A = a->ar.A;
-    const char* names[10] = {"c1.weight", "c1.bias", "c2.weight", "c2.bias", "c3.weight", "c3.bias", "l1.weight", "l1.bias", "l2.weight", "l2.bias"};
-    const std::vector<std::vector<uint64_t>> dims = {{32, 4, 8, 8}, {32}, {64, 32, 4, 4}, {64}, {64, 64, 3, 3}, {64},
-                                                     {512, 3136}, {512}, {(uint64_t)A, 512}, {(uint64_t)A}};
-    uint32_t ver = 1, cnt = 10;
-    fwrite("BDRP", 1, 4, f); fwrite(&ver, 4, 1, f); fwrite(&cnt, 4, 1, f);
-    size_t o = 0;
-    for (int t = 0; t < 10; ++t) {
-        uint32_t nl = (uint32_t)strlen(names[t]), nd = (uint32_t)dims[t].size();
-        fwrite(&nl, 4, 1, f); fwrite(names[t], 1, nl, f); fwrite(&nd, 4, 1, f);
-        size_t n = 1;
-        for (auto d : dims[t]) { fwrite(&d, 8, 1, f); n *= d; }
-        fwrite(ref.data() + o, 4, n, f);
-        o += n;
-    }
-    const bool ok = fflush(f) == 0;
-    fclose(f);
-    return ok ? BDR_OK : fail(BDR_ERR_IO, "write to %s failed", path.c_str());
-}
-
-static int32_t load_arena(bdr_agent* a, int which, const std::string& path)
-{
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return fail(BDR_ERR_IO, "cannot open %s", path.c_str());
-    std::vector<float> ref(ref_param_count(a->ar.A));
-    char magic[4]; uint32_t ver = 0, cnt = 0;
-    bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "BDRP", 4) == 0 && fread(&ver, 4, 1, f) == 1 && fread(&cnt, 4, 1, f) == 1 && cnt == 10;
-    size_t o = 0;
-    for (uint32_t t = 0; ok && t < cnt; ++t) {
-        uint32_t nl = 0, nd = 0; char name[64];
-        ok = fread(&nl, 4, 1, f) == 1 && nl < 64 && fread(name, 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 4;
-        size_t n = 1;
-        for (uint32_t d = 0; ok && d < nd; ++d) { uint64_t x = 0; ok = fread(&x, 8, 1, f) == 1; n *= x; }
-        ok = ok && o + n <= ref.size() && fread(ref.data() + o, 4, n, f) == n;
-        o += n;
-    }
-    fclose(f);
-    if (!ok || o != ref.size()) return fail(BDR_ERR_IO, "%s is not a matching parameter file", path.c_str());
-    return bdr_agent_set_params(a, which, ref.data(), ref.size());
-}
-
-int32_t bdr_agent_save_params(bdr_agent* a, const char* dir)
-{
-    BDR_REQUIRE(a && dir, "null argument");
-    // dqn/base.rs:348-356: qnet.pt.tch, qnet_tgt.pt.tch  (here: same stems, own container)
-    BDR_TRY(save_arena(a, 0, std::string(dir) + "/qnet.bdr"));
-    return save_arena(a, 1, std::string(dir) + "/qnet_tgt.bdr");
-}
-
-int32_t bdr_agent_load_params(bdr_agent* a, const char* dir)
-{
-    BDR_REQUIRE(a && dir, "null argument");
-    BDR_TRY(load_arena(a, 0, std::string(dir) + "/qnet.bdr"));
-    return load_arena(a, 1, std::string(dir) + "/qnet_tgt.bdr");
-}
-
-int32_t bdr_dqn_probe(bdr_agent* a, int32_t what, float* out, uint64_t n)
-{
-    BDR_REQUIRE(a && out, "null argument");
-    BDR_HIP(hipSetDevice(a->device));
+    DqnCnn* a = static_cast<DqnCnn*>(base);
     const float* src = nullptr;
     switch (what) {
         case 0: src = a->qv[0]; break;
@@ -1160,51 +974,6 @@ int32_t bdr_dqn_probe(bdr_agent* a, int32_t what, float* out, uint64_t n)
     }
     BDR_HIP(hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToHost, a->stream));
     BDR_HIP(hipStreamSynchronize(a->stream));
-    return BDR_OK;
-}
-
-int32_t bdr_agent_profile_enable(bdr_agent* a, int32_t on)
-{
-    BDR_REQUIRE(a, "null agent");
-    BDR_HIP(hipSetDevice(a->device));
-    BDR_HIP(hipStreamSynchronize(a->stream));
-    a->prof = on != 0;
-    a->slot_cursor = 0;
-    for (auto& s : a->slots) { s.ms = 0; s.count = 0; }
-    return BDR_OK;
-}
-
-int32_t bdr_agent_profile_read(bdr_agent* a, char* names_out, uint64_t names_cap, float* ms_out, uint64_t* count_inout)
-{
-    BDR_REQUIRE(a && count_inout, "null argument");
-    std::string names;
-    uint64_t k = 0;
-    for (auto& s : a->slots) {
-        if (k < *count_inout && ms_out) ms_out[k] = s.count ? (float)(s.ms / (double)s.count) : 0.f;
-        names += s.name; names += '\n';
-        ++k;
-    }
-    if (names_out && names_cap) { strncpy(names_out, names.c_str(), names_cap - 1); names_out[names_cap - 1] = 0; }
-    *count_inout = k;
-    return BDR_OK;
-}
-
-}  // extern "C"
-
-// used by comm.hip
-namespace bdr {
-float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* stream, int* device)
-{
-    if (n_floats) *n_floats = a->ar.total;
-    if (stream) *stream = a->stream;
-    if (device) *device = a->device;
-    return arena_ptr(a, which);
-}
-int32_t agent_scale(bdr_agent* a, float* p, float s)
-{
-    const size_t n4 = a->ar.total / 4;
-    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, p, n4, s);
-    BDR_HIP(hipGetLastError());
     return BDR_OK;
 }
 }  // namespace bdr

@@ -69,7 +69,7 @@ struct AFwd {
         const int tap = kt / TPT, c0 = (kt % TPT) * BK;
         const int kh = tap / G::KW, kw = tap % G::KW;
         const float* p = r.p + (kh * G::IW + kw) * G::CIN + c0 + q * 4;
-        v[0] = r.ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[0] = *reinterpret_cast<const f32x4*>(p);   // rows >= M alias row 0 (never stored / zero Y row)
     }
 };
 
@@ -96,8 +96,7 @@ struct AFwdU8 {
         static_assert(G::KW == 8 && G::KH == 8, "conv1 geometry");
         const int c = kt >> 1, kh = ((kt & 1) << 2) + q;
         const uint32_t* p = reinterpret_cast<const uint32_t*>(r.p + c * (G::IH * G::IW) + kh * G::IW);
-        uint32_t lo = 0, hi = 0;
-        if (r.ok) { lo = p[0]; hi = p[1]; }
+        const uint32_t lo = p[0], hi = p[1];         // rows >= M alias row 0
         v[0] = f32x4{(float)(lo & 255u), (float)((lo >> 8) & 255u), (float)((lo >> 16) & 255u), (float)(lo >> 24)};
         v[1] = f32x4{(float)(hi & 255u), (float)((hi >> 8) & 255u), (float)((hi >> 16) & 255u), (float)(hi >> 24)};
     }
@@ -125,9 +124,11 @@ struct ADxS1 {
         constexpr int TPT = G::COUT / BK;
         const int tap = kt / TPT, c0 = (kt % TPT) * BK;
         const int oh = r.ih - tap / G::KW, ow = r.iw - tap % G::KW;
-        const bool ok = r.ok && oh >= 0 && oh < G::OH && ow >= 0 && ow < G::OW;
-        const float* p = r.dy + ((size_t)(r.b * G::OH + oh) * G::OW + ow) * G::COUT + c0 + q * 4;
-        v[0] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ok = oh >= 0 && oh < G::OH && ow >= 0 && ow < G::OW;
+        const int ohc = min(max(oh, 0), G::OH - 1), owc = min(max(ow, 0), G::OW - 1);   // branch-free: clamp + select
+        const float* p = r.dy + ((size_t)(r.b * G::OH + ohc) * G::OW + owc) * G::COUT + c0 + q * 4;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 };
 
@@ -157,9 +158,29 @@ struct ADxS2 {
         constexpr int TPT = G::COUT / BK;
         const int tap = kt / TPT, c0 = (kt % TPT) * BK;
         const int oh = r.ihh - (tap >> 1), ow = r.iwh - (tap & 1);
-        const bool ok = r.ok && oh >= 0 && oh < G::OH && ow >= 0 && ow < G::OW;
-        const float* p = r.dy + ((size_t)(r.b * G::OH + oh) * G::OW + ow) * G::COUT + c0 + q * 4;
-        v[0] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ok = oh >= 0 && oh < G::OH && ow >= 0 && ow < G::OW;
+        const int ohc = min(max(oh, 0), G::OH - 1), owc = min(max(ow, 0), G::OW - 1);
+        const float* p = r.dy + ((size_t)(r.b * G::OH + ohc) * G::OW + owc) * G::COUT + c0 + q * 4;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// Dense row-major f32 matrix with a runtime leading dimension (MLP layers of the Mlp / SAC / IQN nets).
+struct DenseSrc { const float* p; int ld; };
+struct ADense {
+    static constexpr int VEC = 4;
+    struct Row { const float* p; bool ok; };
+    __device__ static Row row(DenseSrc s, int m, int M)
+    {
+        Row r;
+        r.ok = m < M;
+        r.p = s.p + (size_t)(r.ok ? m : 0) * s.ld;
+        return r;
+    }
+    __device__ static void load(const Row& r, int kt, int q, f32x4* v)
+    {
+        v[0] = *reinterpret_cast<const f32x4*>(r.p + kt * BK + q * 4);
     }
 };
 
@@ -167,9 +188,12 @@ struct ADxS2 {
 // The MFMA core shared by both kernels: one k-tile (32 deep) from LDS.
 //   As: [rows][LDA] f32, k contiguous.  Bs: [32][LDB] f32, n contiguous.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int TN, int LDB>
+// between(u) is called after the MFMAs of k-group u have been issued: the staging work of the next
+// tiles is sliced into those gaps so that it executes in the shadow of the (dependent, 64-cycle)
+// MFMAs instead of in front of them.
+template <int TM, int TN, int LDB, class F>
 __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const float* __restrict__ Bs, int arow0,
-                                           int bcol0, int lane, f32x16 (&acc)[TM][TN])
+                                           int bcol0, int lane, f32x16 (&acc)[TM][TN], F&& between)
 {
     const int i = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -189,6 +213,7 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn], acc[tm][tn], 0, 0, 0);
         }
+        between(u);
     }
 }
 
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / P::WN, wn = wave % P::WN;
-    constexpr int NT_N = P::N / BN;
+    const int NT_N = P::N(args) / BN;
     const int mt = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
     const int m0 = mt * BM, n0 = nt * BN;
     const int z = blockIdx.z, y = blockIdx.y;
@@ -240,38 +265,36 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
 
     f32x4 ra[A_PASSES][AV];
     f32x4 rb[B_VECS];
-    auto prefetch = [&](int kt) {
-#ifdef BDR_ABL_NOLOAD
-        if (kt > kt0) return;
-#endif
+    auto prefetch_a = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) A::load(rows[p], kt, a_q, ra[p]);
+    };
+    auto prefetch_b = [&](int kt) {
 #pragma unroll
         for (int v = 0; v < B_VECS; ++v) {
             const int e = tid + v * 256;
             if constexpr (!P::B_TR) {
                 const int kr = e / (BN / 4), n4 = e % (BN / 4);
-                rb[v] = *reinterpret_cast<const f32x4*>(w + (size_t)(kt * BK + kr) * P::N + n0 + n4 * 4);
+                rb[v] = *reinterpret_cast<const f32x4*>(w + (size_t)(kt * BK + kr) * P::N(args) + n0 + n4 * 4);
             } else {
                 // k-tile kt = (tap, c0); element (k'=c0+kq*4.., n') = w[(tap*NP + n0+n')*KP + c0 + kq*4]
-                constexpr int TPT = P::KP / BK;
+                const int TPT = P::KP(args) / BK;
                 const int tap = kt / TPT, c0 = (kt % TPT) * BK;
                 const int kq = e % 8, np = e / 8;
-                rb[v] = *reinterpret_cast<const f32x4*>(w + ((size_t)P::tap_index(y, tap) * P::N + n0 + np) * P::KP + c0 + kq * 4);
+                rb[v] = *reinterpret_cast<const f32x4*>(w + ((size_t)P::tap_index(y, tap) * P::N(args) + n0 + np) * P::KP(args) + c0 + kq * 4);
             }
         }
     };
-    auto commit = [&](int stage) {
-#ifdef BDR_ABL_NOCOMMIT
-        if (stage) return;
-#endif
+    auto commit_a = [&](int stage) {
         float* As = smem + stage * STAGE;
-        float* Bs = As + BM * LDA;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p)
 #pragma unroll
             for (int j = 0; j < AV; ++j)
                 *reinterpret_cast<f32x4*>(&As[(p * ROWS_PER_PASS + a_r) * LDA + a_q * A::VEC + j * 4]) = ra[p][j];
+    };
+    auto commit_b = [&](int stage) {
+        float* Bs = smem + stage * STAGE + BM * LDA;
 #pragma unroll
         for (int v = 0; v < B_VECS; ++v) {
             const int e = tid + v * 256;
@@ -294,18 +317,25 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
+    // Software pipeline, branch-free body (tile indices are clamped, so the tail re-stages the last
+    // tile into the idle stage: harmless).  Registers hold tile kt+1 while stage `cur` holds tile kt.
     if (kt0 < kt1) {
-        prefetch(kt0);
-        commit(0);
-        if (kt0 + 1 < kt1) prefetch(kt0 + 1);
+        prefetch_a(kt0); prefetch_b(kt0);
+        commit_a(0); commit_b(0);
+        const int k1 = min(kt0 + 1, kt1 - 1);
+        prefetch_a(k1); prefetch_b(k1);
     }
     __syncthreads();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) commit(cur ^ 1);          // regs hold tile kt+1
-        if (kt + 2 < kt1) prefetch(kt + 2);         // in flight during the MFMAs below
         const float* As = smem + cur * STAGE;
-        mfma_ktile<P::TM, P::TN, LDB>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc);
+        const int k2 = min(kt + 2, kt1 - 1);
+        mfma_ktile<P::TM, P::TN, LDB>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc, [&](int u) {
+            if (u == 0) commit_a(cur ^ 1);          // tile kt+1 -> idle stage, in the shadow of the MFMAs
+            else if (u == 1) commit_b(cur ^ 1);
+            else if (u == 2) prefetch_a(k2);        // tile kt+2 global loads
+            else prefetch_b(k2);
+        });
         __syncthreads();
         cur ^= 1;
     }
@@ -326,7 +356,8 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
 // ------------------------------------------------------------------------------------------------
 // k_igemm_red: G[k][n] = sum_{m in chunk} A(m,k) * Y(m,n).
 //   P::A, P::WM, P::WN, P::TM, P::TN; KO_T = WM*TM*32 output rows, N_T = WN*TN*32 columns.
-//   P::K (total output rows), P::N (columns, == N_T * n-tiles)
+//   P::K(args) (total output rows), P::N(args) (columns, == N_T * n-tiles); compile-time
+//   constants for the conv policies, runtime (padded to 32/64) for the dense policies
 //   hooks: a_src(args), y_src(args), M(args), part(args, chunk) -> float* partial [K*N + N]
 // grid: 1-D (see the XCD-aware map in the kernel).  The bias gradient (column sums of Y) is accumulated
 // by the ko-tile-0 workgroups from the very Y tiles they stage.
@@ -356,8 +387,8 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
     // has its own L2: all output tiles of one row chunk read the same A/Y rows, so they are given
     // to the same XCD (chunk c lives on XCD c % 8) and each XCD's L2 only ever sees 1/8 of the rows.
     // grid: 1-D, TILES * nchunks workgroups with nchunks % 8 == 0 (else the identity map).
-    constexpr int NT_N = P::N / N_T;
-    constexpr int TILES = (P::K / KO_T) * NT_N;
+    const int NT_N = P::N(args) / N_T;
+    const int TILES = (P::K(args) / KO_T) * NT_N;
     const int nchunks = gridDim.x / TILES;
     int tile, chunk;
     if (nchunks % 8 == 0) {
@@ -385,10 +416,7 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
     for (int v = 0; v < Y_VECS; ++v) bsum[v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // pass p covers (row, ksub) pairs: idx = p*ROWS_PER_PASS + a_r; row = idx % 32, ksub = idx / 32
-    auto prefetch = [&](int mt) {
-#ifdef BDR_ABL_NOLOAD
-        if (mt > mt0) return;
-#endif
+    auto prefetch_a = [&](int mt) {
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
             const int idx = p * ROWS_PER_PASS + a_r;
@@ -396,21 +424,19 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
             typename A::Row r = A::row(P::a_src(args), mt * 32 + row, M);
             A::load(r, ko0 / BK + ksub, a_q, ra[p]);
         }
+    };
+    auto prefetch_y = [&](int mt) {   // rows >= M contribute zero (select, no branch)
 #pragma unroll
         for (int v = 0; v < Y_VECS; ++v) {
             const int e = tid + v * 256;
             const int row = e / (N_T / 4), n4 = e % (N_T / 4);
             const int m = mt * 32 + row;
-            ry[v] = m < M ? *reinterpret_cast<const f32x4*>(ysrc + (size_t)m * P::N + n0 + n4 * 4)
-                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ysrc + (size_t)min(m, M - 1) * P::N(args) + n0 + n4 * 4);
+            ry[v] = m < M ? t : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto commit = [&](int stage) {
-#ifdef BDR_ABL_NOCOMMIT
-        if (stage) return;
-#endif
+    auto commit_a = [&](int stage) {
         float* As = smem + stage * STAGE;
-        float* Ys = As + 32 * LDAR;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
             const int idx = p * ROWS_PER_PASS + a_r;
@@ -419,12 +445,15 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
             for (int j = 0; j < AV; ++j)
                 *reinterpret_cast<f32x4*>(&As[row * LDAR + ksub * BK + a_q * A::VEC + j * 4]) = ra[p][j];
         }
+    };
+    auto commit_y = [&](int stage, bool count) {
+        float* Ys = smem + stage * STAGE + 32 * LDAR;
 #pragma unroll
         for (int v = 0; v < Y_VECS; ++v) {
             const int e = tid + v * 256;
             const int row = e / (N_T / 4), n4 = e % (N_T / 4);
             *reinterpret_cast<f32x4*>(&Ys[row * LDY + n4 * 4]) = ry[v];
-            bsum[v] += ry[v];
+            if (count) bsum[v] += ry[v];
         }
     };
 
@@ -437,18 +466,21 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int i = lane & 31, h = lane >> 5;
+    // branch-free software pipeline (see k_igemm); the tail re-stages the last tile into the idle
+    // stage, which must not be counted twice in the bias sums
     if (mt0 < mt1) {
-        prefetch(mt0);
-        commit(0);
-        if (mt0 + 1 < mt1) prefetch(mt0 + 1);
+        prefetch_a(mt0); prefetch_y(mt0);
+        commit_a(0); commit_y(0, true);
+        const int m1 = min(mt0 + 1, mt1 - 1);
+        prefetch_a(m1); prefetch_y(m1);
     }
     __syncthreads();
     int cur = 0;
     for (int mt = mt0; mt < mt1; ++mt) {
-        if (mt + 1 < mt1) commit(cur ^ 1);
-        if (mt + 2 < mt1) prefetch(mt + 2);
         const float* As = smem + cur * STAGE;
         const float* Ys = As + 32 * LDAR;
+        const int m2 = min(mt + 2, mt1 - 1);
+        const bool fresh = mt + 1 < mt1;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int red = 2 * t + h;
@@ -462,6 +494,10 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
 #pragma unroll
                 for (int tn = 0; tn < P::TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            if (t == 1) commit_a(cur ^ 1);               // staging sliced into the MFMA shadows
+            else if (t == 5) commit_y(cur ^ 1, fresh);
+            else if (t == 8) prefetch_a(m2);
+            else if (t == 11) prefetch_y(m2);
         }
         __syncthreads();
         cur ^= 1;
@@ -476,7 +512,7 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
             for (int r = 0; r < 16; ++r) {
                 const int ko = ko0 + (wm * P::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int n = n0 + (wn * P::TN + tn) * 32 + i;
-                part[(size_t)ko * P::N + n] = acc[tm][tn][r];
+                part[(size_t)ko * P::N(args) + n] = acc[tm][tn][r];
             }
 
     // bias gradient: column sums of the Y rows this chunk staged (ko-tile 0 only)
@@ -493,7 +529,7 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
             float s = 0.f;
 #pragma unroll 8
             for (int row = 0; row < 32; ++row) s += red[row * N_T + tid];
-            part[(size_t)P::K * P::N + n0 + tid] = s;
+            part[(size_t)P::K(args) * P::N(args) + n0 + tid] = s;
         }
     }
 }

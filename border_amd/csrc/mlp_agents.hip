@@ -1,0 +1,373 @@
+// Mlp-based agents on MI355X: Dqn<E, Mlp, R> (CartPole-shaped, BASELINE config 1).
+// Reference: border-tch-agent/src/dqn/base.rs:60-200 (update_critic / opt_), mlp/base.rs:13-41.
+// Same FP32-MFMA kernels as the CNN path, driven with runtime (64-padded) dimensions (dense.hpp).
+#include <algorithm>
+#include <cstdlib>
+
+#include "dense.hpp"
+
+using namespace bdr;
+
+namespace {
+
+constexpr int MAXZ = 3;
+
+// TD on dense Q rows [B][ld] (dqn/base.rs:71-74, :91-105, :146-152): one wave per row.  Writes
+// dL/dQ as a dense row (zero except the taken action) so the generic dense backward can follow.
+struct TdDenseArgs {
+    const float* q_on; const float* q_tg; const float* q_on_next; int ld;
+    const uint8_t* act; int act_bytes;
+    const float* reward; const int8_t* term;
+    float* dq_rows;   // [B][ld]
+    float* pred; float* tgt; float* loss_row;
+    int B, A; float gamma; int loss_kind;
+};
+__global__ __launch_bounds__(256) void k_td_dense(TdDenseArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= a.B) return;
+    const long long act = *reinterpret_cast<const long long*>(a.act + (size_t)row * a.act_bytes);
+    const float* sel = a.q_on_next ? a.q_on_next : a.q_tg;
+    // first-max argmax over the A real actions (A <= 64)
+    float v = lane < a.A ? sel[(size_t)row * a.ld + lane] : -INFINITY;
+    int idx = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    const float qn = a.q_tg[(size_t)row * a.ld + idx];
+    const float pred = a.q_on[(size_t)row * a.ld + act];
+    const float tgt = a.reward[row] + ((float)(1 - (int)a.term[row]) * a.gamma) * qn;   // dqn/base.rs:104
+    const float d = pred - tgt;
+    float lossb, dl;
+    if (a.loss_kind == 1) {
+        const float z = fabsf(d);
+        lossb = z < 1.f ? 0.5f * z * z : z - 0.5f;
+        dl = z < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+    } else {
+        lossb = d * d;
+        dl = 2.f * d;
+    }
+    const float dq = dl / (float)a.B;
+    if (lane == 0) { a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb; }
+    for (int c = lane; c < a.ld; c += 64) a.dq_rows[(size_t)row * a.ld + c] = c == act ? dq : 0.f;
+}
+
+// loss = mean(loss_row): fixed-order tree
+__global__ __launch_bounds__(256) void k_mean_rows(const float* __restrict__ x, int n, float* __restrict__ out, float scale)
+{
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n; b += 256) s += x[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+}  // namespace
+
+// ================================================================================================
+struct DqnMlp : bdr_agent {
+    bdr_dqn_config cfg;
+    MlpLayout net;
+    float *q = nullptr, *q_tgt = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
+    int B = 0;
+    float* x_in[MAXZ] = {nullptr};                 // packed inputs [B][Kp0]
+    std::vector<float*> acts[MAXZ];                // per layer [B][Np]
+    std::vector<float*> dys;                       // gradient w.r.t. each layer's (pre-activation) output
+    float *pred = nullptr, *tgt = nullptr, *loss_row = nullptr, *loss = nullptr;
+    // update_on_batch staging
+    uint8_t *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr; float* u_rew = nullptr; int8_t* u_term = nullptr;
+    uint64_t u_cap = 0;
+    const float* last_reward = nullptr; int last_B = 0;
+    uint64_t adam_step = 0, soft_update_counter = 0;
+
+    ~DqnMlp() override
+    {
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(stream);
+        free_batch();
+        (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v); (void)hipFree(loss);
+        (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
+    }
+    void free_batch()
+    {
+        for (int z = 0; z < MAXZ; ++z) {
+            (void)hipFree(x_in[z]); x_in[z] = nullptr;
+            for (auto p : acts[z]) (void)hipFree(p);
+            acts[z].clear();
+        }
+        for (auto p : dys) (void)hipFree(p);
+        dys.clear();
+        (void)hipFree(pred); (void)hipFree(tgt); (void)hipFree(loss_row);
+        pred = tgt = loss_row = nullptr;
+    }
+    int32_t ensure_batch(int Bn)
+    {
+        if (Bn <= B) return BDR_OK;
+        BDR_HIP(hipStreamSynchronize(stream));
+        free_batch();
+        for (int z = 0; z < MAXZ; ++z) {
+            BDR_TRY(alloc_f(&x_in[z], (size_t)Bn * net.L[0].Kp));
+            BDR_HIP(hipMemsetAsync(x_in[z], 0, (size_t)Bn * net.L[0].Kp * 4, stream));
+            for (const auto& l : net.L) {
+                float* p = nullptr;
+                BDR_TRY(alloc_f(&p, (size_t)Bn * l.Np));
+                acts[z].push_back(p);
+            }
+        }
+        for (const auto& l : net.L) {
+            float* p = nullptr;
+            BDR_TRY(alloc_f(&p, (size_t)Bn * l.Np));
+            dys.push_back(p);
+        }
+        BDR_TRY(alloc_f(&pred, Bn)); BDR_TRY(alloc_f(&tgt, Bn)); BDR_TRY(alloc_f(&loss_row, Bn));
+        B = Bn;
+        return BDR_OK;
+    }
+
+    int32_t forward(int z, const float* params, const uint8_t* obs_rows, int Bn)
+    {
+        bdr_agent* a = this;
+        // pack [B][in_dim] f32 rows into the padded input matrix
+        BDR_TRY(pack_rows(stream, reinterpret_cast<const float*>(obs_rows), net.in_dim, net.in_dim, x_in[z], net.L[0].Kp, 0, Bn));
+        DenseSrc x{x_in[z], net.L[0].Kp};
+        for (size_t i = 0; i < net.L.size(); ++i) {
+            Bracket br(a, "mlp_fwd");
+            BDR_TRY(dense_forward(a, stream, net.L[i], params, x, acts[z][i], Bn));
+            x = DenseSrc{acts[z][i], net.L[i].Np};
+        }
+        return BDR_OK;
+    }
+
+    // Dqn::update_critic (dqn/base.rs:60-160) on a device-resident batch
+    int32_t update_critic(int Bn, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
+                          const float* reward, const int8_t* term)
+    {
+        bdr_agent* a = this;
+        BDR_TRY(ensure_batch(Bn));
+        last_reward = reward; last_B = Bn;
+        const int L = (int)net.L.size();
+        BDR_TRY(forward(0, q, obs, Bn));
+        BDR_TRY(forward(1, q_tgt, next_obs, Bn));
+        if (cfg.double_dqn) BDR_TRY(forward(2, q, next_obs, Bn));
+        TdDenseArgs t{};
+        t.q_on = acts[0][L - 1]; t.q_tg = acts[1][L - 1]; t.q_on_next = cfg.double_dqn ? acts[2][L - 1] : nullptr;
+        t.ld = net.L[L - 1].Np; t.act = act; t.act_bytes = act_bytes; t.reward = reward; t.term = term;
+        t.dq_rows = dys[L - 1]; t.pred = pred; t.tgt = tgt; t.loss_row = loss_row;
+        t.B = Bn; t.A = net.out_dim; t.gamma = (float)cfg.discount_factor; t.loss_kind = cfg.critic_loss;
+        { Bracket br(a, "td_dense"); LAUNCH(k_td_dense, dim3((Bn + 3) / 4), t); }
+        {
+            Bracket br(a, "loss_mean");
+            hipLaunchKernelGGL(k_mean_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, loss, 1.0f / (float)Bn);
+            BDR_HIP(hipGetLastError());
+        }
+        for (int i = L - 1; i >= 0; --i) {
+            DenseSrc x = i == 0 ? DenseSrc{x_in[0], net.L[0].Kp} : DenseSrc{acts[0][i - 1], net.L[i - 1].Np};
+            { Bracket br(a, "mlp_dw"); BDR_TRY(dense_dw(stream, net.L[i], grad, x, dys[i], Bn)); }
+            if (i > 0) { Bracket br(a, "mlp_dx"); BDR_TRY(dense_dx(stream, net.L[i], q, dys[i], dys[i - 1], acts[0][i - 1], Bn)); }
+        }
+        adam_step += 1;
+        const AdamScalars s = adam_scalars_for(cfg.opt_kind == BDR_OPT_ADAMW, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, adam_step);
+        { Bracket br(a, "adam"); BDR_TRY(launch_adam(stream, q, grad, m, v, net.total, s)); }
+        return BDR_OK;
+    }
+
+    int32_t after_updates()   // dqn/base.rs:190-198
+    {
+        soft_update_counter += 1;
+        if (soft_update_counter == cfg.soft_update_interval) {
+            soft_update_counter = 0;
+            Bracket br(this, "track");
+            BDR_TRY(launch_track(stream, q_tgt, q, net.total, cfg.tau));
+        }
+        n_opts += 1;
+        return BDR_OK;
+    }
+
+    const char* kind() const override { return "dqn_mlp"; }
+    int32_t opt(bdr_replay* r) override
+    {
+        BDR_REQUIRE(r->obs_bytes == (uint64_t)net.in_dim * 4, "replay obs rows (%llu B) do not match the Mlp input (%d f32)",
+                    (unsigned long long)r->obs_bytes, net.in_dim);
+        BDR_REQUIRE(r->act_bytes >= 8, "discrete actions are stored as i64");
+        BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
+        for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
+            { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, cfg.batch_size, stream)); }
+            BDR_TRY(update_critic((int)cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term));
+        }
+        return after_updates();
+    }
+    int32_t record(float* out, int cap, int* n) override
+    {
+        float l = 0;
+        BDR_HIP(hipMemcpyAsync(&l, loss, 4, hipMemcpyDeviceToHost, stream));
+        BDR_HIP(hipStreamSynchronize(stream));
+        out[0] = l; *n = 1;
+        if (cfg.record_verbose_level >= 2 && cap >= 5) {
+            std::vector<float> p(last_B), t(last_B), rw(last_B);
+            BDR_HIP(hipMemcpy(p.data(), pred, last_B * 4, hipMemcpyDeviceToHost));
+            BDR_HIP(hipMemcpy(t.data(), tgt, last_B * 4, hipMemcpyDeviceToHost));
+            BDR_HIP(hipMemcpy(rw.data(), last_reward, last_B * 4, hipMemcpyDeviceToHost));
+            double sp = 0, st = 0, sr = 0;
+            for (int i = 0; i < last_B; ++i) { sp += p[i]; st += t[i]; sr += rw[i]; }
+            out[1] = (float)(sp / last_B); out[2] = (float)(sr / last_B); out[3] = (float)(st / last_B);
+            out[4] = (float)((st - sp) / last_B);
+            *n = 5;
+        }
+        return BDR_OK;
+    }
+    float* arena_ptr(int which)
+    {
+        switch (which) { case 0: return q; case 1: return q_tgt; case 2: return m; case 3: return v; case 4: return grad; default: return nullptr; }
+    }
+    uint64_t param_count(int which) override { return which == -1 ? (uint64_t)net.out_dim : net.ref_total; }
+    int32_t get_params(int which, float* out, uint64_t n) override
+    {
+        float* src = arena_ptr(which);
+        BDR_REQUIRE(src, "which must be 0..4");
+        BDR_REQUIRE(n == net.ref_total, "parameter count mismatch (%llu vs %llu)", (unsigned long long)n, (unsigned long long)net.ref_total);
+        std::vector<float> in(net.total);
+        BDR_HIP(hipMemcpyAsync(in.data(), src, net.total * 4, hipMemcpyDeviceToHost, stream));
+        BDR_HIP(hipStreamSynchronize(stream));
+        mlp_to_reference(net, 0, in.data(), out);
+        return BDR_OK;
+    }
+    int32_t set_params(int which, const float* inp, uint64_t n) override
+    {
+        float* dst = arena_ptr(which);
+        BDR_REQUIRE(dst, "which must be 0..4");
+        BDR_REQUIRE(n == net.ref_total, "parameter count mismatch");
+        std::vector<float> in(net.total, 0.f);
+        mlp_to_internal(net, 0, inp, in.data());
+        BDR_HIP(hipMemcpyAsync(dst, in.data(), net.total * 4, hipMemcpyHostToDevice, stream));
+        BDR_HIP(hipStreamSynchronize(stream));
+        return BDR_OK;
+    }
+    float* arena(int which, size_t* n) override { if (n) *n = net.total; return arena_ptr(which); }
+    std::vector<NamedTensor> meta() const
+    {
+        std::vector<NamedTensor> mt;
+        for (size_t i = 0; i < net.L.size(); ++i) {
+            mt.push_back({"mlp.ln" + std::to_string(i) + ".weight", {(uint64_t)net.L[i].out, (uint64_t)net.L[i].in}});
+            mt.push_back({"mlp.ln" + std::to_string(i) + ".bias", {(uint64_t)net.L[i].out}});
+        }
+        return mt;
+    }
+    int32_t save(const char* dir) override
+    {
+        std::vector<float> ref(net.ref_total);
+        BDR_TRY(get_params(0, ref.data(), ref.size()));
+        BDR_TRY(save_named(std::string(dir) + "/qnet.bdr", meta(), ref.data(), ref.size()));
+        BDR_TRY(get_params(1, ref.data(), ref.size()));
+        return save_named(std::string(dir) + "/qnet_tgt.bdr", meta(), ref.data(), ref.size());
+    }
+    int32_t load(const char* dir) override
+    {
+        std::vector<float> ref(net.ref_total);
+        BDR_TRY(load_named(std::string(dir) + "/qnet.bdr", meta(), ref.data(), ref.size()));
+        BDR_TRY(set_params(0, ref.data(), ref.size()));
+        BDR_TRY(load_named(std::string(dir) + "/qnet_tgt.bdr", meta(), ref.data(), ref.size()));
+        return set_params(1, ref.data(), ref.size());
+    }
+};
+
+namespace bdr {
+
+int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
+{
+    BDR_REQUIRE(cfg->net.in_dim >= 1 && cfg->net.n_units >= 0 && cfg->net.n_units <= BDR_MAX_UNITS, "bad Mlp config");
+    BDR_REQUIRE(cfg->net.out_dim >= 1 && cfg->net.out_dim <= 64, "out_dim must be in [1,64]");
+    BDR_REQUIRE(!cfg->net.activation_out, "a DQN Q-network has no output activation");
+    DqnMlp* a = new DqnMlp();
+    a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
+    a->net = make_mlp(cfg->net.in_dim, cfg->net.units, cfg->net.n_units, cfg->net.out_dim, false);
+    BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
+    for (auto p : arenas) {
+        BDR_TRY(alloc_f(p, a->net.total));
+        BDR_HIP(hipMemsetAsync(*p, 0, a->net.total * 4, a->stream));
+    }
+    BDR_TRY(alloc_f(&a->loss, 4));
+    std::vector<float> ref(a->net.ref_total);
+    mlp_init_reference(a->net, cfg->param_seed, ref.data());
+    BDR_TRY(a->set_params(0, ref.data(), ref.size()));
+    BDR_TRY(a->set_params(1, ref.data(), ref.size()));   // DqnModel::clone
+    BDR_TRY(a->ensure_batch((int)cfg->batch_size));
+    *out = a;
+    return BDR_OK;
+}
+
+int32_t dqn_mlp_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
+                                const float* reward, const int8_t* term)
+{
+    DqnMlp* a = static_cast<DqnMlp*>(base);
+    const size_t ob = (size_t)a->net.in_dim * 4;
+    if (n > a->u_cap) {
+        BDR_HIP(hipStreamSynchronize(a->stream));
+        (void)hipFree(a->u_obs); (void)hipFree(a->u_next); (void)hipFree(a->u_act); (void)hipFree(a->u_rew); (void)hipFree(a->u_term);
+        BDR_HIP(hipMalloc((void**)&a->u_obs, n * ob)); BDR_HIP(hipMalloc((void**)&a->u_next, n * ob));
+        BDR_HIP(hipMalloc((void**)&a->u_act, n * 8)); BDR_HIP(hipMalloc((void**)&a->u_rew, n * 4));
+        BDR_HIP(hipMalloc((void**)&a->u_term, round_up(n, 16)));
+        a->u_cap = n;
+    }
+    BDR_HIP(hipMemcpyAsync(a->u_obs, obs, n * ob, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->u_next, next_obs, n * ob, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->u_act, act, n * 8, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->u_rew, reward, n * 4, hipMemcpyHostToDevice, a->stream));
+    BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, a->stream));
+    BDR_TRY(a->update_critic((int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term));
+    BDR_TRY(a->after_updates());
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    return BDR_OK;
+}
+
+int32_t dqn_mlp_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_out)
+{
+    DqnMlp* a = static_cast<DqnMlp*>(base);
+    BDR_TRY(a->ensure_batch((int)n));
+    const size_t ob = (size_t)a->net.in_dim * 4;
+    uint8_t* d = nullptr;
+    BDR_HIP(hipMalloc((void**)&d, n * ob));
+    BDR_HIP(hipMemcpyAsync(d, obs, n * ob, hipMemcpyHostToDevice, a->stream));
+    int32_t st = a->forward(0, a->q, d, (int)n);
+    const int L = (int)a->net.L.size(), ld = a->net.L[L - 1].Np, A = a->net.out_dim;
+    std::vector<float> tmp(n * ld);
+    if (st == BDR_OK) {
+        hipError_t e = hipMemcpyAsync(tmp.data(), a->acts[0][L - 1], tmp.size() * 4, hipMemcpyDeviceToHost, a->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+        if (e != hipSuccess) st = fail(BDR_ERR_HIP, "qvalues copy failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    a->slot_cursor = 0;
+    BDR_TRY(st);
+    for (uint64_t i = 0; i < n; ++i) for (int k = 0; k < A; ++k) q_out[i * A + k] = tmp[i * ld + k];
+    return BDR_OK;
+}
+
+int32_t dqn_mlp_probe(bdr_agent* base, int32_t what, float* out, uint64_t n)
+{
+    DqnMlp* a = static_cast<DqnMlp*>(base);
+    const int L = (int)a->net.L.size(), ld = a->net.L[L - 1].Np, A = a->net.out_dim;
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    if (what == 0 || what == 1) {   // [B][A] from the padded rows
+        const uint64_t rows = n / A;
+        std::vector<float> tmp(rows * ld);
+        BDR_HIP(hipMemcpy(tmp.data(), a->acts[what][L - 1], tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < rows; ++i) for (int k = 0; k < A; ++k) out[i * A + k] = tmp[i * ld + k];
+        return BDR_OK;
+    }
+    const float* src = what == 2 ? a->pred : what == 3 ? a->tgt : what == 4 ? a->loss : nullptr;
+    BDR_REQUIRE(src, "unknown probe %d", what);
+    BDR_HIP(hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+    return BDR_OK;
+}
+
+}  // namespace bdr

@@ -182,6 +182,11 @@ typedef struct {
 } bdr_dqn_record;
 BDR_API int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* buffer, bdr_dqn_record* rec);
 
+/* Agent::opt_with_record for any agent kind: the Record scalars in the agent's documented order
+ * (DQN: loss[, pred_mean, reward_mean, tgt_mean, tgt_minus_pred_mean]; IQN: loss_critic;
+ * SAC: loss_critic, loss_actor, ent_coef).  Synchronises. */
+BDR_API int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* buffer, float* out, int32_t cap, int32_t* n_out);
+
 /* One update_critic on a caller-supplied host minibatch (parity tests: "fixed minibatch").
  * act: int64 [n]; obs/next_obs rows as in the replay buffer. */
 BDR_API int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act,
@@ -203,6 +208,7 @@ BDR_API int32_t bdr_agent_n_opts(const bdr_agent* a, uint64_t* n);
  * reference's variable order and layouts (c1.weight OIHW, c1.bias, ... l2.bias / mlp.ln{i}.*).
  * which: 0 = qnet, 1 = qnet_tgt, 2 = Adam exp_avg, 3 = Adam exp_avg_sq, 4 = last gradient. */
 BDR_API int32_t bdr_agent_param_count(const bdr_agent* a, uint64_t* n);
+BDR_API int32_t bdr_agent_param_count_of(bdr_agent* a, int32_t which, uint64_t* n); /* per-model counts (SAC) */
 BDR_API int32_t bdr_agent_get_params(bdr_agent* a, int32_t which, float* out, uint64_t n);
 BDR_API int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* in, uint64_t n);
 

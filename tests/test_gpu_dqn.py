@@ -202,3 +202,74 @@ def test_rccl_comm_single_rank(B):
     assert (a.get_params("qnet") == p).all()
     B._lib.check(L.bdr_comm_destroy(h))
     a.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# Dqn<E, Mlp, R> -- BASELINE config 1 (CartPole-shaped: MLP[64,64], replay 10k, batch 32)
+def make_mlp_agent(B, in_dim=4, units=(64, 64), A=2, **kw):
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.MlpConfig(in_dim=in_dim, units=tuple(units), out_dim=A),
+                                                    opt_config=B.OptimizerConfig.Adam(kw.pop("lr", 1e-3))),
+                      device=0, **kw)
+    return B.Dqn.build(cfg)
+
+
+def _cart(s):
+    rng = np.random.default_rng(300 + s)
+    obs = rng.standard_normal((32, 4)).astype(np.float32)
+    nobs = rng.standard_normal((32, 4)).astype(np.float32)
+    act = rng.integers(0, 2, 32)
+    return obs, act, nobs, np.ones(32, np.float32), (rng.random(32) < 0.1).astype(np.int8)
+
+
+def test_mlp_golden_cartpole(B, golden_dir):
+    """5 opt steps of the CartPole-shaped DQN against the committed PyTorch goldens."""
+    from oracle import torch_ref as T
+    g = np.load(os.path.join(golden_dir, "dqn_mlp_cartpole.npz"))
+    shapes = T.mlp_shapes(4, [64, 64], 2)
+    a = make_mlp_agent(B, batch_size=32, lr=1e-3, critic_loss="Mse", tau=0.01, soft_update_interval=1)
+    p0 = T.init_params(shapes, 3)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    assert (a.get_params("qnet") == p0).all() and a.param_count() == 4610
+    for s in range(5):
+        rec = a.update_on_batch(*_cart(s))
+        assert rel(a.probe("q_pred_all", 64), g[f"s{s}_q_pred_all"].ravel()) < QTOL, s
+        assert rel(a.probe("q_next_all", 64), g[f"s{s}_q_next_all"].ravel()) < QTOL, s
+        assert rel(a.probe("tgt", 32), g[f"s{s}_tgt"]) < QTOL
+        assert abs(rec["loss"] - g[f"s{s}_loss"]) <= QTOL * abs(g[f"s{s}_loss"]) + 1e-9
+        assert_grads_close(a.get_params("grad"), g[f"s{s}_grads_sample"], shapes)   # stride 1: full vectors
+        d = np.abs(a.get_params("qnet").astype(np.float64) - g[f"s{s}_params_sample"])
+        assert d.max() < 0.05 * 1e-3, (s, d.max())
+        assert rel(a.get_params("qnet_tgt"), g[f"s{s}_tgt_params_sample"]) < 1e-5
+    a.close()
+
+
+def test_mlp_opt_over_replay(B):
+    """Agent::opt over the HBM ring for the Mlp agent == oracle replay + oracle update (CartPole sizes)."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    rng = np.random.default_rng(5)
+    cap, Bsz = 10000, 32
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (4,), np.float32)
+    oref = O.Replay(cap, 42, 16, 8)
+    n = 500
+    tr = (rng.standard_normal((n, 4)).astype(np.float32), rng.integers(0, 2, (n, 1)).astype(np.int64),
+          rng.standard_normal((n, 4)).astype(np.float32), np.ones(n, np.float32), (rng.random(n) < .1).astype(np.int8),
+          np.zeros(n, np.int8))
+    rb.push(*tr); oref.push(*tr)
+    shapes = T.mlp_shapes(4, [64, 64], 2)
+    p0 = T.init_params(shapes, 11)
+    a = make_mlp_agent(B, batch_size=Bsz, lr=1e-3, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, double_dqn=True)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    ref = O.DqnOracle(O.mlp_cfg(4, [64, 64], 2), p0, lr=1e-3, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1,
+                      double_dqn=True)
+    for step in range(4):
+        rec = a.opt_with_record(rb)
+        b = oref.batch(Bsz)
+        r = ref.update(b["obs"].view(np.float32).reshape(Bsz, 4), b["act"].view(np.int64).ravel(),
+                       b["next_obs"].view(np.float32).reshape(Bsz, 4), b["reward"], b["is_terminated"], probe=True)
+        assert rel(a.probe("q_pred_all", Bsz * 2), r["q_pred_all"].ravel()) < 3e-4, step
+        assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-7
+    assert rel(a.get_params("qnet_tgt"), ref.q_tgt) < 1e-3
+    q = a.qvalues(tr[0][:7])
+    assert rel(q, O.net_forward(O.mlp_cfg(4, [64, 64], 2), a.get_params("qnet"), tr[0][:7])) < QTOL
+    a.close(); rb.close()

@@ -668,3 +668,280 @@ ORC_API int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* ========================================================================= */
+/* SAC -- border-tch-agent/src/sac/base.rs:73-198 (action_logp, qvals_min,     */
+/* update_actor, update_critic, soft_update, opt_), mlp/mlp2.rs:23-50 (Mlp2:   */
+/* trunk "al{i}" + heads "ml"/"sl", forward returns exp(head2)), mlp/base.rs:  */
+/* 83-107 (critic = Mlp on cat(obs,act)), sac/ent_coef.rs:27-75.               */
+/* The N(0,1) draws of action_logp (sac/base.rs:76, torch global CPU RNG) are  */
+/* inputs here so that a fixed minibatch is reproducible.                      */
+/* Quirks kept: sigma = exp(clip(exp(head2), min_lstd, max_lstd)); log-prob    */
+/* omits -sum(ln sigma); is_truncated ignored; actor is updated BEFORE the     */
+/* critics and the critic target uses the updated actor; track every update.   */
+/* ========================================================================= */
+typedef struct {
+    int32_t obs_dim, act_dim;
+    int32_t n_pi_units, pi_units[ORC_MAX_UNITS];
+    int32_t n_q_units, q_units[ORC_MAX_UNITS];
+    int32_t n_critics;
+    double gamma, tau, epsilon, min_lstd, max_lstd, reward_scale;
+    int32_t critic_loss;       /* 0 Mse, 1 SmoothL1 */
+    int32_t auto_alpha;        /* EntCoefMode::Auto */
+    double target_entropy;
+} orc_sac_cfg;
+
+typedef struct { int n; int in[ORC_MAX_UNITS + 2], out[ORC_MAX_UNITS + 2], relu[ORC_MAX_UNITS + 2]; size_t off[ORC_MAX_UNITS + 2]; size_t total; } sac_mlp;
+
+static sac_mlp sac_mlp_make(int in_dim, const int32_t* units, int n_units, int out_dim, int with_out)
+{
+    sac_mlp m; memset(&m, 0, sizeof m);
+    int in = in_dim; size_t o = 0;
+    for (int i = 0; i < n_units + (with_out ? 1 : 0); ++i) {
+        int out = i < n_units ? units[i] : out_dim;
+        m.in[i] = in; m.out[i] = out; m.relu[i] = i < n_units; m.off[i] = o;
+        o += (size_t)out * in + out; in = out; m.n++;
+    }
+    m.total = o;
+    return m;
+}
+
+/* acts[i] = output of layer i (post-relu where applicable); x = input */
+static void sac_mlp_fwd(const sac_mlp* m, const float* p, const float* x, int B, float** acts)
+{
+    const float* in = x;
+    for (int i = 0; i < m->n; ++i) {
+        linear_fwd(in, p + m->off[i], p + m->off[i] + (size_t)m->out[i] * m->in[i], acts[i], B, m->in[i], m->out[i], m->relu[i]);
+        in = acts[i];
+    }
+}
+
+/* dout: grad wrt the last layer's output (post-activation if relu).  g may be NULL (no param
+ * grads wanted); dx_in may be NULL. */
+static void sac_mlp_bwd(const sac_mlp* m, const float* p, const float* x, int B, float** acts, const float* dout,
+                        float* g, float* dx_in)
+{
+    float* d = (float*)malloc(sizeof(float) * (size_t)B * m->out[m->n - 1]);
+    memcpy(d, dout, sizeof(float) * (size_t)B * m->out[m->n - 1]);
+    for (int i = m->n - 1; i >= 0; --i) {
+        if (m->relu[i]) relu_bwd(acts[i], d, (size_t)B * m->out[i]);
+        const float* in = i == 0 ? x : acts[i - 1];
+        float* dx = (i == 0 && !dx_in) ? NULL : (float*)malloc(sizeof(float) * (size_t)B * m->in[i]);
+        float* gw = g ? g + m->off[i] : (float*)malloc(sizeof(float) * ((size_t)m->out[i] * m->in[i] + m->out[i]));
+        linear_bwd(in, p + m->off[i], d, gw, gw + (size_t)m->out[i] * m->in[i], dx, B, m->in[i], m->out[i]);
+        if (!g) free(gw);
+        free(d);
+        d = dx;
+    }
+    if (dx_in && d) { memcpy(dx_in, d, sizeof(float) * (size_t)B * m->in[0]); }
+    free(d);
+}
+
+static float** acts_alloc(const sac_mlp* m, int B)
+{
+    float** a = (float**)calloc(m->n, sizeof(float*));
+    for (int i = 0; i < m->n; ++i) a[i] = (float*)malloc(sizeof(float) * (size_t)B * m->out[i]);
+    return a;
+}
+static void acts_free(const sac_mlp* m, float** a) { for (int i = 0; i < m->n; ++i) free(a[i]); free(a); }
+
+ORC_API int64_t orc_sac_pi_param_count(const orc_sac_cfg* c)
+{
+    sac_mlp t = sac_mlp_make(c->obs_dim, c->pi_units, c->n_pi_units, 0, 0);
+    int h = c->n_pi_units ? c->pi_units[c->n_pi_units - 1] : c->obs_dim;
+    return (int64_t)t.total + 2 * ((int64_t)c->act_dim * h + c->act_dim);
+}
+ORC_API int64_t orc_sac_q_param_count(const orc_sac_cfg* c)
+{
+    return (int64_t)sac_mlp_make(c->obs_dim + c->act_dim, c->q_units, c->n_q_units, 1, 1).total;
+}
+
+/* action_logp (sac/base.rs:73-87).  Outputs a[B][A], logp[B]; optional intermediates for backward. */
+typedef struct { float** acts; float *mean, *e, *s, *sd, *a; sac_mlp trunk; int h; } sac_pi_cache;
+
+static void sac_action_logp(const orc_sac_cfg* c, const float* pi, const float* o, const float* z, int B, float* a_out,
+                            float* logp, sac_pi_cache* k)
+{
+    const int A = c->act_dim;
+    sac_mlp trunk = sac_mlp_make(c->obs_dim, c->pi_units, c->n_pi_units, 0, 0);
+    const int h = c->n_pi_units ? c->pi_units[c->n_pi_units - 1] : c->obs_dim;
+    float** acts = acts_alloc(&trunk, B);
+    sac_mlp_fwd(&trunk, pi, o, B, acts);
+    const float* hid = trunk.n ? acts[trunk.n - 1] : o;
+    const float* wm = pi + trunk.total; const float* bm = wm + (size_t)A * h;
+    const float* ws = bm + A; const float* bs = ws + (size_t)A * h;
+    float* mean = (float*)malloc(sizeof(float) * (size_t)B * A);
+    float* e = (float*)malloc(sizeof(float) * (size_t)B * A);
+    float* s = (float*)malloc(sizeof(float) * (size_t)B * A);
+    float* sd = (float*)malloc(sizeof(float) * (size_t)B * A);
+    linear_fwd(hid, wm, bm, mean, B, h, A, 0);
+    linear_fwd(hid, ws, bs, e, B, h, A, 0);
+    const float lo = (float)c->min_lstd, hi = (float)c->max_lstd, eps = (float)c->epsilon;
+    const float cst = (float)(-0.5 * log(2.0 * 3.14159265358979323846));   /* f32 pi in the reference: same value after rounding */
+    for (int b = 0; b < B; ++b) {
+        float nl = 0.f, sl = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const size_t q = (size_t)b * A + j;
+            s[q] = expf(e[q]);                                   /* Mlp2::forward: .exp() */
+            float cl = s[q] < lo ? lo : (s[q] > hi ? hi : s[q]); /* lstd.clip(min_lstd, max_lstd) */
+            sd[q] = expf(cl);                                    /* .exp() */
+            const float u = sd[q] * z[q] + mean[q];
+            const float av = tanhf(u);
+            a_out[q] = av;
+            nl += cst - 0.5f * (z[q] * z[q]);
+            sl += logf((1.0f - av * av) + eps);
+        }
+        logp[b] = nl - sl;
+    }
+    if (k) { k->acts = acts; k->mean = mean; k->e = e; k->s = s; k->sd = sd; k->trunk = trunk; k->h = h; k->a = NULL; }
+    else { acts_free(&trunk, acts); free(mean); free(e); free(s); free(sd); }
+}
+
+typedef struct {
+    float loss_critic, loss_actor, ent_coef;
+} orc_sac_record;
+
+typedef struct {
+    float* pi_grads;     /* [pi params]            or NULL */
+    float* q_grads;      /* [n_critics][q params]  or NULL */
+    float* a;            /* [B][A] actor action    or NULL */
+    float* log_p;        /* [B]                    or NULL */
+    float* tgt;          /* [B]                    or NULL */
+} orc_sac_probe;
+
+/* One Sac::opt_ update (sac/base.rs:175-198 body of the loop) on a given minibatch. */
+ORC_API void orc_sac_update(const orc_sac_cfg* c, float* pi, float** qs, float** qs_tgt, float* log_alpha,
+                            orc_adam_cfg* adam_pi, float* pi_m, float* pi_v,
+                            orc_adam_cfg* adam_q, float** q_m, float** q_v,          /* adam_q: array [n_critics] */
+                            orc_adam_cfg* adam_alpha, float* alpha_m, float* alpha_v,
+                            int B, const float* obs, const float* act, const float* next_obs, const float* reward,
+                            const int8_t* term, const float* z_actor, const float* z_next, orc_sac_record* rec,
+                            orc_sac_probe* probe)
+{
+    const int A = c->act_dim, O = c->obs_dim, NC = c->n_critics;
+    const int64_t npi = orc_sac_pi_param_count(c), nq = orc_sac_q_param_count(c);
+    sac_mlp qm = sac_mlp_make(O + A, c->q_units, c->n_q_units, 1, 1);
+    const float lo = (float)c->min_lstd, hi = (float)c->max_lstd, eps = (float)c->epsilon;
+
+    /* ---------------- update_actor (:151-167) ---------------- */
+    float* a = (float*)malloc(sizeof(float) * (size_t)B * A);
+    float* logp = (float*)malloc(sizeof(float) * B);
+    sac_pi_cache k;
+    sac_action_logp(c, pi, obs, z_actor, B, a, logp, &k);
+    if (probe && probe->a) memcpy(probe->a, a, sizeof(float) * (size_t)B * A);
+    if (probe && probe->log_p) memcpy(probe->log_p, logp, sizeof(float) * B);
+    if (c->auto_alpha) {   /* ent_coef.rs:69-75: loss = -(log_alpha * (logp + H)).mean() */
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) s += (double)(logp[b] + (float)c->target_entropy);
+        float g = (float)(-(s / B));
+        orc_adam_step(adam_alpha, log_alpha, &g, alpha_m, alpha_v, 1);
+    }
+    const float alpha = expf(*log_alpha);
+    /* critics on (obs, a): min over critics and its gradient w.r.t. a */
+    float* xin = (float*)malloc(sizeof(float) * (size_t)B * (O + A));
+    for (int b = 0; b < B; ++b) { memcpy(xin + (size_t)b * (O + A), obs + (size_t)b * O, sizeof(float) * O); memcpy(xin + (size_t)b * (O + A) + O, a + (size_t)b * A, sizeof(float) * A); }
+    float* qv = (float*)malloc(sizeof(float) * (size_t)NC * B);
+    float*** qacts = (float***)calloc(NC, sizeof(float**));
+    for (int i = 0; i < NC; ++i) { qacts[i] = acts_alloc(&qm, B); sac_mlp_fwd(&qm, qs[i], xin, B, qacts[i]); memcpy(qv + (size_t)i * B, qacts[i][qm.n - 1], sizeof(float) * B); }
+    double la = 0.0;
+    int* imin = (int*)malloc(sizeof(int) * B);
+    for (int b = 0; b < B; ++b) {
+        int im = 0;
+        for (int i = 1; i < NC; ++i) if (qv[(size_t)i * B + b] < qv[(size_t)im * B + b]) im = i;
+        imin[b] = im;
+        la += (double)(alpha * logp[b] - qv[(size_t)im * B + b]);
+    }
+    const float loss_actor = (float)(la / B);
+    float* dqda = (float*)calloc((size_t)B * A, sizeof(float));   /* d(qmin)/d(a) */
+    for (int i = 0; i < NC; ++i) {
+        float* dout = (float*)calloc(B, sizeof(float));
+        int any = 0;
+        for (int b = 0; b < B; ++b) if (imin[b] == i) { dout[b] = 1.0f; any = 1; }
+        if (any) {
+            float* dx = (float*)malloc(sizeof(float) * (size_t)B * (O + A));
+            sac_mlp_bwd(&qm, qs[i], xin, B, qacts[i], dout, NULL, dx);
+            for (int b = 0; b < B; ++b) for (int j = 0; j < A; ++j) dqda[(size_t)b * A + j] += dx[(size_t)b * (O + A) + O + j];
+            free(dx);
+        }
+        free(dout);
+    }
+    /* dL/dmean, dL/de */
+    float* gmean = (float*)malloc(sizeof(float) * (size_t)B * A);
+    float* ge = (float*)malloc(sizeof(float) * (size_t)B * A);
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < A; ++j) {
+            const size_t q = (size_t)b * A + j;
+            const float av = a[q];
+            const float dlogp_da = (2.0f * av) / ((1.0f - av * av) + eps);   /* d(-ln(1-a^2+eps))/da */
+            const float ga = (alpha * dlogp_da - dqda[q]) / (float)B;
+            const float gu = ga * (1.0f - av * av);                           /* tanh' */
+            gmean[q] = gu;
+            const float inr = (k.s[q] >= lo && k.s[q] <= hi) ? 1.0f : 0.0f;   /* clamp backward */
+            ge[q] = gu * z_actor[q] * k.sd[q] * inr * k.s[q];
+        }
+    /* heads + trunk backward */
+    float* gpi = (float*)calloc((size_t)npi, sizeof(float));
+    {
+        const int h = k.h;
+        const float* hid = k.trunk.n ? k.acts[k.trunk.n - 1] : obs;
+        float* wm = pi + k.trunk.total; float* ws = wm + (size_t)A * h + A;
+        float* gwm = gpi + k.trunk.total; float* gws = gwm + (size_t)A * h + A;
+        float* dh1 = (float*)malloc(sizeof(float) * (size_t)B * h);
+        float* dh2 = (float*)malloc(sizeof(float) * (size_t)B * h);
+        linear_bwd(hid, wm, gmean, gwm, gwm + (size_t)A * h, dh1, B, h, A);
+        linear_bwd(hid, ws, ge, gws, gws + (size_t)A * h, dh2, B, h, A);
+        for (size_t t = 0; t < (size_t)B * h; ++t) dh1[t] += dh2[t];
+        if (k.trunk.n) sac_mlp_bwd(&k.trunk, pi, obs, B, k.acts, dh1, gpi, NULL);
+        free(dh1); free(dh2);
+    }
+    if (probe && probe->pi_grads) memcpy(probe->pi_grads, gpi, sizeof(float) * (size_t)npi);
+    orc_adam_step(adam_pi, pi, gpi, pi_m, pi_v, npi);
+    acts_free(&k.trunk, k.acts); free(k.mean); free(k.e); free(k.s); free(k.sd);
+    for (int i = 0; i < NC; ++i) acts_free(&qm, qacts[i]);
+    free(qacts); free(qv); free(imin); free(dqda); free(gmean); free(ge); free(gpi);
+
+    /* ---------------- update_critic (:107-149) ---------------- */
+    float* na = (float*)malloc(sizeof(float) * (size_t)B * A);
+    float* nlogp = (float*)malloc(sizeof(float) * B);
+    sac_action_logp(c, pi, next_obs, z_next, B, na, nlogp, NULL);   /* updated actor */
+    for (int b = 0; b < B; ++b) { memcpy(xin + (size_t)b * (O + A), next_obs + (size_t)b * O, sizeof(float) * O); memcpy(xin + (size_t)b * (O + A) + O, na + (size_t)b * A, sizeof(float) * A); }
+    float* tgt = (float*)malloc(sizeof(float) * B);
+    {
+        float** ta = acts_alloc(&qm, B);
+        float* nq = (float*)malloc(sizeof(float) * B);
+        for (int i = 0; i < NC; ++i) {
+            sac_mlp_fwd(&qm, qs_tgt[i], xin, B, ta);
+            for (int b = 0; b < B; ++b) nq[b] = (i == 0 || ta[qm.n - 1][b] < nq[b]) ? ta[qm.n - 1][b] : nq[b];
+        }
+        const float gm = (float)c->gamma, rs = (float)c->reward_scale;
+        for (int b = 0; b < B; ++b) {
+            const float nv = nq[b] - alpha * nlogp[b];
+            tgt[b] = rs * reward[b] + ((1.0f - (float)term[b]) * gm) * nv;
+        }
+        acts_free(&qm, ta); free(nq);
+    }
+    if (probe && probe->tgt) memcpy(probe->tgt, tgt, sizeof(float) * B);
+    for (int b = 0; b < B; ++b) { memcpy(xin + (size_t)b * (O + A), obs + (size_t)b * O, sizeof(float) * O); memcpy(xin + (size_t)b * (O + A) + O, act + (size_t)b * A, sizeof(float) * A); }
+    double lc = 0.0;
+    for (int i = 0; i < NC; ++i) {
+        float** ca = acts_alloc(&qm, B);
+        sac_mlp_fwd(&qm, qs[i], xin, B, ca);
+        float* dout = (float*)malloc(sizeof(float) * B);
+        double ls = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const float d = ca[qm.n - 1][b] - tgt[b];
+            if (c->critic_loss == 1) { const float zz = fabsf(d); ls += zz < 1.f ? 0.5 * (double)zz * zz : (double)zz - 0.5; dout[b] = (zz < 1.f ? d : (d > 0.f ? 1.f : -1.f)) / (float)B; }
+            else { ls += (double)d * d; dout[b] = 2.f * d / (float)B; }
+        }
+        lc += (double)(float)(ls / B);
+        float* gq = (float*)calloc((size_t)nq, sizeof(float));
+        sac_mlp_bwd(&qm, qs[i], xin, B, ca, dout, gq, NULL);
+        if (probe && probe->q_grads) memcpy(probe->q_grads + (size_t)i * nq, gq, sizeof(float) * (size_t)nq);
+        orc_adam_step(&adam_q[i], qs[i], gq, q_m[i], q_v[i], nq);
+        acts_free(&qm, ca); free(dout); free(gq);
+    }
+    /* ---------------- soft_update (:169-173) ---------------- */
+    for (int i = 0; i < NC; ++i) orc_track(qs_tgt[i], qs[i], c->tau, nq);
+    rec->loss_critic = (float)(lc / NC); rec->loss_actor = loss_actor; rec->ent_coef = expf(*log_alpha);
+    free(a); free(logp); free(xin); free(na); free(nlogp); free(tgt);
+}

@@ -251,3 +251,74 @@ class DqnOracle:
         self.n_opts += 1
         bufs["loss"] = float(loss)
         return bufs
+
+
+# ----------------------------------------------------------------------------- SAC
+class SacCfg(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_pi_units", C.c_int32), ("pi_units", C.c_int32 * 8),
+                ("n_q_units", C.c_int32), ("q_units", C.c_int32 * 8), ("n_critics", C.c_int32),
+                ("gamma", C.c_double), ("tau", C.c_double), ("epsilon", C.c_double), ("min_lstd", C.c_double),
+                ("max_lstd", C.c_double), ("reward_scale", C.c_double), ("critic_loss", C.c_int32),
+                ("auto_alpha", C.c_int32), ("target_entropy", C.c_double)]
+
+
+class SacRecord(C.Structure):
+    _fields_ = [("loss_critic", C.c_float), ("loss_actor", C.c_float), ("ent_coef", C.c_float)]
+
+
+class SacProbe(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pi_grads", "q_grads", "a", "log_p", "tgt")]
+
+
+class SacOracle:
+    """Sac::opt_ restatement (sac/base.rs:175-198) over explicit minibatches and injected noise."""
+
+    def __init__(self, obs_dim, act_dim, pi_units, q_units, pi_params, q_params_list, *, lr_actor, lr_critic, gamma=0.99,
+                 tau=0.005, ent_coef=("Fix", 1.0), epsilon=1e-4, min_lstd=-20.0, max_lstd=2.0, reward_scale=1.0,
+                 critic_loss="Mse"):
+        import math
+        L = lib()
+        L.orc_sac_pi_param_count.restype = C.c_int64
+        L.orc_sac_q_param_count.restype = C.c_int64
+        c = SacCfg()
+        c.obs_dim, c.act_dim, c.n_pi_units, c.n_q_units, c.n_critics = obs_dim, act_dim, len(pi_units), len(q_units), len(q_params_list)
+        for i, u in enumerate(pi_units):
+            c.pi_units[i] = u
+        for i, u in enumerate(q_units):
+            c.q_units[i] = u
+        c.gamma, c.tau, c.epsilon, c.min_lstd, c.max_lstd, c.reward_scale = gamma, tau, epsilon, min_lstd, max_lstd, reward_scale
+        c.critic_loss = {"Mse": 0, "SmoothL1": 1}[critic_loss]
+        c.auto_alpha = int(ent_coef[0] == "Auto")
+        c.target_entropy = ent_coef[1] if c.auto_alpha else 0.0
+        self.cfg = c
+        self.pi = np.array(pi_params, np.float32, copy=True)
+        self.qs = [np.array(q, np.float32, copy=True) for q in q_params_list]
+        self.qs_tgt = [q.copy() for q in self.qs]
+        self.log_alpha = np.array([0.0 if c.auto_alpha else math.log(ent_coef[1])], np.float32)
+        assert self.pi.size == L.orc_sac_pi_param_count(C.byref(c)) and self.qs[0].size == L.orc_sac_q_param_count(C.byref(c))
+        self.pi_m, self.pi_v = np.zeros_like(self.pi), np.zeros_like(self.pi)
+        self.q_m = [np.zeros_like(q) for q in self.qs]
+        self.q_v = [np.zeros_like(q) for q in self.qs]
+        self.al_m, self.al_v = np.zeros(1, np.float32), np.zeros(1, np.float32)
+        self.adam_pi = AdamCfg(lr_actor, 0.9, 0.999, 1e-8, 0)
+        self.adam_q = (AdamCfg * len(self.qs))(*[AdamCfg(lr_critic, 0.9, 0.999, 1e-8, 0) for _ in self.qs])
+        self.adam_al = AdamCfg(ent_coef[2] if c.auto_alpha else 0.0, 0.9, 0.999, 1e-8, 0)
+
+    def update(self, obs, act, next_obs, reward, term, z_actor, z_next, probe=True):
+        f = lambda x: np.ascontiguousarray(x, dtype=np.float32)
+        obs, act, next_obs, reward, z_actor, z_next = map(f, (obs, act, next_obs, reward, z_actor, z_next))
+        term = np.ascontiguousarray(term, dtype=np.int8)
+        B, NC = len(reward), len(self.qs)
+        arr = lambda xs: (C.c_void_p * NC)(*[x.ctypes.data for x in xs])
+        rec = SacRecord()
+        bufs = dict(pi_grads=np.empty_like(self.pi), q_grads=np.empty((NC, self.qs[0].size), np.float32),
+                    a=np.empty((B, self.cfg.act_dim), np.float32), log_p=np.empty(B, np.float32), tgt=np.empty(B, np.float32))
+        pr = SacProbe(*[bufs[n].ctypes.data for n, _ in SacProbe._fields_])
+        lib().orc_sac_update(C.byref(self.cfg), _p(self.pi), arr(self.qs), arr(self.qs_tgt), _p(self.log_alpha),
+                             C.byref(self.adam_pi), _p(self.pi_m), _p(self.pi_v),
+                             self.adam_q, arr(self.q_m), arr(self.q_v),
+                             C.byref(self.adam_al), _p(self.al_m), _p(self.al_v),
+                             C.c_int(B), _p(obs), _p(act), _p(next_obs), _p(reward), _p(term), _p(z_actor), _p(z_next),
+                             C.byref(rec), C.byref(pr) if probe else None)
+        bufs.update(loss_critic=rec.loss_critic, loss_actor=rec.loss_actor, ent_coef=rec.ent_coef)
+        return bufs

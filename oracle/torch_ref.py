@@ -215,3 +215,149 @@ def time_dqn_atari(batch_size=256, n_actions=6, steps=5, warmup=1, threads=None,
         one()
     dt = time.perf_counter() - t0
     return steps / dt, torch.get_num_threads()
+
+
+# ================================================================================================
+# SAC  (border-tch-agent/src/sac/base.rs:73-198, mlp/mlp2.rs:23-50, sac/ent_coef.rs:27-75)
+# ================================================================================================
+def sac_pi_shapes(obs_dim, units, act_dim):
+    """Actor (Mlp2) variables: mlp.al{i}.weight/bias, ml.weight/bias, sl.weight/bias."""
+    shapes, i = [], obs_dim
+    for u in units:
+        shapes += [(u, i), (u,)]
+        i = u
+    return shapes + [(act_dim, i), (act_dim,), (act_dim, i), (act_dim,)]
+
+
+def sac_q_shapes(obs_dim, act_dim, units):
+    """Critic (Mlp as SubModel2, mlp/base.rs:83-107): cat(obs, act) -> units -> 1."""
+    return mlp_shapes(obs_dim + act_dim, units, 1)
+
+
+class TorchSac:
+    """Sac::opt_ with injected N(0,1) noise (the reference draws it from torch's global CPU
+    generator: sac/base.rs:76) so a fixed (minibatch, z_actor, z_next) is reproducible."""
+
+    def __init__(self, obs_dim, act_dim, pi_units, q_units, pi_params, q_params_list, *, lr_actor, lr_critic, gamma=0.99,
+                 tau=0.005, ent_coef=("Fix", 1.0), epsilon=1e-4, min_lstd=-20.0, max_lstd=2.0, reward_scale=1.0,
+                 critic_loss="Mse"):
+        self.pi_shapes = sac_pi_shapes(obs_dim, pi_units, act_dim)
+        self.q_shapes = sac_q_shapes(obs_dim, act_dim, q_units)
+        self.n_trunk = len(pi_units)
+        self.pi = [t.requires_grad_(True) for t in unflatten(pi_params, self.pi_shapes)]
+        self.qs = [[t.requires_grad_(True) for t in unflatten(p, self.q_shapes)] for p in q_params_list]
+        self.qs_tgt = [unflatten(p, self.q_shapes) for p in q_params_list]   # Critic::clone
+        self.gamma, self.tau, self.eps = gamma, tau, epsilon
+        self.min_lstd, self.max_lstd, self.reward_scale, self.critic_loss = min_lstd, max_lstd, reward_scale, critic_loss
+        if ent_coef[0] == "Fix":   # ent_coef.rs:33-38
+            self.log_alpha = torch.tensor([math.log(ent_coef[1])], dtype=torch.float32)
+            self.target_entropy, self.lr_alpha = None, None
+        else:                      # Auto(target_entropy, lr): ent_coef.rs:39-46
+            self.log_alpha = torch.zeros(1, requires_grad=True)
+            self.target_entropy, self.lr_alpha = ent_coef[1], ent_coef[2]
+        self.opt = {"pi": self._state(self.pi, lr_actor), "alpha": self._state([self.log_alpha], self.lr_alpha or 0.0)}
+        for i, q in enumerate(self.qs):
+            self.opt[f"q{i}"] = self._state(q, lr_critic)
+
+    @staticmethod
+    def _state(params, lr):
+        return dict(m=[torch.zeros_like(p) for p in params], v=[torch.zeros_like(p) for p in params], step=0, lr=lr)
+
+    @staticmethod
+    def _adam(params, st):
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        st["step"] += 1
+        bc1, bc2 = 1 - b1 ** st["step"], 1 - b2 ** st["step"]
+        with torch.no_grad():
+            for p, m, v in zip(params, st["m"], st["v"]):
+                g = p.grad
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+                p.addcdiv_(m, denom, value=-(st["lr"] / bc1))
+
+    def pi_forward(self, o):
+        """Mlp2::forward (mlp2.rs:23-28): returns (mean, exp(head2))."""
+        x = o
+        for i in range(self.n_trunk):
+            x = F.linear(x, self.pi[2 * i], self.pi[2 * i + 1]).relu()
+        k = 2 * self.n_trunk
+        return F.linear(x, self.pi[k], self.pi[k + 1]), F.linear(x, self.pi[k + 2], self.pi[k + 3]).exp()
+
+    def action_logp(self, o, z):
+        """sac/base.rs:73-87 (note: `lstd` is already exp(head2) and is exponentiated again)."""
+        mean, lstd = self.pi_forward(o)
+        std = lstd.clip(self.min_lstd, self.max_lstd).exp()
+        a = (std * z + mean).tanh()
+        normal_logp = (torch.tensor(-0.5 * math.log(2.0 * math.pi), dtype=torch.float32) - 0.5 * z.pow(2)).sum(-1)
+        log_p = normal_logp - (torch.tensor(1.0) - a.pow(2.0) + torch.tensor(self.eps)).log().sum(-1)
+        return a, log_p
+
+    def alpha(self):
+        return self.log_alpha.detach().exp()
+
+    @staticmethod
+    def q_forward(q, o, a):
+        return mlp_forward(q, torch.cat([o, a], -1)).squeeze()
+
+    def update(self, obs, act, next_obs, reward, term, z_actor, z_next):
+        o = torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32))
+        act = torch.from_numpy(np.ascontiguousarray(act, dtype=np.float32))
+        no = torch.from_numpy(np.ascontiguousarray(next_obs, dtype=np.float32))
+        reward = torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32))
+        is_terminated = torch.from_numpy(np.ascontiguousarray(term, dtype=np.int8))
+        z_actor = torch.from_numpy(np.ascontiguousarray(z_actor, dtype=np.float32))
+        z_next = torch.from_numpy(np.ascontiguousarray(z_next, dtype=np.float32))
+        out = {}
+        # ---- update_actor (sac/base.rs:151-167), first (:181)
+        a, log_p = self.action_logp(o, z_actor)
+        if self.target_entropy is not None:   # ent_coef.rs:69-75
+            loss_a = -(self.log_alpha * (log_p.detach() + torch.tensor(self.target_entropy))).mean()
+            self.log_alpha.grad = None
+            loss_a.backward()
+            self._adam([self.log_alpha], self.opt["alpha"])
+        qmin = torch.vstack([self.q_forward(q, o, a) for q in self.qs]).min(0)[0]
+        loss_actor = (self.alpha() * log_p - qmin).mean()
+        for p in self.pi:
+            p.grad = None
+        loss_actor.backward()
+        out["pi_grads"] = flatten([p.grad for p in self.pi])
+        out["a"], out["log_p"] = a.detach().numpy().copy(), log_p.detach().numpy().copy()
+        self._adam(self.pi, self.opt["pi"])
+        # ---- update_critic (:107-149)
+        preds = [self.q_forward(q, o, act) for q in self.qs]
+        with torch.no_grad():
+            next_a, next_log_p = self.action_logp(no, z_next)
+            next_q = torch.vstack([self.q_forward(q, no, next_a) for q in self.qs_tgt]).min(0)[0]
+            next_q = next_q - self.alpha() * next_log_p
+            tgt = self.reward_scale * reward + (1.0 - is_terminated) * torch.tensor(self.gamma) * next_q
+        losses = [F.mse_loss(p, tgt) if self.critic_loss == "Mse" else F.smooth_l1_loss(p, tgt, beta=1.0) for p in preds]
+        out["q_grads"] = []
+        for i, (q, l) in enumerate(zip(self.qs, losses)):
+            for p in q:
+                p.grad = None
+            l.backward()
+            out["q_grads"].append(flatten([p.grad for p in q]))
+            self._adam(q, self.opt[f"q{i}"])
+        # ---- soft_update (:169-173), every update
+        with torch.no_grad():
+            for qt, q in zip(self.qs_tgt, self.qs):
+                for d, s in zip(qt, q):
+                    d.copy_(self.tau * s + (1.0 - self.tau) * d)
+        out.update(loss_critic=float(sum(float(l.detach()) for l in losses) / len(losses)), loss_actor=float(loss_actor.detach()),
+                   ent_coef=float(self.alpha()[0]), tgt=tgt.numpy().copy(), preds=[p.detach().numpy().copy() for p in preds],
+                   pi_params=flatten(self.pi), q_params=[flatten(q) for q in self.qs],
+                   q_tgt_params=[flatten(q) for q in self.qs_tgt], log_alpha=float(self.log_alpha.detach()[0]))
+        return out
+
+
+def sac_batch(B, obs_dim, act_dim, seed):
+    rng = np.random.default_rng(seed)
+    obs = rng.standard_normal((B, obs_dim)).astype(np.float32)
+    nobs = rng.standard_normal((B, obs_dim)).astype(np.float32)
+    act = rng.uniform(-1, 1, (B, act_dim)).astype(np.float32)
+    rew = rng.standard_normal(B).astype(np.float32)
+    term = (rng.random(B) < 0.05).astype(np.int8)
+    z1 = rng.standard_normal((B, act_dim)).astype(np.float32)
+    z2 = rng.standard_normal((B, act_dim)).astype(np.float32)
+    return obs, act, nobs, rew, term, z1, z2

@@ -137,6 +137,46 @@ def make_dqn(name, kind, shapes, batch_fn, n_steps, **kw):
     np.savez_compressed(os.path.join(HERE, name), **out)
 
 
+SAC_CASES = {
+    # name: (obs_dim, act_dim, pi_units, q_units, n_critics, B, steps, kwargs)
+    "sac_17_6_twinq_auto": (17, 6, [64, 64], [64, 64], 2, 32, 3,
+                            dict(lr_actor=3e-4, lr_critic=3e-4, ent_coef=("Auto", -6.0, 3e-4), critic_loss="Mse")),
+    "sac_pendulum_fix_huber": (3, 1, [64, 64], [64, 64], 1, 16, 2,
+                               dict(lr_actor=3e-4, lr_critic=3e-4, ent_coef=("Fix", 1.0), critic_loss="SmoothL1",
+                                    reward_scale=0.5)),
+}
+
+
+def sac_case_params(name):
+    from oracle import torch_ref as T
+    od, ad, pu, qu, nc, B, steps, kw = SAC_CASES[name]
+    seed = sum(map(ord, name))
+    pi0 = T.init_params(T.sac_pi_shapes(od, pu, ad), seed) * np.float32(0.5)
+    q0 = [T.init_params(T.sac_q_shapes(od, ad, qu), seed + 1 + i) for i in range(nc)]
+    return od, ad, pu, qu, nc, B, steps, kw, pi0, q0, seed
+
+
+def make_sac():
+    """SAC goldens: PyTorch CPU autograd on seeded minibatches with injected N(0,1) noise."""
+    from oracle import torch_ref as T
+    import torch
+    torch.set_num_threads(1)
+    for name in SAC_CASES:
+        od, ad, pu, qu, nc, B, steps, kw, pi0, q0, seed = sac_case_params(name)
+        agent = T.TorchSac(od, ad, pu, qu, pi0, q0, **kw)
+        out = {}
+        for s in range(steps):
+            r = agent.update(*T.sac_batch(B, od, ad, seed + 100 + s))
+            for k in ("loss_critic", "loss_actor", "ent_coef", "log_alpha"):
+                out[f"s{s}_{k}"] = np.float32(r[k])
+            out[f"s{s}_a"], out[f"s{s}_log_p"], out[f"s{s}_tgt"] = r["a"], r["log_p"], r["tgt"]
+            out[f"s{s}_pi_grads"], out[f"s{s}_pi_params"] = r["pi_grads"], r["pi_params"]
+            for i in range(nc):
+                out[f"s{s}_q{i}_grads"], out[f"s{s}_q{i}_params"] = r["q_grads"][i], r["q_params"][i]
+                out[f"s{s}_q{i}_tgt_params"] = r["q_tgt_params"][i]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def main():
     make_rng()
     from oracle import torch_ref as T
@@ -160,6 +200,7 @@ def main():
 
     make_dqn("dqn_mlp_cartpole.npz", "mlp", T.mlp_shapes(4, [64, 64], 2), cart, 5,
              param_seed=3, lr=1e-3, critic_loss="Mse", tau=0.01, soft_update_interval=1)
+    make_sac()
     print("fixtures:", sorted(os.listdir(HERE)))
 
 

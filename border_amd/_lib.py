@@ -43,6 +43,16 @@ class DqnConfigC(C.Structure):
                 ("record_verbose_level", C.c_int32), ("device", C.c_int32), ("param_seed", C.c_uint64)]
 
 
+class SacConfigC(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_pi_units", C.c_int32), ("pi_units", C.c_int32 * BDR_MAX_UNITS),
+                ("n_q_units", C.c_int32), ("q_units", C.c_int32 * BDR_MAX_UNITS), ("lr_actor", C.c_double), ("lr_critic", C.c_double),
+                ("gamma", C.c_double), ("tau", C.c_double), ("ent_coef_auto", C.c_int32), ("ent_coef_alpha", C.c_double),
+                ("target_entropy", C.c_double), ("ent_coef_lr", C.c_double), ("epsilon", C.c_double), ("min_lstd", C.c_double),
+                ("max_lstd", C.c_double), ("n_updates_per_opt", C.c_uint64), ("batch_size", C.c_uint64), ("train", C.c_int32),
+                ("critic_loss", C.c_int32), ("reward_scale", C.c_double), ("n_critics", C.c_int32), ("device", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
 class DqnRecordC(C.Structure):
     _fields_ = [("loss", C.c_float), ("pred_mean", C.c_float), ("reward_mean", C.c_float),
                 ("tgt_mean", C.c_float), ("tgt_minus_pred_mean", C.c_float), ("has_verbose", C.c_int32)]
@@ -65,6 +75,7 @@ ABI_SYMBOLS = [
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
     "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_dqn_probe",
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
+    "bdr_sac_config_default", "bdr_sac_create", "bdr_sac_update_on_batch", "bdr_sac_sample",
     "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_agent_allreduce_params",
     "bdr_agent_broadcast_params",
 ]
@@ -89,9 +100,10 @@ def lib() -> C.CDLL:
     L.bdr_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == ABI drift
-        if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default"):
+        if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default"):
             fn.restype = C.c_int32
     L.bdr_dqn_config_default.restype = None
+    L.bdr_sac_config_default.restype = None
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     L.bdr_replay_create.argtypes = [C.POINTER(ReplayConfig), C.POINTER(vp)]
     L.bdr_replay_destroy.argtypes = [vp]
@@ -125,6 +137,10 @@ def lib() -> C.CDLL:
     L.bdr_dqn_probe.argtypes = [vp, i32, vp, u64]
     L.bdr_agent_profile_enable.argtypes = [vp, i32]
     L.bdr_agent_profile_read.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
+    L.bdr_sac_config_default.argtypes = [C.POINTER(SacConfigC)]
+    L.bdr_sac_create.argtypes = [C.POINTER(SacConfigC), C.POINTER(vp)]
+    L.bdr_sac_update_on_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.bdr_sac_sample.argtypes = [vp, u64, vp, vp]
     L.bdr_comm_get_unique_id.argtypes = [vp]
     L.bdr_comm_init_rank.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.bdr_comm_destroy.argtypes = [vp]

@@ -105,6 +105,7 @@ struct DenseArgs {
     const float* mask; int ldm;   // dx: ReLU' mask = post-activation of the previous layer (or null)
     int M, ncols, kred, relu;
     int w_ld;            // row stride of W (= Np of the layer)
+    int accum;           // dx: out += result (sum of several branches' input gradients)
 };
 
 struct DenseFwd {
@@ -143,7 +144,8 @@ struct DenseDx {
     __device__ static void store(const Args& a, int, int, int m, int n, float v)
     {
         if (a.mask && !(a.mask[(size_t)m * a.ldm + n] > 0.f)) v = 0.f;
-        a.out[(size_t)m * a.ldo + n] = v;
+        float* o = a.out + (size_t)m * a.ldo + n;
+        *o = a.accum ? *o + v : v;
     }
 };
 
@@ -202,9 +204,10 @@ inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, 
 
 // dX (masked by the ReLU of the producing layer's post-activation `mask`, may be null)
 inline int32_t dense_dx(hipStream_t st, const DenseLayer& l, const float* params_base, const float* dy, float* dx,
-                        const float* mask, int M)
+                        const float* mask, int M, bool accum = false)
 {
     DenseArgs d{};
+    d.accum = accum ? 1 : 0;
     d.x = DenseSrc{dy, l.Np}; d.w = params_base + l.w; d.out = dx; d.ldo = l.Kp; d.mask = mask; d.ldm = l.Kp;
     d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np;
     hipLaunchKernelGGL(k_igemm<DenseDx>, dim3(((M + 63) / 64) * (l.Kp / 64), 1, 1), dim3(256), 0, st, d);

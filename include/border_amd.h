@@ -233,6 +233,39 @@ BDR_API int32_t bdr_agent_profile_read(bdr_agent* a, char* names_out, uint64_t n
                                        float* ms_out, uint64_t* count_inout);
 
 /* ------------------------------------------------------------------------------------------
+ * SAC agent  (border-tch-agent/src/sac/base.rs, sac/config.rs:85-105, sac/ent_coef.rs,
+ * Actor = Mlp2 (mlp/mlp2.rs), Critic = Mlp on cat(obs, act) (mlp/base.rs:83-107))
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t obs_dim, act_dim;
+    int32_t n_pi_units; int32_t pi_units[BDR_MAX_UNITS];   /* ActorConfig.pi_config (MlpConfig.units) */
+    int32_t n_q_units;  int32_t q_units[BDR_MAX_UNITS];    /* CriticConfig.q_config                  */
+    double lr_actor, lr_critic;                             /* OptimizerConfig::Adam{lr} of each       */
+    double gamma, tau;
+    int32_t ent_coef_auto;       /* EntCoefMode::Auto(target_entropy, lr) vs Fix(alpha) */
+    double ent_coef_alpha, target_entropy, ent_coef_lr;
+    double epsilon, min_lstd, max_lstd;
+    uint64_t n_updates_per_opt, batch_size;
+    int32_t train;
+    int32_t critic_loss;         /* BDR_LOSS_* */
+    double reward_scale;
+    int32_t n_critics;
+    int32_t device;
+    uint64_t seed;
+} bdr_sac_config;
+BDR_API void bdr_sac_config_default(bdr_sac_config* cfg);                    /* sac/config.rs:85-105  */
+BDR_API int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out);  /* sac/base.rs:237-285   */
+/* One Sac::opt_ loop iteration on a host minibatch with injected N(0,1) draws (the reference takes
+ * them from torch's global CPU generator, sac/base.rs:76).  rec3: loss_critic, loss_actor, ent_coef.
+ * Parameter models for bdr_agent_{get,set}_params / param_count_of: 0 pi, 1+i qnet_i,
+ * 1+n_critics+i qnet_tgt_i, 1+2*n_critics log_alpha; +100 gradient, +200 exp_avg, +300 exp_avg_sq. */
+BDR_API int32_t bdr_sac_update_on_batch(bdr_agent* a, uint64_t n, const float* obs, const float* act,
+                                        const float* next_obs, const float* reward, const int8_t* is_terminated,
+                                        const float* z_actor, const float* z_next, float* rec3);
+/* Policy::sample (sac/base.rs:215-225). */
+BDR_API int32_t bdr_sac_sample(bdr_agent* a, uint64_t n, const float* obs, float* act_out);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU parameter exchange (replaces the learner->actors NamedTensors channel of
  * border-async-trainer/src/async_trainer/base.rs:268-272 with RCCL over xGMI).
  * ---------------------------------------------------------------------------------------- */

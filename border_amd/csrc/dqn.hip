@@ -19,240 +19,11 @@
 #include "agent_base.hpp"
 #include "igemm.hpp"
 #include "conv1_bf16.hpp"
+#include "cnn_layers.hpp"
 
 using namespace bdr;
 
 namespace {
-
-constexpr int MAXZ = 3;       // network instances per forward launch
-constexpr int L1_SPLIT = 7;   // split-K of the 3136-deep l1 contraction (98 k-tiles = 7 * 14)
-constexpr float INV255 = 1.0f / 255.0f;
-
-// ---- flat parameter arena (internal layouts; every segment 16-byte aligned) ----------------------
-//   W1 [256][32]  k=(c,kh,kw)      b1[32]
-//   W2 [512][64]  k=(kh,kw,c)      b2[64]
-//   W3 [576][64]  k=(kh,kw,c)      b3[64]
-//   W4 [3136][512] k=(h,w,c)       b4[512]      (NHWC flatten of conv3's output)
-//   W5 [512][A]                    b5[A]
-struct Arena {
-    size_t w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, total;  // offsets in floats
-    int A;
-};
-Arena make_arena(int A)
-{
-    Arena a{};
-    size_t o = 0;
-    auto seg = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
-    a.w1 = seg(256 * 32); a.b1 = seg(32);
-    a.w2 = seg(512 * 64); a.b2 = seg(64);
-    a.w3 = seg(576 * 64); a.b3 = seg(64);
-    a.w4 = seg((size_t)3136 * 512); a.b4 = seg(512);
-    a.w5 = seg((size_t)512 * A); a.b5 = seg(A);
-    a.total = o; a.A = A;
-    return a;
-}
-
-// ================================================================================================
-// forward policies
-// ================================================================================================
-struct FwdArgs {
-    const void* x[MAXZ];     // layer input per instance
-    const float* w[MAXZ];    // weights [K][N]
-    const float* bias[MAXZ];
-    float* out[MAXZ];        // [M][N] (or split-K partials [S][M][N])
-    int M;
-    int nkt_per_split;
-};
-
-template <class G, class APolicy, int WM_, int WN_, bool U8SCALE>
-struct FwdP {
-    using A = APolicy;
-    using Args = FwdArgs;
-    static constexpr int WM = WM_, WN = WN_, TM = 1, TN = 1;
-    static constexpr int NC = G::COUT;
-    static constexpr bool B_TR = false;
-    __device__ static constexpr int N(const Args&) { return NC; }
-    __device__ static constexpr int KP(const Args&) { return 32; }
-    __device__ static int M(const Args& a) { return a.M; }
-    __device__ static auto a_src(const Args& a, int z)
-    {
-        if constexpr (U8SCALE) return reinterpret_cast<const uint8_t*>(a.x[z]);
-        else return reinterpret_cast<const float*>(a.x[z]);
-    }
-    __device__ static const float* w(const Args& a, int z, int) { return a.w[z]; }
-    __device__ static int tap_index(int, int t) { return t; }
-    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
-    __device__ static void store(const Args& a, int z, int, int m, int n, float v)
-    {
-        if constexpr (U8SCALE) v *= INV255;   // cnn/base.rs:26 "/ 255", folded into the epilogue
-        v += a.bias[z][n];
-        a.out[z][(size_t)m * NC + n] = v > 0.f ? v : 0.f;   // relu (cnn/base.rs:28,30,32)
-    }
-};
-using FwdC1 = FwdP<GeomC1, AFwdU8<GeomC1>, 4, 1, true>;    // 128x32 tiles, M = B*400
-using FwdC2 = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false>;     // 64x64,  M = B*81
-using FwdC3 = FwdP<GeomC3, AFwd<GeomC3>, 2, 2, false>;     // 64x64,  M = B*49
-
-// l1: [B][3136] x [3136][512], split-K over blockIdx.y, raw partials (bias/relu in the head kernel)
-struct FwdL1 {
-    using A = AFwd<GeomL1>;
-    using Args = FwdArgs;
-    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
-    static constexpr int NC = 512;
-    static constexpr bool B_TR = false;
-    __device__ static constexpr int N(const Args&) { return NC; }
-    __device__ static constexpr int KP(const Args&) { return 32; }
-    __device__ static int M(const Args& a) { return a.M; }
-    __device__ static const float* a_src(const Args& a, int z) { return reinterpret_cast<const float*>(a.x[z]); }
-    __device__ static const float* w(const Args& a, int z, int) { return a.w[z]; }
-    __device__ static int tap_index(int, int t) { return t; }
-    __device__ static void kt_range(const Args& a, int y, int& k0, int& k1)
-    {
-        k0 = y * a.nkt_per_split; k1 = min(A::NKT, k0 + a.nkt_per_split);
-    }
-    __device__ static void store(const Args& a, int z, int y, int m, int n, float v)
-    {
-        a.out[z][((size_t)y * a.M + m) * NC + n] = v;
-    }
-};
-
-// ================================================================================================
-// input-gradient policies (transposed conv as gather; epilogue applies relu'(previous activation))
-// ================================================================================================
-struct DxArgs {
-    const float* dy;     // gradient w.r.t. this layer's pre-activation output
-    const float* w;      // this layer's weights [K][N]
-    const float* mask;   // previous layer's post-relu activation (same shape as out)
-    float* out;          // gradient w.r.t. the previous layer's pre-activation
-    int M;               // rows (per parity class for stride 2)
-};
-
-// l1: dh0[b][k] = sum_n dh1[b][n] W4[k][n];  treated as 1x1 "conv" with CIN=512 -> N'=3136
-struct DxL1 {
-    using G = Geom<1, 1, 512, 1, 1, 1, 1, 1, 3136>;
-    using A = AFwd<G>;     // dense rows of dh1
-    using Args = DxArgs;
-    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
-    static constexpr int NC = 3136;    // N' (columns of the result)
-    static constexpr bool B_TR = true;
-    __device__ static constexpr int N(const Args&) { return NC; }
-    __device__ static constexpr int KP(const Args&) { return 512; }   // K' per tap (contiguous in memory)
-    __device__ static int M(const Args& a) { return a.M; }
-    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
-    __device__ static const float* w(const Args& a, int, int) { return a.w; }
-    __device__ static int tap_index(int, int t) { return t; }
-    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
-    __device__ static void store(const Args& a, int, int, int m, int n, float v)
-    {
-        const size_t o = (size_t)m * NC + n;
-        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
-    }
-};
-
-// conv3 (3x3, stride 1): rows over the 9x9 input grid, K' = 9 taps * 64, N' = 64
-struct DxC3 {
-    using G = GeomC3;
-    using A = ADxS1<G>;
-    using Args = DxArgs;
-    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
-    static constexpr int NC = G::CIN;
-    static constexpr bool B_TR = true;
-    __device__ static constexpr int N(const Args&) { return NC; }
-    __device__ static constexpr int KP(const Args&) { return G::COUT; }
-    __device__ static int M(const Args& a) { return a.M; }
-    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
-    __device__ static const float* w(const Args& a, int, int) { return a.w; }
-    __device__ static int tap_index(int, int t) { return t; }
-    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
-    __device__ static void store(const Args& a, int, int, int m, int n, float v)
-    {
-        const size_t o = (size_t)m * NC + n;
-        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
-    }
-};
-
-// conv2 (4x4, stride 2): blockIdx.y = parity class (ph,pw); rows (b, ih/2, iw/2); K' = 4 taps * 64
-struct DxC2 {
-    using G = GeomC2;
-    using A = ADxS2<G>;
-    using Args = DxArgs;
-    static constexpr int WM = 4, WN = 1, TM = 1, TN = 1;
-    static constexpr int NC = G::CIN;
-    static constexpr bool B_TR = true;
-    __device__ static constexpr int N(const Args&) { return NC; }
-    __device__ static constexpr int KP(const Args&) { return G::COUT; }
-    __device__ static int M(const Args& a) { return a.M; }
-    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
-    __device__ static const float* w(const Args& a, int, int) { return a.w; }
-    // class y=(ph,pw), tap t=(a,b2) -> (kh,kw) = (ph+2a, pw+2*b2) -> kh*4+kw
-    __device__ static int tap_index(int y, int t) { return ((y >> 1) + 2 * (t >> 1)) * 4 + (y & 1) + 2 * (t & 1); }
-    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
-    __device__ static void store(const Args& a, int, int y, int m, int n, float v)
-    {
-        constexpr int HH = G::IH / 2, WH = G::IW / 2;
-        const int b = m / (HH * WH), rem = m % (HH * WH);
-        const int ih = 2 * (rem / WH) + (y >> 1), iw = 2 * (rem % WH) + (y & 1);
-        const size_t o = ((size_t)(b * G::IH + ih) * G::IW + iw) * NC + n;
-        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
-    }
-};
-
-// ================================================================================================
-// weight-gradient policies
-// ================================================================================================
-struct DwArgs {
-    const void* x;      // layer input (activation of the previous layer)
-    const float* dy;    // [M][N]
-    float* part;        // partials: [chunks][K*N + N]
-    size_t part_stride; // floats between chunks
-    int M;
-};
-template <class G, class APolicy, int WM_, int WN_, bool U8>
-struct DwP {
-    using A = APolicy;
-    using Args = DwArgs;
-    static constexpr int WM = WM_, WN = WN_, TM = 1, TN = 1;
-    __device__ static constexpr int K(const Args&) { return G::K; }
-    __device__ static constexpr int N(const Args&) { return G::COUT; }
-    __device__ static int M(const Args& a) { return a.M; }
-    __device__ static auto a_src(const Args& a)
-    {
-        if constexpr (U8) return reinterpret_cast<const uint8_t*>(a.x);
-        else return reinterpret_cast<const float*>(a.x);
-    }
-    __device__ static const float* y_src(const Args& a) { return a.dy; }
-    __device__ static float* part(const Args& a, int chunk) { return a.part + (size_t)chunk * a.part_stride; }
-};
-using DwC1 = DwP<GeomC1, AFwdU8<GeomC1>, 4, 1, true>;    // 128(k) x 32(n) tiles: 2 ko-tiles
-using DwC2 = DwP<GeomC2, AFwd<GeomC2>, 2, 2, false>;     // 64 x 64: 8 ko-tiles
-using DwC3 = DwP<GeomC3, AFwd<GeomC3>, 2, 2, false>;     // 64 x 64: 9 ko-tiles
-using DwL1 = DwP<GeomL1, AFwd<GeomL1>, 2, 2, false>;     // 64 x 64: 49 x 8 tiles, single chunk
-
-// g[i] = scale * sum_c part[c][i].  64 outputs per workgroup, 4 chunk groups per output (chunk c goes
-// to group c % 4), fixed-order combine through LDS => deterministic.
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, size_t stride, int chunks,
-                                                          float* __restrict__ g, int n, int n_weights, float wscale)
-{
-    __shared__ float red[4][64];
-    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + o;
-    float s = 0.f;
-    if (i < n) {
-        int c = grp;
-        for (; c + 12 < chunks; c += 16) {
-            const float v0 = part[(size_t)c * stride + i], v1 = part[(size_t)(c + 4) * stride + i];
-            const float v2 = part[(size_t)(c + 8) * stride + i], v3 = part[(size_t)(c + 12) * stride + i];
-            s += v0; s += v1; s += v2; s += v3;
-        }
-        for (; c < chunks; c += 4) s += part[(size_t)c * stride + i];
-    }
-    red[grp][o] = s;
-    __syncthreads();
-    if (grp == 0 && i < n) {
-        const float t = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
-        g[i] = i < n_weights ? t * wscale : t;
-    }
-}
 
 // ================================================================================================
 // head: l1 finish + l2, one wave per (row, instance)
@@ -478,23 +249,6 @@ void free_batch_buffers(DqnCnn* a)
     (void)hipFree(a->dq); (void)hipFree(a->pred); (void)hipFree(a->tgt); (void)hipFree(a->loss_row);
     (void)hipFree(a->part);
     a->dh1 = a->dy3 = a->dy2 = a->dy1 = a->dq = a->pred = a->tgt = a->loss_row = a->part = nullptr;
-}
-
-// chunk counts of the weight-gradient reductions (rows M split across workgroups)
-struct DwPlan { int chunks_c1, chunks_c2, chunks_c3; size_t stride_c1, stride_c2, stride_c3, off_c1, off_c2, off_c3, total; };
-DwPlan dw_plan(int B)
-{
-    DwPlan p{};
-    auto mt = [](int M) { return (M + 31) / 32; };
-    p.chunks_c1 = std::min(256, mt(B * 400));
-    p.chunks_c2 = std::min(64, mt(B * 81));
-    p.chunks_c3 = std::min(56, mt(B * 49));
-    p.stride_c1 = 256 * 32 + 32; p.stride_c2 = 512 * 64 + 64; p.stride_c3 = 576 * 64 + 64;
-    p.off_c1 = 0;
-    p.off_c2 = p.off_c1 + p.chunks_c1 * p.stride_c1;
-    p.off_c3 = p.off_c2 + p.chunks_c2 * p.stride_c2;
-    p.total = p.off_c3 + p.chunks_c3 * p.stride_c3;
-    return p;
 }
 
 int32_t ensure_batch(DqnCnn* a, int B)

@@ -945,3 +945,190 @@ ORC_API void orc_sac_update(const orc_sac_cfg* c, float* pi, float** qs, float**
     rec->loss_critic = (float)(lc / NC); rec->loss_actor = loss_actor; rec->ent_coef = expf(*log_alpha);
     free(a); free(logp); free(xin); free(na); free(nlogp); free(tgt);
 }
+
+/* ========================================================================= */
+/* IQN -- border-tch-agent/src/iqn/base.rs:63-170 (update_critic),             */
+/* iqn/model/base.rs:162-191 (cos embedding: cos(tau * (PI * i)), i = 1..embed */
+/* INCLUSIVE, linear "iqn_cos_to_feature" + relu), :198-234 (forward: psi(x)   */
+/* [B,1,F] * phi [B,N,F] -> f), util/quantile_loss.rs:7-13.                    */
+/* Percent points tau are inputs (the reference draws them with Tensor::rand). */
+/* psi: kind 0 AtariCnn{skip_linear} (c1..c3, flatten(C,H,W) = 3136) or kind 1 */
+/* Mlp(in -> units -> feature_dim, activation_out).  f: Mlp(F -> units -> A).   */
+/* Flat parameter order: psi vars, iqn_cos_to_feature.weight [F][E], .bias [F], */
+/* f vars.                                                                     */
+/* ========================================================================= */
+typedef struct {
+    int32_t psi_kind;            /* 0 cnn, 1 mlp */
+    int32_t psi_in, n_psi_units, psi_units[ORC_MAX_UNITS], psi_activation_out;
+    int32_t feature_dim, embed_dim;
+    int32_t n_f_units, f_units[ORC_MAX_UNITS];
+    int32_t n_actions;
+    double discount_factor;
+} orc_iqn_cfg;
+
+static int64_t iqn_psi_count(const orc_iqn_cfg* c)
+{
+    if (c->psi_kind == 0) return 8192 + 32 + 32768 + 64 + 36864 + 64;
+    return (int64_t)sac_mlp_make(c->psi_in, c->psi_units, c->n_psi_units, c->feature_dim, 1).total;
+}
+ORC_API int64_t orc_iqn_param_count(const orc_iqn_cfg* c)
+{
+    return iqn_psi_count(c) + (int64_t)c->feature_dim * c->embed_dim + c->feature_dim +
+           (int64_t)sac_mlp_make(c->feature_dim, c->f_units, c->n_f_units, c->n_actions, 1).total;
+}
+
+typedef struct {
+    int B, N;
+    /* psi */
+    float *x0, *a1, *a2, *psi;          /* cnn activations (psi = post-relu conv3, flattened C,H,W) */
+    float** pacts; sac_mlp pm; const float* px;   /* mlp psi */
+    float *cosv, *phi, *m;              /* [B*N][E], [B*N][F], [B*N][F] */
+    float** facts; sac_mlp fm;
+} iqn_cache;
+
+static void iqn_forward(const orc_iqn_cfg* c, const float* p, const void* x, const float* tau, int B, int N, iqn_cache* k)
+{
+    const int F = c->feature_dim, E = c->embed_dim;
+    memset(k, 0, sizeof *k);
+    k->B = B; k->N = N;
+    const float* q = p;
+    if (c->psi_kind == 0) {
+        const uint8_t* u = (const uint8_t*)x;
+        const size_t n = (size_t)B * 4 * 84 * 84;
+        k->x0 = (float*)malloc(sizeof(float) * n);
+        for (size_t i = 0; i < n; ++i) k->x0[i] = (float)u[i] / 255.0f;
+        k->a1 = (float*)malloc(sizeof(float) * (size_t)B * 32 * 400);
+        k->a2 = (float*)malloc(sizeof(float) * (size_t)B * 64 * 81);
+        k->psi = (float*)malloc(sizeof(float) * (size_t)B * 3136);
+        conv2d_fwd(k->x0, q, q + 8192, k->a1, B, 4, 84, 84, 32, 8, 4, 1);
+        conv2d_fwd(k->a1, q + 8224, q + 8224 + 32768, k->a2, B, 32, 20, 20, 64, 4, 2, 1);
+        conv2d_fwd(k->a2, q + 41056, q + 41056 + 36864, k->psi, B, 64, 9, 9, 64, 3, 1, 1);
+    } else {
+        k->pm = sac_mlp_make(c->psi_in, c->psi_units, c->n_psi_units, c->feature_dim, 1);
+        k->pm.relu[k->pm.n - 1] = c->psi_activation_out;
+        k->pacts = acts_alloc(&k->pm, B);
+        k->px = (const float*)x;
+        sac_mlp_fwd(&k->pm, q, k->px, B, k->pacts);
+        k->psi = (float*)malloc(sizeof(float) * (size_t)B * F);
+        memcpy(k->psi, k->pacts[k->pm.n - 1], sizeof(float) * (size_t)B * F);
+    }
+    q += iqn_psi_count(c);
+    const float* wc = q; const float* bc = q + (size_t)F * E;
+    q = bc + F;
+    const int M = B * N;
+    k->cosv = (float*)malloc(sizeof(float) * (size_t)M * E);
+    const float pif = (float)3.14159265358979323846;
+    for (int r = 0; r < M; ++r)
+        for (int i = 0; i < E; ++i) k->cosv[(size_t)r * E + i] = cosf(tau[r] * (pif * (float)(i + 1)));
+    k->phi = (float*)malloc(sizeof(float) * (size_t)M * F);
+    linear_fwd(k->cosv, wc, bc, k->phi, M, E, F, 1);
+    k->m = (float*)malloc(sizeof(float) * (size_t)M * F);
+    for (int r = 0; r < M; ++r)
+        for (int j = 0; j < F; ++j) k->m[(size_t)r * F + j] = k->psi[(size_t)(r / N) * F + j] * k->phi[(size_t)r * F + j];
+    k->fm = sac_mlp_make(F, c->f_units, c->n_f_units, c->n_actions, 1);
+    k->facts = acts_alloc(&k->fm, M);
+    sac_mlp_fwd(&k->fm, q, k->m, M, k->facts);
+}
+
+static void iqn_cache_free(iqn_cache* k)
+{
+    free(k->x0); free(k->a1); free(k->a2); free(k->psi); free(k->cosv); free(k->phi); free(k->m);
+    if (k->pacts) acts_free(&k->pm, k->pacts);
+    if (k->facts) acts_free(&k->fm, k->facts);
+}
+
+typedef struct { float* z_pred; float* z_tgt; float* tgt; float* grads; } orc_iqn_probe;
+
+/* One Iqn::update_critic (iqn/base.rs:63-170) on a minibatch; returns the loss. */
+ORC_API float orc_iqn_update(const orc_iqn_cfg* c, float* iqn, const float* iqn_tgt, orc_adam_cfg* adam, float* am, float* av,
+                             int B, const void* obs, const int64_t* act, const void* next_obs, const float* reward,
+                             const int8_t* term, const float* tau_pred, int n_pred, const float* tau_tgt, int n_tgt,
+                             orc_iqn_probe* probe)
+{
+    const int A = c->n_actions, F = c->feature_dim, E = c->embed_dim;
+    const int64_t np = orc_iqn_param_count(c);
+    iqn_cache k, kt;
+    iqn_forward(c, iqn, obs, tau_pred, B, n_pred, &k);
+    iqn_forward(c, iqn_tgt, next_obs, tau_tgt, B, n_tgt, &kt);
+    const float* z = k.facts[k.fm.n - 1];      /* [B*Np][A] */
+    const float* zt = kt.facts[kt.fm.n - 1];   /* [B*Nt][A] */
+    if (probe && probe->z_pred) memcpy(probe->z_pred, z, sizeof(float) * (size_t)B * n_pred * A);
+    if (probe && probe->z_tgt) memcpy(probe->z_tgt, zt, sizeof(float) * (size_t)B * n_tgt * A);
+    float* tgt = (float*)malloc(sizeof(float) * (size_t)B * n_tgt);
+    const float gamma = (float)c->discount_factor;
+    for (int b = 0; b < B; ++b) {
+        /* a* = argmax_a mean_tau z_tgt */
+        int best = 0; float bv = 0.f;
+        for (int a = 0; a < A; ++a) {
+            double s = 0.0;
+            for (int n = 0; n < n_tgt; ++n) s += zt[((size_t)b * n_tgt + n) * A + a];
+            float mv = (float)(s / n_tgt);
+            if (a == 0 || mv > bv) { bv = mv; best = a; }
+        }
+        for (int n = 0; n < n_tgt; ++n)
+            tgt[(size_t)b * n_tgt + n] = reward[b] + ((float)(1 - term[b]) * gamma) * zt[((size_t)b * n_tgt + n) * A + best];
+    }
+    if (probe && probe->tgt) memcpy(probe->tgt, tgt, sizeof(float) * (size_t)B * n_tgt);
+    /* loss = mean_{b,n',n} |tau_p[b,n] - 1{d<0}| * huber_1(d),  d = tgt[b,n'] - pred[b,n] */
+    double lsum = 0.0;
+    float* dz = (float*)calloc((size_t)B * n_pred * A, sizeof(float));
+    const float inv = 1.0f / ((float)B * (float)n_tgt * (float)n_pred);
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < n_pred; ++n) {
+            const float pred = z[((size_t)b * n_pred + n) * A + act[b]];
+            const float tp = tau_pred[(size_t)b * n_pred + n];
+            double g = 0.0;
+            for (int m = 0; m < n_tgt; ++m) {
+                const float d = tgt[(size_t)b * n_tgt + m] - pred;
+                const float zabs = fabsf(d);
+                const float hub = zabs < 1.f ? 0.5f * zabs * zabs : zabs - 0.5f;
+                const float dh = zabs < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+                const float w = fabsf(tp - (d < 0.f ? 1.f : 0.f));
+                lsum += (double)(w * hub);
+                g += (double)(w * dh) * -1.0;   /* d(diff)/d(pred) = -1 */
+            }
+            dz[((size_t)b * n_pred + n) * A + act[b]] = (float)g * inv;
+        }
+    const float loss = (float)(lsum * (double)inv);
+    /* backward */
+    float* g = (float*)calloc((size_t)np, sizeof(float));
+    const int64_t npsi = iqn_psi_count(c);
+    float* gwc = g + npsi; float* gbc = gwc + (size_t)F * E; float* gf = gbc + F;
+    const float* fparams = iqn + npsi + (size_t)F * E + F;
+    const int M = B * n_pred;
+    float* dm = (float*)malloc(sizeof(float) * (size_t)M * F);
+    sac_mlp_bwd(&k.fm, fparams, k.m, M, k.facts, dz, gf, dm);
+    float* dphi = (float*)malloc(sizeof(float) * (size_t)M * F);
+    float* dpsi = (float*)calloc((size_t)B * F, sizeof(float));
+    for (int r = 0; r < M; ++r)
+        for (int j = 0; j < F; ++j) {
+            const size_t q = (size_t)r * F + j;
+            dphi[q] = k.phi[q] > 0.f ? dm[q] * k.psi[(size_t)(r / n_pred) * F + j] : 0.f;
+        }
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < F; ++j) {
+            double s = 0.0;
+            for (int n = 0; n < n_pred; ++n) { const size_t q = ((size_t)b * n_pred + n) * F + j; s += (double)dm[q] * k.phi[q]; }
+            dpsi[(size_t)b * F + j] = (float)s;
+        }
+    linear_bwd(k.cosv, iqn + npsi, dphi, gwc, gbc, NULL, M, E, F);
+    if (c->psi_kind == 0) {
+        float* d3 = dpsi;   /* grad wrt post-relu conv3 output, (C,H,W) order */
+        relu_bwd(k.psi, d3, (size_t)B * 3136);
+        float* d2 = (float*)malloc(sizeof(float) * (size_t)B * 64 * 81);
+        float* d1 = (float*)malloc(sizeof(float) * (size_t)B * 32 * 400);
+        conv2d_bwd(k.a2, iqn + 41056, d3, g + 41056, g + 41056 + 36864, d2, B, 64, 9, 9, 64, 3, 1);
+        relu_bwd(k.a2, d2, (size_t)B * 64 * 81);
+        conv2d_bwd(k.a1, iqn + 8224, d2, g + 8224, g + 8224 + 32768, d1, B, 32, 20, 20, 64, 4, 2);
+        relu_bwd(k.a1, d1, (size_t)B * 32 * 400);
+        conv2d_bwd(k.x0, iqn, d1, g, g + 8192, NULL, B, 4, 84, 84, 32, 8, 4);
+        free(d2); free(d1);
+    } else {
+        sac_mlp_bwd(&k.pm, iqn, k.px, B, k.pacts, dpsi, g, NULL);
+    }
+    if (probe && probe->grads) memcpy(probe->grads, g, sizeof(float) * (size_t)np);
+    orc_adam_step(adam, iqn, g, am, av, np);
+    free(tgt); free(dz); free(g); free(dm); free(dphi); free(dpsi);
+    iqn_cache_free(&k); iqn_cache_free(&kt);
+    return loss;
+}

@@ -322,3 +322,61 @@ class SacOracle:
                              C.byref(rec), C.byref(pr) if probe else None)
         bufs.update(loss_critic=rec.loss_critic, loss_actor=rec.loss_actor, ent_coef=rec.ent_coef)
         return bufs
+
+
+# ----------------------------------------------------------------------------- IQN
+class IqnCfg(C.Structure):
+    _fields_ = [("psi_kind", C.c_int32), ("psi_in", C.c_int32), ("n_psi_units", C.c_int32), ("psi_units", C.c_int32 * 8),
+                ("psi_activation_out", C.c_int32), ("feature_dim", C.c_int32), ("embed_dim", C.c_int32),
+                ("n_f_units", C.c_int32), ("f_units", C.c_int32 * 8), ("n_actions", C.c_int32), ("discount_factor", C.c_double)]
+
+
+class IqnProbe(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("z_pred", "z_tgt", "tgt", "grads")]
+
+
+class IqnOracle:
+    """Iqn::opt_ restatement (iqn/base.rs:172-191) over explicit minibatches and injected percent points."""
+
+    def __init__(self, psi_kind, params, *, lr, feature_dim, embed_dim, f_units, n_actions, psi_in=0, psi_units=(),
+                 psi_activation_out=True, discount_factor=0.99, tau=0.005, soft_update_interval=1):
+        L = lib()
+        L.orc_iqn_param_count.restype = C.c_int64
+        L.orc_iqn_update.restype = C.c_float
+        c = IqnCfg()
+        c.psi_kind = 0 if psi_kind == "cnn" else 1
+        c.psi_in, c.n_psi_units, c.psi_activation_out = psi_in, len(psi_units), int(psi_activation_out)
+        for i, u in enumerate(psi_units):
+            c.psi_units[i] = u
+        c.feature_dim, c.embed_dim, c.n_f_units, c.n_actions, c.discount_factor = feature_dim, embed_dim, len(f_units), n_actions, discount_factor
+        for i, u in enumerate(f_units):
+            c.f_units[i] = u
+        self.cfg = c
+        self.p = np.array(params, np.float32, copy=True)
+        assert self.p.size == L.orc_iqn_param_count(C.byref(c)), (self.p.size, L.orc_iqn_param_count(C.byref(c)))
+        self.p_tgt = self.p.copy()
+        self.m, self.v = np.zeros_like(self.p), np.zeros_like(self.p)
+        self.adam = AdamCfg(lr, 0.9, 0.999, 1e-8, 0)
+        self.tau, self.soft_update_interval, self.soft_update_counter = tau, soft_update_interval, 0
+
+    def update(self, obs, act, next_obs, reward, term, tau_pred, tau_tgt):
+        B = len(reward)
+        A = self.cfg.n_actions
+        obs, next_obs = np.ascontiguousarray(obs), np.ascontiguousarray(next_obs)
+        act = np.ascontiguousarray(act, dtype=np.int64).reshape(B)
+        reward = np.ascontiguousarray(reward, dtype=np.float32)
+        term = np.ascontiguousarray(term, dtype=np.int8)
+        tp = np.ascontiguousarray(tau_pred, dtype=np.float32)
+        tt = np.ascontiguousarray(tau_tgt, dtype=np.float32)
+        bufs = dict(z_pred=np.empty((B, tp.shape[1], A), np.float32), z_tgt=np.empty((B, tt.shape[1], A), np.float32),
+                    tgt=np.empty((B, tt.shape[1]), np.float32), grads=np.empty_like(self.p))
+        pr = IqnProbe(*[bufs[n].ctypes.data for n, _ in IqnProbe._fields_])
+        loss = lib().orc_iqn_update(C.byref(self.cfg), _p(self.p), _p(self.p_tgt), C.byref(self.adam), _p(self.m), _p(self.v),
+                                    C.c_int(B), _p(obs), _p(act), _p(next_obs), _p(reward), _p(term), _p(tp), C.c_int(tp.shape[1]),
+                                    _p(tt), C.c_int(tt.shape[1]), C.byref(pr))
+        self.soft_update_counter += 1
+        if self.soft_update_counter == self.soft_update_interval:
+            self.soft_update_counter = 0
+            lib().orc_track(_p(self.p_tgt), _p(self.p), C.c_double(self.tau), self.p.size)
+        bufs["loss"] = float(loss)
+        return bufs

@@ -361,3 +361,119 @@ def sac_batch(B, obs_dim, act_dim, seed):
     z1 = rng.standard_normal((B, act_dim)).astype(np.float32)
     z2 = rng.standard_normal((B, act_dim)).astype(np.float32)
     return obs, act, nobs, rew, term, z1, z2
+
+
+# ================================================================================================
+# IQN  (border-tch-agent/src/iqn/base.rs:63-170, iqn/model/base.rs:162-234, util/quantile_loss.rs:7-13)
+# ================================================================================================
+def iqn_shapes(psi_kind, feature_dim, embed_dim, f_units, n_actions, psi_in=None, psi_units=()):
+    """IqnModel variables: psi (AtariCnn{skip_linear:true}: c1..c3 | Mlp in->units->feature_dim),
+    iqn_cos_to_feature.weight/bias, f = Mlp(feature_dim -> f_units -> n_actions)."""
+    if psi_kind == "cnn":
+        psi = [(32, 4, 8, 8), (32,), (64, 32, 4, 4), (64,), (64, 64, 3, 3), (64,)]
+        assert feature_dim == 3136
+    else:
+        psi = mlp_shapes(psi_in, psi_units, feature_dim)
+    return psi, [(feature_dim, embed_dim), (feature_dim,)], mlp_shapes(feature_dim, f_units, n_actions)
+
+
+def quantile_huber_loss(x, tau):
+    """util/quantile_loss.rs:7-13."""
+    lt_0 = x.lt(0.0).detach()
+    loss = F.smooth_l1_loss(x, torch.zeros_like(x), reduction="none", beta=1.0)
+    return (tau - torch.where(lt_0, 1.0, 0.0)).abs() * loss
+
+
+class TorchIqn:
+    """Iqn::update_critic / opt_ with injected percent points (the reference draws them with
+    Tensor::rand on the CPU generator: iqn/model/base.rs:365-368)."""
+
+    def __init__(self, psi_kind, shapes3, params, *, lr, feature_dim, embed_dim, discount_factor=0.99, tau=0.005,
+                 soft_update_interval=1, psi_activation_out=True):
+        self.psi_kind = psi_kind
+        self.shapes = shapes3[0] + shapes3[1] + shapes3[2]
+        self.n_psi, self.n_f = len(shapes3[0]), len(shapes3[2])
+        self.p = [t.requires_grad_(True) for t in unflatten(params, self.shapes)]
+        self.p_tgt = unflatten(params, self.shapes)   # IqnModel::clone
+        self.m = [torch.zeros_like(t) for t in self.p]
+        self.v = [torch.zeros_like(t) for t in self.p]
+        self.lr, self.step, self.gamma, self.tau = lr, 0, discount_factor, tau
+        self.F, self.E = feature_dim, embed_dim
+        self.soft_update_interval, self.soft_update_counter = soft_update_interval, 0
+        self.psi_activation_out = psi_activation_out
+
+    def forward(self, p, x, tau):
+        """IqnModel::forward (iqn/model/base.rs:198-234)."""
+        psi_p, cos_p, f_p = p[:self.n_psi], p[self.n_psi:self.n_psi + 2], p[self.n_psi + 2:]
+        if self.psi_kind == "cnn":   # AtariCnn::create_net_wo_linear (cnn/base.rs:38-47)
+            h = x.squeeze(2).to(torch.float32) / 255
+            h = F.conv2d(h, psi_p[0], psi_p[1], stride=4).relu()
+            h = F.conv2d(h, psi_p[2], psi_p[3], stride=2).relu()
+            psi = F.conv2d(h, psi_p[4], psi_p[5], stride=1).relu().flatten(1)
+        else:
+            psi = mlp_forward(psi_p, x, activation_out=self.psi_activation_out)
+        B, N = tau.shape
+        i = torch.arange(1, self.E + 1, dtype=torch.float32).reshape(1, 1, -1)        # Tensor::range(1, embed_dim) inclusive
+        cos = torch.cos(tau.unsqueeze(-1) * (math.pi * i)).reshape(-1, self.E)         # :162-182
+        phi = F.linear(cos, cos_p[0], cos_p[1]).relu().reshape(B, N, self.F)            # iqn_cos_to_feature + relu
+        m = psi.unsqueeze(1) * phi
+        return mlp_forward(f_p, m)                                                     # [B, N, A]
+
+    def update(self, obs, act, next_obs, reward, term, tau_pred, tau_tgt):
+        """iqn/base.rs:63-170 + opt_ :172-191."""
+        obs = torch.from_numpy(np.ascontiguousarray(obs))
+        next_obs = torch.from_numpy(np.ascontiguousarray(next_obs))
+        act = torch.from_numpy(np.ascontiguousarray(act, dtype=np.int64)).reshape(-1, 1)
+        reward = torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)).unsqueeze(-1)
+        is_terminated = torch.from_numpy(np.ascontiguousarray(term, dtype=np.int8)).unsqueeze(-1)
+        tau_p = torch.from_numpy(np.ascontiguousarray(tau_pred, dtype=np.float32))
+        tau_t = torch.from_numpy(np.ascontiguousarray(tau_tgt, dtype=np.float32))
+        n_p, n_t = tau_p.shape[1], tau_t.shape[1]
+        z = self.forward(self.p, obs, tau_p)
+        a = act.unsqueeze(1).repeat(1, n_p, 1)
+        pred = z.gather(-1, a).squeeze(-1).unsqueeze(1)          # [B,1,Np]
+        with torch.no_grad():
+            zt = self.forward(self.p_tgt, next_obs, tau_t)
+            y = zt.clone().mean(1)
+            a2 = y.argmax(-1).unsqueeze(-1).unsqueeze(-1).repeat(1, n_t, 1)
+            zsel = zt.gather(2, a2).squeeze(-1)
+            tgt = (reward + (1 - is_terminated) * self.gamma * zsel).unsqueeze(-1)   # [B,Nt,1]
+        diff = tgt - pred
+        tau_rep = tau_p.unsqueeze(1).repeat(1, n_t, 1)
+        loss = quantile_huber_loss(diff, tau_rep).mean()
+        for p in self.p:
+            p.grad = None
+        loss.backward()
+        grads = flatten([p.grad for p in self.p])
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        self.step += 1
+        bc1, bc2 = 1 - b1 ** self.step, 1 - b2 ** self.step
+        with torch.no_grad():
+            for p, m, v in zip(self.p, self.m, self.v):
+                g = p.grad
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+                p.addcdiv_(m, denom, value=-(self.lr / bc1))
+        self.soft_update_counter += 1
+        if self.soft_update_counter == self.soft_update_interval:
+            self.soft_update_counter = 0
+            with torch.no_grad():
+                for d, s in zip(self.p_tgt, self.p):
+                    d.copy_(self.tau * s + (1.0 - self.tau) * d)
+        return dict(loss=float(loss.detach()), z_pred=z.detach().numpy().copy(), z_tgt=zt.numpy().copy(),
+                    tgt=tgt.squeeze(-1).numpy().copy(), grads=grads, params=flatten(self.p), tgt_params=flatten(self.p_tgt))
+
+
+def iqn_batch(B, psi_kind, n_actions, n_pred, n_tgt, seed, in_dim=None):
+    rng = np.random.default_rng(seed)
+    if psi_kind == "cnn":
+        obs = rng.integers(0, 256, size=(B, 4, 1, 84, 84), dtype=np.uint8)
+        nobs = rng.integers(0, 256, size=(B, 4, 1, 84, 84), dtype=np.uint8)
+    else:
+        obs = rng.standard_normal((B, in_dim)).astype(np.float32)
+        nobs = rng.standard_normal((B, in_dim)).astype(np.float32)
+    act = rng.integers(0, n_actions, size=B)
+    rew = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=B).astype(np.float32)
+    term = (rng.random(B) < 0.1).astype(np.int8)
+    return obs, act, nobs, rew, term, rng.random((B, n_pred), dtype=np.float32), rng.random((B, n_tgt), dtype=np.float32)

@@ -177,6 +177,47 @@ def make_sac():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+IQN_CASES = {
+    # name: (psi_kind, feature_dim, embed_dim, f_units, n_actions, psi_in, psi_units, B, n_pred, n_tgt, steps, lr)
+    "iqn_mlp_small": ("mlp", 64, 16, [32], 3, 5, [48], 8, 8, 8, 3, 1e-3),
+    "iqn_cnn_b2": ("cnn", 3136, 64, [512], 6, None, [], 2, 8, 8, 2, 1e-4),
+}
+
+
+def iqn_case(name):
+    from oracle import torch_ref as T
+    kind, F_, E, fu, A, pin, pu, B, n_p, n_t, steps, lr = IQN_CASES[name]
+    sh = T.iqn_shapes(kind, F_, E, fu, A, psi_in=pin, psi_units=pu)
+    seed = sum(map(ord, name))
+    p0 = T.init_params(sh[0] + sh[1] + sh[2], seed)
+    return kind, F_, E, fu, A, pin, pu, B, n_p, n_t, steps, lr, sh, p0, seed
+
+
+def make_iqn():
+    """IQN goldens: PyTorch CPU autograd, injected percent points; CNN case stores strided samples."""
+    from oracle import torch_ref as T
+    import torch
+    torch.set_num_threads(1)
+    for name in IQN_CASES:
+        kind, F_, E, fu, A, pin, pu, B, n_p, n_t, steps, lr, sh, p0, seed = iqn_case(name)
+        agent = T.TorchIqn(kind, sh, p0, lr=lr, feature_dim=F_, embed_dim=E, tau=0.01, soft_update_interval=2)
+        st = sample_stride(p0.size)
+        out = {}
+        for s in range(steps):
+            r = agent.update(*T.iqn_batch(B, kind, A, n_p, n_t, seed + 50 + s, in_dim=pin))
+            out[f"s{s}_loss"] = np.float32(r["loss"])
+            out[f"s{s}_z_pred"], out[f"s{s}_z_tgt"], out[f"s{s}_tgt"] = r["z_pred"], r["z_tgt"], r["tgt"]
+            out[f"s{s}_grads_sample"], out[f"s{s}_params_sample"] = r["grads"][::st], r["params"][::st]
+            out[f"s{s}_tgt_params_sample"] = r["tgt_params"][::st]
+            o, gn = 0, []
+            for shp in sh[0] + sh[1] + sh[2]:
+                n = int(np.prod(shp))
+                gn.append(np.linalg.norm(r["grads"][o:o + n].astype(np.float64)))
+                o += n
+            out[f"s{s}_grad_norms"] = np.array(gn)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def main():
     make_rng()
     from oracle import torch_ref as T
@@ -201,6 +242,7 @@ def main():
     make_dqn("dqn_mlp_cartpole.npz", "mlp", T.mlp_shapes(4, [64, 64], 2), cart, 5,
              param_seed=3, lr=1e-3, critic_loss="Mse", tau=0.01, soft_update_interval=1)
     make_sac()
+    make_iqn()
     print("fixtures:", sorted(os.listdir(HERE)))
 
 

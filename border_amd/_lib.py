@@ -43,6 +43,15 @@ class DqnConfigC(C.Structure):
                 ("record_verbose_level", C.c_int32), ("device", C.c_int32), ("param_seed", C.c_uint64)]
 
 
+class IqnConfigC(C.Structure):
+    _fields_ = [("psi", NetConfig), ("feature_dim", C.c_int32), ("embed_dim", C.c_int32), ("n_f_units", C.c_int32),
+                ("f_units", C.c_int32 * BDR_MAX_UNITS), ("n_actions", C.c_int32), ("lr", C.c_double),
+                ("soft_update_interval", C.c_uint64), ("n_updates_per_opt", C.c_uint64), ("batch_size", C.c_uint64),
+                ("discount_factor", C.c_double), ("tau", C.c_double), ("sample_percents_pred", C.c_int32),
+                ("sample_percents_tgt", C.c_int32), ("sample_percents_act", C.c_int32), ("train", C.c_int32),
+                ("device", C.c_int32), ("seed", C.c_uint64)]
+
+
 class SacConfigC(C.Structure):
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_pi_units", C.c_int32), ("pi_units", C.c_int32 * BDR_MAX_UNITS),
                 ("n_q_units", C.c_int32), ("q_units", C.c_int32 * BDR_MAX_UNITS), ("lr_actor", C.c_double), ("lr_critic", C.c_double),
@@ -75,6 +84,7 @@ ABI_SYMBOLS = [
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
     "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_dqn_probe",
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
+    "bdr_iqn_config_default", "bdr_iqn_create", "bdr_iqn_update_on_batch", "bdr_iqn_forward", "bdr_iqn_qvalues",
     "bdr_sac_config_default", "bdr_sac_create", "bdr_sac_update_on_batch", "bdr_sac_sample",
     "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_agent_allreduce_params",
     "bdr_agent_broadcast_params",
@@ -100,10 +110,11 @@ def lib() -> C.CDLL:
     L.bdr_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == ABI drift
-        if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default"):
+        if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default", "bdr_iqn_config_default"):
             fn.restype = C.c_int32
     L.bdr_dqn_config_default.restype = None
     L.bdr_sac_config_default.restype = None
+    L.bdr_iqn_config_default.restype = None
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     L.bdr_replay_create.argtypes = [C.POINTER(ReplayConfig), C.POINTER(vp)]
     L.bdr_replay_destroy.argtypes = [vp]
@@ -137,6 +148,11 @@ def lib() -> C.CDLL:
     L.bdr_dqn_probe.argtypes = [vp, i32, vp, u64]
     L.bdr_agent_profile_enable.argtypes = [vp, i32]
     L.bdr_agent_profile_read.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
+    L.bdr_iqn_config_default.argtypes = [C.POINTER(IqnConfigC)]
+    L.bdr_iqn_create.argtypes = [C.POINTER(IqnConfigC), C.POINTER(vp)]
+    L.bdr_iqn_update_on_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp]
+    L.bdr_iqn_forward.argtypes = [vp, i32, u64, vp, vp, i32, vp]
+    L.bdr_iqn_qvalues.argtypes = [vp, u64, vp, vp, vp]
     L.bdr_sac_config_default.argtypes = [C.POINTER(SacConfigC)]
     L.bdr_sac_create.argtypes = [C.POINTER(SacConfigC), C.POINTER(vp)]
     L.bdr_sac_update_on_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -53,7 +53,7 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint32_t lo, uint32_t hi)
 // instance b % nz.  Prologue: split the instance's f32 weights into the three bf16 planes directly
 // into LDS (each thread 2 fragments of 8 k).  Then every wave walks 32-pixel items with stride G*8;
 // the next item's pixels are prefetched into registers, no barrier inside the item loop.
-__global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
+static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
 {
     __shared__ uint4 wl[3 * C1_PLANE_VECS];   // 48 KiB: three bf16 weight planes in B-fragment order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -106,6 +106,8 @@ struct DenseArgs {
     int M, ncols, kred, relu;
     int w_ld;            // row stride of W (= Np of the layer)
     int accum;           // dx: out += result (sum of several branches' input gradients)
+    // fwd: optional Hadamard merge (IQN: m = relu(cos-embed) * psi[b]):  out2[m][n] = out[m][n] * had[(m / had_group)][n]
+    const float* had; int had_ld, had_group; float* out2;
 };
 
 struct DenseFwd {
@@ -125,6 +127,7 @@ struct DenseFwd {
         v += a.bias[n];
         if (a.relu) v = v > 0.f ? v : 0.f;
         a.out[(size_t)m * a.ldo + n] = v;
+        if (a.had) a.out2[(size_t)m * a.ldo + n] = v * a.had[(size_t)(m / a.had_group) * a.had_ld + n];
     }
 };
 
@@ -192,9 +195,11 @@ __global__ void k_pack_rows(const float* __restrict__ src, int src_ld, int cols,
 }
 
 // ---- host-side layer launches ------------------------------------------------------------------------
-inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, const float* params_base, DenseSrc x, float* out, int M)
+inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, const float* params_base, DenseSrc x, float* out, int M,
+                             const float* had = nullptr, int had_ld = 0, int had_group = 1, float* out2 = nullptr)
 {
     DenseArgs d{};
+    d.had = had; d.had_ld = had_ld; d.had_group = had_group; d.out2 = out2;
     d.x = x; d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
     d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
     hipLaunchKernelGGL(k_igemm<DenseFwd>, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), dim3(256), 0, st, d);

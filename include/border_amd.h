@@ -233,6 +233,39 @@ BDR_API int32_t bdr_agent_profile_read(bdr_agent* a, char* names_out, uint64_t n
                                        float* ms_out, uint64_t* count_inout);
 
 /* ------------------------------------------------------------------------------------------
+ * IQN agent  (border-tch-agent/src/iqn/base.rs, iqn/config.rs:50-67, iqn/model/base.rs)
+ * ---------------------------------------------------------------------------------------- */
+/* IqnSample (iqn/model/base.rs:327-387); Const32 yields 33 points like the reference. */
+enum { BDR_IQN_CONST10 = 0, BDR_IQN_CONST32 = 1, BDR_IQN_UNIFORM10 = 2, BDR_IQN_UNIFORM8 = 3,
+       BDR_IQN_UNIFORM32 = 4, BDR_IQN_UNIFORM64 = 5, BDR_IQN_MEDIAN = 6 };
+typedef struct {
+    bdr_net_config psi;          /* feature extractor F: AtariCnn{skip_linear:true} or Mlp (out_dim = feature_dim) */
+    int32_t feature_dim, embed_dim;                   /* IqnModelConfig */
+    int32_t n_f_units; int32_t f_units[BDR_MAX_UNITS];   /* merge net M = Mlp(feature_dim -> units -> n_actions) */
+    int32_t n_actions;
+    double lr;                                        /* OptimizerConfig::Adam{lr} */
+    uint64_t soft_update_interval, n_updates_per_opt, batch_size;
+    double discount_factor, tau;
+    int32_t sample_percents_pred, sample_percents_tgt, sample_percents_act;
+    int32_t train;
+    int32_t device;
+    uint64_t seed;
+} bdr_iqn_config;
+BDR_API void bdr_iqn_config_default(bdr_iqn_config* cfg);                    /* iqn/config.rs:50-67 */
+BDR_API int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out);  /* iqn/base.rs:230-268 */
+/* One Iqn::opt_ update on a host minibatch with injected percent points (the reference draws them with
+ * Tensor::rand, iqn/model/base.rs:365-368). */
+BDR_API int32_t bdr_iqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act,
+                                        const void* next_obs, const float* reward, const int8_t* is_terminated,
+                                        const float* tau_pred, int32_t n_pred, const float* tau_tgt, int32_t n_tgt,
+                                        float* loss_out);
+/* IqnModel::forward (iqn/model/base.rs:198-234): z_out [n][n_tau][n_actions]; which 0 = iqn, 1 = iqn_tgt. */
+BDR_API int32_t bdr_iqn_forward(bdr_agent* a, int32_t which, uint64_t n, const void* obs, const float* tau,
+                                int32_t n_tau, float* z_out);
+/* Policy::sample greedy part (iqn/base.rs:204-228): values averaged over sample_percents_act. */
+BDR_API int32_t bdr_iqn_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out, int64_t* argmax_out);
+
+/* ------------------------------------------------------------------------------------------
  * SAC agent  (border-tch-agent/src/sac/base.rs, sac/config.rs:85-105, sac/ent_coef.rs,
  * Actor = Mlp2 (mlp/mlp2.rs), Critic = Mlp on cat(obs, act) (mlp/base.rs:83-107))
  * ---------------------------------------------------------------------------------------- */

@@ -1,0 +1,108 @@
+"""HIP IQN step (through the C ABI) vs the committed PyTorch-autograd goldens and the C oracle.
+BASELINE config 4 shape: AtariCnn{skip_linear} trunk, F = 3136, embed 64, merge Mlp(3136,[512],A)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import make_golden as MG  # noqa: E402
+
+QTOL = 1e-4
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def B():
+    import border_amd
+    if border_amd.device_count() == 0:
+        pytest.fail("no MI355X visible: the HIP path must run on the GPU box")
+    return border_amd
+
+
+def _agent(B, kind, F_, E, fu, A, pin, pu, Bsz, lr, p0, **kw):
+    f_cfg = B.AtariCnnConfig(n_stack=4, skip_linear=True) if kind == "cnn" else B.MlpConfig(in_dim=pin, units=tuple(pu), out_dim=F_, activation_out=True)
+    cfg = B.IqnConfig(f_config=f_cfg, feature_dim=F_, embed_dim=E, m_units=tuple(fu), n_actions=A, lr=lr, batch_size=Bsz, device=0, **kw)
+    a = B.Iqn.build(cfg)
+    a.set_params(p0, "iqn"); a.set_params(p0, "iqn_tgt")
+    return a
+
+
+def _run(B, name, golden_dir):
+    from oracle import torch_ref as T
+    kind, F_, E, fu, A, pin, pu, Bsz, n_p, n_t, steps, lr, sh, p0, seed = MG.iqn_case(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    a = _agent(B, kind, F_, E, fu, A, pin, pu, Bsz, lr, p0, tau=0.01, soft_update_interval=2)
+    assert (a.get_params("iqn") == p0).all() and a.param_count() == p0.size
+    st = MG.sample_stride(p0.size)
+    for s in range(steps):
+        batch = T.iqn_batch(Bsz, kind, A, n_p, n_t, seed + 50 + s, in_dim=pin)
+        assert rel(a.forward(batch[0], batch[5], "iqn"), g[f"s{s}_z_pred"]) < QTOL, s
+        assert rel(a.forward(batch[2], batch[6], "iqn_tgt"), g[f"s{s}_z_tgt"]) < QTOL, s
+        rec = a.update_on_batch(*batch)
+        assert abs(rec["loss_critic"] - g[f"s{s}_loss"]) <= QTOL * abs(g[f"s{s}_loss"]) + 1e-9, (s, rec, g[f"s{s}_loss"])
+        grads = a.get_params("grad")
+        assert rel(grads[::st], g[f"s{s}_grads_sample"]) < 5e-4, (s, rel(grads[::st], g[f"s{s}_grads_sample"]))
+        o = 0
+        for i, shp in enumerate(sh[0] + sh[1] + sh[2]):
+            n = int(np.prod(shp))
+            gn = np.linalg.norm(grads[o:o + n].astype(np.float64))
+            assert abs(gn - g[f"s{s}_grad_norms"][i]) <= 1e-3 * g[f"s{s}_grad_norms"][i] + 1e-12, (s, i)
+            o += n
+        assert np.abs(a.get_params("iqn")[::st].astype(np.float64) - g[f"s{s}_params_sample"]).max() < 0.1 * lr
+        assert rel(a.get_params("iqn_tgt")[::st], g[f"s{s}_tgt_params_sample"]) < 1e-5
+    a.close()
+
+
+def test_iqn_golden_mlp_small(B, golden_dir):
+    _run(B, "iqn_mlp_small", golden_dir)
+
+
+def test_iqn_golden_cnn_b2(B, golden_dir):
+    _run(B, "iqn_cnn_b2", golden_dir)
+
+
+def test_iqn_cnn_64_quantiles_vs_oracle(B):
+    """BASELINE config 4 shape at a reduced batch (B=16, 64 pred/tgt quantiles, Nature trunk): one update vs the C oracle."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    sh = T.iqn_shapes("cnn", 3136, 64, [512], 6)
+    p0 = T.init_params(sh[0] + sh[1] + sh[2], 31)
+    a = _agent(B, "cnn", 3136, 64, [512], 6, None, [], 16, 1e-4, p0, tau=1.0, soft_update_interval=10000)
+    ref = O.IqnOracle("cnn", p0, lr=1e-4, feature_dim=3136, embed_dim=64, f_units=[512], n_actions=6, tau=1.0, soft_update_interval=10000)
+    batch = T.iqn_batch(16, "cnn", 6, 64, 64, 77)
+    rec = a.update_on_batch(*batch)
+    r = ref.update(*batch)
+    assert abs(rec["loss_critic"] - r["loss"]) <= QTOL * abs(r["loss"])
+    g = a.get_params("grad")
+    assert rel(g, r["grads"]) < 5e-4, rel(g, r["grads"])
+    a.close()
+
+
+def test_iqn_opt_over_replay_and_qvalues(B, tmp_path):
+    """Agent::opt over the HBM ring with device-drawn percent points (Uniform64, batch 32): finite loss, counters,
+    checkpoint round trip; Policy::sample's averaged action values == mean over Const32's 33 points of forward()."""
+    cap, Bsz, A = 2000, 32, 6
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (4, 1, 84, 84), np.uint8)
+    rb.fill_synthetic(cap, seed=2, kind=0, n_actions=A)
+    cfg = B.IqnConfig(n_actions=A, lr=1e-4, batch_size=Bsz, sample_percents_pred="Uniform64", sample_percents_tgt="Uniform64",
+                      soft_update_interval=2, tau=1.0, device=0, seed=4)
+    a = B.Iqn.build(cfg)
+    for _ in range(3):
+        rec = a.opt_with_record(rb)
+        assert np.isfinite(rec["loss_critic"]) and rec["loss_critic"] > 0
+    assert a.n_opts == 3
+    obs = np.random.default_rng(0).integers(0, 256, (5, 4, 1, 84, 84), dtype=np.uint8)
+    tau = np.tile((np.arange(33, dtype=np.float32) * np.float32(1.0 / 32.0))[None], (5, 1))
+    assert rel(a.qvalues(obs), a.forward(obs, tau).mean(1)) < 1e-5
+    files = a.save_params(str(tmp_path))
+    b = B.Iqn.build(cfg)
+    b.load_params(str(tmp_path))
+    assert all(os.path.exists(f) for f in files) and (b.get_params("iqn") == a.get_params("iqn")).all()
+    a.close(); b.close(); rb.close()

@@ -239,6 +239,37 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     }
 }
 
+// All three conv layers' partial reductions in ONE launch: 32 outputs x 8 chunk groups per workgroup
+// (chunk c -> group c % 8), fixed-order combine => deterministic.
+struct ReduceSeg { const float* part; size_t stride; int chunks; float* g; int n, n_weights; float wscale; int wg0; };
+struct Reduce3Args { ReduceSeg seg[3]; };
+__global__ __launch_bounds__(256) void k_reduce_partials3(Reduce3Args a)
+{
+    __shared__ float red[8][32];
+    const int s_id = (int)blockIdx.x >= a.seg[2].wg0 ? 2 : ((int)blockIdx.x >= a.seg[1].wg0 ? 1 : 0);
+    const ReduceSeg& sg = a.seg[s_id];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = ((int)blockIdx.x - sg.wg0) * 32 + o;
+    float s = 0.f;
+    if (i < sg.n) {
+        int c = grp;
+        for (; c + 24 < sg.chunks; c += 32) {
+            const float v0 = sg.part[(size_t)c * sg.stride + i], v1 = sg.part[(size_t)(c + 8) * sg.stride + i];
+            const float v2 = sg.part[(size_t)(c + 16) * sg.stride + i], v3 = sg.part[(size_t)(c + 24) * sg.stride + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < sg.chunks; c += 8) s += sg.part[(size_t)c * sg.stride + i];
+    }
+    red[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && i < sg.n) {
+        float t = red[0][o];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][o];
+        sg.g[i] = i < sg.n_weights ? t * sg.wscale : t;
+    }
+}
+
 // chunk counts of the weight-gradient reductions (rows M split across workgroups)
 struct DwPlan { int chunks_c1, chunks_c2, chunks_c3; size_t stride_c1, stride_c2, stride_c3, off_c1, off_c2, off_c3, total; };
 DwPlan dw_plan(int B)

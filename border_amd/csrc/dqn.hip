@@ -25,6 +25,15 @@ using namespace bdr;
 
 namespace {
 
+// 4-wave teams per workgroup of each implicit-GEMM launch (see k_igemm): 2 where the grid gives ~1 workgroup per CU
+#ifndef BDR_TEAMS
+#define BDR_TEAMS 2
+#endif
+// measured on MI355X (profiles/): conv3 fwd 27.1->25.4us, l1 dX 22.7->17.1us, conv3 dX 32.2->31.3us with 2 teams; the
+// other launches already have >= 2.5 workgroups per CU and lose (conv2 dX 37.9->49.6us)
+constexpr int TEAMS_FWD_C2 = 1, TEAMS_FWD_C3 = BDR_TEAMS, TEAMS_FWD_L1 = 1, TEAMS_DX_L1 = BDR_TEAMS, TEAMS_DX_C3 = BDR_TEAMS,
+              TEAMS_DX_C2 = 1;
+
 // ================================================================================================
 // head: l1 finish + l2, one wave per (row, instance)
 // ================================================================================================
@@ -300,13 +309,13 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B)
     }
     f.M = B * 81;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a1[inst[z].slot]; f.w[z] = inst[z].params + ar.w2; f.bias[z] = inst[z].params + ar.b2; f.out[z] = a->a2[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv2"); LAUNCH(k_igemm<FwdC2>, dim3((f.M + 63) / 64, 1, nz), f); }
+    { Bracket br(a, "fwd_conv2"); BDR_HIP((launch_igemm<FwdC2, TEAMS_FWD_C2>(a->stream, dim3((f.M + 63) / 64, 1, nz), f))); }
     f.M = B * 49;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a2[inst[z].slot]; f.w[z] = inst[z].params + ar.w3; f.bias[z] = inst[z].params + ar.b3; f.out[z] = a->a3[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv3"); LAUNCH(k_igemm<FwdC3>, dim3((f.M + 63) / 64, 1, nz), f); }
+    { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3, TEAMS_FWD_C3>(a->stream, dim3((f.M + 63) / 64, 1, nz), f))); }
     f.M = B; f.nkt_per_split = (98 + L1_SPLIT - 1) / L1_SPLIT;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a3[inst[z].slot]; f.w[z] = inst[z].params + ar.w4; f.bias[z] = nullptr; f.out[z] = a->p1[inst[z].slot]; }
-    { Bracket br(a, "fwd_l1"); LAUNCH(k_igemm<FwdL1>, dim3(((B + 63) / 64) * 8, L1_SPLIT, nz), f); }
+    { Bracket br(a, "fwd_l1"); BDR_HIP((launch_igemm<FwdL1, TEAMS_FWD_L1>(a->stream, dim3(((B + 63) / 64) * 8, L1_SPLIT, nz), f))); }
     HeadArgs h{};
     h.B = B; h.A = ar.A; h.S = L1_SPLIT;
     for (int z = 0; z < nz; ++z) {
@@ -365,54 +374,56 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     {
         DxArgs d{a->dh1, a->q + ar.w4, a->a3[0], a->dy3, B};
         Bracket br(a, "bwd_l1_dx");
-        LAUNCH(k_igemm<DxL1>, dim3(((B + 63) / 64) * 49, 1, 1), d);
+        BDR_HIP((launch_igemm<DxL1, TEAMS_DX_L1>(a->stream, dim3(((B + 63) / 64) * 49, 1, 1), d)));
     }
     BDR_TRY(fork(1));                  // dy3 ready
     {
         const int M = B * 49, chunks = std::min(pl.chunks_c3, (M + 31) / 32);
         DwArgs d{a->a2[0], a->dy3, a->part + pl.off_c3, pl.stride_c3, M};
         { Bracket br(a, "bwd_conv3_dw"); LAUNCH_ON(sd, k_igemm_red<DwC3>, dim3(9 * chunks), d); }
-        const int n = 576 * 64 + 64;
-        Bracket br(a, "bwd_conv3_red");
-        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, sd, a->part + pl.off_c3, pl.stride_c3,
-                           chunks, a->grad + ar.w3, n, 576 * 64, 1.0f);
-        BDR_HIP(hipGetLastError());
     }
     {
         DxArgs d{a->dy3, a->q + ar.w3, a->a2[0], a->dy2, B * 81};
         Bracket br(a, "bwd_conv3_dx");
-        LAUNCH(k_igemm<DxC3>, dim3((d.M + 63) / 64, 1, 1), d);
+        BDR_HIP((launch_igemm<DxC3, TEAMS_DX_C3>(a->stream, dim3((d.M + 63) / 64, 1, 1), d)));
     }
     BDR_TRY(fork(2));                  // dy2 ready
     {
         const int M = B * 81, chunks = std::min(pl.chunks_c2, (M + 31) / 32);
         DwArgs d{a->a1[0], a->dy2, a->part + pl.off_c2, pl.stride_c2, M};
         { Bracket br(a, "bwd_conv2_dw"); LAUNCH_ON(sd, k_igemm_red<DwC2>, dim3(8 * chunks), d); }
-        const int n = 512 * 64 + 64;
-        Bracket br(a, "bwd_conv2_red");
-        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, sd, a->part + pl.off_c2, pl.stride_c2,
-                           chunks, a->grad + ar.w2, n, 512 * 64, 1.0f);
-        BDR_HIP(hipGetLastError());
     }
     {
         DxArgs d{a->dy2, a->q + ar.w2, a->a1[0], a->dy1, B * 100};
         Bracket br(a, "bwd_conv2_dx");
-        LAUNCH(k_igemm<DxC2>, dim3((d.M + 127) / 128, 4, 1), d);
+        BDR_HIP((launch_igemm<DxC2, TEAMS_DX_C2>(a->stream, dim3((d.M + 127) / 128, 4, 1), d)));
     }
     // conv1 (no input gradient) stays on the main stream
     {
         const int M = B * 400, chunks = std::min(pl.chunks_c1, (M + 31) / 32);
         DwArgs d{obs, a->dy1, a->part + pl.off_c1, pl.stride_c1, M};
         { Bracket br(a, "bwd_conv1_dw"); LAUNCH(k_igemm_red<DwC1>, dim3(2 * chunks), d); }
-        const int n = 256 * 32 + 32;
-        Bracket br(a, "bwd_conv1_red");
-        hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, a->stream, a->part + pl.off_c1, pl.stride_c1,
-                           chunks, a->grad + ar.w1, n, 256 * 32, INV255);
-        BDR_HIP(hipGetLastError());
     }
-    if (ov) {                          // join: all gradients complete before Adam
+    if (ov) {                          // join: all weight-gradient partials complete
         BDR_HIP(hipEventRecord(a->ev_join, a->side));
         BDR_HIP(hipStreamWaitEvent(a->stream, a->ev_join, 0));
+    }
+    {   // conv1..conv3 partials -> gradient arena, one launch
+        Reduce3Args r{};
+        const int Ms[3] = {B * 400, B * 81, B * 49};
+        const int plc[3] = {pl.chunks_c1, pl.chunks_c2, pl.chunks_c3};
+        const size_t offs[3] = {pl.off_c1, pl.off_c2, pl.off_c3}, strides[3] = {pl.stride_c1, pl.stride_c2, pl.stride_c3};
+        const size_t gw[3] = {ar.w1, ar.w2, ar.w3};
+        const int nw[3] = {256 * 32, 512 * 64, 576 * 64}, nb[3] = {32, 64, 64};
+        int wg = 0;
+        for (int k = 0; k < 3; ++k) {
+            r.seg[k] = ReduceSeg{a->part + offs[k], strides[k], std::min(plc[k], (Ms[k] + 31) / 32), a->grad + gw[k], nw[k] + nb[k], nw[k],
+                                 k == 0 ? INV255 : 1.0f, wg};
+            wg += (nw[k] + nb[k] + 31) / 32;
+        }
+        Bracket br(a, "bwd_conv_reduce");
+        hipLaunchKernelGGL(k_reduce_partials3, dim3(wg), dim3(256), 0, a->stream, r);
+        BDR_HIP(hipGetLastError());
     }
     // :150 backward_step -> Adam
     a->adam_step += 1;

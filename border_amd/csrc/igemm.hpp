@@ -191,7 +191,9 @@ struct ADense {
 // between(u) is called after the MFMAs of k-group u have been issued: the staging work of the next
 // tiles is sliced into those gaps so that it executes in the shadow of the (dependent, 64-cycle)
 // MFMAs instead of in front of them.
-template <int TM, int TN, int LDB, class F>
+// B_KMAJOR: the B tile is stored like the A tile ([n][LDA], k contiguous: transposed-weight operands of
+// the dX kernels are k-contiguous in memory) and a lane fetches its 4 k-values with one ds_read_b128.
+template <int TM, int TN, int LDB, bool B_KMAJOR, class F>
 __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const float* __restrict__ Bs, int arow0,
                                            int bcol0, int lane, f32x16 (&acc)[TM][TN], F&& between)
 {
@@ -202,11 +204,20 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
             a[tm] = *reinterpret_cast<const f32x4*>(&As[(arow0 + tm * 32 + i) * LDA + 8 * u + 4 * h]);
+        f32x4 bq[TN];
+        if constexpr (B_KMAJOR) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                bq[tn] = *reinterpret_cast<const f32x4*>(&Bs[(bcol0 + tn * 32 + i) * LDA + 8 * u + 4 * h]);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float b[TN];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[(8 * u + 4 * h + s) * LDB + bcol0 + tn * 32 + i];
+            for (int tn = 0; tn < TN; ++tn) {
+                if constexpr (B_KMAJOR) b[tn] = bq[tn][s];
+                else b[tn] = Bs[(8 * u + 4 * h + s) * LDB + bcol0 + tn * 32 + i];
+            }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -228,24 +239,32 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
 //     store(args, z, cls/split, m, n, value)
 // grid: x = m-tiles * n-tiles (n fastest), y = split or parity class, z = problem instance.
 // ------------------------------------------------------------------------------------------------
-template <class P>
-__global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
+// TEAMS = 2 runs two independent 4-wave teams in one 512-thread workgroup: team g stages and multiplies
+// the k-tiles kt = g (mod 2) in its own LDS stages and the two accumulators are summed through LDS
+// at the end.  Kernels whose grids give only ~1 workgroup per CU get 2 waves per SIMD this way (the
+// staging of one team runs in the shadow of the other team's MFMAs) without more, smaller tiles.
+template <class P, int TEAMS = 1>
+__global__ __launch_bounds__(256 * TEAMS) void k_igemm(typename P::Args args)
 {
     using A = typename P::A;
     constexpr int BM = P::WM * P::TM * 32, BN = P::WN * P::TN * 32;
-    constexpr int LDB = P::B_TR ? BN + 1 : BN;
+    constexpr int LDB = BN;
     constexpr int ROWS_PER_PASS = 256 * A::VEC / BK;   // rows of the A tile staged per pass
     constexpr int A_PASSES = BM / ROWS_PER_PASS;
     constexpr int AV = A::VEC / 4;
     constexpr int B_VECS = BK * BN / 4 / 256;          // f32x4 per thread for the B tile
-    static_assert(P::WM * P::WN == 4, "4 waves");
+    static_assert(P::WM * P::WN == 4, "4 waves per team");
     static_assert(A_PASSES >= 1 && B_VECS >= 1, "tile too small for 256 threads");
+    static_assert(TEAMS == 1 || TEAMS == 2, "one or two teams");
 
-    // two LDS stages: tile t+1 is written while tile t feeds the matrix pipe (one barrier per k-tile)
-    constexpr int STAGE = BM * LDA + BK * LDB;
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    // two LDS stages per team: tile t+1 is written while tile t feeds the matrix pipe (one barrier per k-tile)
+    constexpr int STAGE = BM * LDA + (P::B_TR ? BN * LDA : BK * LDB);
+    static_assert(TEAMS == 1 || 2 * STAGE >= BM * BN, "team reduction buffer must fit one team's stages");
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * STAGE * TEAMS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = TEAMS == 1 ? 0 : (int)(threadIdx.x >> 8);
+    float* smem = smem_all + team * 2 * STAGE;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / P::WN, wn = wave % P::WN;
     const int NT_N = P::N(args) / BN;
     const int mt = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
@@ -262,6 +281,11 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
 
     int kt0, kt1;
     P::kt_range(args, y, kt0, kt1);
+    // team g owns k-tiles kt0+g, kt0+g+TEAMS, ...; both teams run the same number of iterations so the
+    // workgroup barriers match (the shorter team idles through its last one)
+    const int iters = (kt1 - kt0 + TEAMS - 1) / TEAMS;
+    const int my_n = kt0 + team < kt1 ? (kt1 - kt0 - team + TEAMS - 1) / TEAMS : 0;
+    auto tile = [&](int it) { return kt0 + team + min(it, max(my_n - 1, 0)) * TEAMS; };   // clamped to my last tile
 
     f32x4 ra[A_PASSES][AV];
     f32x4 rb[B_VECS];
@@ -303,8 +327,7 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
                 *reinterpret_cast<f32x4*>(&Bs[kr * LDB + n4 * 4]) = rb[v];
             } else {
                 const int kq = e % 8, np = e / 8;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[(kq * 4 + j) * LDB + np] = rb[v][j];
+                *reinterpret_cast<f32x4*>(&Bs[np * LDA + kq * 4]) = rb[v];   // [n'][k'] like the A tile
             }
         }
     };
@@ -318,26 +341,47 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     // Software pipeline, branch-free body (tile indices are clamped, so the tail re-stages the last
-    // tile into the idle stage: harmless).  Registers hold tile kt+1 while stage `cur` holds tile kt.
-    if (kt0 < kt1) {
-        prefetch_a(kt0); prefetch_b(kt0);
+    // tile into the idle stage: harmless).  Registers hold tile it+1 while stage `cur` holds tile it.
+    if (my_n > 0) {
+        prefetch_a(tile(0)); prefetch_b(tile(0));
         commit_a(0); commit_b(0);
-        const int k1 = min(kt0 + 1, kt1 - 1);
-        prefetch_a(k1); prefetch_b(k1);
+        prefetch_a(tile(1)); prefetch_b(tile(1));
     }
     __syncthreads();
     int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const float* As = smem + cur * STAGE;
-        const int k2 = min(kt + 2, kt1 - 1);
-        mfma_ktile<P::TM, P::TN, LDB>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc, [&](int u) {
-            if (u == 0) commit_a(cur ^ 1);          // tile kt+1 -> idle stage, in the shadow of the MFMAs
-            else if (u == 1) commit_b(cur ^ 1);
-            else if (u == 2) prefetch_a(k2);        // tile kt+2 global loads
-            else prefetch_b(k2);
-        });
+    for (int it = 0; it < iters; ++it) {
+        if (it < my_n) {   // team-uniform
+            const float* As = smem + cur * STAGE;
+            const int k2 = tile(it + 2);
+            mfma_ktile<P::TM, P::TN, LDB, P::B_TR>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc, [&](int u) {
+                if (u == 0) commit_a(cur ^ 1);          // tile it+1 -> idle stage, in the shadow of the MFMAs
+                else if (u == 1) commit_b(cur ^ 1);
+                else if (u == 2) prefetch_a(k2);        // tile it+2 global loads
+                else prefetch_b(k2);
+            });
+        }
         __syncthreads();
         cur ^= 1;
+    }
+    if constexpr (TEAMS == 2) {   // acc(team 0) += acc(team 1), through team 1's (now idle) stages
+        constexpr int PER_WAVE = P::TM * P::TN * 16 * 64;
+        float* red = smem_all + 2 * STAGE;
+        if (team == 1) {
+#pragma unroll
+            for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < P::TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[wave * PER_WAVE + ((tm * P::TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+        }
+        __syncthreads();
+        if (team == 1) return;
+#pragma unroll
+        for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < P::TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] += red[wave * PER_WAVE + ((tm * P::TN + tn) * 16 + r) * 64 + lane];
     }
 
     const int j = lane & 31, h = lane >> 5;
@@ -351,6 +395,13 @@ __global__ __launch_bounds__(256) void k_igemm(typename P::Args args)
                 const int n = n0 + (wn * P::TN + tn) * 32 + j;
                 if (m < M) P::store(args, z, y, m, n, acc[tm][tn][r]);
             }
+}
+
+template <class P, int TEAMS>
+inline hipError_t launch_igemm(hipStream_t st, dim3 grid, const typename P::Args& args)
+{
+    hipLaunchKernelGGL((k_igemm<P, TEAMS>), grid, dim3(256 * TEAMS), 0, st, args);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -79,7 +79,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct GatherArgs {
     const uint8_t* ring;
     uint64_t stride, obs_bytes, act_bytes, next_off, act_off, tail_off;
-    const uint64_t* ixs;
+    uint64_t* ixs;           // [n] sampled indices (written by chunk 0 of every sample)
+    ChaChaKey key;           // K1 fused: every workgroup draws its own index (wave-uniform -> scalar unit)
+    uint64_t word_pos, size;
     uint8_t *b_obs, *b_next, *b_act;
     float* b_reward;
     int8_t *b_term, *b_trunc;
@@ -91,7 +93,9 @@ template <typename V>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a)
 {
     const uint32_t sample = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-    const uint64_t row = a.ixs[sample];
+    // ixs[k] = (StdRng::next_u32() as usize) % size   (base.rs:386): word k of this batch's key stream
+    const uint64_t row = (uint64_t)chacha12_word(a.key, a.word_pos + sample) % a.size;
+    if (chunk == 0 && threadIdx.x == 0) a.ixs[sample] = row;
     const uint8_t* rec = a.ring + row * a.stride;
     const uint64_t nvec = a.obs_bytes / sizeof(V);
     const V* src0 = reinterpret_cast<const V*>(rec);
@@ -405,9 +409,13 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     BDR_REQUIRE(n > 0 && n < (1ull << 24), "batch size out of range");
     BDR_TRY(replay_ensure_batch_capacity(r, n));
     BDR_HIP(hipStreamWaitEvent(stream, r->written, 0));  // RAW against pushes / fills
-    BDR_TRY(launch_indices(r, n, stream));
-    GatherArgs a{r->ring, r->stride, r->obs_bytes, r->act_bytes, r->next_off, r->act_off, r->tail_off, r->b_ixs,
-                 r->b_obs, r->b_next, r->b_act, r->b_reward, r->b_term, r->b_trunc, 1, 0};
+    GatherArgs a{};
+    a.ring = r->ring; a.stride = r->stride; a.obs_bytes = r->obs_bytes; a.act_bytes = r->act_bytes;
+    a.next_off = r->next_off; a.act_off = r->act_off; a.tail_off = r->tail_off; a.ixs = r->b_ixs;
+    memcpy(a.key.k, r->key, sizeof a.key.k); a.word_pos = r->word_pos; a.size = r->size;
+    a.b_obs = r->b_obs; a.b_next = r->b_next; a.b_act = r->b_act; a.b_reward = r->b_reward; a.b_term = r->b_term; a.b_trunc = r->b_trunc;
+    a.chunks = 1; a.vec_per_chunk = 0;
+    r->word_pos += n;  // one next_u32() per index
     if (r->obs_bytes % 16 == 0) {
         const uint64_t nvec = r->obs_bytes / 16;
         // ~4 vectors per thread per section; >= 4 workgroups per sample for Atari rows (1764 vectors)

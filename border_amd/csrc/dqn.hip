@@ -465,6 +465,7 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
                 (unsigned long long)r->obs_bytes);
     BDR_REQUIRE(r->act_bytes >= 8, "discrete actions are stored as i64");
     BDR_REQUIRE(r->device == a->device, "agent and replay buffer live on different devices");
+    { Bracket br(a, "_null"); }   // empty bracket: the event pair's own cost, subtracted by bench.py
     for (uint64_t u = 0; u < a->cfg.n_updates_per_opt; ++u) {
         { Bracket br(a, "sample"); BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->stream)); }
         BDR_TRY(update_critic(a, (int)a->cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term));

@@ -49,12 +49,18 @@ struct FwdArgs {
     int nkt_per_split;
 };
 
-template <class G, class APolicy, int WM_, int WN_, bool U8SCALE>
+template <class G, class APolicy, int WM_, int WN_, bool U8SCALE, int RPIP_ = 0, int TM_ = 1, int TN_ = 1>
 struct FwdP {
     using A = APolicy;
     using Args = FwdArgs;
-    static constexpr int WM = WM_, WN = WN_, TM = 1, TN = 1;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int RPI = G::OH * G::OW, RPIP = RPIP_;   // rows per image / padded (0: flat rows)
     static constexpr int NC = G::COUT;
+    __device__ static bool vrow(const Args& a, int mv, int& mr)
+    {
+        if constexpr (RPIP == 0) return vrow_flat(a.M, mv, mr);
+        else return vrow_img<RPI, RPIP>(a.M, mv, mr);
+    }
     static constexpr bool B_TR = false;
     __device__ static constexpr int N(const Args&) { return NC; }
     __device__ static constexpr int KP(const Args&) { return 32; }
@@ -67,11 +73,14 @@ struct FwdP {
     __device__ static const float* w(const Args& a, int z, int) { return a.w[z]; }
     __device__ static int tap_index(int, int t) { return t; }
     __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
-    __device__ static void store(const Args& a, int z, int, int m, int n, float v)
+    struct Epi { gptr<const float> bias; gptr<float> out; };
+    __device__ static Epi epi(const Args& a, int z, int) { return Epi{pin_sgpr(a.bias[z]), pin_sgpr(a.out[z])}; }
+    __device__ static float epi_load(const Epi& e, int, int n) { return e.bias[n]; }
+    __device__ static void store(const Epi& e, int m, int n, float v, float bias)
     {
         if constexpr (U8SCALE) v *= INV255;   // cnn/base.rs:26 "/ 255", folded into the epilogue
-        v += a.bias[z][n];
-        a.out[z][(size_t)m * NC + n] = v > 0.f ? v : 0.f;   // relu (cnn/base.rs:28,30,32)
+        v += bias;
+        e.out[(size_t)m * NC + n] = v > 0.f ? v : 0.f;   // relu (cnn/base.rs:28,30,32)
     }
 };
 using FwdC1 = FwdP<GeomC1, AFwdU8<GeomC1>, 4, 1, true>;    // 128x32 tiles, M = B*400
@@ -83,8 +92,10 @@ struct FwdL1 {
     using A = AFwd<GeomL1>;
     using Args = FwdArgs;
     static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int RPI = 1, RPIP = 0;
     static constexpr int NC = 512;
     static constexpr bool B_TR = false;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.M, mv, mr); }
     __device__ static constexpr int N(const Args&) { return NC; }
     __device__ static constexpr int KP(const Args&) { return 32; }
     __device__ static int M(const Args& a) { return a.M; }
@@ -95,10 +106,10 @@ struct FwdL1 {
     {
         k0 = y * a.nkt_per_split; k1 = min(A::NKT, k0 + a.nkt_per_split);
     }
-    __device__ static void store(const Args& a, int z, int y, int m, int n, float v)
-    {
-        a.out[z][((size_t)y * a.M + m) * NC + n] = v;
-    }
+    struct Epi { gptr<float> out; };
+    __device__ static Epi epi(const Args& a, int z, int y) { return Epi{pin_sgpr(a.out[z] + (size_t)y * a.M * NC)}; }
+    __device__ static float epi_load(const Epi&, int, int) { return 0.f; }
+    __device__ static void store(const Epi& e, int m, int n, float v, float) { e.out[(size_t)m * NC + n] = v; }
 };
 
 // ================================================================================================
@@ -118,8 +129,10 @@ struct DxL1 {
     using A = AFwd<G>;     // dense rows of dh1
     using Args = DxArgs;
     static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int RPI = 1, RPIP = 0;
     static constexpr int NC = 3136;    // N' (columns of the result)
     static constexpr bool B_TR = true;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.M, mv, mr); }
     __device__ static constexpr int N(const Args&) { return NC; }
     __device__ static constexpr int KP(const Args&) { return 512; }   // K' per tap (contiguous in memory)
     __device__ static int M(const Args& a) { return a.M; }
@@ -127,21 +140,30 @@ struct DxL1 {
     __device__ static const float* w(const Args& a, int, int) { return a.w; }
     __device__ static int tap_index(int, int t) { return t; }
     __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
-    __device__ static void store(const Args& a, int, int, int m, int n, float v)
+    struct Epi { gptr<const float> mask; gptr<float> out; };
+    __device__ static Epi epi(const Args& a, int, int) { return Epi{pin_sgpr(a.mask), pin_sgpr(a.out)}; }
+    __device__ static float epi_load(const Epi& e, int m, int n) { return e.mask[(size_t)m * NC + n]; }
+    __device__ static void store(const Epi& e, int m, int n, float v, float mask)
     {
-        const size_t o = (size_t)m * NC + n;
-        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
+        e.out[(size_t)m * NC + n] = mask > 0.f ? v : 0.f;
     }
 };
 
 // conv3 (3x3, stride 1): rows over the 9x9 input grid, K' = 9 taps * 64, N' = 64
-struct DxC3 {
+template <int WM_, int WN_, int RPIP_ = 0, int TM_ = 1, int TN_ = 1>
+struct DxC3P {
     using G = GeomC3;
     using A = ADxS1<G>;
     using Args = DxArgs;
-    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int RPI = G::IH * G::IW, RPIP = RPIP_;
     static constexpr int NC = G::CIN;
     static constexpr bool B_TR = true;
+    __device__ static bool vrow(const Args& a, int mv, int& mr)
+    {
+        if constexpr (RPIP == 0) return vrow_flat(a.M, mv, mr);
+        else return vrow_img<RPI, RPIP>(a.M, mv, mr);
+    }
     __device__ static constexpr int N(const Args&) { return NC; }
     __device__ static constexpr int KP(const Args&) { return G::COUT; }
     __device__ static int M(const Args& a) { return a.M; }
@@ -149,21 +171,31 @@ struct DxC3 {
     __device__ static const float* w(const Args& a, int, int) { return a.w; }
     __device__ static int tap_index(int, int t) { return t; }
     __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
-    __device__ static void store(const Args& a, int, int, int m, int n, float v)
+    struct Epi { gptr<const float> mask; gptr<float> out; };
+    __device__ static Epi epi(const Args& a, int, int) { return Epi{pin_sgpr(a.mask), pin_sgpr(a.out)}; }
+    __device__ static float epi_load(const Epi& e, int m, int n) { return e.mask[(size_t)m * NC + n]; }
+    __device__ static void store(const Epi& e, int m, int n, float v, float mask)
     {
-        const size_t o = (size_t)m * NC + n;
-        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
+        e.out[(size_t)m * NC + n] = mask > 0.f ? v : 0.f;
     }
 };
+using DxC3 = DxC3P<2, 2>;      // 64x64 flat tiles, M = B*81
 
 // conv2 (4x4, stride 2): blockIdx.y = parity class (ph,pw); rows (b, ih/2, iw/2); K' = 4 taps * 64
-struct DxC2 {
+template <int WM_, int WN_, int RPIP_ = 0, int TM_ = 1, int TN_ = 1>
+struct DxC2P {
     using G = GeomC2;
     using A = ADxS2<G>;
     using Args = DxArgs;
-    static constexpr int WM = 4, WN = 1, TM = 1, TN = 1;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int RPI = (G::IH / 2) * (G::IW / 2), RPIP = RPIP_;
     static constexpr int NC = G::CIN;
     static constexpr bool B_TR = true;
+    __device__ static bool vrow(const Args& a, int mv, int& mr)
+    {
+        if constexpr (RPIP == 0) return vrow_flat(a.M, mv, mr);
+        else return vrow_img<RPI, RPIP>(a.M, mv, mr);
+    }
     __device__ static constexpr int N(const Args&) { return NC; }
     __device__ static constexpr int KP(const Args&) { return G::COUT; }
     __device__ static int M(const Args& a) { return a.M; }
@@ -172,15 +204,22 @@ struct DxC2 {
     // class y=(ph,pw), tap t=(a,b2) -> (kh,kw) = (ph+2a, pw+2*b2) -> kh*4+kw
     __device__ static int tap_index(int y, int t) { return ((y >> 1) + 2 * (t >> 1)) * 4 + (y & 1) + 2 * (t & 1); }
     __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
-    __device__ static void store(const Args& a, int, int y, int m, int n, float v)
+    __device__ static size_t out_index(int y, int m, int n)
     {
         constexpr int HH = G::IH / 2, WH = G::IW / 2;
         const int b = m / (HH * WH), rem = m % (HH * WH);
         const int ih = 2 * (rem / WH) + (y >> 1), iw = 2 * (rem % WH) + (y & 1);
-        const size_t o = ((size_t)(b * G::IH + ih) * G::IW + iw) * NC + n;
-        a.out[o] = a.mask[o] > 0.f ? v : 0.f;
+        return ((size_t)(b * G::IH + ih) * G::IW + iw) * NC + n;
+    }
+    struct Epi { gptr<const float> mask; gptr<float> out; int y; };
+    __device__ static Epi epi(const Args& a, int, int y) { return Epi{pin_sgpr(a.mask), pin_sgpr(a.out), y}; }
+    __device__ static float epi_load(const Epi& e, int m, int n) { return e.mask[out_index(e.y, m, n)]; }
+    __device__ static void store(const Epi& e, int m, int n, float v, float mask)
+    {
+        e.out[out_index(e.y, m, n)] = mask > 0.f ? v : 0.f;
     }
 };
+using DxC2 = DxC2P<4, 1>;      // 128x32 flat tiles per class, M = B*100
 
 // ================================================================================================
 // weight-gradient policies

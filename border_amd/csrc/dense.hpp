@@ -114,6 +114,8 @@ struct DenseFwd {
     using A = ADense;
     using Args = DenseArgs;
     static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int RPI = 1, RPIP = 0;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.M, mv, mr); }
     static constexpr bool B_TR = false;
     __device__ static int N(const Args& a) { return a.ncols; }
     __device__ static int KP(const Args&) { return 32; }
@@ -122,9 +124,12 @@ struct DenseFwd {
     __device__ static const float* w(const Args& a, int, int) { return a.w; }
     __device__ static int tap_index(int, int t) { return t; }
     __device__ static void kt_range(const Args& a, int, int& k0, int& k1) { k0 = 0; k1 = a.kred / BK; }
-    __device__ static void store(const Args& a, int, int, int m, int n, float v)
+    using Epi = Args;   // dense arguments are not instance-indexed: plain kernel-argument reads
+    __device__ static const Epi& epi(const Args& a, int, int) { return a; }
+    __device__ static float epi_load(const Epi& a, int, int n) { return a.bias[n]; }
+    __device__ static void store(const Epi& a, int m, int n, float v, float bias)
     {
-        v += a.bias[n];
+        v += bias;
         if (a.relu) v = v > 0.f ? v : 0.f;
         a.out[(size_t)m * a.ldo + n] = v;
         if (a.had) a.out2[(size_t)m * a.ldo + n] = v * a.had[(size_t)(m / a.had_group) * a.had_ld + n];
@@ -136,6 +141,8 @@ struct DenseDx {
     using A = ADense;
     using Args = DenseArgs;
     static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int RPI = 1, RPIP = 0;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.M, mv, mr); }
     static constexpr bool B_TR = true;
     __device__ static int N(const Args& a) { return a.ncols; }     // = Kp of the layer
     __device__ static int KP(const Args& a) { return a.w_ld; }     // = Np of the layer (contiguous)
@@ -144,9 +151,15 @@ struct DenseDx {
     __device__ static const float* w(const Args& a, int, int) { return a.w; }
     __device__ static int tap_index(int, int t) { return t; }
     __device__ static void kt_range(const Args& a, int, int& k0, int& k1) { k0 = 0; k1 = a.kred / BK; }
-    __device__ static void store(const Args& a, int, int, int m, int n, float v)
+    using Epi = Args;
+    __device__ static const Epi& epi(const Args& a, int, int) { return a; }
+    __device__ static float epi_load(const Epi& a, int m, int n)
     {
-        if (a.mask && !(a.mask[(size_t)m * a.ldm + n] > 0.f)) v = 0.f;
+        return a.mask ? a.mask[(size_t)m * a.ldm + n] : 1.f;
+    }
+    __device__ static void store(const Epi& a, int m, int n, float v, float mask)
+    {
+        if (!(mask > 0.f)) v = 0.f;
         float* o = a.out + (size_t)m * a.ldo + n;
         *o = a.accum ? *o + v : v;
     }

@@ -20,11 +20,16 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace bdr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef IGEMM_ABL    // tools/probes only: timing ablations (results are wrong when non-zero)
+#define IGEMM_ABL 0  // 1: no global prefetch in the loop, 2: no LDS commit, 4: no barrier, 8: no LDS fragment reads
+#endif
 
 constexpr int BK = 32;        // k-tile
 constexpr int LDA = BK + 4;   // A tile row stride (floats): conflict-free ds_read_b128, 16B aligned
@@ -184,6 +189,41 @@ struct ADense {
     }
 };
 
+// Keeps a wave-uniform pointer in an SGPR pair from here on (otherwise the compiler re-loads kernel-argument
+// pointers inside every conditional store block of the epilogue: 16 scalar-load round trips per tile).
+// The pinned pointer is typed as global address space so that accesses stay global_load / global_store
+// (an opaque generic pointer would turn them into flat_* instructions, which also tick lgkmcnt).
+template <class T>
+using gptr = __attribute__((address_space(1))) T*;
+template <class T>
+__device__ __forceinline__ gptr<T> pin_sgpr(T* p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (gptr<T>)(((uint64_t)hi << 32) | lo);
+}
+
+// Row maps of k_igemm.  Flat: virtual row == real row.  Per-image: every image's RPI rows are padded to
+// RPIP (a multiple of the tile height) so that tiles never straddle images and a B-image batch is
+// B * RPIP / BM equal workgroups.
+__device__ __forceinline__ bool vrow_flat(int M, int mv, int& mr) { mr = mv; return mv < M; }
+template <int RPI, int RPIP>
+__device__ __forceinline__ bool vrow_img(int M, int mv, int& mr)
+{
+    const int b = mv / RPIP, r = mv % RPIP;
+    mr = b * RPI + r;
+    return r < RPI && mr < M;
+}
+// m-tiles of a launch: RPIP == 0 -> flat
+template <class P>
+inline int m_tiles(int M)
+{
+    constexpr int BM = P::WM * P::TM * 32;
+    if constexpr (P::RPIP == 0) return (M + BM - 1) / BM;
+    else return (M / P::RPI) * (P::RPIP / BM);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The MFMA core shared by both kernels: one k-tile (32 deep) from LDS.
 //   As: [rows][LDA] f32, k contiguous.  Bs: [32][LDB] f32, n contiguous.
@@ -203,7 +243,8 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
         f32x4 a[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
-            a[tm] = *reinterpret_cast<const f32x4*>(&As[(arow0 + tm * 32 + i) * LDA + 8 * u + 4 * h]);
+            a[tm] = (IGEMM_ABL & 8) ? f32x4{1.f * lane, 2.f, 3.f, 4.f}
+                                    : *reinterpret_cast<const f32x4*>(&As[(arow0 + tm * 32 + i) * LDA + 8 * u + 4 * h]);
         f32x4 bq[TN];
         if constexpr (B_KMAJOR) {
 #pragma unroll
@@ -216,7 +257,7 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 if constexpr (B_KMAJOR) b[tn] = bq[tn][s];
-                else b[tn] = Bs[(8 * u + 4 * h + s) * LDB + bcol0 + tn * 32 + i];
+                else b[tn] = (IGEMM_ABL & 8) ? 0.5f * lane : Bs[(8 * u + 4 * h + s) * LDB + bcol0 + tn * 32 + i];
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
@@ -236,25 +277,42 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
 //   P::Args    kernel arguments;  device hooks:
 //     a_src(args,z) -> input pointer;  M(args);  w(args,z,cls) -> weight pointer
 //     kt_range(args, &kt0, &kt1)  (split-K over blockIdx.y when P::SPLITK)
-//     store(args, z, cls/split, m, n, value)
+//     epi(args, z, cls/split) -> Epi   (epilogue pointers, read from the kernel arguments once and pinned)
+//     epi_load(epi, m, n) -> aux       (bias / mask operand of the epilogue, loaded before the k loop)
+//     store(epi, m, n, value, aux)
 // grid: x = m-tiles * n-tiles (n fastest), y = split or parity class, z = problem instance.
 // ------------------------------------------------------------------------------------------------
 // TEAMS = 2 runs two independent 4-wave teams in one 512-thread workgroup: team g stages and multiplies
 // the k-tiles kt = g (mod 2) in its own LDS stages and the two accumulators are summed through LDS
 // at the end.  Kernels whose grids give only ~1 workgroup per CU get 2 waves per SIMD this way (the
 // staging of one team runs in the shadow of the other team's MFMAs) without more, smaller tiles.
+// Virtual rows: a policy may pad every image's rows to a multiple of the tile height
+// (P::vrow(args, mv, m_real) -> valid), so that one workgroup == one image and a B-image batch maps
+// onto the 256 CUs without the round-robin tail of a flat row tiling (81 conv2 rows -> 96, 49 -> 64).
+#ifdef IGEMM_TRACE   // tools/probes only: per-workgroup phase timestamps (100 MHz wall clock)
+__device__ unsigned long long* g_igemm_trace;
+#define IGEMM_TP(slot) do { if (threadIdx.x == 0 && g_igemm_trace) { \
+    unsigned long long* t_ = g_igemm_trace + ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
+    t_[slot] = wall_clock64(); t_[4 + (slot)] = clock64(); } } while (0)
+#else
+#define IGEMM_TP(slot) do { } while (0)
+#endif
+
 template <class P, int TEAMS = 1>
-__global__ __launch_bounds__(256 * TEAMS) void k_igemm(typename P::Args args)
+__global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P::Args args)
 {
+    IGEMM_TP(0);
     using A = typename P::A;
+    constexpr int NW = P::WM * P::WN, NT = 64 * NW;          // waves / threads per team
     constexpr int BM = P::WM * P::TM * 32, BN = P::WN * P::TN * 32;
     constexpr int LDB = BN;
-    constexpr int ROWS_PER_PASS = 256 * A::VEC / BK;   // rows of the A tile staged per pass
-    constexpr int A_PASSES = BM / ROWS_PER_PASS;
+    constexpr int APR = BK / A::VEC;                         // staging loads per A row
+    static_assert(NT % APR == 0, "thread count must keep the k-quad of a thread fixed across passes");
+    constexpr int A_ELEMS = BM * APR;
+    constexpr int A_PASSES = (A_ELEMS + NT - 1) / NT;
     constexpr int AV = A::VEC / 4;
-    constexpr int B_VECS = BK * BN / 4 / 256;          // f32x4 per thread for the B tile
-    static_assert(P::WM * P::WN == 4, "4 waves per team");
-    static_assert(A_PASSES >= 1 && B_VECS >= 1, "tile too small for 256 threads");
+    constexpr int B_ELEMS = BK * BN / 4;
+    constexpr int B_VECS = (B_ELEMS + NT - 1) / NT;          // f32x4 per thread for the B tile
     static_assert(TEAMS == 1 || TEAMS == 2, "one or two teams");
 
     // two LDS stages per team: tile t+1 is written while tile t feeds the matrix pipe (one barrier per k-tile)
@@ -262,21 +320,25 @@ __global__ __launch_bounds__(256 * TEAMS) void k_igemm(typename P::Args args)
     static_assert(TEAMS == 1 || 2 * STAGE >= BM * BN, "team reduction buffer must fit one team's stages");
     __shared__ __attribute__((aligned(16))) float smem_all[2 * STAGE * TEAMS];
 
-    const int team = TEAMS == 1 ? 0 : (int)(threadIdx.x >> 8);
+    const int team = TEAMS == 1 ? 0 : (int)(threadIdx.x / NT);
     float* smem = smem_all + team * 2 * STAGE;
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / P::WN, wn = wave % P::WN;
     const int NT_N = P::N(args) / BN;
     const int mt = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * BM, n0 = nt * BN;                    // m0: virtual row
     const int z = blockIdx.z, y = blockIdx.y;
     const int M = P::M(args);
 
-    // per-thread staging coordinates
-    const int a_q = tid % (BK / A::VEC), a_r = tid / (BK / A::VEC);
+    // per-thread staging coordinates: element e = tid + p*NT of the A tile -> (row e / APR, k-quad e % APR)
+    const int a_q = tid % APR, a_r = tid / APR;
     typename A::Row rows[A_PASSES];
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) rows[p] = A::row(P::a_src(args, z), m0 + p * ROWS_PER_PASS + a_r, M);
+    for (int p = 0; p < A_PASSES; ++p) {
+        int mr;
+        const bool ok = P::vrow(args, m0 + p * (NT / APR) + a_r, mr);
+        rows[p] = A::row(P::a_src(args, z), ok ? mr : M, M);   // invalid rows alias row 0 and are never stored
+    }
     const float* w = P::w(args, z, y);
 
     int kt0, kt1;
@@ -287,50 +349,63 @@ __global__ __launch_bounds__(256 * TEAMS) void k_igemm(typename P::Args args)
     const int my_n = kt0 + team < kt1 ? (kt1 - kt0 - team + TEAMS - 1) / TEAMS : 0;
     auto tile = [&](int it) { return kt0 + team + min(it, max(my_n - 1, 0)) * TEAMS; };   // clamped to my last tile
 
-    f32x4 ra[A_PASSES][AV];
-    f32x4 rb[B_VECS];
-    auto prefetch_a = [&](int kt) {
+    // Two register sets: global loads are issued ~2 k-tiles before they are committed to LDS (one k-tile
+    // of MFMAs is ~0.5 us; an L2/MALL round trip under load is longer than that).
+    f32x4 ra[2][A_PASSES][AV];
+    f32x4 rb[2][B_VECS];
+    auto prefetch_a = [&](auto set, int kt) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) A::load(rows[p], kt, a_q, ra[p]);
+        for (int p = 0; p < A_PASSES; ++p)
+            if (A_ELEMS % NT == 0 || tid + p * NT < A_ELEMS) A::load(rows[p], kt, a_q, ra[S][p]);
     };
-    auto prefetch_b = [&](int kt) {
+    auto prefetch_b = [&](auto set, int kt) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int v = 0; v < B_VECS; ++v) {
-            const int e = tid + v * 256;
+            const int e = tid + v * NT;
+            if (B_ELEMS % NT != 0 && e >= B_ELEMS) continue;
             if constexpr (!P::B_TR) {
                 const int kr = e / (BN / 4), n4 = e % (BN / 4);
-                rb[v] = *reinterpret_cast<const f32x4*>(w + (size_t)(kt * BK + kr) * P::N(args) + n0 + n4 * 4);
+                rb[S][v] = *reinterpret_cast<const f32x4*>(w + (size_t)(kt * BK + kr) * P::N(args) + n0 + n4 * 4);
             } else {
                 // k-tile kt = (tap, c0); element (k'=c0+kq*4.., n') = w[(tap*NP + n0+n')*KP + c0 + kq*4]
                 const int TPT = P::KP(args) / BK;
                 const int tap = kt / TPT, c0 = (kt % TPT) * BK;
                 const int kq = e % 8, np = e / 8;
-                rb[v] = *reinterpret_cast<const f32x4*>(w + ((size_t)P::tap_index(y, tap) * P::N(args) + n0 + np) * P::KP(args) + c0 + kq * 4);
+                rb[S][v] = *reinterpret_cast<const f32x4*>(w + ((size_t)P::tap_index(y, tap) * P::N(args) + n0 + np) * P::KP(args) + c0 + kq * 4);
             }
         }
     };
-    auto commit_a = [&](int stage) {
+    auto commit_a = [&](auto set, int stage) {
+        constexpr int S = decltype(set)::value;
         float* As = smem + stage * STAGE;
 #pragma unroll
-        for (int p = 0; p < A_PASSES; ++p)
+        for (int p = 0; p < A_PASSES; ++p) {
+            if (A_ELEMS % NT != 0 && tid + p * NT >= A_ELEMS) continue;
 #pragma unroll
             for (int j = 0; j < AV; ++j)
-                *reinterpret_cast<f32x4*>(&As[(p * ROWS_PER_PASS + a_r) * LDA + a_q * A::VEC + j * 4]) = ra[p][j];
+                *reinterpret_cast<f32x4*>(&As[(p * (NT / APR) + a_r) * LDA + a_q * A::VEC + j * 4]) = ra[S][p][j];
+        }
     };
-    auto commit_b = [&](int stage) {
+    auto commit_b = [&](auto set, int stage) {
+        constexpr int S = decltype(set)::value;
         float* Bs = smem + stage * STAGE + BM * LDA;
 #pragma unroll
         for (int v = 0; v < B_VECS; ++v) {
-            const int e = tid + v * 256;
+            const int e = tid + v * NT;
+            if (B_ELEMS % NT != 0 && e >= B_ELEMS) continue;
             if constexpr (!P::B_TR) {
                 const int kr = e / (BN / 4), n4 = e % (BN / 4);
-                *reinterpret_cast<f32x4*>(&Bs[kr * LDB + n4 * 4]) = rb[v];
+                *reinterpret_cast<f32x4*>(&Bs[kr * LDB + n4 * 4]) = rb[S][v];
             } else {
                 const int kq = e % 8, np = e / 8;
-                *reinterpret_cast<f32x4*>(&Bs[np * LDA + kq * 4]) = rb[v];   // [n'][k'] like the A tile
+                *reinterpret_cast<f32x4*>(&Bs[np * LDA + kq * 4]) = rb[S][v];   // [n'][k'] like the A tile
             }
         }
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
 
     f32x16 acc[P::TM][P::TN];
 #pragma unroll
@@ -341,30 +416,60 @@ __global__ __launch_bounds__(256 * TEAMS) void k_igemm(typename P::Args args)
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     // Software pipeline, branch-free body (tile indices are clamped, so the tail re-stages the last
-    // tile into the idle stage: harmless).  Registers hold tile it+1 while stage `cur` holds tile it.
+    // tile into the idle stage: harmless).  While stage `cur` (tile it) feeds the matrix pipe, register
+    // set (it+1)&1 holds tile it+1 and the other set tile it+2.
     if (my_n > 0) {
-        prefetch_a(tile(0)); prefetch_b(tile(0));
-        commit_a(0); commit_b(0);
-        prefetch_a(tile(1)); prefetch_b(tile(1));
+        prefetch_a(Set0{}, tile(0)); prefetch_b(Set0{}, tile(0));
+        prefetch_a(Set1{}, tile(1)); prefetch_b(Set1{}, tile(1));
+        commit_a(Set0{}, 0); commit_b(Set0{}, 0);
+        prefetch_a(Set0{}, tile(2)); prefetch_b(Set0{}, tile(2));
+    }
+
+    // Epilogue operands (row map, bias / ReLU mask) are fetched here, so the k loop hides their latency and
+    // the 16 stores per tile go out back to back.  (vmcnt counts stores as well as loads on gfx9: a
+    // load -> wait -> store sequence per element would serialise 16 memory round trips per wave.)
+    const int j = lane & 31, h = lane >> 5;
+    typename P::Epi epi = P::epi(args, z, y);   // output / bias / mask pointers, pinned in SGPRs for the epilogue
+    int mrow[P::TM][16];
+    unsigned okmask[P::TM];
+    float aux[P::TM][P::TN][16];
+#pragma unroll
+    for (int tm = 0; tm < P::TM; ++tm) {
+        okmask[tm] = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mv = m0 + (wm * P::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (P::vrow(args, mv, mrow[tm][r])) okmask[tm] |= 1u << r;
+            else mrow[tm][r] = 0;
+#pragma unroll
+            for (int tn = 0; tn < P::TN; ++tn)
+                aux[tm][tn][r] = P::epi_load(epi, mrow[tm][r], n0 + (wn * P::TN + tn) * 32 + j);
+        }
     }
     __syncthreads();
+    IGEMM_TP(1);
     int cur = 0;
-    for (int it = 0; it < iters; ++it) {
-        if (it < my_n) {   // team-uniform
+    auto step = [&](auto set, int it) {   // set = (it+1)&1: holds tile it+1; refilled with tile it+3
+        if (it < my_n) {                  // team-uniform
             const float* As = smem + cur * STAGE;
-            const int k2 = tile(it + 2);
+            const int k3 = tile(it + 3);
             mfma_ktile<P::TM, P::TN, LDB, P::B_TR>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc, [&](int u) {
-                if (u == 0) commit_a(cur ^ 1);          // tile it+1 -> idle stage, in the shadow of the MFMAs
-                else if (u == 1) commit_b(cur ^ 1);
-                else if (u == 2) prefetch_a(k2);        // tile it+2 global loads
-                else prefetch_b(k2);
+                if (u == 0) { if (!(IGEMM_ABL & 2)) { commit_a(set, cur ^ 1); commit_b(set, cur ^ 1); } }   // tile it+1 -> idle stage
+                else if (u == 1) { if (!(IGEMM_ABL & 1)) prefetch_a(set, k3); }                       // tile it+3 global loads
+                else if (u == 2) { if (!(IGEMM_ABL & 1)) prefetch_b(set, k3); }
             });
         }
-        __syncthreads();
+        if (!(IGEMM_ABL & 4)) __syncthreads();
         cur ^= 1;
+    };
+    for (int it = 0; it < iters; it += 2) {
+        step(Set1{}, it);
+        if (it + 1 < iters) step(Set0{}, it + 1);
     }
+    IGEMM_TP(2);
     if constexpr (TEAMS == 2) {   // acc(team 0) += acc(team 1), through team 1's (now idle) stages
         constexpr int PER_WAVE = P::TM * P::TN * 16 * 64;
+        static_assert(2 * STAGE >= NW * PER_WAVE, "team reduction buffer");
         float* red = smem_all + 2 * STAGE;
         if (team == 1) {
 #pragma unroll
@@ -384,23 +489,26 @@ __global__ __launch_bounds__(256 * TEAMS) void k_igemm(typename P::Args args)
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] += red[wave * PER_WAVE + ((tm * P::TN + tn) * 16 + r) * 64 + lane];
     }
 
-    const int j = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int tm = 0; tm < P::TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < P::TN; ++tn)
+        for (int tn = 0; tn < P::TN; ++tn) {
+            const int n = n0 + (wn * P::TN + tn) * 32 + j;
+            // land the operand loads here, in straight-line code: otherwise every conditional store block
+            // gets its own vmcnt(0), which also waits for the previous block's store
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * P::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int n = n0 + (wn * P::TN + tn) * 32 + j;
-                if (m < M) P::store(args, z, y, m, n, acc[tm][tn][r]);
-            }
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(aux[tm][tn][r]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (okmask[tm] >> r & 1) P::store(epi, mrow[tm][r], n, acc[tm][tn][r], aux[tm][tn][r]);
+        }
+    IGEMM_TP(3);
 }
 
 template <class P, int TEAMS>
 inline hipError_t launch_igemm(hipStream_t st, dim3 grid, const typename P::Args& args)
 {
-    hipLaunchKernelGGL((k_igemm<P, TEAMS>), grid, dim3(256 * TEAMS), 0, st, args);
+    hipLaunchKernelGGL((k_igemm<P, TEAMS>), grid, dim3(64 * P::WM * P::WN * TEAMS), 0, st, args);
     return hipGetLastError();
 }
 

@@ -45,6 +45,10 @@ using GeomC2 = Geom<20, 20, 32, 4, 4, 2, 9, 9, 64>;
 using GeomC3 = Geom<9, 9, 64, 3, 3, 1, 7, 7, 64>;
 using GeomL1 = Geom<1, 1, 3136, 1, 1, 1, 1, 1, 512>;
 
+// 16 bytes of zeros in global memory: what structurally-zero im2col taps load in the direct-to-LDS path
+__device__ __attribute__((aligned(16))) static const float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ const float* zero_page() { return g_zero_page; }
+
 // ------------------------------------------------------------------------------------------------
 // A-operand policies.  Interface:
 //   VEC            k elements one thread stages per load (4: one f32x4; 8: 8 bytes of u8 pixels)
@@ -75,6 +79,14 @@ struct AFwd {
         const int kh = tap / G::KW, kw = tap % G::KW;
         const float* p = r.p + (kh * G::IW + kw) * G::CIN + c0 + q * 4;
         v[0] = *reinterpret_cast<const f32x4*>(p);   // rows >= M alias row 0 (never stored / zero Y row)
+    }
+    // address of the 16-byte chunk q of k-tile kt (direct-to-LDS staging)
+    __device__ static const float* chunk(const Row& r, int kt, int q)
+    {
+        constexpr int TPT = G::CIN / BK;
+        const int tap = kt / TPT, c0 = (kt % TPT) * BK;
+        const int kh = tap / G::KW, kw = tap % G::KW;
+        return r.p + (kh * G::IW + kw) * G::CIN + c0 + q * 4;
     }
 };
 
@@ -135,6 +147,15 @@ struct ADxS1 {
         const f32x4 t = *reinterpret_cast<const f32x4*>(p);
         v[0] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    __device__ static const float* chunk(const Row& r, int kt, int q)   // out-of-range taps read the zero page
+    {
+        constexpr int TPT = G::COUT / BK;
+        const int tap = kt / TPT, c0 = (kt % TPT) * BK;
+        const int oh = r.ih - tap / G::KW, ow = r.iw - tap % G::KW;
+        const bool ok = oh >= 0 && oh < G::OH && ow >= 0 && ow < G::OW;
+        const float* p = r.dy + ((size_t)(r.b * G::OH + oh) * G::OW + ow) * G::COUT + c0 + q * 4;
+        return ok ? p : zero_page();
+    }
 };
 
 // Input gradient of a stride-2, 4x4 conv: the input grid splits into 4 parity classes (ih%2, iw%2);
@@ -169,6 +190,15 @@ struct ADxS2 {
         const f32x4 t = *reinterpret_cast<const f32x4*>(p);
         v[0] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    __device__ static const float* chunk(const Row& r, int kt, int q)
+    {
+        constexpr int TPT = G::COUT / BK;
+        const int tap = kt / TPT, c0 = (kt % TPT) * BK;
+        const int oh = r.ihh - (tap >> 1), ow = r.iwh - (tap & 1);
+        const bool ok = oh >= 0 && oh < G::OH && ow >= 0 && ow < G::OW;
+        const float* p = r.dy + ((size_t)(r.b * G::OH + oh) * G::OW + ow) * G::COUT + c0 + q * 4;
+        return ok ? p : zero_page();
+    }
 };
 
 // Dense row-major f32 matrix with a runtime leading dimension (MLP layers of the Mlp / SAC / IQN nets).
@@ -187,6 +217,7 @@ struct ADense {
     {
         v[0] = *reinterpret_cast<const f32x4*>(r.p + kt * BK + q * 4);
     }
+    __device__ static const float* chunk(const Row& r, int kt, int q) { return r.p + kt * BK + q * 4; }
 };
 
 // Keeps a wave-uniform pointer in an SGPR pair from here on (otherwise the compiler re-loads kernel-argument
@@ -504,6 +535,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
         }
     IGEMM_TP(3);
 }
+
 
 template <class P, int TEAMS>
 inline hipError_t launch_igemm(hipStream_t st, dim3 grid, const typename P::Args& args)

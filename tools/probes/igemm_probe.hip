@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "cnn_layers.hpp"
+#include "igemm_dl.hpp"
 
 using namespace bdr;
 
@@ -23,6 +24,23 @@ static double checksum(const float* d, size_t n)
     std::vector<float> h(n); CK(hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost));
     double s = 0; for (size_t i = 0; i < n; ++i) s += (double)h[i] * (double)((i % 97) + 1);
     return s;
+}
+
+template <class P, int STAGES>
+static void run_dl(const char* name, dim3 grid, const typename P::Args& args, const float* out, size_t nout)
+{
+    hipStream_t st = 0;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) CK((launch_igemm_dl<P, STAGES>(st, grid, args)));
+    CK(hipDeviceSynchronize());
+    const int IT = 50;
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < IT; ++i) CK((launch_igemm_dl<P, STAGES>(st, grid, args)));
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-34s grid=(%4u,%u,%u) thr=%4d  %7.2f us   sum=%.9e  [direct-to-LDS, %d stages]\n", name, grid.x, grid.y, grid.z, 64 * P::WM * P::WN,
+           ms * 1000.0 / IT, checksum(out, nout), STAGES);
+    fflush(stdout);
 }
 
 template <class P, int TEAMS>
@@ -65,31 +83,28 @@ int main()
 #define FWD3(WM, WN, RP, TM, TN, T) { using P = FwdP<GeomC3, AFwd<GeomC3>, WM, WN, false, RP, TM, TN>; \
     CK(hipMemset(h3[1], 0, n3 * 4)); run<P, T>("fwd_c3 " #WM "x" #WN " rp" #RP " t" #TM #TN " teams" #T, dim3(m_tiles<P>(f3.M) * (64 / (WN * TN * 32)), 1, NZ), f3, h3[1], n3); }
 
+#define FWD2D(WM, WN, RP, TM, TN, S) { using P = FwdP<GeomC2, AFwd<GeomC2>, WM, WN, false, RP, TM, TN>; \
+    CK(hipMemset(h2[1], 0, n2 * 4)); run_dl<P, S>("fwd_c2 " #WM "x" #WN " rp" #RP " t" #TM #TN, dim3(m_tiles<P>(f2.M) * (64 / (WN * TN * 32)), 1, NZ), f2, h2[1], n2); }
+#define FWD3D(WM, WN, RP, TM, TN, S) { using P = FwdP<GeomC3, AFwd<GeomC3>, WM, WN, false, RP, TM, TN>; \
+    CK(hipMemset(h3[1], 0, n3 * 4)); run_dl<P, S>("fwd_c3 " #WM "x" #WN " rp" #RP " t" #TM #TN, dim3(m_tiles<P>(f3.M) * (64 / (WN * TN * 32)), 1, NZ), f3, h3[1], n3); }
     FWD2(2, 2, 0, 1, 1, 1)   // current
-    FWD2(2, 2, 0, 1, 1, 2)
-    FWD2(3, 2, 96, 1, 1, 1)  // one workgroup per image
-    FWD2(3, 2, 96, 1, 1, 2)
-    FWD2(4, 2, 0, 1, 1, 1)
-    FWD2(2, 2, 0, 2, 1, 1)   // 128x64, 4 waves
-    FWD2(2, 1, 0, 1, 2, 1)   // 64x64, 2 waves
-    FWD2(1, 2, 0, 1, 1, 1)   // 32x64, 2 waves
-    FWD2(1, 2, 0, 1, 1, 2)   // 32x64, 2x2 waves
-    FWD2(3, 1, 96, 1, 2, 1)  // per image, 3 waves x (32x64)
-    FWD2(3, 1, 96, 1, 2, 2)
-    FWD2(4, 1, 0, 1, 2, 1)   // 128x64, 4 waves x (32x64)
-    FWD2(2, 1, 0, 1, 1, 2)   // 64x32 x 2 teams
-
+    FWD2D(2, 2, 0, 1, 1, 3)
+    FWD2D(2, 2, 0, 1, 1, 4)
+    FWD2D(2, 2, 0, 2, 1, 3)
+    FWD2D(4, 2, 0, 1, 1, 3)
+    FWD2D(2, 1, 0, 1, 2, 3)
+    FWD2D(4, 1, 0, 1, 2, 3)
+    FWD2D(4, 1, 0, 1, 2, 4)
+    FWD2D(2, 2, 0, 2, 1, 4)
     FWD3(2, 2, 0, 1, 1, 1)
     FWD3(2, 2, 0, 1, 1, 2)   // current
-    FWD3(2, 2, 64, 1, 1, 1)
-    FWD3(2, 2, 64, 1, 1, 2)
-    FWD3(1, 2, 0, 1, 1, 2)
-    FWD3(1, 2, 0, 1, 1, 1)
-    FWD3(2, 1, 0, 1, 2, 1)
-    FWD3(2, 1, 64, 1, 2, 2)
-    FWD3(4, 2, 0, 1, 1, 1)
-    FWD3(2, 1, 0, 1, 1, 2)
-    FWD3(4, 1, 0, 1, 2, 1)
+    FWD3D(2, 2, 0, 1, 1, 3)
+    FWD3D(2, 2, 0, 1, 1, 4)
+    FWD3D(2, 2, 64, 1, 1, 3)
+    FWD3D(4, 2, 0, 1, 1, 3)
+    FWD3D(4, 1, 0, 1, 2, 3)
+    FWD3D(2, 2, 0, 2, 1, 3)
+
 
     // dX conv3: dy [B][7][7][64] -> dx over [B][9][9][64]; dX conv2: dy [B][9][9][64] -> [B][20][20][32]
     float* dy3 = dev_rand(n3, -1.f, 1.f, 6);
@@ -107,25 +122,21 @@ int main()
 #define DX2(WM, WN, RP, TM, TN, T) { using P = DxC2P<WM, WN, RP, TM, TN>; \
     CK(hipMemset(dx1, 0, n1 * 4)); run<P, T>("dx_c2 " #WM "x" #WN " rp" #RP " t" #TM #TN " teams" #T, dim3(m_tiles<P>(d2.M) * (32 / (WN * TN * 32)), 4, 1), d2, dx1, n1); }
 
+#define DX3D(WM, WN, RP, TM, TN, S) { using P = DxC3P<WM, WN, RP, TM, TN>; \
+    CK(hipMemset(dx2, 0, n2 * 4)); run_dl<P, S>("dx_c3 " #WM "x" #WN " rp" #RP " t" #TM #TN, dim3(m_tiles<P>(d3.M) * (64 / (WN * TN * 32)), 1, 1), d3, dx2, n2); }
+#define DX2D(WM, WN, RP, TM, TN, S) { using P = DxC2P<WM, WN, RP, TM, TN>; \
+    CK(hipMemset(dx1, 0, n1 * 4)); run_dl<P, S>("dx_c2 " #WM "x" #WN " rp" #RP " t" #TM #TN, dim3(m_tiles<P>(d2.M) * (32 / (WN * TN * 32)), 4, 1), d2, dx1, n1); }
     DX3(2, 2, 0, 1, 1, 1)
+    DX3D(2, 2, 0, 1, 1, 3)
+    DX3D(2, 2, 0, 1, 1, 4)
+    DX3D(4, 2, 0, 1, 1, 3)
+    DX3D(4, 1, 0, 1, 2, 3)
+    DX3D(2, 2, 0, 2, 1, 3)
+    DX2D(4, 1, 0, 1, 1, 3)
+    DX2D(4, 1, 0, 1, 1, 4)
+    DX2D(4, 1, 0, 2, 1, 3)
     DX3(2, 2, 0, 1, 1, 2)    // current
-    DX3(3, 2, 96, 1, 1, 1)
-    DX3(3, 2, 96, 1, 1, 2)
-    DX3(1, 2, 0, 1, 1, 2)
-    DX3(1, 2, 0, 1, 1, 1)
-    DX3(3, 1, 96, 1, 2, 2)
-    DX3(2, 1, 0, 1, 2, 2)
-    DX3(2, 1, 0, 1, 1, 2)
-    DX3(4, 2, 0, 1, 1, 1)
 
     DX2(4, 1, 0, 1, 1, 1)    // current
-    DX2(4, 1, 0, 1, 1, 2)
-    DX2(4, 1, 128, 1, 1, 1)
-    DX2(4, 1, 128, 1, 1, 2)
-    DX2(2, 1, 0, 1, 1, 1)
-    DX2(2, 1, 0, 1, 1, 2)
-    DX2(2, 1, 0, 2, 1, 1)
-    DX2(1, 1, 0, 1, 1, 2)
-    DX2(8, 1, 0, 1, 1, 1)
     return 0;
 }

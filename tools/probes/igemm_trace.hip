@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "cnn_layers.hpp"
+#include "igemm_dl.hpp"
 
 using namespace bdr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -20,17 +21,18 @@ static float* dev_rand(size_t n, float lo, float hi, unsigned seed)
     return d;
 }
 
-template <class P, int TEAMS>
+template <class P, int TEAMS, bool DL = false>
 static void trace(const char* name, dim3 grid, const typename P::Args& args)
 {
+    auto launch = [&]() { if constexpr (DL) return launch_igemm_dl<P, TEAMS>(0, grid, args); else return launch_igemm<P, TEAMS>(0, grid, args); };
     const size_t nwg = (size_t)grid.x * grid.y * grid.z;
     unsigned long long* d; CK(hipMalloc(&d, nwg * 8 * 8)); CK(hipMemset(d, 0, nwg * 8 * 8));
     unsigned long long* null = nullptr;
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_trace), &null, sizeof(d)));
-    for (int i = 0; i < 3; ++i) CK((launch_igemm<P, TEAMS>(0, grid, args)));
+    for (int i = 0; i < 3; ++i) CK(launch());
     CK(hipDeviceSynchronize());
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_trace), &d, sizeof(d)));
-    CK((launch_igemm<P, TEAMS>(0, grid, args)));
+    CK(launch());
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(nwg * 8); CK(hipMemcpy(h.data(), d, nwg * 8 * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull, tend = 0;
@@ -74,6 +76,11 @@ int main(int argc, char** argv)
     FwdArgs f3{}; for (int z = 0; z < NZ; ++z) { f3.x[z] = x2; f3.w[z] = w3; f3.bias[z] = b2; f3.out[z] = h3[z]; }
     f3.M = B * 49;
     if (solo_only) {
+        { FwdArgs g = f2; g.M = 64 * 128; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 3, true>("DL3 fwd_c2 64x64 solo (1 WG/CU)", dim3(128, 1, NZ), g); }
+        { FwdArgs g = f2; g.M = 64 * 128; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 4, true>("DL4 fwd_c2 64x64 solo (1 WG/CU)", dim3(128, 1, NZ), g); }
+        { FwdArgs g = f2; g.M = 128 * 128; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 2, 1>; trace<P, 3, true>("DL3 fwd_c2 128x64 tm2 solo (1 WG/CU)", dim3(128, 1, NZ), g); }
+        { using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 3, true>("DL3 fwd_c2 64x64 flat", dim3(m_tiles<P>(f2.M), 1, NZ), f2); }
+        { using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 4, true>("DL4 fwd_c2 64x64 flat", dim3(m_tiles<P>(f2.M), 1, NZ), f2); }
         { FwdArgs g = f2; g.M = 64 * 128; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 1>("fwd_c2 64x64 solo (1 WG/CU)", dim3(128, 1, NZ), g); }
         { FwdArgs g = f2; g.M = 128 * 128; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 2, 1>; trace<P, 1>("fwd_c2 128x64 tm2 solo (1 WG/CU)", dim3(128, 1, NZ), g); }
         { using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 1>("fwd_c2 64x64 flat", dim3(m_tiles<P>(f2.M), 1, NZ), f2); }

@@ -5,7 +5,7 @@ and the host-side mirror of the reference interfaces (replay.py, dqn.py, trainer
 """
 from ._lib import BdrError, device_count  # noqa: F401
 from .replay import GenericTransitionBatch, SimpleReplayBuffer, SimpleReplayBufferConfig  # noqa: F401
-from .dqn import AtariCnnConfig, Dqn, DqnConfig, DqnModelConfig, MlpConfig, OptimizerConfig  # noqa: F401
+from .dqn import AtariCnnConfig, Dqn, DqnConfig, DqnModelConfig, EpsilonGreedy, MlpConfig, OptimizerConfig, Softmax  # noqa: F401
 from .sac import Sac, SacConfig  # noqa: F401
 from .iqn import Iqn, IqnConfig  # noqa: F401
 from .trainer import ParamExchange, Trainer, TrainerConfig, shard_seed  # noqa: F401

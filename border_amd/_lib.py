@@ -67,6 +67,16 @@ class DqnRecordC(C.Structure):
                 ("tgt_mean", C.c_float), ("tgt_minus_pred_mean", C.c_float), ("has_verbose", C.c_int32)]
 
 
+class ExplorerConfigC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("eps_start", C.c_double), ("eps_final", C.c_double),
+                ("final_step", C.c_uint64), ("n_calls", C.c_uint64), ("seed", C.c_uint64)]
+
+
+class SampleInfoC(C.Structure):
+    _fields_ = [("eps", C.c_double), ("is_random", C.c_int32), ("n_samples_act", C.c_uint64),
+                ("n_samples_best_act", C.c_uint64)]
+
+
 class DeviceBatch(C.Structure):
     _fields_ = [("n", C.c_uint64), ("obs", C.c_void_p), ("next_obs", C.c_void_p), ("act", C.c_void_p),
                 ("reward", C.c_void_p), ("is_terminated", C.c_void_p), ("is_truncated", C.c_void_p),
@@ -81,6 +91,7 @@ ABI_SYMBOLS = [
     "bdr_replay_read_rows",
     "bdr_dqn_config_default", "bdr_dqn_create", "bdr_agent_destroy", "bdr_agent_set_train", "bdr_agent_is_train",
     "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_agent_opt_with_scalars", "bdr_agent_param_count_of", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
+    "bdr_explorer_config_default", "bdr_agent_set_explorer", "bdr_agent_get_explorer", "bdr_agent_sample",
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
     "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_dqn_probe",
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
@@ -110,11 +121,13 @@ def lib() -> C.CDLL:
     L.bdr_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == ABI drift
-        if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default", "bdr_iqn_config_default"):
+        if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default", "bdr_iqn_config_default",
+                        "bdr_explorer_config_default"):
             fn.restype = C.c_int32
     L.bdr_dqn_config_default.restype = None
     L.bdr_sac_config_default.restype = None
     L.bdr_iqn_config_default.restype = None
+    L.bdr_explorer_config_default.restype = None
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     L.bdr_replay_create.argtypes = [C.POINTER(ReplayConfig), C.POINTER(vp)]
     L.bdr_replay_destroy.argtypes = [vp]

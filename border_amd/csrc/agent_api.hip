@@ -2,6 +2,9 @@
 // polymorphic handle of agent_base.hpp.  Agent-specific constructors live next to their kernels.
 #include <cstdlib>
 
+#include <algorithm>
+#include <cmath>
+
 #include "agent_base.hpp"
 
 using namespace bdr;
@@ -172,32 +175,131 @@ int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const
     return BDR_OK;
 }
 
+// action values [n][A] of any value-based agent, on the host
+static int32_t action_values(bdr_agent* a, uint64_t n, const void* obs, std::vector<float>& q, int* A_out)
+{
+    BDR_REQUIRE(n >= 1 && n <= 65536, "batch size out of range");
+    BDR_HIP(hipSetDevice(a->device));
+    const int A = (int)a->param_count(-1);   // number of actions (every value agent reports it as which = -1)
+    q.resize(n * A);
+    if (!strcmp(a->kind(), "dqn_cnn")) BDR_TRY(dqn_cnn_qvalues(a, n, obs, q.data()));
+    else if (!strcmp(a->kind(), "dqn_mlp")) BDR_TRY(dqn_mlp_qvalues(a, n, obs, q.data()));
+    else if (!strcmp(a->kind(), "iqn")) BDR_TRY(bdr_iqn_qvalues(a, n, obs, q.data(), nullptr));
+    else return fail(BDR_ERR_INVALID, "agent kind '%s' has no discrete action values", a->kind());
+    *A_out = A;
+    return BDR_OK;
+}
+
+static int argmax_row(const float* q, int A)   // first maximum, like Tensor::argmax
+{
+    int best = 0;
+    for (int k = 1; k < A; ++k) if (q[k] > q[best]) best = k;
+    return best;
+}
+
 int32_t bdr_agent_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out, int64_t* argmax_out)
 {
     BDR_REQUIRE(a && obs, "null argument");
-    BDR_REQUIRE(is_dqn(a), "not a DQN agent");
-    BDR_REQUIRE(n >= 1 && n <= 65536, "batch size out of range");
-    BDR_HIP(hipSetDevice(a->device));
-    uint64_t np = 0;
-    (void)np;
-    // number of actions = rows of the last weight; ask the agent through its Q output size
     std::vector<float> q;
     int A = 0;
-    {
-        float probe[1]; (void)probe;
-        // the concrete agents report A as the last bias length: param layout ends with [A] bias
-        A = (int)a->param_count(-1);
-    }
-    q.resize(n * A);
-    if (!strcmp(a->kind(), "dqn_cnn")) BDR_TRY(dqn_cnn_qvalues(a, n, obs, q.data()));
-    else BDR_TRY(dqn_mlp_qvalues(a, n, obs, q.data()));
+    BDR_TRY(action_values(a, n, obs, q, &A));
     if (q_out) memcpy(q_out, q.data(), q.size() * 4);
     if (argmax_out)
-        for (uint64_t i = 0; i < n; ++i) {
-            int best = 0;
-            for (int k = 1; k < A; ++k) if (q[i * A + k] > q[i * A + best]) best = k;
-            argmax_out[i] = best;
+        for (uint64_t i = 0; i < n; ++i) argmax_out[i] = argmax_row(&q[i * A], A);
+    return BDR_OK;
+}
+
+void bdr_explorer_config_default(bdr_explorer_config* e, int32_t kind)
+{
+    if (!e) return;
+    e->kind = kind;
+    e->eps_start = 1.0; e->eps_final = 0.02; e->final_step = 100000;   // dqn/explorer.rs:44-52
+    e->n_calls = 0; e->seed = 0;
+}
+
+int32_t bdr_agent_set_explorer(bdr_agent* a, const bdr_explorer_config* e)
+{
+    BDR_REQUIRE(a && e, "null argument");
+    BDR_REQUIRE(e->kind == BDR_EXPLORER_SOFTMAX || e->kind == BDR_EXPLORER_EPS_GREEDY, "unknown explorer kind");
+    BDR_REQUIRE(e->kind != BDR_EXPLORER_EPS_GREEDY || e->final_step > 0, "final_step must be positive");
+    Explorer& x = a->explorer;
+    x.kind = e->kind; x.eps_start = e->eps_start; x.eps_final = e->eps_final; x.final_step = e->final_step;
+    x.n_calls = e->n_calls;
+    seed_from_u64(e->seed, x.key.k);
+    x.word_pos = 0;
+    return BDR_OK;
+}
+
+int32_t bdr_agent_get_explorer(const bdr_agent* a, bdr_explorer_config* e)
+{
+    BDR_REQUIRE(a && e, "null argument");
+    const Explorer& x = a->explorer;
+    e->kind = x.kind; e->eps_start = x.eps_start; e->eps_final = x.eps_final; e->final_step = x.final_step;
+    e->n_calls = x.n_calls; e->seed = 0;   // the seed itself is not retained (only the expanded key)
+    return BDR_OK;
+}
+
+// Policy::sample (dqn/base.rs:211-242; iqn/base.rs:204-228)
+int32_t bdr_agent_sample(bdr_agent* a, uint64_t n, const void* obs, int64_t* act_out, bdr_sample_info* info)
+{
+    BDR_REQUIRE(a && obs && act_out, "null argument");
+    std::vector<float> q;
+    int A = 0;
+    BDR_TRY(action_values(a, n, obs, q, &A));
+    Explorer& x = a->explorer;
+    double eps = 0.0;
+    bool is_random = false;
+    if (a->train) {
+        a->n_samples_act += 1;                                            // dqn/base.rs:215
+        if (x.kind == BDR_EXPLORER_SOFTMAX) {                             // explorer.rs:29-31: softmax(-1).multinomial(1)
+            bool all_best = true;
+            for (uint64_t i = 0; i < n; ++i) {
+                const float* qi = &q[i * A];
+                float mx = qi[0];
+                for (int k = 1; k < A; ++k) mx = std::max(mx, qi[k]);
+                double z = 0.0;
+                for (int k = 0; k < A; ++k) z += std::exp((double)(qi[k] - mx));
+                const double u = x.f64() * z;
+                double c = 0.0;
+                int act = A - 1;
+                for (int k = 0; k < A; ++k) {
+                    c += std::exp((double)(qi[k] - mx));
+                    if (c > u) { act = k; break; }
+                }
+                act_out[i] = act;
+                all_best = all_best && act == argmax_row(qi, A);
+            }
+            if (all_best) a->n_samples_best_act += 1;
+        } else {                                                          // explorer.rs:68-90
+            const double d = (x.eps_start - x.eps_final) / (double)x.final_step;
+            eps = std::max(x.eps_start - d * (double)x.n_calls, x.eps_final);
+            is_random = x.f64() < eps;
+            x.n_calls += 1;
+            bool all_best = true;
+            for (uint64_t i = 0; i < n; ++i) {
+                const int best = argmax_row(&q[i * A], A);
+                const int act = is_random ? (int)x.below((uint32_t)A) : best;
+                act_out[i] = act;
+                all_best = all_best && act == best;
+            }
+            if (all_best) a->n_samples_best_act += 1;                     // action_with_best, dqn/base.rs:219-224
         }
+    } else {
+        // eval: DQN takes a uniformly random action 1 % of the time (dqn/base.rs:231-234; the reference
+        // returns ONE scalar action for the call, applied to every row here); IQN is purely greedy
+        const bool dqn = !strncmp(a->kind(), "dqn", 3);
+        if (dqn && x.f32() < 0.01f) {
+            is_random = true;
+            const int act = (int)x.below((uint32_t)A);
+            for (uint64_t i = 0; i < n; ++i) act_out[i] = act;
+        } else {
+            for (uint64_t i = 0; i < n; ++i) act_out[i] = argmax_row(&q[i * A], A);
+        }
+    }
+    if (info) {
+        info->eps = eps; info->is_random = is_random ? 1 : 0;
+        info->n_samples_act = a->n_samples_act; info->n_samples_best_act = a->n_samples_best_act;
+    }
     return BDR_OK;
 }
 

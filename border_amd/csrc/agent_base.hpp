@@ -1,12 +1,41 @@
 // Common agent plumbing of libborder_amd.so: the polymorphic handle behind `bdr_agent*`, per-kernel
 // HIP-event profiling brackets, launch macros, and the optimizer kernels every agent shares.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <vector>
 
+#include "chacha.hpp"
 #include "common.hpp"
 #include "igemm.hpp"
+
+// DqnExplorer / IqnExplorer state (dqn/explorer.rs:8-120, iqn/explorer.rs:9-108).  The reference draws from
+// fastrand's global, unseeded generator; here the draws come from a seeded ChaCha12 stream (same generator
+// as the replay buffer's StdRng), so a run is reproducible and testable draw by draw.
+struct Explorer {
+    int32_t kind = BDR_EXPLORER_SOFTMAX;      // dqn/config.rs:93 default explorer
+    double eps_start = 1.0, eps_final = 0.02; // explorer.rs:47-50
+    uint64_t final_step = 100000;
+    uint64_t n_calls = 0;                     // the reference's `n_opts` field: counts action() calls
+    bdr::ChaChaKey key{};
+    uint64_t word_pos = 0;
+    uint32_t next_u32() { return bdr::chacha12_word(key, word_pos++); }
+    uint64_t next_u64() { const uint64_t lo = next_u32(); return lo | ((uint64_t)next_u32() << 32); }   // rand: low word first
+    double f64() { return (double)(next_u64() >> 12) * (1.0 / 4503599627370496.0); }     // 52 random bits, [0,1)
+    float f32() { return (float)(next_u32() >> 9) * (1.0f / 8388608.0f); }               // 23 random bits
+    // unbiased integer in [0,n): Lemire's multiply-shift with rejection (what fastrand::u32(..n) does)
+    uint32_t below(uint32_t n)
+    {
+        uint64_t m = (uint64_t)next_u32() * n;
+        uint32_t lo = (uint32_t)m;
+        if (lo < n) {
+            const uint32_t t = (0u - n) % n;
+            while (lo < t) { m = (uint64_t)next_u32() * n; lo = (uint32_t)m; }
+        }
+        return (uint32_t)(m >> 32);
+    }
+};
 
 struct ProfSlot { std::string name; hipEvent_t e0, e1; double ms = 0; uint64_t count = 0; };
 
@@ -17,12 +46,28 @@ struct bdr_agent {
     hipStream_t stream = nullptr;
     bool train = false;
     uint64_t n_opts = 0;
+    // Policy::sample state (dqn/base.rs:211-242)
+    Explorer explorer;
+    uint64_t n_samples_act = 0, n_samples_best_act = 0;
+    void* act_stage = nullptr;      // device staging for the observations of Policy::sample (grown on demand)
+    size_t act_stage_bytes = 0;
     // profiling
     bool prof = false;
     std::vector<ProfSlot> slots;
     size_t slot_cursor = 0;
 
-    virtual ~bdr_agent() {}
+    virtual ~bdr_agent() { if (act_stage) (void)hipFree(act_stage); }
+    int32_t act_buffer(size_t bytes, void** out)
+    {
+        if (bytes > act_stage_bytes) {
+            if (act_stage) { BDR_HIP(hipStreamSynchronize(stream)); BDR_HIP(hipFree(act_stage)); act_stage = nullptr; act_stage_bytes = 0; }
+            const size_t cap = std::max(bytes, (size_t)1 << 16);
+            BDR_HIP(hipMalloc(&act_stage, cap));
+            act_stage_bytes = cap;
+        }
+        *out = act_stage;
+        return BDR_OK;
+    }
     virtual const char* kind() const = 0;
     virtual int32_t opt(bdr_replay* r) = 0;                       // Agent::opt, asynchronous
     virtual int32_t record(float* out, int cap, int* n) = 0;      // scalars of the last update (syncs)

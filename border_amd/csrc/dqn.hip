@@ -712,7 +712,7 @@ int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     BDR_TRY(ensure_batch(a, (int)n));
     const size_t ob = (size_t)a->cfg.net.n_stack * 84 * 84;
     uint8_t* d = nullptr;
-    BDR_HIP(hipMalloc((void**)&d, n * ob));
+    BDR_TRY(a->act_buffer(n * ob, (void**)&d));
     BDR_HIP(hipMemcpyAsync(d, obs, n * ob, hipMemcpyHostToDevice, a->stream));
     NetInst inst[1] = {{d, a->q, 0}};
     int32_t st = forward(a, inst, 1, (int)n);
@@ -721,7 +721,6 @@ int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
         if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
         if (e != hipSuccess) st = fail(BDR_ERR_HIP, "qvalues copy failed: %s", hipGetErrorString(e));
     }
-    (void)hipFree(d);
     a->slot_cursor = 0;
     return st;
 }

@@ -335,7 +335,7 @@ int32_t dqn_mlp_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     BDR_TRY(a->ensure_batch((int)n));
     const size_t ob = (size_t)a->net.in_dim * 4;
     uint8_t* d = nullptr;
-    BDR_HIP(hipMalloc((void**)&d, n * ob));
+    BDR_TRY(a->act_buffer(n * ob, (void**)&d));
     BDR_HIP(hipMemcpyAsync(d, obs, n * ob, hipMemcpyHostToDevice, a->stream));
     int32_t st = a->forward(0, a->q, d, (int)n);
     const int L = (int)a->net.L.size(), ld = a->net.L[L - 1].Np, A = a->net.out_dim;
@@ -345,7 +345,6 @@ int32_t dqn_mlp_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
         if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
         if (e != hipSuccess) st = fail(BDR_ERR_HIP, "qvalues copy failed: %s", hipGetErrorString(e));
     }
-    (void)hipFree(d);
     a->slot_cursor = 0;
     BDR_TRY(st);
     for (uint64_t i = 0; i < n; ++i) for (int k = 0; k < A; ++k) q_out[i * A + k] = tmp[i * ld + k];

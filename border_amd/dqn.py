@@ -53,6 +53,36 @@ class OptimizerConfig:
 
 
 @dataclass
+class Softmax:
+    """dqn/explorer.rs:17-32 (the DqnConfig default, dqn/config.rs:93)."""
+
+    def to_c(self, seed: int = 0) -> "_lib.ExplorerConfigC":
+        e = _lib.ExplorerConfigC()
+        _lib.lib().bdr_explorer_config_default(C.byref(e), 0)
+        e.seed = seed
+        return e
+
+
+@dataclass
+class EpsilonGreedy:
+    """dqn/explorer.rs:34-120: eps decays linearly over `final_step` action() calls."""
+    n_opts: int = 0
+    eps_start: float = 1.0
+    eps_final: float = 0.02
+    final_step: int = 100_000
+
+    @classmethod
+    def with_final_step(cls, final_step: int) -> "EpsilonGreedy":
+        return cls(final_step=final_step)
+
+    def to_c(self, seed: int = 0) -> "_lib.ExplorerConfigC":
+        e = _lib.ExplorerConfigC()
+        _lib.lib().bdr_explorer_config_default(C.byref(e), 1)
+        e.eps_start, e.eps_final, e.final_step, e.n_calls, e.seed = self.eps_start, self.eps_final, self.final_step, self.n_opts, seed
+        return e
+
+
+@dataclass
 class DqnModelConfig:
     q_config: Optional[object] = None
     opt_config: OptimizerConfig = field(default_factory=lambda: OptimizerConfig.Adam(0.0))
@@ -199,7 +229,30 @@ class Dqn:
     def load_params(self, path: str):
         _lib.check(_lib.lib().bdr_agent_load_params(self._h, path.encode()))
 
-    # Policy (greedy part; exploration stays with the caller) ----------------------------------
+    # Policy ----------------------------------------------------------------------------------------
+    def set_explorer(self, explorer: "Softmax | EpsilonGreedy", seed: int = 0) -> None:
+        """DqnConfig::explorer (dqn/config.rs:45); `seed` seeds the library's exploration stream."""
+        _lib.check(_lib.lib().bdr_agent_set_explorer(self._h, C.byref(explorer.to_c(seed))))
+
+    def explorer_state(self) -> dict:
+        e = _lib.ExplorerConfigC()
+        _lib.check(_lib.lib().bdr_agent_get_explorer(self._h, C.byref(e)))
+        return {"kind": "softmax" if e.kind == 0 else "eps_greedy", "eps_start": e.eps_start, "eps_final": e.eps_final,
+                "final_step": e.final_step, "n_opts": e.n_calls}
+
+    def sample(self, obs, return_info: bool = False):
+        """Policy::sample (dqn/base.rs:211-242): forward on the device + the configured exploration.
+        obs: [n_procs, ...] rows as stored in the replay buffer; returns int64 actions [n_procs]."""
+        obs = np.ascontiguousarray(obs)
+        n = obs.shape[0]
+        a = np.empty(n, np.int64)
+        info = _lib.SampleInfoC()
+        _lib.check(_lib.lib().bdr_agent_sample(self._h, n, _p(obs), _p(a), C.byref(info)))
+        if return_info:
+            return a, {"eps": info.eps, "is_random": bool(info.is_random), "n_samples_act": info.n_samples_act,
+                       "n_samples_best_act": info.n_samples_best_act}
+        return a
+
     def qvalues(self, obs) -> np.ndarray:
         obs = np.ascontiguousarray(obs)
         n = obs.shape[0]

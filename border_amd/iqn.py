@@ -137,6 +137,22 @@ class Iqn:
         _lib.check(_lib.lib().bdr_iqn_qvalues(self._h, obs.shape[0], _p(obs), _p(q), None))
         return q
 
+    def set_explorer(self, explorer, seed: int = 0) -> None:
+        """IqnConfig::explorer (iqn/config.rs:35; default Softmax, :62)."""
+        _lib.check(_lib.lib().bdr_agent_set_explorer(self._h, C.byref(explorer.to_c(seed))))
+
+    def sample(self, obs, return_info: bool = False):
+        """Policy::sample (iqn/base.rs:204-228): quantile-averaged action values + exploration (train) / argmax (eval)."""
+        obs = np.ascontiguousarray(obs)
+        n = obs.shape[0]
+        a = np.empty(n, np.int64)
+        info = _lib.SampleInfoC()
+        _lib.check(_lib.lib().bdr_agent_sample(self._h, n, _p(obs), _p(a), C.byref(info)))
+        if return_info:
+            return a, {"eps": info.eps, "is_random": bool(info.is_random), "n_samples_act": info.n_samples_act,
+                       "n_samples_best_act": info.n_samples_best_act}
+        return a
+
     def sync(self):
         _lib.check(_lib.lib().bdr_agent_sync(self._h))
 

@@ -193,11 +193,43 @@ BDR_API int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* ob
                                         const void* next_obs, const float* reward,
                                         const int8_t* is_terminated, bdr_dqn_record* rec);
 
-/* Policy::sample (dqn/base.rs:211-242), greedy part: Q(obs) for n observations -> q_out[n][A]
- * and argmax actions (either pointer may be NULL).  Exploration (eps-greedy / softmax) uses
- * host RNG in the reference (fastrand, unseeded) and stays in the caller. */
+/* Q(obs) for n observations -> q_out[n][A] and argmax actions (either pointer may be NULL).
+ * DQN: qnet.forward (dqn/base.rs:213); IQN: quantile average (iqn/base.rs:209-215). */
 BDR_API int32_t bdr_agent_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out,
                                   int64_t* argmax_out);
+
+/* DqnExplorer / IqnExplorer (dqn/explorer.rs:8-15, iqn/explorer.rs:9-16) with its mutable state.
+ * The reference draws from fastrand's global unseeded generator; this library draws from a seeded
+ * ChaCha12 stream (StdRng::seed_from_u64(seed)), so action sequences are reproducible:
+ *   eps-greedy call:  eps = max(eps_start - (eps_start-eps_final)/final_step * n_calls, eps_final);
+ *                     coin = f64 (one u64 of the stream, top 52 bits); n_calls += 1;
+ *                     coin < eps ? n_procs x below(A) (one draw each, row order) : argmax per row
+ *   softmax call:     per row one f64 u, action = first k with cumsum(softmax(q))[k] > u
+ *   eval (DQN only):  f32 (one u32, top 23 bits) < 0.01 ? one below(A) for every row : argmax   */
+enum { BDR_EXPLORER_SOFTMAX = 0, BDR_EXPLORER_EPS_GREEDY = 1 };
+typedef struct {
+    int32_t kind;          /* BDR_EXPLORER_* */
+    double eps_start;      /* 1.0  (explorer.rs:47) */
+    double eps_final;      /* 0.02 */
+    uint64_t final_step;   /* 100_000; dqn_atari: 1_000_000 */
+    uint64_t n_calls;      /* the reference's `n_opts` field of EpsilonGreedy: action() calls so far */
+    uint64_t seed;         /* seed of the exploration stream (set_explorer rewinds the stream) */
+} bdr_explorer_config;
+BDR_API void bdr_explorer_config_default(bdr_explorer_config* e, int32_t kind);
+BDR_API int32_t bdr_agent_set_explorer(bdr_agent* a, const bdr_explorer_config* e);
+BDR_API int32_t bdr_agent_get_explorer(const bdr_agent* a, bdr_explorer_config* e);
+
+/* Policy::sample (dqn/base.rs:211-242, iqn/base.rs:204-228) for n_procs observations (host rows as in the
+ * replay buffer): device forward, exploration as configured, act_out[n_procs] (int64).
+ * train: n_samples_act += 1 (and n_samples_best_act += 1 when every row took its greedy action, the
+ * reference's `record_verbose_level >= 2` bookkeeping).  info may be NULL. */
+typedef struct {
+    double eps;            /* eps used by this call (eps-greedy), else 0 */
+    int32_t is_random;     /* the call took the random branch */
+    uint64_t n_samples_act, n_samples_best_act;
+} bdr_sample_info;
+BDR_API int32_t bdr_agent_sample(bdr_agent* a, uint64_t n_procs, const void* obs, int64_t* act_out,
+                                 bdr_sample_info* info);
 
 /* Block until everything enqueued on the agent's stream has finished. */
 BDR_API int32_t bdr_agent_sync(bdr_agent* a);

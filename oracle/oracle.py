@@ -380,3 +380,81 @@ class IqnOracle:
             lib().orc_track(_p(self.p_tgt), _p(self.p), C.c_double(self.tau), self.p.size)
         bufs["loss"] = float(loss)
         return bufs
+
+
+class Explorer:
+    """CPU restatement of Policy::sample's exploration (test infrastructure only).
+
+    dqn/explorer.rs:29-31 (softmax -> multinomial), :68-90 (eps-greedy: one coin per CALL, eps linear in the
+    number of calls), dqn/base.rs:229-236 (eval: 1 % uniformly random action), iqn/explorer.rs:28-30,78-96,
+    iqn/base.rs:223 (eval: argmax).  The reference draws from fastrand's global *unseeded* generator, so its
+    action stream is not reproducible; the build draws the same quantities, in the same order, from a
+    seeded StdRng stream - which is what this class replays:
+      f64  = (next_u64 >> 12) * 2^-52;  f32 = (next_u32 >> 9) * 2^-23;
+      below(n) = Lemire multiply-shift with rejection (the algorithm behind fastrand::u32(..n)).
+    """
+
+    def __init__(self, kind: str = "softmax", eps_start=1.0, eps_final=0.02, final_step=100_000, n_opts=0, seed=0):
+        self.kind, self.eps_start, self.eps_final, self.final_step, self.n_opts = kind, eps_start, eps_final, final_step, n_opts
+        self.rng = StdRng.seed_from_u64(seed)
+        self.n_samples_act = 0
+        self.n_samples_best_act = 0
+
+    def f64(self) -> float:
+        return (self.rng.next_u64() >> 12) * (1.0 / 4503599627370496.0)
+
+    def f32(self) -> np.float32:
+        return np.float32(self.rng.next_u32() >> 9) * np.float32(1.0 / 8388608.0)
+
+    def below(self, n: int) -> int:
+        m = self.rng.next_u32() * n
+        lo = m & 0xFFFFFFFF
+        if lo < n:
+            t = ((1 << 32) - n) % n
+            while lo < t:
+                m = self.rng.next_u32() * n
+                lo = m & 0xFFFFFFFF
+        return m >> 32
+
+    def eps(self) -> float:
+        d = (self.eps_start - self.eps_final) / float(self.final_step)
+        return max(self.eps_start - d * float(self.n_opts), self.eps_final)
+
+    def sample(self, q: np.ndarray, train: bool, dqn: bool = True):
+        """q: [n_procs, A] float32 action values -> (actions int64 [n_procs], eps, is_random)."""
+        import math
+        q = np.asarray(q, np.float32)
+        n, A = q.shape
+        best = np.array([int(np.argmax(row)) for row in q], np.int64)   # first maximum
+        if train:
+            self.n_samples_act += 1
+            if self.kind == "softmax":
+                act = np.empty(n, np.int64)
+                for i in range(n):
+                    mx = np.max(q[i])
+                    e = [math.exp(float(np.float32(v - mx))) for v in q[i]]
+                    z = 0.0
+                    for v in e:
+                        z += v
+                    u = self.f64() * z
+                    c, a = 0.0, A - 1
+                    for k in range(A):
+                        c += e[k]
+                        if c > u:
+                            a = k
+                            break
+                    act[i] = a
+                if np.array_equal(act, best):
+                    self.n_samples_best_act += 1
+                return act, 0.0, False
+            eps = self.eps()
+            is_random = self.f64() < eps
+            self.n_opts += 1
+            act = np.array([self.below(A) for _ in range(n)], np.int64) if is_random else best
+            if np.array_equal(act, best):
+                self.n_samples_best_act += 1
+            return act, eps, is_random
+        if dqn and self.f32() < np.float32(0.01):
+            a = self.below(A)
+            return np.full(n, a, np.int64), 0.0, True
+        return best, 0.0, False

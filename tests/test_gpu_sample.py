@@ -1,0 +1,113 @@
+"""Policy::sample through the C ABI (device forward + exploration) vs the CPU restatement.
+
+Row (f)-1 of the scope table: dqn/base.rs:211-242, dqn/explorer.rs:29-31,68-90, iqn/base.rs:204-228.  The
+library and oracle/oracle.py::Explorer draw the same quantities in the same order from the same seeded
+ChaCha12 stream, so the action sequences must agree exactly (integer parity), given the Q-values."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import border_amd
+    if border_amd.device_count() == 0:
+        pytest.fail("no MI355X visible: the HIP path must run on the GPU box")
+    return border_amd
+
+
+def _cnn_agent(B, A=6, **kw):
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=A),
+                                                    opt_config=B.OptimizerConfig.Adam(1e-4)), device=0, batch_size=4, **kw)
+    return B.Dqn.build(cfg)
+
+
+def _mlp_agent(B, A=3, **kw):
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.MlpConfig(in_dim=4, units=(64, 64), out_dim=A),
+                                                    opt_config=B.OptimizerConfig.Adam(1e-3)), device=0, batch_size=32, **kw)
+    return B.Dqn.build(cfg)
+
+
+def test_eps_greedy_sequence_matches_oracle_exactly(B):
+    from oracle.oracle import Explorer
+    rng = np.random.default_rng(0)
+    a = _mlp_agent(B, train=True)
+    a.set_explorer(B.EpsilonGreedy(final_step=50), seed=7)
+    ref = Explorer("eps_greedy", final_step=50, seed=7)
+    for call in range(300):
+        obs = rng.standard_normal((5, 4)).astype(np.float32)
+        q = a.qvalues(obs)
+        act, info = a.sample(obs, return_info=True)
+        ract, reps, rrand = ref.sample(q, train=True)
+        assert act.tolist() == ract.tolist(), call
+        assert info["is_random"] == rrand and abs(info["eps"] - reps) < 1e-15
+    assert info["n_samples_act"] == 300 == ref.n_samples_act
+    assert info["n_samples_best_act"] == ref.n_samples_best_act
+    assert a.explorer_state()["n_opts"] == 300
+    a.close()
+
+
+def test_softmax_sequence_matches_oracle_and_softmax_law(B):
+    from oracle.oracle import Explorer
+    rng = np.random.default_rng(1)
+    a = _mlp_agent(B, train=True)
+    a.set_explorer(B.Softmax(), seed=3)
+    ref = Explorer("softmax", seed=3)
+    obs = rng.standard_normal((4, 4)).astype(np.float32)
+    q = a.qvalues(obs)
+    acts = []
+    for call in range(1500):
+        act = a.sample(obs)
+        ract, _, _ = ref.sample(q, train=True)
+        assert act.tolist() == ract.tolist(), call
+        acts.append(act)
+    acts = np.stack(acts)
+    for r in range(4):
+        p = np.exp(q[r] - q[r].max()); p /= p.sum()
+        freq = np.bincount(acts[:, r], minlength=3) / len(acts)
+        assert np.abs(freq - p).max() < 0.05
+    a.close()
+
+
+def test_eval_mode_cnn_greedy_with_one_percent_random(B):
+    from oracle.oracle import Explorer
+    from oracle import torch_ref as T
+    rng = np.random.default_rng(2)
+    a = _cnn_agent(B, train=False)
+    a.set_params(T.init_params(T.cnn_shapes(6), 5), "qnet")
+    a.set_explorer(B.Softmax(), seed=21)
+    ref = Explorer("softmax", seed=21)
+    n_rand = 0
+    for call in range(400):
+        obs = rng.integers(0, 256, (2, 4, 1, 84, 84), dtype=np.uint8)
+        q = a.qvalues(obs)
+        act, info = a.sample(obs, return_info=True)
+        ract, _, rrand = ref.sample(q, train=False, dqn=True)
+        assert act.tolist() == ract.tolist() and info["is_random"] == rrand
+        if not rrand:
+            assert act.tolist() == q.argmax(1).tolist()
+        n_rand += rrand
+    assert info["n_samples_act"] == 0           # only counted in train mode (dqn/base.rs:215)
+    assert n_rand <= 15
+    a.close()
+
+
+def test_iqn_sample_eval_is_argmax_and_train_explores(B):
+    from oracle.oracle import Explorer
+    rng = np.random.default_rng(3)
+    f_cfg = B.MlpConfig(in_dim=4, units=(32,), out_dim=16)
+    cfg = B.IqnConfig(f_config=f_cfg, feature_dim=16, embed_dim=8, m_units=(32,), n_actions=3, lr=1e-3, batch_size=8, device=0, train=False)
+    a = B.Iqn(cfg)
+    obs = rng.standard_normal((6, 4)).astype(np.float32)
+    q = a.qvalues(obs)     # Const32 percent points: deterministic
+    for _ in range(20):
+        assert a.sample(obs).tolist() == q.argmax(1).tolist()
+    a.train()
+    a.set_explorer(B.EpsilonGreedy(final_step=10), seed=4)
+    ref = Explorer("eps_greedy", final_step=10, seed=4)
+    for call in range(100):
+        act = a.sample(obs)
+        ract, _, _ = ref.sample(q, train=True, dqn=False)
+        assert act.tolist() == ract.tolist(), call
+    a.close()

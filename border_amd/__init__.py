@@ -4,7 +4,7 @@ Only what the hot path needs lives here: csrc/ (HIP kernels + the C ABI of inclu
 and the host-side mirror of the reference interfaces (replay.py, dqn.py, trainer.py).
 """
 from ._lib import BdrError, device_count  # noqa: F401
-from .replay import GenericTransitionBatch, SimpleReplayBuffer, SimpleReplayBufferConfig  # noqa: F401
+from .replay import GenericTransitionBatch, PerConfig, SimpleReplayBuffer, SimpleReplayBufferConfig  # noqa: F401
 from .dqn import AtariCnnConfig, Dqn, DqnConfig, DqnModelConfig, EpsilonGreedy, MlpConfig, OptimizerConfig, Softmax  # noqa: F401
 from .sac import Sac, SacConfig  # noqa: F401
 from .iqn import Iqn, IqnConfig  # noqa: F401

@@ -67,6 +67,16 @@ class DqnRecordC(C.Structure):
                 ("tgt_mean", C.c_float), ("tgt_minus_pred_mean", C.c_float), ("has_verbose", C.c_int32)]
 
 
+class PerConfigC(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("beta_0", C.c_float), ("beta_final", C.c_float), ("n_opts_final", C.c_uint64),
+                ("normalize", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PerInfoC(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("n_opts", C.c_uint64), ("beta", C.c_float), ("total", C.c_float),
+                ("max_p", C.c_float), ("min_p", C.c_float)]
+
+
 class ExplorerConfigC(C.Structure):
     _fields_ = [("kind", C.c_int32), ("eps_start", C.c_double), ("eps_final", C.c_double),
                 ("final_step", C.c_uint64), ("n_calls", C.c_uint64), ("seed", C.c_uint64)]
@@ -80,7 +90,7 @@ class SampleInfoC(C.Structure):
 class DeviceBatch(C.Structure):
     _fields_ = [("n", C.c_uint64), ("obs", C.c_void_p), ("next_obs", C.c_void_p), ("act", C.c_void_p),
                 ("reward", C.c_void_p), ("is_terminated", C.c_void_p), ("is_truncated", C.c_void_p),
-                ("ixs", C.c_void_p)]
+                ("ixs", C.c_void_p), ("weight", C.c_void_p)]
 
 
 # every symbol include/border_amd.h declares (checked by tests/test_abi.py)
@@ -89,6 +99,8 @@ ABI_SYMBOLS = [
     "bdr_replay_create", "bdr_replay_destroy", "bdr_replay_push", "bdr_replay_len", "bdr_replay_head",
     "bdr_replay_sample_indices", "bdr_replay_batch", "bdr_replay_last_batch", "bdr_replay_fill_synthetic",
     "bdr_replay_read_rows",
+    "bdr_per_config_default", "bdr_replay_enable_per", "bdr_replay_update_priority", "bdr_replay_batch_weights",
+    "bdr_replay_per_info", "bdr_replay_per_read", "bdr_replay_per_get", "bdr_dqn_update_on_batch_weighted",
     "bdr_dqn_config_default", "bdr_dqn_create", "bdr_agent_destroy", "bdr_agent_set_train", "bdr_agent_is_train",
     "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_agent_opt_with_scalars", "bdr_agent_param_count_of", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
     "bdr_explorer_config_default", "bdr_agent_set_explorer", "bdr_agent_get_explorer", "bdr_agent_sample",
@@ -122,12 +134,13 @@ def lib() -> C.CDLL:
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == ABI drift
         if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default", "bdr_iqn_config_default",
-                        "bdr_explorer_config_default"):
+                        "bdr_explorer_config_default", "bdr_per_config_default"):
             fn.restype = C.c_int32
     L.bdr_dqn_config_default.restype = None
     L.bdr_sac_config_default.restype = None
     L.bdr_iqn_config_default.restype = None
     L.bdr_explorer_config_default.restype = None
+    L.bdr_per_config_default.restype = None
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     L.bdr_replay_create.argtypes = [C.POINTER(ReplayConfig), C.POINTER(vp)]
     L.bdr_replay_destroy.argtypes = [vp]

@@ -13,9 +13,9 @@ namespace bdr {
 int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out);
 int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out);
 int32_t dqn_cnn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
-                                const float* reward, const int8_t* term);
+                                const float* reward, const int8_t* term, const float* weight);
 int32_t dqn_mlp_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
-                                const float* reward, const int8_t* term);
+                                const float* reward, const int8_t* term, const float* weight);
 int32_t dqn_cnn_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out);
 int32_t dqn_mlp_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out);
 int32_t dqn_cnn_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
@@ -159,12 +159,23 @@ int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* r, float* out, int3
 int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
                                 const float* reward, const int8_t* term, bdr_dqn_record* rec)
 {
+    return bdr_dqn_update_on_batch_weighted(a, n, obs, act, next_obs, reward, term, nullptr, nullptr, rec);
+}
+
+int32_t bdr_dqn_update_on_batch_weighted(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
+                                         const float* reward, const int8_t* term, const float* weight, float* td_errs_out,
+                                         bdr_dqn_record* rec)
+{
     BDR_REQUIRE(a && obs && act && next_obs && reward && term, "null argument");
     BDR_REQUIRE(is_dqn(a), "not a DQN agent");
     BDR_REQUIRE(n >= 1 && n <= 65536, "batch size out of range");
     BDR_HIP(hipSetDevice(a->device));
-    if (!strcmp(a->kind(), "dqn_cnn")) BDR_TRY(dqn_cnn_update_on_batch(a, n, obs, act, next_obs, reward, term));
-    else BDR_TRY(dqn_mlp_update_on_batch(a, n, obs, act, next_obs, reward, term));
+    if (!strcmp(a->kind(), "dqn_cnn")) BDR_TRY(dqn_cnn_update_on_batch(a, n, obs, act, next_obs, reward, term, weight));
+    else BDR_TRY(dqn_mlp_update_on_batch(a, n, obs, act, next_obs, reward, term, weight));
+    if (td_errs_out) {
+        BDR_HIP(hipMemcpyAsync(td_errs_out, a->td_abs, n * 4, hipMemcpyDeviceToHost, a->stream));
+        BDR_HIP(hipStreamSynchronize(a->stream));
+    }
     prof_collect(a);
     if (rec) {
         float v[8]; int k = 0;

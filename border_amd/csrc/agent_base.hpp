@@ -51,12 +51,26 @@ struct bdr_agent {
     uint64_t n_samples_act = 0, n_samples_best_act = 0;
     void* act_stage = nullptr;      // device staging for the observations of Policy::sample (grown on demand)
     size_t act_stage_bytes = 0;
+    // prioritized replay (dqn/base.rs:123-145): |pred - tgt| of the last update, and staged host weights
+    float* td_abs = nullptr; float* w_stage = nullptr; size_t td_cap = 0;
+    int32_t td_buffer(size_t n)
+    {
+        if (n > td_cap) {
+            BDR_HIP(hipStreamSynchronize(stream));
+            (void)hipFree(td_abs); (void)hipFree(w_stage); td_abs = w_stage = nullptr; td_cap = 0;
+            const size_t cap = std::max(n, (size_t)256);
+            BDR_HIP(hipMalloc((void**)&td_abs, cap * 4));
+            BDR_HIP(hipMalloc((void**)&w_stage, cap * 4));
+            td_cap = cap;
+        }
+        return BDR_OK;
+    }
     // profiling
     bool prof = false;
     std::vector<ProfSlot> slots;
     size_t slot_cursor = 0;
 
-    virtual ~bdr_agent() { if (act_stage) (void)hipFree(act_stage); }
+    virtual ~bdr_agent() { if (act_stage) (void)hipFree(act_stage); (void)hipFree(td_abs); (void)hipFree(w_stage); }
     int32_t act_buffer(size_t bytes, void** out)
     {
         if (bytes > act_stage_bytes) {
@@ -80,6 +94,42 @@ struct bdr_agent {
 };
 
 namespace bdr {
+
+// TD loss of one row (dqn/base.rs:123-151).  Without importance weights: smooth_l1 / mse of (pred, tgt).
+// With weights (PER): td = |pred - tgt| (clipped to [cmin, cmax] when clip_td_err is set), x = w * td,
+// loss = smooth_l1(x, 0) / mse(x, 0); the gradient follows autograd through abs / clip (clip passes the
+// gradient inside its closed range).  Returns dLoss_row/dpred (before the 1/B of Reduction::Mean).
+struct TdLossIn { int loss_kind; int weighted; float w; int has_clip; float cmin, cmax; };
+__device__ __forceinline__ float td_loss_row(float pred, float tgt, const TdLossIn& c, float& lossb, float& td_abs)
+{
+    const float d = pred - tgt;
+    if (!c.weighted) {
+        td_abs = fabsf(d);
+        if (c.loss_kind == 1) {   // smooth_l1_loss(beta=1.0)
+            const float z = fabsf(d);
+            lossb = z < 1.f ? 0.5f * z * z : z - 0.5f;
+            return z < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+        }
+        lossb = d * d;            // mse_loss
+        return 2.f * d;
+    }
+    const float raw = fabsf(d);
+    float td = raw, pass = 1.f;
+    if (c.has_clip) { td = fminf(fmaxf(raw, c.cmin), c.cmax); pass = (raw >= c.cmin && raw <= c.cmax) ? 1.f : 0.f; }
+    td_abs = td;
+    const float x = c.w * td;
+    float dx;
+    if (c.loss_kind == 1) {
+        const float z = fabsf(x);
+        lossb = z < 1.f ? 0.5f * z * z : z - 0.5f;
+        dx = z < 1.f ? x : (x > 0.f ? 1.f : -1.f);
+    } else {
+        lossb = x * x;
+        dx = 2.f * x;
+    }
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    return dx * c.w * pass * sgn;
+}
 
 struct Bracket {
     bdr_agent* a; ProfSlot* s = nullptr;

@@ -57,8 +57,11 @@ int32_t ensure_device(int32_t device);
 //   [act_off, act_off + act_bytes)       act
 //   [tail_off + 0]  f32 reward, [+4] i8 is_terminated, [+5] i8 is_truncated
 // ---------------------------------------------------------------------------------------------
+struct bdr_per;   // per.hip
+
 struct bdr_replay {
     int32_t device = 0;
+    bdr_per* per = nullptr;    // prioritized replay state (nullptr: uniform sampling)
     uint64_t capacity = 0, i = 0, size = 0;
     uint64_t obs_bytes = 0, act_bytes = 0;
     uint64_t next_off = 0, act_off = 0, tail_off = 0, stride = 0;
@@ -85,4 +88,19 @@ namespace bdr {
 // cross-stream ordering against pushes.  Advances the RNG like one batch(n).
 int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream);
 int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n);
+
+// per.hip
+int32_t per_create(const bdr_per_config* c, uint64_t capacity, hipStream_t stream, bdr_per** out);
+void per_destroy(bdr_per* p);
+int32_t per_push(bdr_per* p, uint64_t i0, uint64_t len, hipStream_t st);
+int32_t per_sample(bdr_per* p, const uint32_t key[8], uint64_t word_pos, uint64_t n, uint64_t* ixs_dev, hipStream_t st);
+int32_t per_update(bdr_per* p, uint64_t n, const uint64_t* ixs_dev, const float* td_dev, hipStream_t st);
+const float* per_weights(const bdr_per* p);
+int32_t per_read(const bdr_per* p, int32_t what, float* out, uint64_t n, hipStream_t st);
+int32_t per_get(const bdr_per* p, float s, uint64_t* ix, hipStream_t st);
+void per_info(const bdr_per* p, bdr_per_info* o);
+// weights of the batch last drawn on the consumer's stream (nullptr without PER), and the priority update
+// an agent enqueues after its backward pass (device arrays, the agent's stream)
+inline const float* replay_batch_weights(const bdr_replay* r) { return r->per ? per_weights(r->per) : nullptr; }
+int32_t replay_update_priority_on_stream(bdr_replay* r, uint64_t n, const float* td_dev, hipStream_t stream);
 }  // namespace bdr

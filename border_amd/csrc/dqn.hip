@@ -100,6 +100,9 @@ struct TdArgs {
     int B, A;
     float gamma;
     int loss_kind;         // 0 mse, 1 smooth-l1
+    const float* weight;   // [B] importance weights (PER) or nullptr
+    float* td_abs;         // [B] |pred - tgt| (clipped) for update_priority, or nullptr
+    int has_clip; float clip_min, clip_max;
 };
 
 __global__ __launch_bounds__(256) void k_td_rows(TdArgs a)
@@ -122,18 +125,14 @@ __global__ __launch_bounds__(256) void k_td_rows(TdArgs a)
     const float pred = a.q_on[(size_t)row * a.A + act];
     // reward + (1 - is_terminated) * discount_factor * q   (dqn/base.rs:104)
     const float tgt = a.reward[row] + ((float)(1 - (int)a.term[row]) * a.gamma) * qn;
-    const float d = pred - tgt;
-    float lossb, dl;
-    if (a.loss_kind == 1) {   // smooth_l1_loss(beta=1.0)
-        const float zabs = fabsf(d);
-        lossb = zabs < 1.f ? 0.5f * zabs * zabs : zabs - 0.5f;
-        dl = zabs < 1.f ? d : (d > 0.f ? 1.f : -1.f);
-    } else {                  // mse_loss
-        lossb = d * d;
-        dl = 2.f * d;
-    }
+    const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
+    float lossb, td;
+    const float dl = td_loss_row(pred, tgt, li, lossb, td);
     const float dq = dl / (float)a.B;   // Reduction::Mean
-    if (lane == 0) { a.dq[row] = dq; a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb; }
+    if (lane == 0) {
+        a.dq[row] = dq; a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb;
+        if (a.td_abs) a.td_abs[row] = td;
+    }
     // dL/dh1[row][j] = relu'(h1) * dq * W5[j][act]
     const float* hr = a.h1 + (size_t)row * 512 + lane * 8;
     float out[8];
@@ -333,9 +332,10 @@ AdamScalars adam_scalars(const bdr_dqn_config& c, uint64_t step)
 
 // Dqn::update_critic on a device-resident batch (dqn/base.rs:60-160)
 int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
-                      const float* reward, const int8_t* term)
+                      const float* reward, const int8_t* term, const float* weight = nullptr, bdr_replay* per_buffer = nullptr)
 {
     BDR_TRY(ensure_batch(a, B));
+    BDR_TRY(a->td_buffer(B));
     a->last_reward = reward; a->last_B = B;
     const Arena& ar = a->ar;
     const bdr_dqn_config& c = a->cfg;
@@ -348,7 +348,11 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     t.act = act; t.act_bytes = act_bytes; t.reward = reward; t.term = term;
     t.h1 = a->h1[0]; t.w5 = a->q + ar.w5; t.dh1 = a->dh1; t.dq = a->dq; t.pred = a->pred; t.tgt = a->tgt;
     t.loss_row = a->loss_row; t.B = B; t.A = ar.A; t.gamma = (float)c.discount_factor; t.loss_kind = c.critic_loss;
+    t.weight = weight; t.td_abs = a->td_abs;
+    t.has_clip = c.has_clip_td_err; t.clip_min = (float)c.clip_td_err_min; t.clip_max = (float)c.clip_td_err_max;
     { Bracket br(a, "td_rows"); LAUNCH(k_td_rows, dim3((B + 3) / 4), t); }
+    // dqn/base.rs:143: buffer.update_priority(&ixs, &Some(td_errs)); independent of the backward kernels
+    if (per_buffer && weight) { Bracket br(a, "per_update"); BDR_TRY(replay_update_priority_on_stream(per_buffer, B, a->td_abs, a->stream)); }
 
     // Backward.  The input-gradient chain (dX of l1 -> conv3 -> conv2) is the critical path; every
     // weight-gradient kernel only needs the dY produced one link earlier, so those run on a second
@@ -468,7 +472,8 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
     { Bracket br(a, "_null"); }   // empty bracket: the event pair's own cost, subtracted by bench.py
     for (uint64_t u = 0; u < a->cfg.n_updates_per_opt; ++u) {
         { Bracket br(a, "sample"); BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->stream)); }
-        BDR_TRY(update_critic(a, (int)a->cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term));
+        BDR_TRY(update_critic(a, (int)a->cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
+                              replay_batch_weights(r), r));
     }
     return after_updates(a);
 }
@@ -683,7 +688,7 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
 }
 
 int32_t dqn_cnn_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
-                                const float* reward, const int8_t* term)
+                                const float* reward, const int8_t* term, const float* weight)
 {
     DqnCnn* a = static_cast<DqnCnn*>(base);
     const size_t ob = (size_t)a->cfg.net.n_stack * 84 * 84;
@@ -700,7 +705,9 @@ int32_t dqn_cnn_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, co
     BDR_HIP(hipMemcpyAsync(a->u_act, act, n * 8, hipMemcpyHostToDevice, a->stream));
     BDR_HIP(hipMemcpyAsync(a->u_rew, reward, n * 4, hipMemcpyHostToDevice, a->stream));
     BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, a->stream));
-    BDR_TRY(update_critic(a, (int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term));
+    const float* wd = nullptr;
+    if (weight) { BDR_TRY(a->td_buffer(n)); BDR_HIP(hipMemcpyAsync(a->w_stage, weight, n * 4, hipMemcpyHostToDevice, a->stream)); wd = a->w_stage; }
+    BDR_TRY(update_critic(a, (int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term, wd, nullptr));
     BDR_TRY(after_updates(a));
     BDR_HIP(hipStreamSynchronize(a->stream));   // host buffers may be reused by the caller
     return BDR_OK;

@@ -21,6 +21,7 @@ struct TdDenseArgs {
     float* dq_rows;   // [B][ld]
     float* pred; float* tgt; float* loss_row;
     int B, A; float gamma; int loss_kind;
+    const float* weight; float* td_abs; int has_clip; float clip_min, clip_max;   // PER (dqn/base.rs:123-145)
 };
 __global__ __launch_bounds__(256) void k_td_dense(TdDenseArgs a)
 {
@@ -41,18 +42,11 @@ __global__ __launch_bounds__(256) void k_td_dense(TdDenseArgs a)
     const float qn = a.q_tg[(size_t)row * a.ld + idx];
     const float pred = a.q_on[(size_t)row * a.ld + act];
     const float tgt = a.reward[row] + ((float)(1 - (int)a.term[row]) * a.gamma) * qn;   // dqn/base.rs:104
-    const float d = pred - tgt;
-    float lossb, dl;
-    if (a.loss_kind == 1) {
-        const float z = fabsf(d);
-        lossb = z < 1.f ? 0.5f * z * z : z - 0.5f;
-        dl = z < 1.f ? d : (d > 0.f ? 1.f : -1.f);
-    } else {
-        lossb = d * d;
-        dl = 2.f * d;
-    }
+    const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
+    float lossb, td;
+    const float dl = td_loss_row(pred, tgt, li, lossb, td);
     const float dq = dl / (float)a.B;
-    if (lane == 0) { a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb; }
+    if (lane == 0) { a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb; if (a.td_abs) a.td_abs[row] = td; }
     for (int c = lane; c < a.ld; c += 64) a.dq_rows[(size_t)row * a.ld + c] = c == act ? dq : 0.f;
 }
 
@@ -149,10 +143,11 @@ struct DqnMlp : bdr_agent {
 
     // Dqn::update_critic (dqn/base.rs:60-160) on a device-resident batch
     int32_t update_critic(int Bn, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
-                          const float* reward, const int8_t* term)
+                          const float* reward, const int8_t* term, const float* weight = nullptr, bdr_replay* per_buffer = nullptr)
     {
         bdr_agent* a = this;
         BDR_TRY(ensure_batch(Bn));
+        BDR_TRY(td_buffer(Bn));
         last_reward = reward; last_B = Bn;
         const int L = (int)net.L.size();
         BDR_TRY(forward(0, q, obs, Bn));
@@ -163,7 +158,10 @@ struct DqnMlp : bdr_agent {
         t.ld = net.L[L - 1].Np; t.act = act; t.act_bytes = act_bytes; t.reward = reward; t.term = term;
         t.dq_rows = dys[L - 1]; t.pred = pred; t.tgt = tgt; t.loss_row = loss_row;
         t.B = Bn; t.A = net.out_dim; t.gamma = (float)cfg.discount_factor; t.loss_kind = cfg.critic_loss;
+        t.weight = weight; t.td_abs = td_abs;
+        t.has_clip = cfg.has_clip_td_err; t.clip_min = (float)cfg.clip_td_err_min; t.clip_max = (float)cfg.clip_td_err_max;
         { Bracket br(a, "td_dense"); LAUNCH(k_td_dense, dim3((Bn + 3) / 4), t); }
+        if (per_buffer && weight) { Bracket br(a, "per_update"); BDR_TRY(replay_update_priority_on_stream(per_buffer, Bn, td_abs, stream)); }
         {
             Bracket br(a, "loss_mean");
             hipLaunchKernelGGL(k_mean_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, loss, 1.0f / (float)Bn);
@@ -201,7 +199,8 @@ struct DqnMlp : bdr_agent {
         BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
         for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
             { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, cfg.batch_size, stream)); }
-            BDR_TRY(update_critic((int)cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term));
+            BDR_TRY(update_critic((int)cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
+                                  replay_batch_weights(r), r));
         }
         return after_updates();
     }
@@ -306,7 +305,7 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
 }
 
 int32_t dqn_mlp_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
-                                const float* reward, const int8_t* term)
+                                const float* reward, const int8_t* term, const float* weight)
 {
     DqnMlp* a = static_cast<DqnMlp*>(base);
     const size_t ob = (size_t)a->net.in_dim * 4;
@@ -323,7 +322,9 @@ int32_t dqn_mlp_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, co
     BDR_HIP(hipMemcpyAsync(a->u_act, act, n * 8, hipMemcpyHostToDevice, a->stream));
     BDR_HIP(hipMemcpyAsync(a->u_rew, reward, n * 4, hipMemcpyHostToDevice, a->stream));
     BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, a->stream));
-    BDR_TRY(a->update_critic((int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term));
+    const float* wd = nullptr;
+    if (weight) { BDR_TRY(a->td_buffer(n)); BDR_HIP(hipMemcpyAsync(a->w_stage, weight, n * 4, hipMemcpyHostToDevice, a->stream)); wd = a->w_stage; }
+    BDR_TRY(a->update_critic((int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term, wd, nullptr));
     BDR_TRY(a->after_updates());
     BDR_HIP(hipStreamSynchronize(a->stream));
     return BDR_OK;

@@ -55,6 +55,7 @@ struct GatherArgs {
     int8_t *b_term, *b_trunc;
     uint32_t chunks;      // workgroups per sample
     uint32_t vec_per_chunk;  // 16-byte vectors per chunk
+    uint32_t given;       // 1: ixs[] was produced by the PER sampler, gather those rows
 };
 
 template <typename V>
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a)
 {
     const uint32_t sample = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
     // ixs[k] = (StdRng::next_u32() as usize) % size   (base.rs:386): word k of this batch's key stream
-    const uint64_t row = (uint64_t)chacha12_word(a.key, a.word_pos + sample) % a.size;
-    if (chunk == 0 && threadIdx.x == 0) a.ixs[sample] = row;
+    const uint64_t row = a.given ? a.ixs[sample] : (uint64_t)chacha12_word(a.key, a.word_pos + sample) % a.size;
+    if (!a.given && chunk == 0 && threadIdx.x == 0) a.ixs[sample] = row;
     const uint8_t* rec = a.ring + row * a.stride;
     const uint64_t nvec = a.obs_bytes / sizeof(V);
     const V* src0 = reinterpret_cast<const V*>(rec);
@@ -226,6 +227,7 @@ int32_t bdr_replay_destroy(bdr_replay* r)
     (void)hipHostFree(r->stage);
     (void)hipFree(r->b_obs); (void)hipFree(r->b_next); (void)hipFree(r->b_act);
     (void)hipFree(r->b_reward); (void)hipFree(r->b_term); (void)hipFree(r->b_trunc); (void)hipFree(r->b_ixs);
+    per_destroy(r->per);
     (void)hipEventDestroy(r->written); (void)hipEventDestroy(r->read);
     (void)hipStreamDestroy(r->stream);
     delete r;
@@ -277,6 +279,10 @@ int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, const void* 
         BDR_HIP(hipMemcpyAsync(r->ring + pos * r->stride, r->stage, m * r->stride, hipMemcpyHostToDevice, r->stream));
         done += m;
     }
+    if (r->per) {   // base.rs:304-306 set_priority(len); ordered behind an agent's update_priority on its own stream
+        BDR_HIP(hipStreamWaitEvent(r->stream, r->written, 0));
+        BDR_TRY(per_push(r->per, r->i, n, r->stream));
+    }
     BDR_HIP(hipEventRecord(r->written, r->stream));
     BDR_HIP(hipStreamSynchronize(r->stream));  // caller may reuse its host buffers; staging reusable
     // base.rs:308-312
@@ -301,6 +307,10 @@ int32_t bdr_replay_fill_synthetic(bdr_replay* r, uint64_t n, uint64_t seed, int3
     // grid.x is limited to 2^31-1; n <= capacity fits comfortably for the sizes used here
     hipLaunchKernelGGL(k_fill_synthetic, dim3((uint32_t)n), dim3(256), 0, r->stream, a);
     BDR_HIP(hipGetLastError());
+    if (r->per) {   // the fill is one push of n rows into an empty ring: one set_priority(n)
+        BDR_REQUIRE(r->size == 0, "synthetic fill with PER needs an empty buffer");
+        BDR_TRY(per_push(r->per, 0, n, r->stream));
+    }
     BDR_HIP(hipEventRecord(r->written, r->stream));
     r->i = n % r->capacity;
     r->size = n;
@@ -370,7 +380,11 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     a.next_off = r->next_off; a.act_off = r->act_off; a.tail_off = r->tail_off; a.ixs = r->b_ixs;
     memcpy(a.key.k, r->key, sizeof a.key.k); a.word_pos = r->word_pos; a.size = r->size;
     a.b_obs = r->b_obs; a.b_next = r->b_next; a.b_act = r->b_act; a.b_reward = r->b_reward; a.b_term = r->b_term; a.b_trunc = r->b_trunc;
-    a.chunks = 1; a.vec_per_chunk = 0;
+    a.chunks = 1; a.vec_per_chunk = 0; a.given = 0;
+    if (r->per) {   // base.rs:377-383: sum-tree sampling + importance weights; one stream word per sample
+        BDR_TRY(per_sample(r->per, r->key, r->word_pos, n, r->b_ixs, stream));
+        a.given = 1;
+    }
     r->word_pos += n;  // one next_u32() per index
     if (r->obs_bytes % 16 == 0) {
         const uint64_t nvec = r->obs_bytes / 16;
@@ -388,6 +402,16 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     BDR_HIP(hipEventRecord(r->read, stream));
     r->read_pending = true;
     r->batch_n = n;
+    return BDR_OK;
+}
+
+// dqn/base.rs:143: buffer.update_priority(&ixs, &Some(td_errs)) for the batch last drawn on `stream`
+int32_t replay_update_priority_on_stream(bdr_replay* r, uint64_t n, const float* td_dev, hipStream_t stream)
+{
+    if (!r->per) return BDR_OK;
+    BDR_REQUIRE(n == r->batch_n, "update_priority size differs from the last batch");
+    BDR_TRY(per_update(r->per, n, r->b_ixs, td_dev, stream));
+    BDR_HIP(hipEventRecord(r->written, stream));   // later pushes / samples order behind the tree update
     return BDR_OK;
 }
 
@@ -432,7 +456,88 @@ int32_t bdr_replay_last_batch(const bdr_replay* r, bdr_device_batch* out)
     BDR_REQUIRE(r->batch_n > 0, "no batch has been drawn yet");
     out->n = r->batch_n; out->obs = r->b_obs; out->next_obs = r->b_next; out->act = r->b_act;
     out->reward = r->b_reward; out->is_terminated = r->b_term; out->is_truncated = r->b_trunc; out->ixs = r->b_ixs;
+    out->weight = replay_batch_weights(r);
     return BDR_OK;
+}
+
+void bdr_per_config_default(bdr_per_config* c)   // config.rs:67-83
+{
+    if (!c) return;
+    c->alpha = 0.6f; c->beta_0 = 0.4f; c->beta_final = 1.0f; c->n_opts_final = 500000;
+    c->normalize = BDR_PER_NORMALIZE_ALL; c->reserved = 0;
+}
+
+int32_t bdr_replay_enable_per(bdr_replay* r, const bdr_per_config* c)
+{
+    BDR_REQUIRE(r && c, "null argument");
+    BDR_REQUIRE(!r->per, "PER is already enabled");
+    BDR_REQUIRE(r->size == 0 && r->i == 0, "PER must be enabled on an empty buffer");
+    BDR_HIP(hipSetDevice(r->device));
+    BDR_TRY(per_create(c, r->capacity, r->stream, &r->per));
+    BDR_HIP(hipEventRecord(r->written, r->stream));
+    return BDR_OK;
+}
+
+int32_t bdr_replay_update_priority(bdr_replay* r, uint64_t n, const uint64_t* ixs, const float* td_errs)
+{
+    BDR_REQUIRE(r, "null replay handle");
+    if (!r->per) return BDR_OK;   // base.rs:414: no-op without per_state
+    BDR_REQUIRE(ixs && td_errs, "ixs and td_errs must be given when PER is enabled");   // the reference's expect()s
+    BDR_REQUIRE(n > 0 && n <= (1ull << 20), "update size out of range");
+    BDR_HIP(hipSetDevice(r->device));
+    for (uint64_t k = 0; k < n; ++k) BDR_REQUIRE(ixs[k] < r->capacity, "index %llu out of range", (unsigned long long)ixs[k]);
+    uint64_t* d_ix = nullptr; float* d_td = nullptr;
+    BDR_HIP(hipMalloc((void**)&d_ix, n * 8));
+    hipError_t e = hipMalloc((void**)&d_td, n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ix, ixs, n * 8, hipMemcpyHostToDevice, r->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_td, td_errs, n * 4, hipMemcpyHostToDevice, r->stream);
+    int32_t rc = e == hipSuccess ? per_update(r->per, n, d_ix, d_td, r->stream) : fail(BDR_ERR_HIP, "update_priority copy failed: %s", hipGetErrorString(e));
+    if (rc == BDR_OK) (void)hipEventRecord(r->written, r->stream);
+    (void)hipStreamSynchronize(r->stream);
+    (void)hipFree(d_ix); (void)hipFree(d_td);
+    return rc;
+}
+
+int32_t bdr_replay_batch_weights(bdr_replay* r, uint64_t n, float* w_out)
+{
+    BDR_REQUIRE(r && w_out, "null argument");
+    BDR_REQUIRE(r->per, "PER is not enabled on this buffer (weight: None)");
+    BDR_REQUIRE(r->batch_n > 0 && n <= r->batch_n, "no batch of that size has been drawn");
+    BDR_HIP(hipSetDevice(r->device));
+    BDR_HIP(hipMemcpyAsync(w_out, per_weights(r->per), n * 4, hipMemcpyDeviceToHost, r->stream));
+    BDR_HIP(hipStreamSynchronize(r->stream));
+    return BDR_OK;
+}
+
+int32_t bdr_replay_per_info(bdr_replay* r, bdr_per_info* out)
+{
+    BDR_REQUIRE(r && out, "null argument");
+    BDR_REQUIRE(r->per, "PER is not enabled on this buffer");
+    BDR_HIP(hipSetDevice(r->device));
+    per_info(r->per, out);
+    float root[3];
+    BDR_TRY(per_read(r->per, 0, &root[0], 1, r->stream));
+    float t2[2];
+    BDR_TRY(per_read(r->per, 1, t2, 2, r->stream)); root[1] = t2[1];
+    BDR_TRY(per_read(r->per, 2, t2, 2, r->stream)); root[2] = t2[1];
+    out->total = root[0]; out->min_p = root[1]; out->max_p = root[2];   // transformed (p+eps)^alpha domain
+    return BDR_OK;
+}
+
+int32_t bdr_replay_per_read(bdr_replay* r, int32_t what, float* out, uint64_t n)
+{
+    BDR_REQUIRE(r && out, "null argument");
+    BDR_REQUIRE(r->per, "PER is not enabled on this buffer");
+    BDR_HIP(hipSetDevice(r->device));
+    return per_read(r->per, what, out, n, r->stream);
+}
+
+int32_t bdr_replay_per_get(bdr_replay* r, float s, uint64_t* ix)
+{
+    BDR_REQUIRE(r && ix, "null argument");
+    BDR_REQUIRE(r->per, "PER is not enabled on this buffer");
+    BDR_HIP(hipSetDevice(r->device));
+    return per_get(r->per, s, ix, r->stream);
 }
 
 }  // extern "C"

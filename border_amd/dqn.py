@@ -200,17 +200,26 @@ class Dqn:
                        tgt_minus_pred_mean=r.tgt_minus_pred_mean)
         return rec
 
-    def update_on_batch(self, obs, act, next_obs, reward, is_terminated) -> dict:
-        """One Dqn::opt_ on a caller-supplied minibatch (fixed-minibatch parity tests)."""
+    def update_on_batch(self, obs, act, next_obs, reward, is_terminated, weight=None) -> dict:
+        """One Dqn::opt_ on a caller-supplied minibatch (fixed-minibatch parity tests).  With `weight` the
+        importance-weighted branch of update_critic runs (dqn/base.rs:123-145) and the record carries `td_errs`."""
         reward = np.ascontiguousarray(reward, dtype=np.float32)
         n = len(reward)
         obs, next_obs = np.ascontiguousarray(obs), np.ascontiguousarray(next_obs)
         act = np.ascontiguousarray(act, dtype=np.int64).reshape(n)
         term = np.ascontiguousarray(is_terminated, dtype=np.int8)
         r = _lib.DqnRecordC()
-        _lib.check(_lib.lib().bdr_dqn_update_on_batch(self._h, n, _p(obs), _p(act), _p(next_obs), _p(reward), _p(term),
-                                                      C.byref(r)))
-        return self._record(r)
+        if weight is None:
+            _lib.check(_lib.lib().bdr_dqn_update_on_batch(self._h, n, _p(obs), _p(act), _p(next_obs), _p(reward), _p(term),
+                                                          C.byref(r)))
+            return self._record(r)
+        w = np.ascontiguousarray(weight, dtype=np.float32)
+        td = np.empty(n, np.float32)
+        _lib.check(_lib.lib().bdr_dqn_update_on_batch_weighted(self._h, n, _p(obs), _p(act), _p(next_obs), _p(reward), _p(term),
+                                                               _p(w), _p(td), C.byref(r)))
+        rec = self._record(r)
+        rec["td_errs"] = td
+        return rec
 
     def sync(self):
         _lib.check(_lib.lib().bdr_agent_sync(self._h))

@@ -18,6 +18,23 @@ from . import _lib
 
 
 @dataclass
+class PerConfig:
+    """generic_replay_buffer/config.rs:45-83 (defaults alpha 0.6, beta 0.4 -> 1.0 over 500 000 opts, All)."""
+    alpha: float = 0.6
+    beta_0: float = 0.4
+    beta_final: float = 1.0
+    n_opts_final: int = 500_000
+    normalize: str = "All"          # WeightNormalizer::{All, Batch} (sum_tree.rs:13-18)
+
+    def to_c(self) -> "_lib.PerConfigC":
+        c = _lib.PerConfigC()
+        _lib.lib().bdr_per_config_default(C.byref(c))
+        c.alpha, c.beta_0, c.beta_final, c.n_opts_final = self.alpha, self.beta_0, self.beta_final, self.n_opts_final
+        c.normalize = {"All": 0, "Batch": 1}[self.normalize]
+        return c
+
+
+@dataclass
 class SimpleReplayBufferConfig:
     """generic_replay_buffer/config.rs:185-210 (defaults: capacity 10000, seed 42, per None)."""
     capacity: int = 10000
@@ -62,8 +79,6 @@ class SimpleReplayBuffer:
 
     def __init__(self, config: SimpleReplayBufferConfig, obs_shape, obs_dtype, act_shape=(1,), act_dtype=np.int64,
                  device: int = 0):
-        if config.per_config is not None:
-            raise NotImplementedError("prioritized replay is not built yet (SURVEY.md section 8(f) rank 2)")
         self.config = config
         self.obs_shape, self.obs_dtype = tuple(obs_shape), np.dtype(obs_dtype)
         self.act_shape, self.act_dtype = tuple(act_shape), np.dtype(act_dtype)
@@ -73,6 +88,8 @@ class SimpleReplayBuffer:
         h = C.c_void_p()
         _lib.check(_lib.lib().bdr_replay_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        if config.per_config is not None:      # base.rs:341-345: per_state = Some(PerState::new(..))
+            _lib.check(_lib.lib().bdr_replay_enable_per(self._h, C.byref(config.per_config.to_c())))
 
     @classmethod
     def build(cls, config: SimpleReplayBufferConfig, **kw) -> "SimpleReplayBuffer":
@@ -130,7 +147,11 @@ class SimpleReplayBuffer:
         trunc = np.empty(size, np.int8)
         _lib.check(_lib.lib().bdr_replay_batch(self._h, size, _p(ixs), _p(obs), _p(act), _p(nobs), _p(rew), _p(term),
                                                _p(trunc)))
-        return GenericTransitionBatch(obs, act, nobs, rew, term, trunc, ixs, None)
+        weight = None
+        if self.config.per_config is not None:  # base.rs:382: weight = Some(ws)
+            weight = np.empty(size, np.float32)
+            _lib.check(_lib.lib().bdr_replay_batch_weights(self._h, size, _p(weight)))
+        return GenericTransitionBatch(obs, act, nobs, rew, term, trunc, ixs, weight)
 
     def sample_indices(self, size: int) -> np.ndarray:
         """The index draw of batch() alone (advances the RNG like batch(size))."""
@@ -139,8 +160,29 @@ class SimpleReplayBuffer:
         return ixs
 
     def update_priority(self, ixs, td_errs) -> None:
-        """base.rs:413-426: a no-op without PER, like the reference."""
-        return None
+        """base.rs:413-426: sum_tree.update(ix, td_err) in order + iw_scheduler.add_n_opts(); a no-op without PER."""
+        if self.config.per_config is None:
+            return None
+        assert ixs is not None and td_errs is not None, "ixs / td_errs should be Some(_) in update_priority()"
+        ixs = np.ascontiguousarray(ixs, np.uint64)
+        td = np.ascontiguousarray(td_errs, np.float32)
+        _lib.check(_lib.lib().bdr_replay_update_priority(self._h, len(ixs), _p(ixs), _p(td)))
+
+    # PER introspection (parity tests) --------------------------------------------------------
+    def per_info(self) -> dict:
+        o = _lib.PerInfoC()
+        _lib.check(_lib.lib().bdr_replay_per_info(self._h, C.byref(o)))
+        return {k: getattr(o, k) for k in ("n_samples", "n_opts", "beta", "total", "max_p", "min_p")}
+
+    def per_tree(self) -> np.ndarray:
+        out = np.empty(2 * self.config.capacity - 1, np.float32)
+        _lib.check(_lib.lib().bdr_replay_per_read(self._h, 0, _p(out), out.size))
+        return out
+
+    def per_get(self, s: float) -> int:
+        ix = C.c_uint64()
+        _lib.check(_lib.lib().bdr_replay_per_get(self._h, C.c_float(s), C.byref(ix)))
+        return ix.value
 
     # benchmark / test helpers ---------------------------------------------------------------
     def fill_synthetic(self, n: int, seed: int = 0, kind: int = 0, n_actions: int = 6) -> None:

@@ -102,6 +102,7 @@ typedef struct {
     const int8_t* is_terminated;
     const int8_t* is_truncated;
     const uint64_t* ixs;
+    const float* weight;  /* [n] importance weights when PER is enabled, else NULL */
 } bdr_device_batch;
 BDR_API int32_t bdr_replay_last_batch(const bdr_replay* r, bdr_device_batch* out);
 
@@ -115,6 +116,41 @@ BDR_API int32_t bdr_replay_fill_synthetic(bdr_replay* r, uint64_t n, uint64_t se
 /* Test helper: copy ring rows [first, first+n) back to the host (any pointer may be NULL). */
 BDR_API int32_t bdr_replay_read_rows(bdr_replay* r, uint64_t first, uint64_t n, void* obs, void* act,
                                      void* next_obs, float* reward, int8_t* term, int8_t* trunc);
+
+/* ------------------------------------------------------------------------------------------
+ * Prioritized experience replay  (SimpleReplayBufferConfig::per_config, config.rs:45-83;
+ * generic_replay_buffer/base/sum_tree.rs; base/iw_scheduler.rs)
+ * ---------------------------------------------------------------------------------------- */
+enum { BDR_PER_NORMALIZE_ALL = 0, BDR_PER_NORMALIZE_BATCH = 1 };   /* WeightNormalizer, sum_tree.rs:13-18 */
+typedef struct {
+    float alpha;            /* 0.6   (config.rs:76) */
+    float beta_0;           /* 0.4 */
+    float beta_final;       /* 1.0 */
+    uint64_t n_opts_final;  /* 500_000 */
+    int32_t normalize;      /* BDR_PER_NORMALIZE_ALL */
+    int32_t reserved;
+} bdr_per_config;
+BDR_API void bdr_per_config_default(bdr_per_config* c);
+
+/* SimpleReplayBuffer::build with per_config: Some(..) (base.rs:336-356).  Must be called on an empty
+ * buffer.  From then on push() gives new rows the current maximum priority (set_priority, :227-235),
+ * batch() samples through the sum tree and carries importance weights (:377-383), and agents that
+ * consume weights (DQN, dqn/base.rs:123-145) call update_priority with their TD errors. */
+BDR_API int32_t bdr_replay_enable_per(bdr_replay* r, const bdr_per_config* c);
+
+/* ReplayBufferBase::update_priority (base.rs:413-426): sum_tree.update(ix, td_err) in order, then the
+ * importance-weight schedule advances by one optimisation step.  Host arrays. */
+BDR_API int32_t bdr_replay_update_priority(bdr_replay* r, uint64_t n, const uint64_t* ixs, const float* td_errs);
+
+/* `weight` of the last batch() (Some(ws), base.rs:382): n floats.  Error when PER is not enabled. */
+BDR_API int32_t bdr_replay_batch_weights(bdr_replay* r, uint64_t n, float* w_out);
+
+/* Introspection for parity tests: scheduler state, SumTree::{total,max}, the raw arrays
+ * (what: 0 sum tree [2*capacity-1] in the reference's layout, 1 min / 2 max tournament trees), SumTree::get. */
+typedef struct { uint64_t n_samples, n_opts; float beta, total, max_p, min_p; } bdr_per_info;
+BDR_API int32_t bdr_replay_per_info(bdr_replay* r, bdr_per_info* out);
+BDR_API int32_t bdr_replay_per_read(bdr_replay* r, int32_t what, float* out, uint64_t n);
+BDR_API int32_t bdr_replay_per_get(bdr_replay* r, float s, uint64_t* ix);
 
 /* ------------------------------------------------------------------------------------------
  * DQN agent  (border-tch-agent/src/dqn/base.rs, dqn/config.rs:26-48, dqn/model/base.rs)
@@ -192,6 +228,13 @@ BDR_API int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* buffer, flo
 BDR_API int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act,
                                         const void* next_obs, const float* reward,
                                         const int8_t* is_terminated, bdr_dqn_record* rec);
+
+/* The `if let Some(ws) = weight` branch of update_critic (dqn/base.rs:123-145) on a caller-supplied minibatch:
+ * weight[n] importance weights (NULL = the unweighted branch); td_errs_out[n] (optional) receives
+ * |pred - tgt| (clipped by clip_td_err), the values the reference hands to update_priority. */
+BDR_API int32_t bdr_dqn_update_on_batch_weighted(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act,
+                                                 const void* next_obs, const float* reward, const int8_t* is_terminated,
+                                                 const float* weight, float* td_errs_out, bdr_dqn_record* rec);
 
 /* Q(obs) for n observations -> q_out[n][A] and argmax actions (either pointer may be NULL).
  * DQN: qnet.forward (dqn/base.rs:213); IQN: quantile average (iqn/base.rs:209-215). */

@@ -1132,3 +1132,108 @@ ORC_API float orc_iqn_update(const orc_iqn_cfg* c, float* iqn, const float* iqn_
     iqn_cache_free(&k); iqn_cache_free(&kt);
     return loss;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Prioritized replay: SumTree -- generic_replay_buffer/base/sum_tree.rs       */
+/* (pinned by the reference's own KATs, sum_tree.rs:180-217: see              */
+/* tests/test_oracle_per.py).  f32 throughout, same operation order: the sums  */
+/* in the tree are INCREMENTAL (`tree[parent] += change`, :46-52), so parity    */
+/* of the sampled indices needs the same sequence of float additions.         */
+/* min/max trees (segment-tree 2.0 SegmentPoint, MinIgnoreNaN / MaxIgnoreNaN)  */
+/* are exact operations: plain leaf arrays + scans restate them bit for bit.   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    float eps, alpha;
+    size_t capacity, n_samples;
+    float* tree;    /* 2*capacity - 1, leaves at [capacity-1, 2*capacity-2]  (:39)  */
+    float* minleaf; /* init f32::MAX  (:40) */
+    float* maxleaf; /* init 1e-8      (:41) */
+    int normalize;  /* 0 = All, 1 = Batch (:13-18) */
+} orc_sumtree;
+
+ORC_API orc_sumtree* orc_sumtree_new(uint64_t capacity, float alpha, int normalize)
+{
+    orc_sumtree* t = (orc_sumtree*)calloc(1, sizeof *t);
+    t->eps = 1e-8f; t->alpha = alpha; t->capacity = capacity; t->n_samples = 0; t->normalize = normalize;
+    t->tree = (float*)calloc(2 * capacity - 1, sizeof(float));
+    t->minleaf = (float*)malloc(capacity * sizeof(float));
+    t->maxleaf = (float*)malloc(capacity * sizeof(float));
+    for (size_t i = 0; i < capacity; ++i) { t->minleaf[i] = 3.40282347e+38f; t->maxleaf[i] = 1e-8f; }
+    return t;
+}
+ORC_API void orc_sumtree_free(orc_sumtree* t)
+{
+    if (!t) return;
+    free(t->tree); free(t->minleaf); free(t->maxleaf); free(t);
+}
+ORC_API float orc_sumtree_total(const orc_sumtree* t) { return t->tree[0]; }                 /* :68-70 */
+ORC_API uint64_t orc_sumtree_n_samples(const orc_sumtree* t) { return t->n_samples; }
+ORC_API const float* orc_sumtree_tree(const orc_sumtree* t) { return t->tree; }
+static float st_max_all(const orc_sumtree* t)
+{
+    float m = t->maxleaf[0];
+    for (size_t i = 1; i < t->capacity; ++i) if (t->maxleaf[i] > m) m = t->maxleaf[i];
+    return m;
+}
+static float st_min_prefix(const orc_sumtree* t, size_t n)
+{
+    float m = 3.40282347e+38f;   /* MinIgnoreNaN identity */
+    for (size_t i = 0; i < n; ++i) if (t->minleaf[i] < m) m = t->minleaf[i];
+    return m;
+}
+ORC_API float orc_sumtree_max(const orc_sumtree* t) { return powf(st_max_all(t), 1.0f / t->alpha); }   /* :72-76 */
+ORC_API float orc_sumtree_min_p(const orc_sumtree* t) { return st_min_prefix(t, t->n_samples); }
+
+ORC_API void orc_sumtree_update(orc_sumtree* t, uint64_t ix, float p)                           /* :92-107 */
+{
+    const float pa = powf(p + t->eps, t->alpha);
+    t->minleaf[ix] = pa; t->maxleaf[ix] = pa;
+    size_t i = ix + t->capacity - 1;
+    const float change = pa - t->tree[i];
+    t->tree[i] = pa;
+    while (i != 0) {   /* propagate (:46-52): every ancestor += change, leaf to root */
+        i = (i - 1) / 2;
+        t->tree[i] += change;
+    }
+}
+ORC_API void orc_sumtree_add(orc_sumtree* t, uint64_t ix, float p)                              /* :81-89 */
+{
+    orc_sumtree_update(t, ix, p);
+    if (t->n_samples < t->capacity) t->n_samples += 1;
+}
+ORC_API uint64_t orc_sumtree_get(const orc_sumtree* t, float s)                                  /* :54-66, :110-114 */
+{
+    const size_t len = 2 * t->capacity - 1;
+    size_t ix = 0;
+    for (;;) {
+        const size_t left = 2 * ix + 1, right = left + 1;
+        if (left >= len) break;
+        if (s <= t->tree[left] || t->tree[right] == 0.0f) ix = left;
+        else { s -= t->tree[left]; ix = right; }
+    }
+    return ix + 1 - t->capacity;
+}
+/* sample (:120-157) with the batch's uniforms u[k] in [0,1) supplied by the caller (the reference calls
+ * fastrand::f32(), an unseeded global generator).  Returns indices and normalised weights. */
+ORC_API void orc_sumtree_sample(const orc_sumtree* t, int n, float beta, const float* u, int64_t* ixs, float* ws)
+{
+    const float p_sum = t->tree[0];
+    for (int k = 0; k < n; ++k) ixs[k] = (int64_t)orc_sumtree_get(t, p_sum * u[k]);
+    const float nn = (float)t->n_samples / p_sum;
+    for (int k = 0; k < n; ++k) ws[k] = powf(nn * t->tree[ixs[k] + t->capacity - 1], -beta);
+    float w_max_inv;
+    if (t->normalize == 0) w_max_inv = powf(nn * st_min_prefix(t, t->n_samples), beta);
+    else {
+        float m = ws[0];   /* fold(NaN, |m, v| v.max(m)) == max of the batch */
+        for (int k = 1; k < n; ++k) if (ws[k] > m) m = ws[k];
+        w_max_inv = 1.0f / m;
+    }
+    for (int k = 0; k < n; ++k) ws[k] = ws[k] * w_max_inv;
+}
+/* IwScheduler::beta (base/iw_scheduler.rs:35-43) */
+ORC_API float orc_iw_beta(float beta_0, float beta_final, uint64_t n_opts_final, uint64_t n_opts)
+{
+    if (n_opts >= n_opts_final) return beta_final;
+    const float d = beta_final - beta_0;
+    return beta_0 + d * ((float)n_opts / (float)n_opts_final);
+}

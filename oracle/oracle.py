@@ -458,3 +458,90 @@ class Explorer:
             a = self.below(A)
             return np.full(n, a, np.int64), 0.0, True
         return best, 0.0, False
+
+
+class SumTree:
+    """sum_tree.rs restatement (f32, incremental sums)."""
+
+    def __init__(self, capacity: int, alpha: float, normalize: str = "All"):
+        L = lib()
+        L.orc_sumtree_new.restype = C.c_void_p
+        L.orc_sumtree_new.argtypes = [C.c_uint64, C.c_float, C.c_int]
+        L.orc_sumtree_total.restype = C.c_float; L.orc_sumtree_total.argtypes = [C.c_void_p]
+        L.orc_sumtree_max.restype = C.c_float; L.orc_sumtree_max.argtypes = [C.c_void_p]
+        L.orc_sumtree_min_p.restype = C.c_float; L.orc_sumtree_min_p.argtypes = [C.c_void_p]
+        L.orc_sumtree_n_samples.restype = C.c_uint64; L.orc_sumtree_n_samples.argtypes = [C.c_void_p]
+        L.orc_sumtree_tree.restype = C.POINTER(C.c_float); L.orc_sumtree_tree.argtypes = [C.c_void_p]
+        L.orc_sumtree_get.restype = C.c_uint64; L.orc_sumtree_get.argtypes = [C.c_void_p, C.c_float]
+        L.orc_sumtree_update.restype = None; L.orc_sumtree_update.argtypes = [C.c_void_p, C.c_uint64, C.c_float]
+        L.orc_sumtree_add.restype = None; L.orc_sumtree_add.argtypes = [C.c_void_p, C.c_uint64, C.c_float]
+        L.orc_sumtree_free.restype = None; L.orc_sumtree_free.argtypes = [C.c_void_p]
+        L.orc_sumtree_sample.restype = None
+        L.orc_sumtree_sample.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_iw_beta.restype = C.c_float; L.orc_iw_beta.argtypes = [C.c_float, C.c_float, C.c_uint64, C.c_uint64]
+        self.capacity = capacity
+        self.h = L.orc_sumtree_new(capacity, alpha, {"All": 0, "Batch": 1}[normalize])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_sumtree_free(self.h)
+            self.h = None
+
+    def add(self, ix, p): lib().orc_sumtree_add(self.h, ix, p)
+    def update(self, ix, p): lib().orc_sumtree_update(self.h, ix, p)
+    def get(self, s) -> int: return int(lib().orc_sumtree_get(self.h, s))
+    def total(self) -> float: return float(lib().orc_sumtree_total(self.h))
+    def max(self) -> float: return float(lib().orc_sumtree_max(self.h))
+    def min_p(self) -> float: return float(lib().orc_sumtree_min_p(self.h))
+
+    @property
+    def n_samples(self) -> int: return int(lib().orc_sumtree_n_samples(self.h))
+
+    def tree(self) -> np.ndarray:
+        return np.ctypeslib.as_array(lib().orc_sumtree_tree(self.h), shape=(2 * self.capacity - 1,)).copy()
+
+    def sample(self, u: np.ndarray, beta: float):
+        u = np.ascontiguousarray(u, np.float32)
+        ixs = np.empty(len(u), np.int64)
+        ws = np.empty(len(u), np.float32)
+        lib().orc_sumtree_sample(self.h, len(u), beta, _p(u), _p(ixs), _p(ws))
+        return ixs, ws
+
+
+def iw_beta(beta_0, beta_final, n_opts_final, n_opts) -> float:
+    SumTree  # noqa: B018  (argtypes are registered by the first SumTree)
+    L = lib()
+    L.orc_iw_beta.restype = C.c_float; L.orc_iw_beta.argtypes = [C.c_float, C.c_float, C.c_uint64, C.c_uint64]
+    return float(L.orc_iw_beta(beta_0, beta_final, n_opts_final, n_opts))
+
+
+class PerReplay:
+    """SimpleReplayBuffer with `per_config: Some(..)` (generic_replay_buffer/base.rs:227-235, 295-316, 376-383,
+    413-426): index/weight logic only (rows are gathered by the plain Replay restatement).  The batch's
+    uniforms come from the buffer's StdRng as f32 = (next_u32 >> 9) * 2^-23 (the reference uses the unseeded
+    fastrand::f32())."""
+
+    def __init__(self, capacity, seed, alpha=0.6, beta_0=0.4, beta_final=1.0, n_opts_final=500_000, normalize="All"):
+        self.capacity, self.i, self.size = capacity, 0, 0
+        self.tree = SumTree(capacity, alpha, normalize)
+        self.rng = StdRng.seed_from_u64(seed)
+        self.beta_0, self.beta_final, self.n_opts_final, self.n_opts = beta_0, beta_final, n_opts_final, 0
+
+    def push(self, length: int):
+        max_p = self.tree.max()                      # set_priority: one max for the whole pushed block
+        for j in range(length):
+            self.tree.add((self.i + j) % self.capacity, max_p)
+        self.i = (self.i + length) % self.capacity
+        self.size = min(self.size + length, self.capacity)
+
+    def beta(self) -> float:
+        return iw_beta(self.beta_0, self.beta_final, self.n_opts_final, self.n_opts)
+
+    def batch(self, n: int):
+        u = np.array([np.float32(self.rng.next_u32() >> 9) * np.float32(1.0 / 8388608.0) for _ in range(n)], np.float32)
+        return self.tree.sample(u, self.beta())
+
+    def update_priority(self, ixs, td_errs):
+        for ix, td in zip(ixs, td_errs):
+            self.tree.update(int(ix), float(td))
+        self.n_opts += 1

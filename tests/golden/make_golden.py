@@ -106,7 +106,12 @@ def sample_stride(n):
     return max(1, n // 4096) | 1
 
 
-def make_dqn(name, kind, shapes, batch_fn, n_steps, **kw):
+def per_weights(s, n):
+    """importance weights of the PER fixtures (fixed-seed uniform in (0.2, 1])"""
+    return (0.2 + 0.8 * np.random.default_rng(900 + s).random(n)).astype(np.float32)
+
+
+def make_dqn(name, kind, shapes, batch_fn, n_steps, weighted=False, **kw):
     from oracle import torch_ref as T
     import torch
     torch.manual_seed(0)
@@ -116,7 +121,9 @@ def make_dqn(name, kind, shapes, batch_fn, n_steps, **kw):
     out = {}
     for s in range(n_steps):
         obs, act, nobs, rew, term = batch_fn(s)
-        r = agent.update(obs, act, nobs, rew, term)
+        r = agent.update(obs, act, nobs, rew, term, weight=per_weights(s, len(rew)) if weighted else None)
+        if weighted:
+            out[f"s{s}_td_errs"] = r["td_abs"]
         out[f"s{s}_loss"] = np.float32(r["loss"])
         out[f"s{s}_q_pred_all"] = r["q_pred_all"]
         out[f"s{s}_q_next_all"] = r["q_next_all"]
@@ -241,6 +248,16 @@ def main():
 
     make_dqn("dqn_mlp_cartpole.npz", "mlp", T.mlp_shapes(4, [64, 64], 2), cart, 5,
              param_seed=3, lr=1e-3, critic_loss="Mse", tau=0.01, soft_update_interval=1)
+    # (4) the importance-weighted branch of update_critic (dqn/base.rs:123-145): SmoothL1 without clipping,
+    #     Mse with clip_td_err; rewards scaled so that |td| straddles both the Huber knee and the clip range
+    def cart_per(s):
+        obs, act, nobs, rew, term = cart(s)
+        return obs, act, nobs, (rew * np.random.default_rng(700 + s).uniform(-2, 2, 32)).astype(np.float32), term
+
+    make_dqn("dqn_mlp_per_huber.npz", "mlp", T.mlp_shapes(4, [64, 64], 2), cart_per, 3, weighted=True,
+             param_seed=4, lr=1e-3, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1)
+    make_dqn("dqn_mlp_per_mse_clip.npz", "mlp", T.mlp_shapes(4, [64, 64], 2), cart_per, 3, weighted=True,
+             param_seed=5, lr=1e-3, critic_loss="Mse", clip_td_err=(0.05, 0.9), double_dqn=True, tau=0.01, soft_update_interval=1)
     make_sac()
     make_iqn()
     print("fixtures:", sorted(os.listdir(HERE)))

@@ -70,6 +70,8 @@ def main():
         # (parameter all-reduce) is the library's own RCCL communicator over xGMI
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if os.environ.get("BDR_BENCH_SHARE_GPU") == "1":   # flow test of the N>1 path on a 1-GPU box (ranks share device 0)
+        local_rank = local_rank % max(B.device_count(), 1)
     if B.device_count() <= local_rank:
         sys.exit(f"rank {rank}: HIP device {local_rank} not visible")
 
@@ -90,7 +92,9 @@ def main():
                       tau=1.0, double_dqn=args.double_dqn, critic_loss=args.loss, device=local_rank, param_seed=0)
     agent = B.Dqn.build(cfg)
     agent.train()
-    exch = B.ParamExchange(world, rank, args.sync_interval, "rccl", local_rank, bcast_bytes) if world > 1 else None
+    # data plane: the library's own RCCL communicator; demoted (by all ranks together) to torch's RCCL on the same
+    # device arena, then to host staging, only if the communicator cannot be brought up on this node
+    exch = B.ParamExchange.with_fallback(world, rank, args.sync_interval, local_rank, bcast_bytes) if world > 1 else None
 
     def run(n, first_step):
         for s in range(n):
@@ -153,12 +157,12 @@ def main():
                   "unit": "opt-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                   "dtype": "f32", "data": "synthetic",
-                  "config": {"workload": "synthetic Atari DQN Nature-CNN, replay 1M u8 transitions/GPU, batch 256/GPU",
+                  "config": {"workload": f"synthetic Atari DQN Nature-CNN, replay {args.capacity} u8 transitions/GPU, batch {args.batch}/GPU",
                              "batch_size": args.batch, "replay_capacity": args.capacity, "n_actions": N_ACTIONS,
                              "critic_loss": args.loss, "double_dqn": args.double_dqn, "optimizer": "Adam lr=1e-4",
                              "soft_update_interval": 10000, "tau": 1.0,
                              "parallelism": f"dp{world} (replica + replay shard per GPU"
-                                            + (f", RCCL param all-reduce every {args.sync_interval} opts)" if world > 1 else ")"),
+                                            + (f", parameter all-reduce every {args.sync_interval} opts over {exch.backend})" if world > 1 else ")"),
                              "samples_per_sec": round(value * args.batch, 1)},
                   "roofline": roof}
     agent.close()

@@ -279,6 +279,12 @@ class Dqn:
     # SyncModel / parameter access --------------------------------------------------------------
     WHICH = {"qnet": 0, "qnet_tgt": 1, "exp_avg": 2, "exp_avg_sq": 3, "grad": 4}
 
+    def arena_device_ptr(self, which="qnet"):
+        """(device pointer, float count) of the flat parameter arena in the kernels' internal layout."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _lib.check(_lib.lib().bdr_agent_arena_device_ptr(self._h, self.WHICH[which], C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
     def param_count(self) -> int:
         n = C.c_uint64()
         _lib.check(_lib.lib().bdr_agent_param_count(self._h, C.byref(n)))

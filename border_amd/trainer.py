@@ -89,7 +89,10 @@ class ParamExchange:
                  bcast_bytes=None, which=("qnet",)):
         self.world_size, self.rank, self.sync_interval, self.backend = world_size, rank, sync_interval, backend
         self.which = tuple(which)
+        self.device = device
         self._comm = None
+        self._group = None
+        self.fallback_reason = None
         if world_size > 1 and backend == "rccl":
             L = _lib.lib()
             uid = (C.c_uint8 * _lib.BDR_UNIQUE_ID_BYTES)()
@@ -101,10 +104,61 @@ class ParamExchange:
             _lib.check(L.bdr_comm_init_rank(uid, world_size, rank, device, C.byref(h)))
             self._comm = h
 
+    @classmethod
+    def with_fallback(cls, world_size: int, rank: int, sync_interval: int, device: int, bcast_bytes, which=("qnet",)):
+        """The library's RCCL communicator if every rank can bring it up, else torch.distributed's own RCCL
+        ("nccl" backend) on a zero-copy view of the device arena, else the host-staged path.  Every step of
+        the ladder is agreed on by all ranks (MIN-reduce of a success flag over the control-plane group), so
+        the ranks never end up on different data planes."""
+        import torch
+        import torch.distributed as dist
+
+        def all_ok(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t[0])
+
+        ex, err = None, None
+        try:
+            ex = cls(world_size, rank, sync_interval, "rccl", device, bcast_bytes, which)
+        except Exception as e:  # noqa: BLE001  (any failure demotes every rank together)
+            err = e
+        if all_ok(ex is not None):
+            return ex
+        if ex is not None:
+            ex.close()
+        ex = cls(world_size, rank, sync_interval, "torch-nccl", device, None, which)
+        grp = None
+        try:
+            grp = dist.new_group(backend="nccl")
+            probe = torch.ones(1, device=f"cuda:{device}")   # communicators are created lazily: force it now
+            dist.all_reduce(probe, group=grp)
+            torch.cuda.synchronize(device)
+            if int(probe[0].item()) != world_size:
+                raise RuntimeError("probe all-reduce returned a wrong sum")
+        except Exception as e:  # noqa: BLE001
+            err, grp = e, None
+        if all_ok(grp is not None):
+            ex._group = grp
+            return ex
+        ex = cls(world_size, rank, sync_interval, "torch", device, None, which)
+        ex.fallback_reason = repr(err)
+        return ex
+
     def close(self):
         if self._comm:
             _lib.lib().bdr_comm_destroy(self._comm)
             self._comm = None
+
+    def _arena_tensor(self, agent, w):
+        """torch view (no copy) of the agent's flat device arena, through __cuda_array_interface__."""
+        import torch
+        ptr, n = agent.arena_device_ptr(w)
+
+        class _Arena:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_Arena(), device=f"cuda:{self.device}")
 
     def after_opt(self, agent, opt_steps: int) -> bool:
         """Called after every opt step; averages every sync_interval-th step."""
@@ -119,6 +173,15 @@ class ParamExchange:
         if self.backend == "rccl":
             for w in self.which:
                 _lib.check(_lib.lib().bdr_agent_allreduce_params(agent.handle, self._comm, agent.WHICH[w]))
+        elif self.backend == "torch-nccl":
+            import torch
+            import torch.distributed as dist
+            agent.sync()                                  # the agent's stream is not torch's
+            for w in self.which:
+                t = self._arena_tensor(agent, w)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._group)
+                t /= self.world_size
+            torch.cuda.synchronize(self.device)
         else:
             import torch
             import torch.distributed as dist
@@ -135,6 +198,13 @@ class ParamExchange:
         if self.backend == "rccl":
             for w in self.which:
                 _lib.check(_lib.lib().bdr_agent_broadcast_params(agent.handle, self._comm, agent.WHICH[w], root))
+        elif self.backend == "torch-nccl":
+            import torch
+            import torch.distributed as dist
+            agent.sync()
+            for w in self.which:
+                dist.broadcast(self._arena_tensor(agent, w), src=root, group=self._group)
+            torch.cuda.synchronize(self.device)
         else:
             import torch
             import torch.distributed as dist

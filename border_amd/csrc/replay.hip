@@ -73,11 +73,21 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a)
     V* dst1 = reinterpret_cast<V*>(a.b_next + (uint64_t)sample * a.obs_bytes);
     const uint64_t v0 = (uint64_t)chunk * a.vec_per_chunk;
     const uint64_t v1 = min(v0 + a.vec_per_chunk, nvec);
-    for (uint64_t v = v0 + threadIdx.x; v < v1; v += 256) {
-        V x = __builtin_nontemporal_load(src0 + v);
-        V y = __builtin_nontemporal_load(src1 + v);
-        dst0[v] = x;
-        dst1[v] = y;
+    // 4 vectors of each section per thread and pass: all 8 loads are issued before the first store, so a
+    // thread keeps 8 x 16 B in flight (the row addresses are random, every load is an HBM round trip)
+    for (uint64_t v = v0 + threadIdx.x; v < v1; v += 1024) {
+        V x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t w = min(v + (uint64_t)u * 256, v1 - 1);   // clamped: tail lanes re-read the last vector
+            x[u] = __builtin_nontemporal_load(src0 + w);
+            y[u] = __builtin_nontemporal_load(src1 + w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t w = v + (uint64_t)u * 256;
+            if (w < v1) { dst0[w] = x[u]; dst1[w] = y[u]; }
+        }
     }
     if (chunk == 0) {
         for (uint32_t t = threadIdx.x; t < a.act_bytes; t += 256)
@@ -388,8 +398,8 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     r->word_pos += n;  // one next_u32() per index
     if (r->obs_bytes % 16 == 0) {
         const uint64_t nvec = r->obs_bytes / 16;
-        // ~4 vectors per thread per section; >= 4 workgroups per sample for Atari rows (1764 vectors)
-        a.chunks = (uint32_t)std::max<uint64_t>(1, (nvec + 511) / 512);
+        // up to 4 vectors per thread per section and pass: 2 workgroups per sample for Atari rows (1764 vectors)
+        a.chunks = (uint32_t)std::max<uint64_t>(1, (nvec + 1023) / 1024);
         a.vec_per_chunk = (uint32_t)((nvec + a.chunks - 1) / a.chunks);
         hipLaunchKernelGGL(k_gather<u32x4>, dim3((uint32_t)(n * a.chunks)), dim3(256), 0, stream, a);
     } else {

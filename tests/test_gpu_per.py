@@ -176,3 +176,37 @@ def test_dqn_opt_over_per_buffer_updates_priorities(B):
         np.testing.assert_allclose(rb.per_tree(), ref.tree.tree(), rtol=2e-4, atol=1e-6)
         assert rb.per_info()["n_opts"] == step + 1
     a.close(); rb.close()
+
+
+def test_large_updates_and_wrapping_pushes_chunk_correctly(B):
+    """update_priority with more rows than one device chunk (1024) and pushes that wrap / exceed the capacity:
+    still the sequential semantics of base.rs:227-235 and :421-423."""
+    from oracle.oracle import PerReplay
+    rng = np.random.default_rng(21)
+    cap = 1500
+    rb = _buf(B, cap, seed=3, alpha=1.0, normalize="All")
+    ref = PerReplay(cap, 3, alpha=1.0, normalize="All")
+    for n_push in (1200, 700, 1, 1499):                 # second push wraps the ring
+        _push(rb, n_push, rng); ref.push(n_push)
+        assert (rb.per_tree() == ref.tree.tree()).all(), n_push
+    assert rb.per_info()["n_samples"] == cap == ref.tree.n_samples
+    ixs = rng.integers(0, cap, 3000).astype(np.uint64)   # many duplicates, 3 device chunks
+    td = (rng.random(3000) * 2).astype(np.float32)
+    rb.update_priority(ixs, td); ref.update_priority(ixs, td)
+    assert (rb.per_tree() == ref.tree.tree()).all()
+    b = rb.batch(1024)                                   # the largest PER batch
+    r_ix, r_w = ref.batch(1024)
+    assert b.ix_sample.tolist() == r_ix.tolist()
+    np.testing.assert_allclose(b.weight, r_w, rtol=5e-6)
+    with pytest.raises(B.BdrError):
+        rb.batch(1025)
+    rb.close()
+
+
+def test_per_must_be_enabled_on_an_empty_buffer(B):
+    import ctypes as C
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=16, seed=1), (4,), np.float32)
+    _push(rb, 3, np.random.default_rng(0))
+    rc = B._lib.lib().bdr_replay_enable_per(rb.handle, C.byref(B.PerConfig().to_c()))
+    assert rc != 0
+    rb.close()

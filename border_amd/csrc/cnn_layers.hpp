@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "agent_base.hpp"
+#include "conv1_dw_bf16.hpp"
 #include "igemm.hpp"
 
 namespace {
@@ -83,7 +84,7 @@ struct FwdP {
         e.out[(size_t)m * NC + n] = v > 0.f ? v : 0.f;   // relu (cnn/base.rs:28,30,32)
     }
 };
-using FwdC1 = FwdP<GeomC1, AFwdU8<GeomC1>, 4, 1, true>;    // 128x32 tiles, M = B*400
+// (conv1 runs on the bf16 matrix cores with exact operands: conv1_bf16.hpp forward, conv1_dw_bf16.hpp weight gradient)
 using FwdC2 = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false>;     // 64x64,  M = B*81
 using FwdC3 = FwdP<GeomC3, AFwd<GeomC3>, 2, 2, false>;     // 64x64,  M = B*49
 
@@ -247,7 +248,6 @@ struct DwP {
     __device__ static const float* y_src(const Args& a) { return a.dy; }
     __device__ static float* part(const Args& a, int chunk) { return a.part + (size_t)chunk * a.part_stride; }
 };
-using DwC1 = DwP<GeomC1, AFwdU8<GeomC1>, 4, 1, true>;    // 128(k) x 32(n) tiles: 2 ko-tiles
 using DwC2 = DwP<GeomC2, AFwd<GeomC2>, 2, 2, false>;     // 64 x 64: 8 ko-tiles
 using DwC3 = DwP<GeomC3, AFwd<GeomC3>, 2, 2, false>;     // 64 x 64: 9 ko-tiles
 using DwL1 = DwP<GeomL1, AFwd<GeomL1>, 2, 2, false>;     // 64 x 64: 49 x 8 tiles, single chunk
@@ -315,7 +315,7 @@ DwPlan dw_plan(int B)
 {
     DwPlan p{};
     auto mt = [](int M) { return (M + 31) / 32; };
-    p.chunks_c1 = std::min(256, mt(B * 400));
+    p.chunks_c1 = std::min(256, B);           // conv1: one partial per workgroup, workgroups stride over the images
     p.chunks_c2 = std::min(64, mt(B * 81));
     p.chunks_c3 = std::min(56, mt(B * 49));
     p.stride_c1 = 256 * 32 + 32; p.stride_c2 = 512 * 64 + 64; p.stride_c3 = 576 * 64 + 64;

@@ -404,9 +404,9 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     }
     // conv1 (no input gradient) stays on the main stream
     {
-        const int M = B * 400, chunks = std::min(pl.chunks_c1, (M + 31) / 32);
-        DwArgs d{obs, a->dy1, a->part + pl.off_c1, pl.stride_c1, M};
-        { Bracket br(a, "bwd_conv1_dw"); LAUNCH(k_igemm_red<DwC1>, dim3(2 * chunks), d); }
+        const int chunks = std::min(pl.chunks_c1, B);
+        Conv1DwArgs d{obs, a->dy1, a->part + pl.off_c1, pl.stride_c1, B};
+        { Bracket br(a, "bwd_conv1_dw"); hipLaunchKernelGGL(k_conv1_dw_bf16, dim3(chunks), dim3(512), 0, a->stream, d); BDR_HIP(hipGetLastError()); }
     }
     if (ov) {                          // join: all weight-gradient partials complete
         BDR_HIP(hipEventRecord(a->ev_join, a->side));
@@ -421,7 +421,8 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         const int nw[3] = {256 * 32, 512 * 64, 576 * 64}, nb[3] = {32, 64, 64};
         int wg = 0;
         for (int k = 0; k < 3; ++k) {
-            r.seg[k] = ReduceSeg{a->part + offs[k], strides[k], std::min(plc[k], (Ms[k] + 31) / 32), a->grad + gw[k], nw[k] + nb[k], nw[k],
+            const int nchunks = k == 0 ? std::min(plc[0], B) : std::min(plc[k], (Ms[k] + 31) / 32);   // conv1: one partial per workgroup
+            r.seg[k] = ReduceSeg{a->part + offs[k], strides[k], nchunks, a->grad + gw[k], nw[k] + nb[k], nw[k],
                                  k == 0 ? INV255 : 1.0f, wg};
             wg += (nw[k] + nb[k] + 31) / 32;
         }

@@ -90,35 +90,6 @@ struct AFwd {
     }
 };
 
-// conv1: NCHW u8 input [B][4][84][84], k=(c,kh,kw); one load = the 8 contiguous pixels of one
-// patch row.  Values stay integers 0..255 (exact in f32); the 1/255 of cnn/base.rs:26 is applied in
-// the epilogue.
-template <class G>
-struct AFwdU8 {
-    static constexpr int VEC = 8;
-    static constexpr int NKT = G::K / BK;
-    struct Row { const uint8_t* p; bool ok; };
-    __device__ static Row row(const uint8_t* x, int m, int M)
-    {
-        Row r;
-        r.ok = m < M;
-        const int mm = r.ok ? m : 0;
-        const int b = mm / (G::OH * G::OW), rem = mm % (G::OH * G::OW);
-        const int oh = rem / G::OW, ow = rem % G::OW;
-        r.p = x + (size_t)b * (G::CIN * G::IH * G::IW) + (oh * G::S) * G::IW + ow * G::S;
-        return r;
-    }
-    __device__ static void load(const Row& r, int kt, int q, f32x4* v)
-    {
-        static_assert(G::KW == 8 && G::KH == 8, "conv1 geometry");
-        const int c = kt >> 1, kh = ((kt & 1) << 2) + q;
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(r.p + c * (G::IH * G::IW) + kh * G::IW);
-        const uint32_t lo = p[0], hi = p[1];         // rows >= M alias row 0
-        v[0] = f32x4{(float)(lo & 255u), (float)((lo >> 8) & 255u), (float)((lo >> 16) & 255u), (float)(lo >> 24)};
-        v[1] = f32x4{(float)(hi & 255u), (float)((hi >> 8) & 255u), (float)((hi >> 16) & 255u), (float)(hi >> 24)};
-    }
-};
-
 // Input gradient of a stride-1 conv as a gather: rows m'=(b,ih,iw) over the conv INPUT grid,
 // k'=(kh,kw,cout) over dY [B][OH][OW][COUT]; out-of-range taps read zero.
 template <class G>

@@ -332,9 +332,9 @@ struct Iqn : bdr_agent {
             }
             { DxArgs d{dy2, p + conv.w2, a1, dy1, Bn * 100}; Bracket br(a, "psi_conv2_dx"); LAUNCH(k_igemm<DxC2>, dim3((d.M + 127) / 128, 4, 1), d); }
             {
-                const int Mr = Bn * 400, chunks = std::min(pl.chunks_c1, (Mr + 31) / 32);
-                DwArgs d{obs, dy1, part_conv + pl.off_c1, pl.stride_c1, Mr};
-                { Bracket br(a, "psi_conv1_dw"); LAUNCH(k_igemm_red<DwC1>, dim3(2 * chunks), d); }
+                const int chunks = std::min(pl.chunks_c1, Bn);
+                Conv1DwArgs d{obs, dy1, part_conv + pl.off_c1, pl.stride_c1, Bn};
+                { Bracket br(a, "psi_conv1_dw"); hipLaunchKernelGGL(k_conv1_dw_bf16, dim3(chunks), dim3(512), 0, a->stream, d); BDR_HIP(hipGetLastError()); }
                 const int n = 256 * 32 + 32;
                 hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, stream, part_conv + pl.off_c1, pl.stride_c1, chunks, grad + conv.w1, n, 256 * 32, INV255);
                 BDR_HIP(hipGetLastError());

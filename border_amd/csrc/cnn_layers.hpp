@@ -19,7 +19,7 @@ constexpr float INV255 = 1.0f / 255.0f;
 //   W2 [512][64]  k=(kh,kw,c)      b2[64]
 //   W3 [576][64]  k=(kh,kw,c)      b3[64]
 //   W4 [3136][512] k=(h,w,c)       b4[512]      (NHWC flatten of conv3's output)
-//   W5 [512][A]                    b5[A]
+//   W5 [A][512]  (= the reference's [out][in]: k_head reads a lane's 8 columns of an action as two f32x4)   b5[A]
 struct Arena {
     size_t w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, total;  // offsets in floats
     int A;

@@ -47,41 +47,6 @@ struct HeadArgs {
     int B, A, S;
 };
 
-__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave, z = blockIdx.y;
-    if (row >= a.B) return;
-    // lane owns columns [lane*8, lane*8+8)
-    f32x4 h[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    for (int s = 0; s < a.S; ++s) {
-        const float* p = a.p1[z] + ((size_t)s * a.B + row) * 512 + lane * 8;
-        h[0] += *reinterpret_cast<const f32x4*>(p);
-        h[1] += *reinterpret_cast<const f32x4*>(p + 4);
-    }
-    float hv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float v = h[j >> 2][j & 3] + a.b4[z][lane * 8 + j];
-        hv[j] = v > 0.f ? v : 0.f;   // cnn/base.rs:34 relu
-    }
-    float* ho = a.h1[z] + (size_t)row * 512 + lane * 8;
-    *reinterpret_cast<f32x4*>(ho) = f32x4{hv[0], hv[1], hv[2], hv[3]};
-    *reinterpret_cast<f32x4*>(ho + 4) = f32x4{hv[4], hv[5], hv[6], hv[7]};
-    for (int act = 0; act < a.A; ++act) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s = fmaf(hv[j], a.w5[z][(size_t)(lane * 8 + j) * a.A + act], s);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) a.q[z][(size_t)row * a.A + act] = s + a.b5[z][act];
-    }
-}
-
-// ================================================================================================
-// TD: dqn/base.rs:71-74 (pred), :91-105 (target), :146-152 (loss), plus dL/dQ and dL/dh1.
-// One wave per batch row.
-// ================================================================================================
 struct TdArgs {
     const float* q_on;     // [B][A]  qnet(obs)
     const float* q_tg;     // [B][A]  qnet_tgt(next_obs)
@@ -105,15 +70,96 @@ struct TdArgs {
     int has_clip; float clip_min, clip_max;
 };
 
-__global__ __launch_bounds__(256) void k_td_rows(TdArgs a)
+// One workgroup = HEAD_ROWS batch rows x nz network instances, one wave per (row, instance):
+//   l1 finish (split-K partials summed in split order) + bias + ReLU -> h1, then l2 -> Q(row, .).
+// With td != 0 the TD step of the row follows in the same launch (dqn/base.rs:71-74 pred, :91-105 target,
+// :123-152 loss): the instance-0 wave of the row picks up the other instances' Q rows from LDS and still
+// holds its own h1 row in registers for dL/dh1, so neither Q nor h1 is read back from memory.
+// Latency shape: EVERYTHING the wave will need (the 2*S partial vectors, its 8 x A block of W5, the row's action /
+// reward / flags) is requested up front, so the kernel pays one memory round trip; AMAX is the compile-time bound
+// of the register-resident W5 block (A <= AMAX).
+constexpr int HEAD_ROWS = 2;
+template <int S, int AMAX>
+__global__ __launch_bounds__(64 * HEAD_ROWS * MAXZ) void k_head(HeadArgs a, TdArgs t, int nz, int td)
 {
+    __shared__ float sq[HEAD_ROWS][MAXZ][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= a.B) return;
-    const long long act = *reinterpret_cast<const long long*>(a.act + (size_t)row * a.act_bytes);
+    const int r = wave / nz, z = wave % nz;
+    const int row = blockIdx.x * HEAD_ROWS + r;
+    const bool valid = row < a.B;
+    const int rw = valid ? row : 0;
+    const int A = a.A;
+    // lane owns columns [lane*8, lane*8+8)
+    f32x4 part[S][2];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const float* p = a.p1[z] + ((size_t)s * a.B + rw) * 512 + lane * 8;
+        part[s][0] = *reinterpret_cast<const f32x4*>(p);
+        part[s][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    const f32x4 b4lo = *reinterpret_cast<const f32x4*>(a.b4[z] + lane * 8), b4hi = *reinterpret_cast<const f32x4*>(a.b4[z] + lane * 8 + 4);
+    // W5 is [A][512] (the reference's own [out][in]): action k's weights for this lane's 8 columns are two f32x4
+    const float* w5 = a.w5[z] + lane * 8;
+    float wreg[8][AMAX];
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k) {
+        const float* wk = w5 + (size_t)min(k, A - 1) * 512;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wk), hi = *reinterpret_cast<const f32x4*>(wk + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wreg[j][k] = lo[j]; wreg[4 + j][k] = hi[j]; }
+    }
+    const float b5 = lane < A ? a.b5[z][lane] : 0.f;
+    long long act = 0; float reward = 0.f, wgt = 1.f; int term = 0;
+    if (td && z == 0) {
+        act = *reinterpret_cast<const long long*>(t.act + (size_t)rw * t.act_bytes);
+        reward = t.reward[rw]; term = (int)t.term[rw];
+        if (t.weight) wgt = t.weight[rw];
+    }
+
+    f32x4 h[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+    for (int s = 0; s < S; ++s) { h[0] += part[s][0]; h[1] += part[s][1]; }
+    float hv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = h[j >> 2][j & 3] + (j < 4 ? b4lo[j & 3] : b4hi[j & 3]);
+        hv[j] = v > 0.f ? v : 0.f;   // cnn/base.rs:34 relu
+    }
+    if (valid) {
+        float* ho = a.h1[z] + (size_t)row * 512 + lane * 8;
+        *reinterpret_cast<f32x4*>(ho) = f32x4{hv[0], hv[1], hv[2], hv[3]};
+        *reinterpret_cast<f32x4*>(ho + 4) = f32x4{hv[4], hv[5], hv[6], hv[7]};
+    }
+    // l2: one dot product per action over the 512 columns; the AMAX butterflies interleave
+    float sk[AMAX];
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(hv[j], wreg[j][k], s);
+        sk[k] = s;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) sk[k] += __shfl_xor(sk[k], off);
+    // every lane holds all sums: lane k keeps action k
+    float qv = 0.f;
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k) qv = lane == k ? sk[k] : qv;
+    qv += b5;
+    if (lane < A) {
+        if (valid) a.q[z][(size_t)row * A + lane] = qv;
+        sq[r][z][lane] = qv;
+    }
+    if (!td) return;
+    __syncthreads();
+    if (z != 0 || !valid) return;
+    // ---- TD of this row (instance 0 = qnet(obs), 1 = qnet_tgt(next_obs), 2 = qnet(next_obs) for double DQN)
+    const float* q_tg = sq[r][1];
+    const float* sel = t.q_on_next ? sq[r][2] : q_tg;
     // argmax over actions: first maximal index (at::argmax), lanes >= A hold -inf
-    const float* sel = a.q_on_next ? a.q_on_next : a.q_tg;
-    float v = lane < a.A ? sel[(size_t)row * a.A + lane] : -INFINITY;
+    float v = lane < A ? sel[lane] : -INFINITY;
     int idx = lane;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -121,24 +167,28 @@ __global__ __launch_bounds__(256) void k_td_rows(TdArgs a)
         const int oi = __shfl_xor(idx, off);
         if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
-    const float qn = a.q_tg[(size_t)row * a.A + idx];
-    const float pred = a.q_on[(size_t)row * a.A + act];
+    const float qn = q_tg[idx];
+    const float pred = sq[r][0][act];
     // reward + (1 - is_terminated) * discount_factor * q   (dqn/base.rs:104)
-    const float tgt = a.reward[row] + ((float)(1 - (int)a.term[row]) * a.gamma) * qn;
-    const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
-    float lossb, td;
-    const float dl = td_loss_row(pred, tgt, li, lossb, td);
+    const float tgt = reward + ((float)(1 - term) * t.gamma) * qn;
+    const TdLossIn li{t.loss_kind, t.weight != nullptr, wgt, t.has_clip, t.clip_min, t.clip_max};
+    float lossb, tdv;
+    const float dl = td_loss_row(pred, tgt, li, lossb, tdv);
     const float dq = dl / (float)a.B;   // Reduction::Mean
     if (lane == 0) {
-        a.dq[row] = dq; a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb;
-        if (a.td_abs) a.td_abs[row] = td;
+        t.dq[row] = dq; t.pred[row] = pred; t.tgt[row] = tgt; t.loss_row[row] = lossb;
+        if (t.td_abs) t.td_abs[row] = tdv;
     }
-    // dL/dh1[row][j] = relu'(h1) * dq * W5[j][act]
-    const float* hr = a.h1 + (size_t)row * 512 + lane * 8;
+    // dL/dh1[row][j] = relu'(h1) * dq * W5[j][act]  (column `act` of the register block)
     float out[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[j] = hr[j] > 0.f ? dq * a.w5[(size_t)(lane * 8 + j) * a.A + act] : 0.f;
-    float* o = a.dh1 + (size_t)row * 512 + lane * 8;
+    for (int j = 0; j < 8; ++j) {
+        float wj = 0.f;
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) wj = (int)act == k ? wreg[j][k] : wj;
+        out[j] = hv[j] > 0.f ? dq * wj : 0.f;
+    }
+    float* o = t.dh1 + (size_t)row * 512 + lane * 8;
     *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
     *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
 }
@@ -199,7 +249,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
         if (tid == 0) for (int q = 0; q < total; ++q) bacc += s_dq[q];
         __syncthreads();
     }
-    a.gw5[(size_t)j * a.A + ac] = acc;
+    a.gw5[(size_t)ac * 512 + j] = acc;
     if (tid == 0 && (blockIdx.x & 1) == 0) a.gb5[ac] = bacc;
 }
 
@@ -289,7 +339,7 @@ int32_t ensure_batch(DqnCnn* a, int B)
 // ---- the forward pass of nz network instances ------------------------------------------------------
 struct NetInst { const uint8_t* x; const float* params; int slot; };
 
-int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B)
+int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td = nullptr)
 {
     const Arena& ar = a->ar;
     FwdArgs f{};
@@ -321,7 +371,16 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B)
         h.p1[z] = a->p1[inst[z].slot]; h.b4[z] = inst[z].params + ar.b4; h.w5[z] = inst[z].params + ar.w5;
         h.b5[z] = inst[z].params + ar.b5; h.h1[z] = a->h1[inst[z].slot]; h.q[z] = a->qv[inst[z].slot];
     }
-    { Bracket br(a, "head_fwd"); LAUNCH(k_head_fwd, dim3((B + 3) / 4, nz), h); }
+    {
+        static_assert(L1_SPLIT == 7, "k_head is instantiated for the l1 split");
+        Bracket br(a, td ? "head_fwd_td" : "head_fwd");
+        const dim3 grid((B + HEAD_ROWS - 1) / HEAD_ROWS), block(64 * HEAD_ROWS * nz);
+        const TdArgs tv = td ? *td : TdArgs{};
+        if (ar.A <= 8) hipLaunchKernelGGL((k_head<L1_SPLIT, 8>), grid, block, 0, a->stream, h, tv, nz, td ? 1 : 0);
+        else if (ar.A <= 24) hipLaunchKernelGGL((k_head<L1_SPLIT, 24>), grid, block, 0, a->stream, h, tv, nz, td ? 1 : 0);
+        else hipLaunchKernelGGL((k_head<L1_SPLIT, 64>), grid, block, 0, a->stream, h, tv, nz, td ? 1 : 0);
+        BDR_HIP(hipGetLastError());
+    }
     return BDR_OK;
 }
 
@@ -341,7 +400,6 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     const bdr_dqn_config& c = a->cfg;
     // :71-74 + :91-103  slot 0 = qnet(obs), slot 1 = qnet_tgt(next_obs), slot 2 = qnet(next_obs) for double DQN
     NetInst inst[3] = {{obs, a->q, 0}, {next_obs, a->q_tgt, 1}, {next_obs, a->q, 2}};
-    BDR_TRY(forward(a, inst, c.double_dqn ? 3 : 2, B));
 
     TdArgs t{};
     t.q_on = a->qv[0]; t.q_tg = a->qv[1]; t.q_on_next = c.double_dqn ? a->qv[2] : nullptr;
@@ -350,7 +408,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     t.loss_row = a->loss_row; t.B = B; t.A = ar.A; t.gamma = (float)c.discount_factor; t.loss_kind = c.critic_loss;
     t.weight = weight; t.td_abs = a->td_abs;
     t.has_clip = c.has_clip_td_err; t.clip_min = (float)c.clip_td_err_min; t.clip_max = (float)c.clip_td_err_max;
-    { Bracket br(a, "td_rows"); LAUNCH(k_td_rows, dim3((B + 3) / 4), t); }
+    BDR_TRY(forward(a, inst, c.double_dqn ? 3 : 2, B, &t));   // the TD step rides on the head kernel
     // dqn/base.rs:143: buffer.update_priority(&ixs, &Some(td_errs)); independent of the backward kernels
     if (per_buffer && weight) { Bracket br(a, "per_update"); BDR_TRY(replay_update_priority_on_stream(per_buffer, B, a->td_abs, a->stream)); }
 
@@ -518,7 +576,7 @@ void to_internal(const Arena& ar, const float* ref, float* in)
     for (int o = 0; o < 512; ++o) for (int c = 0; c < 64; ++c) for (int hw = 0; hw < 49; ++hw)
         in[ar.w4 + (size_t)(hw * 64 + c) * 512 + o] = p[(size_t)o * 3136 + c * 49 + hw];
     p += (size_t)512 * 3136; std::copy(p, p + 512, in + ar.b4); p += 512;
-    for (int o = 0; o < ar.A; ++o) for (int k = 0; k < 512; ++k) in[ar.w5 + (size_t)k * ar.A + o] = p[(size_t)o * 512 + k];
+    std::copy(p, p + (size_t)ar.A * 512, in + ar.w5);   // l2: [A][512] on both sides
     p += (size_t)ar.A * 512; std::copy(p, p + ar.A, in + ar.b5);
 }
 
@@ -536,7 +594,7 @@ void to_reference(const Arena& ar, const float* in, float* ref)
     for (int o = 0; o < 512; ++o) for (int c = 0; c < 64; ++c) for (int hw = 0; hw < 49; ++hw)
         p[(size_t)o * 3136 + c * 49 + hw] = in[ar.w4 + (size_t)(hw * 64 + c) * 512 + o];
     p += (size_t)512 * 3136; std::copy(in + ar.b4, in + ar.b4 + 512, p); p += 512;
-    for (int o = 0; o < ar.A; ++o) for (int k = 0; k < 512; ++k) p[(size_t)o * 512 + k] = in[ar.w5 + (size_t)k * ar.A + o];
+    std::copy(in + ar.w5, in + ar.w5 + (size_t)ar.A * 512, p);
     p += (size_t)ar.A * 512; std::copy(in + ar.b5, in + ar.b5 + ar.A, p);
 }
 

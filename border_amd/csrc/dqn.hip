@@ -239,6 +239,13 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
         }
         __syncthreads();
         int k = 0;
+        for (; k + 16 <= total; k += 16) {   // 16 row loads in flight per thread (each is an L2 round trip)
+            float hvv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) hvv[u] = a.h1[(size_t)s_rows[k + u] * 512 + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fmaf(hvv[u], s_dq[k + u], acc);
+        }
         for (; k + 4 <= total; k += 4) {
             const float h0 = a.h1[(size_t)s_rows[k] * 512 + j], h1v = a.h1[(size_t)s_rows[k + 1] * 512 + j];
             const float h2 = a.h1[(size_t)s_rows[k + 2] * 512 + j], h3 = a.h1[(size_t)s_rows[k + 3] * 512 + j];

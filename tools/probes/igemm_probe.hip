@@ -26,6 +26,13 @@ static double checksum(const float* d, size_t n)
     return s;
 }
 
+// forward policy with k-major (per-tap transposed) weights [tap][cout][cin]: timing experiment only
+template <class G, int WM_, int WN_>
+struct FwdPT : FwdP<G, AFwd<G>, WM_, WN_, false> {
+    static constexpr bool B_TR = true;
+    __device__ static constexpr int KP(const FwdArgs&) { return G::CIN; }
+};
+
 template <class P, int STAGES>
 static void run_dl(const char* name, dim3 grid, const typename P::Args& args, const float* out, size_t nout)
 {
@@ -88,6 +95,8 @@ int main()
 #define FWD3D(WM, WN, RP, TM, TN, S) { using P = FwdP<GeomC3, AFwd<GeomC3>, WM, WN, false, RP, TM, TN>; \
     CK(hipMemset(h3[1], 0, n3 * 4)); run_dl<P, S>("fwd_c3 " #WM "x" #WN " rp" #RP " t" #TM #TN, dim3(m_tiles<P>(f3.M) * (64 / (WN * TN * 32)), 1, NZ), f3, h3[1], n3); }
     FWD2(2, 2, 0, 1, 1, 1)   // current
+    { using P = FwdPT<GeomC2, 2, 2>; run<P, 1>("fwd_c2 2x2 k-major B", dim3(m_tiles<P>(f2.M), 1, NZ), f2, h2[1], n2); }
+    { using P = FwdPT<GeomC2, 2, 2>; run<P, 2>("fwd_c2 2x2 k-major B teams2", dim3(m_tiles<P>(f2.M), 1, NZ), f2, h2[1], n2); }
     FWD2D(2, 2, 0, 1, 1, 3)
     FWD2D(2, 2, 0, 1, 1, 4)
     FWD2D(2, 2, 0, 2, 1, 3)
@@ -97,6 +106,8 @@ int main()
     FWD2D(4, 1, 0, 1, 2, 4)
     FWD2D(2, 2, 0, 2, 1, 4)
     FWD3(2, 2, 0, 1, 1, 1)
+    { using P = FwdPT<GeomC3, 2, 2>; run<P, 1>("fwd_c3 2x2 k-major B", dim3(m_tiles<P>(f3.M), 1, NZ), f3, h3[1], n3); }
+    { using P = FwdPT<GeomC3, 2, 2>; run<P, 2>("fwd_c3 2x2 k-major B teams2", dim3(m_tiles<P>(f3.M), 1, NZ), f3, h3[1], n3); }
     FWD3(2, 2, 0, 1, 1, 2)   // current
     FWD3D(2, 2, 0, 1, 1, 3)
     FWD3D(2, 2, 0, 1, 1, 4)
@@ -138,5 +149,19 @@ int main()
     DX3(2, 2, 0, 1, 1, 2)    // current
 
     DX2(4, 1, 0, 1, 1, 1)    // current
+    // ---- quantisation study: time per tile at balanced grids (multiples of 256 workgroups) vs the real grids
+    printf("\n# balance study (us per launch; tiles = workgroups)\n");
+    auto fwd3 = [&](int wgs_per_net) { FwdArgs g = f3; g.M = 64 * wgs_per_net; using P = FwdP<GeomC3, AFwd<GeomC3>, 2, 2, false, 0, 1, 1>;
+        char nm[64]; snprintf(nm, 64, "fwd_c3 t2 %d tiles", 2 * wgs_per_net); run<P, 2>(nm, dim3(wgs_per_net, 1, NZ), g, h3[1], (size_t)g.M * 64); };
+    fwd3(128); fwd3(196);
+    auto fwd2 = [&](int wgs_per_net) { FwdArgs g = f2; g.M = 64 * wgs_per_net; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>;
+        char nm[64]; snprintf(nm, 64, "fwd_c2 %d tiles", 2 * wgs_per_net); run<P, 1>(nm, dim3(wgs_per_net, 1, NZ), g, h2[1], (size_t)g.M * 64); };
+    fwd2(256); fwd2(324);
+    auto dx3 = [&](int wgs) { DxArgs g = d3; g.M = 64 * wgs; using P = DxC3P<2, 2>;
+        char nm[64]; snprintf(nm, 64, "dx_c3 t2 %d tiles", wgs); run<P, 2>(nm, dim3(wgs, 1, 1), g, dx2, (size_t)g.M * 64); };
+    dx3(256); dx3(324);
+    auto dx2f = [&](int wgs_per_class) { DxArgs g = d2; g.M = 128 * wgs_per_class; using P = DxC2P<4, 1>;
+        char nm[64]; snprintf(nm, 64, "dx_c2 %d tiles", 4 * wgs_per_class); run<P, 1>(nm, dim3(wgs_per_class, 4, 1), g, dx1, (size_t)1); };
+    dx2f(128); dx2f(192); dx2f(200);
     return 0;
 }

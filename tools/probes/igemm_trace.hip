@@ -83,6 +83,8 @@ int main(int argc, char** argv)
         { using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 4, true>("DL4 fwd_c2 64x64 flat", dim3(m_tiles<P>(f2.M), 1, NZ), f2); }
         { FwdArgs g = f2; g.M = 64 * 128; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 1>("fwd_c2 64x64 solo (1 WG/CU)", dim3(128, 1, NZ), g); }
         { FwdArgs g = f2; g.M = 128 * 128; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 2, 1>; trace<P, 1>("fwd_c2 128x64 tm2 solo (1 WG/CU)", dim3(128, 1, NZ), g); }
+        { FwdArgs g = f2; g.M = 64 * 256; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 1>("fwd_c2 64x64 duo (2 WG/CU)", dim3(256, 1, NZ), g); }
+        { FwdArgs g = f2; g.M = 64 * 384; using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 1>("fwd_c2 64x64 trio (3 WG/CU)", dim3(384, 1, NZ), g); }
         { using P = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false, 0, 1, 1>; trace<P, 1>("fwd_c2 64x64 flat", dim3(m_tiles<P>(f2.M), 1, NZ), f2); }
         return 0;
     }

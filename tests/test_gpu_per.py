@@ -210,3 +210,31 @@ def test_per_must_be_enabled_on_an_empty_buffer(B):
     rc = B._lib.lib().bdr_replay_enable_per(rb.handle, C.byref(B.PerConfig().to_c()))
     assert rc != 0
     rb.close()
+
+
+@pytest.mark.parametrize("loss,clip,ddqn", [("SmoothL1", None, False), ("Mse", (0.05, 0.9), True)])
+def test_weighted_update_critic_nature_cnn_vs_aten(B, loss, clip, ddqn):
+    """The importance-weighted branch on the Nature-CNN agent (TD step fused into the head kernel) against the
+    ATen restatement, B = 6, three steps."""
+    from oracle import torch_ref as T
+    shapes = T.cnn_shapes(6)
+    p0 = T.init_params(shapes, 17)
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=6),
+                                                    opt_config=B.OptimizerConfig.Adam(1e-4)),
+                      device=0, batch_size=6, tau=1.0, soft_update_interval=2, critic_loss=loss, clip_td_err=clip, double_dqn=ddqn)
+    a = B.Dqn.build(cfg)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    t = T.TorchDqn("cnn", shapes, p0, lr=1e-4, critic_loss=loss, clip_td_err=clip, double_dqn=ddqn, tau=1.0, soft_update_interval=2)
+    rng = np.random.default_rng(77)
+    for s in range(3):
+        obs, act, nobs, rew, term = T.synthetic_atari_batch(6, 6, 400 + s)
+        rew = (rew + rng.uniform(-1.5, 1.5, 6)).astype(np.float32)       # |td| on both sides of the Huber knee / clip range
+        w = (0.2 + 0.8 * rng.random(6)).astype(np.float32)
+        r = t.update(obs, act, nobs, rew, term, weight=w)
+        rec = a.update_on_batch(obs, act, nobs, rew, term, weight=w)
+        np.testing.assert_allclose(rec["td_errs"], r["td_abs"], rtol=2e-4, atol=1e-6)
+        assert abs(rec["loss"] - r["loss"]) <= 2e-4 * abs(r["loss"]) + 1e-8, s
+        g, gr = a.get_params("grad").astype(np.float64), r["grads"].astype(np.float64)
+        assert np.abs(g - gr).max() <= 5e-4 * np.abs(gr).max(), s
+        assert np.abs(a.get_params("qnet").astype(np.float64) - t.params()).max() < 0.05 * 1e-4
+    a.close()

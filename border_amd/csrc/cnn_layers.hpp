@@ -11,7 +11,10 @@
 namespace {
 
 constexpr int MAXZ = 3;       // network instances per forward launch
-constexpr int L1_SPLIT = 7;   // split-K of the 3136-deep l1 contraction (98 k-tiles = 7 * 14)
+#ifndef BDR_L1_SPLIT
+#define BDR_L1_SPLIT 7
+#endif
+constexpr int L1_SPLIT = BDR_L1_SPLIT;   // split-K of the 3136-deep l1 contraction (98 k-tiles)
 constexpr float INV255 = 1.0f / 255.0f;
 
 // ---- flat parameter arena (internal layouts; every segment 16-byte aligned) ----------------------

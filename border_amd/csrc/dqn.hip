@@ -379,7 +379,6 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         h.b5[z] = inst[z].params + ar.b5; h.h1[z] = a->h1[inst[z].slot]; h.q[z] = a->qv[inst[z].slot];
     }
     {
-        static_assert(L1_SPLIT == 7, "k_head is instantiated for the l1 split");
         Bracket br(a, td ? "head_fwd_td" : "head_fwd");
         const dim3 grid((B + HEAD_ROWS - 1) / HEAD_ROWS), block(64 * HEAD_ROWS * nz);
         const TdArgs tv = td ? *td : TdArgs{};

@@ -51,6 +51,13 @@ class OptimizerConfig:
     def Adam(cls, lr: float) -> "OptimizerConfig":
         return cls("Adam", lr)
 
+    @classmethod
+    def AdamW(cls, lr: float, beta1: float = 0.9, beta2: float = 0.999, wd: float = 0.01, eps: float = 1e-8,
+              amsgrad: bool = False) -> "OptimizerConfig":
+        if amsgrad:
+            raise NotImplementedError("AdamW{amsgrad: true} is not built (no example of the reference sets it)")
+        return cls("AdamW", lr, beta1, beta2, wd, eps)
+
 
 @dataclass
 class Softmax:

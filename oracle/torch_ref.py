@@ -84,7 +84,7 @@ class TorchDqn:
     """Dqn (dqn/base.rs) with DqnModel (dqn/model/base.rs) and tch's Adam (opt.rs:35)."""
 
     def __init__(self, kind, shapes, params: np.ndarray, *, lr, discount_factor=0.99, double_dqn=False,
-                 critic_loss="Mse", clip_td_err=None, tau=0.005, soft_update_interval=1):
+                 critic_loss="Mse", clip_td_err=None, tau=0.005, soft_update_interval=1, adamw=None):
         self.kind, self.shapes = kind, shapes
         self.q = [t.requires_grad_(True) for t in unflatten(params, shapes)]
         self.q_tgt = unflatten(params, shapes)  # DqnModel::clone, dqn/model/base.rs:94-115
@@ -93,20 +93,26 @@ class TorchDqn:
         self.lr, self.step = lr, 0
         self.gamma, self.double_dqn, self.critic_loss = discount_factor, double_dqn, critic_loss
         self.clip_td_err = clip_td_err
+        self.adamw = adamw   # None (opt.rs:35 Adam) or dict(beta1, beta2, wd, eps) (opt.rs:38-55 AdamW, amsgrad False)
         self.tau, self.soft_update_interval, self.soft_update_counter = tau, soft_update_interval, 0
 
     def fwd(self, p, x):
         return cnn_forward(p, x) if self.kind == "cnn" else mlp_forward(p, x)
 
     def _adam(self):
-        """libtorch torch/csrc/api/src/optim/adam.cpp (Adam::step), defaults of opt.rs:35."""
-        b1, b2, eps = 0.9, 0.999, 1e-8
+        """libtorch torch/csrc/api/src/optim/adam.cpp (Adam::step), defaults of opt.rs:35; adamw.cpp (AdamW::step:
+        decoupled decay `param.mul_(1 - lr * weight_decay)` first) for OptimizerConfig::AdamW (opt.rs:38-55)."""
+        b1, b2, eps, wd = 0.9, 0.999, 1e-8, 0.0
+        if self.adamw is not None:
+            b1, b2, eps, wd = self.adamw["beta1"], self.adamw["beta2"], self.adamw["eps"], self.adamw["wd"]
         self.step += 1
         bc1 = 1 - b1 ** self.step
         bc2 = 1 - b2 ** self.step
         with torch.no_grad():
             for p, m, v in zip(self.q, self.m, self.v):
                 g = p.grad
+                if self.adamw is not None:
+                    p.mul_(1 - self.lr * wd)
                 m.mul_(b1).add_(g, alpha=1 - b1)
                 v.mul_(b2).addcmul_(g, g, value=1 - b2)
                 denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)

@@ -273,3 +273,25 @@ def test_mlp_opt_over_replay(B):
     q = a.qvalues(tr[0][:7])
     assert rel(q, O.net_forward(O.mlp_cfg(4, [64, 64], 2), a.get_params("qnet"), tr[0][:7])) < QTOL
     a.close(); rb.close()
+
+
+def test_mlp_adamw_matches_aten(B):
+    """OptimizerConfig::AdamW (opt.rs:20-27,38-55): decoupled weight decay, custom betas / eps, 5 steps vs ATen."""
+    from oracle import torch_ref as T
+    shapes = T.mlp_shapes(4, [64, 64], 2)
+    kw = dict(beta1=0.8, beta2=0.95, wd=0.05, eps=1e-6)
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.MlpConfig(in_dim=4, units=(64, 64), out_dim=2),
+                                                    opt_config=B.OptimizerConfig.AdamW(2e-3, **kw)),
+                      device=0, batch_size=32, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1)
+    a = B.Dqn.build(cfg)
+    p0 = T.init_params(shapes, 23)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    t = T.TorchDqn("mlp", shapes, p0, lr=2e-3, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, adamw=kw)
+    for s in range(5):
+        batch = _cart(s)
+        r = t.update(*batch)
+        rec = a.update_on_batch(*batch)
+        assert abs(rec["loss"] - r["loss"]) <= QTOL * abs(r["loss"]) + 1e-9
+        d = np.abs(a.get_params("qnet").astype(np.float64) - t.params())
+        assert d.max() < 0.05 * 2e-3, (s, d.max())          # a small fraction of one optimizer step
+    a.close()

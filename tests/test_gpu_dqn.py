@@ -295,3 +295,44 @@ def test_mlp_adamw_matches_aten(B):
         d = np.abs(a.get_params("qnet").astype(np.float64) - t.params())
         assert d.max() < 0.05 * 2e-3, (s, d.max())          # a small fraction of one optimizer step
     a.close()
+
+
+def test_n_updates_per_opt_and_soft_update_counter(B):
+    """opt_ (dqn/base.rs:182-200): n_updates_per_opt critic updates (one batch() each) per opt, ONE soft-update
+    counter tick per opt, n_opts += 1 per opt."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    rng = np.random.default_rng(8)
+    cap, Bsz = 1000, 16
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=9), (4,), np.float32)
+    oref = O.Replay(cap, 9, 16, 8)
+    n = 300
+    tr = (rng.standard_normal((n, 4)).astype(np.float32), rng.integers(0, 2, (n, 1)).astype(np.int64),
+          rng.standard_normal((n, 4)).astype(np.float32), rng.uniform(-1, 1, n).astype(np.float32),
+          (rng.random(n) < .1).astype(np.int8), np.zeros(n, np.int8))
+    rb.push(*tr); oref.push(*tr)
+    shapes = T.mlp_shapes(4, [64, 64], 2)
+    p0 = T.init_params(shapes, 31)
+    a = make_mlp_agent(B, batch_size=Bsz, lr=1e-3, critic_loss="Mse", tau=0.5, soft_update_interval=2, n_updates_per_opt=3)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    t = T.TorchDqn("mlp", shapes, p0, lr=1e-3, critic_loss="Mse", tau=0.5, soft_update_interval=10**9)   # soft update driven below
+    counter = 0
+    for opt in range(4):
+        a.opt(rb)
+        for _ in range(3):
+            b = oref.batch(Bsz)
+            t.update(b["obs"].view(np.float32).reshape(Bsz, 4), b["act"].view(np.int64).ravel(),
+                     b["next_obs"].view(np.float32).reshape(Bsz, 4), b["reward"], b["is_terminated"])
+        counter += 1
+        if counter == 2:      # dqn/base.rs:190-194
+            counter = 0
+            tg = 0.5 * t.params() + 0.5 * t.tgt_params()
+            import torch
+            with torch.no_grad():
+                for d, s_ in zip(t.q_tgt, T.unflatten(tg.astype(np.float32), shapes)):
+                    d.copy_(s_)
+        assert a.n_opts == opt + 1
+    assert rel(a.get_params("qnet"), t.params()) < 2e-4
+    assert rel(a.get_params("qnet_tgt"), t.tgt_params()) < 2e-4
+    assert rb.sample_indices(4).tolist() == oref.batch(4)["ixs"].tolist()     # 12 batches were drawn on both sides
+    a.close(); rb.close()

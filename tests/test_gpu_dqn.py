@@ -336,3 +336,28 @@ def test_n_updates_per_opt_and_soft_update_counter(B):
     assert rel(a.get_params("qnet_tgt"), t.tgt_params()) < 2e-4
     assert rb.sample_indices(4).tolist() == oref.batch(4)["ixs"].tolist()     # 12 batches were drawn on both sides
     a.close(); rb.close()
+
+
+@pytest.mark.parametrize("Bsz,ddqn", [(1, False), (3, True), (33, False), (100, True)])
+def test_ragged_batch_sizes_vs_oracle(B, Bsz, ddqn):
+    """Batch sizes that are not multiples of any tile (rows 81*B / 49*B / B, one image per conv1-dW workgroup, two
+    rows per head workgroup): Q-values, targets, loss and gradients against the C oracle."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    shapes = T.cnn_shapes(6)
+    p0 = T.init_params(shapes, 40 + Bsz)
+    obs, act, nobs, rew, term = T.synthetic_atari_batch(Bsz, 6, 500 + Bsz)
+    term[0] = 1
+    a = make_agent(B, batch_size=Bsz, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, double_dqn=ddqn)
+    a.set_params(p0, "qnet")
+    a.set_params(T.init_params(shapes, 41 + Bsz), "qnet_tgt")
+    ref = O.DqnOracle(O.cnn_cfg(6), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, double_dqn=ddqn)
+    ref.q_tgt[:] = T.init_params(shapes, 41 + Bsz)
+    rec = a.update_on_batch(obs, act, nobs, rew, term)
+    r = ref.update(obs, act, nobs, rew, term, probe=True)
+    assert rel(a.probe("q_pred_all", Bsz * 6), r["q_pred_all"].ravel()) < QTOL
+    assert rel(a.probe("pred", Bsz), r["pred"]) < QTOL and rel(a.probe("tgt", Bsz), r["tgt"]) < QTOL
+    assert abs(rec["loss"] - r["loss"]) <= QTOL * abs(r["loss"]) + 1e-9
+    assert_grads_close(a.get_params("grad"), r["grads"], shapes)
+    assert rel(a.qvalues(obs[:1]), O.net_forward(O.cnn_cfg(6), a.get_params("qnet"), obs[:1])) < QTOL
+    a.close()

@@ -31,8 +31,20 @@ namespace {
 #endif
 // measured on MI355X (profiles/): conv3 fwd 27.1->25.4us, l1 dX 22.7->17.1us, conv3 dX 32.2->31.3us with 2 teams; the
 // other launches already have >= 2.5 workgroups per CU and lose (conv2 dX 37.9->49.6us)
-constexpr int TEAMS_FWD_C2 = 1, TEAMS_FWD_C3 = BDR_TEAMS, TEAMS_FWD_L1 = 1, TEAMS_DX_L1 = BDR_TEAMS, TEAMS_DX_C3 = BDR_TEAMS,
-              TEAMS_DX_C2 = 1;
+#ifndef BDR_TEAMS_FWD_C3
+#define BDR_TEAMS_FWD_C3 BDR_TEAMS
+#endif
+#ifndef BDR_TEAMS_DX_L1
+#define BDR_TEAMS_DX_L1 BDR_TEAMS
+#endif
+#ifndef BDR_TEAMS_DX_C3
+#define BDR_TEAMS_DX_C3 BDR_TEAMS
+#endif
+#ifndef BDR_TEAMS_FWD_L1
+#define BDR_TEAMS_FWD_L1 1
+#endif
+constexpr int TEAMS_FWD_C2 = 1, TEAMS_FWD_C3 = BDR_TEAMS_FWD_C3, TEAMS_FWD_L1 = BDR_TEAMS_FWD_L1, TEAMS_DX_L1 = BDR_TEAMS_DX_L1,
+              TEAMS_DX_C3 = BDR_TEAMS_DX_C3, TEAMS_DX_C2 = 1;
 
 // ================================================================================================
 // head: l1 finish + l2, one wave per (row, instance)

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--loss", default="SmoothL1", choices=["SmoothL1", "Mse"])
     ap.add_argument("--double-dqn", action="store_true")
     ap.add_argument("--sync-interval", type=int, default=10, help="opt steps between RCCL parameter averaging (N>1)")
+    ap.add_argument("--per", action="store_true", help="prioritized replay (PerConfig defaults) instead of uniform sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--profile-steps", type=int, default=30)
@@ -83,7 +84,8 @@ def main():
         return bytes(t.tolist())
 
     # replay shard: 1M transitions of synthetic 84x84x4 u8 frames per GPU, own StdRng stream
-    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=args.capacity, seed=B.shard_seed(42, rank)),
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=args.capacity, seed=B.shard_seed(42, rank),
+                                                          per_config=B.PerConfig() if args.per else None),
                               (4, 1, 84, 84), "uint8", device=local_rank)
     rb.fill_synthetic(args.capacity, seed=rank, kind=0, n_actions=N_ACTIONS)
     cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=N_ACTIONS),
@@ -163,7 +165,8 @@ def main():
                   "dtype": "f32", "data": "synthetic",
                   "config": {"workload": f"synthetic Atari DQN Nature-CNN, replay {args.capacity} u8 transitions/GPU, batch {args.batch}/GPU",
                              "batch_size": args.batch, "replay_capacity": args.capacity, "n_actions": N_ACTIONS,
-                             "critic_loss": args.loss, "double_dqn": args.double_dqn, "optimizer": "Adam lr=1e-4",
+                             "critic_loss": args.loss, "double_dqn": args.double_dqn, "prioritized_replay": bool(args.per),
+                             "optimizer": "Adam lr=1e-4",
                              "soft_update_interval": 10000, "tau": 1.0,
                              "parallelism": f"dp{world} (replica + replay shard per GPU"
                                             + (f", parameter all-reduce every {args.sync_interval} opts over {exch.backend})" if world > 1 else ")"),

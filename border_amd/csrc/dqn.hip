@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
 struct DqnCnn : bdr_agent {
     bdr_dqn_config cfg;
     hipStream_t side = nullptr;          // weight-gradient kernels run here, concurrently with the dX chain
+    hipStream_t aux = nullptr;           // prioritized-replay tree updates (created on first use)
     hipEvent_t ev_fork[4] = {nullptr}, ev_join = nullptr;
     bool overlap = true;
     Arena ar;
@@ -427,8 +428,6 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     t.weight = weight; t.td_abs = a->td_abs;
     t.has_clip = c.has_clip_td_err; t.clip_min = (float)c.clip_td_err_min; t.clip_max = (float)c.clip_td_err_max;
     BDR_TRY(forward(a, inst, c.double_dqn ? 3 : 2, B, &t));   // the TD step rides on the head kernel
-    // dqn/base.rs:143: buffer.update_priority(&ixs, &Some(td_errs)); independent of the backward kernels
-    if (per_buffer && weight) { Bracket br(a, "per_update"); BDR_TRY(replay_update_priority_on_stream(per_buffer, B, a->td_abs, a->stream)); }
 
     // Backward.  The input-gradient chain (dX of l1 -> conv3 -> conv2) is the critical path; every
     // weight-gradient kernel only needs the dY produced one link earlier, so those run on a second
@@ -443,7 +442,19 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         return BDR_OK;
     };
     const DwPlan pl = dw_plan(a->B);   // buffer layout follows the allocated batch capacity
-    BDR_TRY(fork(0));                  // dh1, dq ready
+    BDR_TRY(fork(0));                  // dh1, dq, td_abs ready
+    // dqn/base.rs:143: buffer.update_priority(&ixs, &Some(td_errs)).  Nothing in this update depends on it, so it runs
+    // on the weight-gradient stream; the next batch() waits for it through the buffer's `written` event.
+    if (per_buffer && weight) {
+        hipStream_t ps = a->stream;
+        if (ov) {   // own stream: the weight-gradient stream is already as long as the dX chain
+            if (!a->aux) BDR_HIP(hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking));
+            BDR_HIP(hipStreamWaitEvent(a->aux, a->ev_fork[0], 0));
+            ps = a->aux;
+        }
+        Bracket br(a, "per_update");
+        BDR_TRY(replay_update_priority_on_stream(per_buffer, B, a->td_abs, ps));
+    }
     HeadBwdArgs hb{a->h1[0], a->dq, act, act_bytes, a->loss_row, a->grad + ar.w5, a->grad + ar.b5, a->loss, B, ar.A};
     { Bracket br(a, "head_bwd"); LAUNCH_ON(sd, k_head_bwd, dim3(2 * ar.A + 1), hb); }
     {
@@ -659,6 +670,7 @@ DqnCnn::~DqnCnn()
     (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
     for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (aux) (void)hipStreamDestroy(aux);
     if (side) (void)hipStreamDestroy(side);
 }
 

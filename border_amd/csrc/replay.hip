@@ -525,12 +525,10 @@ int32_t bdr_replay_per_info(bdr_replay* r, bdr_per_info* out)
     BDR_REQUIRE(r->per, "PER is not enabled on this buffer");
     BDR_HIP(hipSetDevice(r->device));
     per_info(r->per, out);
-    float root[3];
-    BDR_TRY(per_read(r->per, 0, &root[0], 1, r->stream));
-    float t2[2];
-    BDR_TRY(per_read(r->per, 1, t2, 2, r->stream)); root[1] = t2[1];
-    BDR_TRY(per_read(r->per, 2, t2, 2, r->stream)); root[2] = t2[1];
-    out->total = root[0]; out->min_p = root[1]; out->max_p = root[2];   // transformed (p+eps)^alpha domain
+    float total = 0.f, mm[2];
+    BDR_TRY(per_read(r->per, 0, &total, 1, r->stream));
+    BDR_TRY(per_read(r->per, 1, mm, 2, r->stream));
+    out->total = total; out->min_p = mm[0]; out->max_p = mm[1];   // transformed (p+eps)^alpha domain
     return BDR_OK;
 }
 

@@ -146,7 +146,7 @@ BDR_API int32_t bdr_replay_update_priority(bdr_replay* r, uint64_t n, const uint
 BDR_API int32_t bdr_replay_batch_weights(bdr_replay* r, uint64_t n, float* w_out);
 
 /* Introspection for parity tests: scheduler state, SumTree::{total,max}, the raw arrays
- * (what: 0 sum tree [2*capacity-1] in the reference's layout, 1 min / 2 max tournament trees), SumTree::get. */
+ * (what: 0 sum tree [2*capacity-1] in the reference's layout, 1 {min over [0,n_samples), max} as two floats), SumTree::get. */
 typedef struct { uint64_t n_samples, n_opts; float beta, total, max_p, min_p; } bdr_per_info;
 BDR_API int32_t bdr_replay_per_info(bdr_replay* r, bdr_per_info* out);
 BDR_API int32_t bdr_replay_per_read(bdr_replay* r, int32_t what, float* out, uint64_t n);

@@ -4,6 +4,10 @@
                           Agent::opt; warmup_period = 0, opt_interval = 1) and the gating / timing
                           of Trainer::train_step (:197-228): every record_agent_info_interval-th
                           step is opt_with_record, the timer wraps opt*() only.
+  Trainer.train           trainer.rs:267-327: the online loop - Sampler::sample_and_push (trainer/sampler.rs:99-144:
+                          Policy::sample on the device, env step, SimpleStepProcessor, push) then train_step.
+  SimpleStepProcessor     generic_replay_buffer/step_proc.rs:62-137.
+  SyntheticEnv            the benchmark's stand-in environment (envs stay in the caller).
   ParamExchange           the N>1 replacement of border-async-trainer's learner->actors model
                           channel (async_trainer/base.rs:268-272): one replica per GPU, local replay
                           shard, parameter averaging every sync_interval opt steps over RCCL.
@@ -27,6 +31,89 @@ class TrainerConfig:
     record_agent_info_interval: int = 0   # 0: never (the reference default is usize::MAX-like "0 => unset")
     record_compute_cost_interval: int = 0
     warmup_period: int = 0
+
+
+@dataclass
+class Step:
+    """border-core/src/base/step.rs:68-92 (single-process env: every field has one row)."""
+    act: np.ndarray
+    obs: np.ndarray
+    reward: np.ndarray          # f32 [1]
+    is_terminated: np.ndarray   # i8 [1]
+    is_truncated: np.ndarray    # i8 [1]
+    init_obs: "np.ndarray | None" = None
+
+    def is_done(self) -> bool:  # step.rs:136-138
+        return bool(self.is_terminated[0] == 1 or self.is_truncated[0] == 1)
+
+
+class SyntheticEnv:
+    """Stand-in for `Env` (border-core/src/base/env.rs:45-181): i.i.d. observations from a seeded generator, rewards
+    and episode ends independent of the action.  obs rows have the replay buffer's row type."""
+
+    def __init__(self, obs_shape, obs_dtype, seed: int = 0, p_term: float = 0.02, p_trunc: float = 0.0):
+        self.obs_shape, self.obs_dtype = tuple(obs_shape), np.dtype(obs_dtype)
+        self.rng = np.random.default_rng(seed)
+        self.p_term, self.p_trunc = p_term, p_trunc
+
+    def _obs(self):
+        if self.obs_dtype == np.uint8:
+            return self.rng.integers(0, 256, (1,) + self.obs_shape, dtype=np.uint8)
+        return self.rng.standard_normal((1,) + self.obs_shape).astype(self.obs_dtype)
+
+    def reset(self, is_done=None):
+        return self._obs()
+
+    def step_with_reset(self, act) -> Step:     # env.rs:137-161: the step; on done, init_obs = reset()
+        obs = self._obs()
+        rew = np.array([self.rng.choice([-1.0, 0.0, 1.0], p=[0.05, 0.9, 0.05])], np.float32)
+        term = np.array([1 if self.rng.random() < self.p_term else 0], np.int8)
+        trunc = np.array([1 if self.rng.random() < self.p_trunc else 0], np.int8)
+        st = Step(np.asarray(act), obs, rew, term, trunc)
+        if st.is_done():
+            st.init_obs = self.reset()
+        return st
+
+
+class SimpleStepProcessor:
+    """generic_replay_buffer/step_proc.rs:62-137: (prev_obs, act, obs, ...) transitions; after a terminal step the
+    next transition starts from init_obs."""
+
+    def __init__(self):
+        self.prev_obs = None
+
+    def reset(self, init_obs):
+        self.prev_obs = init_obs
+
+    def process(self, step: Step):
+        assert len(step.obs) == 1
+        if self.prev_obs is None:
+            raise RuntimeError("prev_obs is not set. Forgot to call reset()?")
+        obs, self.prev_obs = self.prev_obs, step.obs
+        if step.is_done():
+            assert step.init_obs is not None, "Failed to unwrap init_obs"
+            self.prev_obs = step.init_obs
+        return obs, step.act, step.obs, step.reward, step.is_terminated, step.is_truncated
+
+
+class Sampler:
+    """trainer/sampler.rs:99-144."""
+
+    def __init__(self, env, step_proc):
+        self.env, self.step_processor, self.prev_obs = env, step_proc, None
+
+    def sample_and_push(self, agent, buffer):
+        if self.prev_obs is None:
+            self.prev_obs = self.env.reset(None)
+            self.step_processor.reset(self.prev_obs.copy())
+        act = agent.sample(self.prev_obs)                       # Policy::sample on the device
+        step = self.env.step_with_reset(act)
+        is_done = step.is_done()
+        self.prev_obs = step.init_obs.copy() if is_done else step.obs.copy()
+        buffer.push(*self.step_processor.process(step))
+        if is_done:
+            self.step_processor.reset(self.prev_obs.copy())
+        return step
 
 
 class Trainer:
@@ -57,6 +144,25 @@ class Trainer:
     def average_opt_time_ms(self):
         """trainer.rs:164-174 (host-side enqueue time unless the step synchronised)."""
         return 1000.0 * self.timer_for_opt_steps / max(1, self.opt_steps_counter)
+
+    def train(self, env, step_proc, agent, buffer, on_step=None):
+        """trainer.rs:267-327 without recorder / evaluator sinks: sample_and_push, then train_step, until max_opts.
+        `on_step(step, record, is_opt)` observes every iteration (tests)."""
+        sampler = Sampler(env, step_proc)
+        agent.train()
+        self.timer_for_samples = 0.0
+        while True:
+            t0 = time.perf_counter()
+            step = sampler.sample_and_push(agent, buffer)
+            self.timer_for_samples += time.perf_counter() - t0
+            self.env_steps += 1
+            rec, is_opt = self.train_step(agent, buffer)
+            if rec is not None:
+                self.records.append((self.opt_steps, rec))
+            if on_step is not None:
+                on_step(step, rec, is_opt)
+            if self.opt_steps == self.config.max_opts:
+                return
 
     def train_offline(self, agent, buffer, exchange=None):
         """trainer.rs:330-384 without recorder / evaluator sinks (out of scope: SURVEY.md 2.1 #4)."""

@@ -50,9 +50,15 @@ def _worker(rank, world, port, out):
     c = FakeAgent(base + rank)
     ex.broadcast(c, root=0)
     ok_bcast = bool((c.get_params() == base).all())
+    # (v) the data-plane ladder: without a GPU neither RCCL communicator can come up, so every rank must land on
+    #     host staging TOGETHER (here rank 1 additionally "fails" one step earlier than rank 0 would)
+    lad = ParamExchange.with_fallback(world, rank, 3, 0, lambda b: b if b is not None else bytes(128))
+    d = FakeAgent(base * (rank + 1))
+    lad.average(d)
+    ok_ladder = lad.backend == "torch" and bool(np.allclose(d.get_params(), expect, rtol=1e-6, atol=1e-7))
     # (iv) distinct replay streams per shard
     ix = O.StdRng.seed_from_u64(shard_seed(42, rank)).sample_indices(1_000_000, 8).tolist()
-    out.put((rank, ok_identity, ok_mean, ok_bcast, ix))
+    out.put((rank, ok_identity, ok_mean, ok_bcast and ok_ladder, ix))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -299,6 +299,12 @@ __device__ unsigned long long* g_igemm_trace;
 #else
 #define IGEMM_TP(slot) do { } while (0)
 #endif
+#ifdef IGEMM_TRACE2  // tools/probes only: cycles of one wave inside the k loop, per phase (s_memtime)
+__device__ unsigned long long* g_igemm_phase;
+#define IGEMM_PH(var) const long long var = clock64()
+#else
+#define IGEMM_PH(var) do { } while (0)
+#endif
 
 template <class P, int TEAMS = 1>
 __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P::Args args)
@@ -451,17 +457,36 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
     __syncthreads();
     IGEMM_TP(1);
     int cur = 0;
+#ifdef IGEMM_TRACE2
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+#endif
     auto step = [&](auto set, int it) {   // set = (it+1)&1: holds tile it+1; refilled with tile it+3
+        IGEMM_PH(t_a);
+#ifdef IGEMM_TRACE2
+        long long t_b = t_a, t_c = t_a, t_d = t_a;
+#endif
         if (it < my_n) {                  // team-uniform
             const float* As = smem + cur * STAGE;
             const int k3 = tile(it + 3);
             mfma_ktile<P::TM, P::TN, LDB, P::B_TR>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc, [&](int u) {
+#ifdef IGEMM_TRACE2
+                if (u == 0) t_b = clock64();
+                if (u == 3) t_d = clock64();
+#endif
                 if (u == 0) { if (!(IGEMM_ABL & 2)) { commit_a(set, cur ^ 1); commit_b(set, cur ^ 1); } }   // tile it+1 -> idle stage
                 else if (u == 1) { if (!(IGEMM_ABL & 1)) prefetch_a(set, k3); }                       // tile it+3 global loads
                 else if (u == 2) { if (!(IGEMM_ABL & 1)) prefetch_b(set, k3); }
+#ifdef IGEMM_TRACE2
+                if (u == 0) t_c = clock64();
+#endif
             });
         }
+        IGEMM_PH(t_e);
         if (!(IGEMM_ABL & 4)) __syncthreads();
+#ifdef IGEMM_TRACE2
+        const long long t_f = clock64();
+        ph[0] += t_b - t_a; ph[1] += t_c - t_b; ph[2] += t_d - t_c; ph[3] += t_e - t_d; ph[4] += t_f - t_e; ph[5] += 1;
+#endif
         cur ^= 1;
     };
     for (int it = 0; it < iters; it += 2) {
@@ -469,6 +494,12 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
         if (it + 1 < iters) step(Set0{}, it + 1);
     }
     IGEMM_TP(2);
+#ifdef IGEMM_TRACE2
+    if (threadIdx.x == 0 && g_igemm_phase) {
+        unsigned long long* o = g_igemm_phase + ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+        for (int q = 0; q < 6; ++q) o[q] = (unsigned long long)ph[q];
+    }
+#endif
     if constexpr (TEAMS == 2) {   // acc(team 0) += acc(team 1), through team 1's (now idle) stages
         constexpr int PER_WAVE = P::TM * P::TN * 16 * 64;
         static_assert(2 * STAGE >= NW * PER_WAVE, "team reduction buffer");

@@ -338,7 +338,7 @@ def test_n_updates_per_opt_and_soft_update_counter(B):
     a.close(); rb.close()
 
 
-@pytest.mark.parametrize("Bsz,ddqn", [(1, False), (3, True), (33, False), (100, True)])
+@pytest.mark.parametrize("Bsz,ddqn", [(1, False), (3, True), (33, False), (100, True), (300, False)])   # 300: conv1-dW workgroups take two images
 def test_ragged_batch_sizes_vs_oracle(B, Bsz, ddqn):
     """Batch sizes that are not multiples of any tile (rows 81*B / 49*B / B, one image per conv1-dW workgroup, two
     rows per head workgroup): Q-values, targets, loss and gradients against the C oracle."""

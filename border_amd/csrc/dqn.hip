@@ -52,23 +52,21 @@ constexpr int TEAMS_FWD_C2 = 1, TEAMS_FWD_C3 = BDR_TEAMS_FWD_C3, TEAMS_FWD_L1 = 
 struct HeadArgs {
     const float* p1[MAXZ];   // l1 split-K partials [S][B][512]
     const float* b4[MAXZ];
-    const float* w5[MAXZ];   // [512][A]
+    const float* w5[MAXZ];   // [A][512]
     const float* b5[MAXZ];
     float* h1[MAXZ];         // [B][512] post-relu
     float* q[MAXZ];          // [B][A]
     int B, A, S;
 };
 
+// TD step of a row, executed by k_head right after the row's Q-values: instance 0 = qnet(obs), 1 = qnet_tgt(next_obs),
+// 2 = qnet(next_obs) when double_dqn (dqn/base.rs:91-103); the Q rows and h1 never leave the workgroup.
 struct TdArgs {
-    const float* q_on;     // [B][A]  qnet(obs)
-    const float* q_tg;     // [B][A]  qnet_tgt(next_obs)
-    const float* q_on_next;  // [B][A] qnet(next_obs) (double DQN) or nullptr
+    int double_dqn;
     const uint8_t* act;    // [B] rows of act_bytes; first 8 bytes = i64 action
     int act_bytes;
     const float* reward;
     const int8_t* term;
-    const float* h1;       // [B][512] online net, post-relu
-    const float* w5;       // [512][A] online
     float* dh1;            // [B][512]
     float* dq;             // [B]   dL/dQ(s,a) (already divided by B)
     float* pred;           // [B]
@@ -169,7 +167,7 @@ __global__ __launch_bounds__(64 * HEAD_ROWS * MAXZ) void k_head(HeadArgs a, TdAr
     if (z != 0 || !valid) return;
     // ---- TD of this row (instance 0 = qnet(obs), 1 = qnet_tgt(next_obs), 2 = qnet(next_obs) for double DQN)
     const float* q_tg = sq[r][1];
-    const float* sel = t.q_on_next ? sq[r][2] : q_tg;
+    const float* sel = t.double_dqn ? sq[r][2] : q_tg;
     // argmax over actions: first maximal index (at::argmax), lanes >= A hold -inf
     float v = lane < A ? sel[lane] : -INFINITY;
     int idx = lane;
@@ -421,9 +419,9 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     NetInst inst[3] = {{obs, a->q, 0}, {next_obs, a->q_tgt, 1}, {next_obs, a->q, 2}};
 
     TdArgs t{};
-    t.q_on = a->qv[0]; t.q_tg = a->qv[1]; t.q_on_next = c.double_dqn ? a->qv[2] : nullptr;
+    t.double_dqn = c.double_dqn;
     t.act = act; t.act_bytes = act_bytes; t.reward = reward; t.term = term;
-    t.h1 = a->h1[0]; t.w5 = a->q + ar.w5; t.dh1 = a->dh1; t.dq = a->dq; t.pred = a->pred; t.tgt = a->tgt;
+    t.dh1 = a->dh1; t.dq = a->dq; t.pred = a->pred; t.tgt = a->tgt;
     t.loss_row = a->loss_row; t.B = B; t.A = ar.A; t.gamma = (float)c.discount_factor; t.loss_kind = c.critic_loss;
     t.weight = weight; t.td_abs = a->td_abs;
     t.has_clip = c.has_clip_td_err; t.clip_min = (float)c.clip_td_err_min; t.clip_max = (float)c.clip_td_err_max;

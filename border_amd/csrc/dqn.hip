@@ -6,9 +6,10 @@
 //   replay: ChaCha12 indices + row gather                       (replay.hip)
 //   fwd   : conv1..conv3, l1 (split-K) for {online(obs), target(next_obs)[, online(next_obs)]}
 //           in ONE launch per layer (blockIdx.z = network instance), FP32 MFMA implicit GEMM
-//   head  : l1 finish (+bias, relu) + l2 (wave dot products)     -> Q-values
-//   td    : gather Q(s,a), max/argmax target, r + (1-term)*gamma*q', Huber/MSE, dL/dQ, dL/dh1
-//   bwd   : l2 grads, l1 dW/dX, conv3 dW/dX, conv2 dW/dX, conv1 dW   (FP32 MFMA)
+//           (conv1 on the bf16 matrix cores with exact operands)
+//   head  : l1 finish (+bias, relu) + l2 (wave dot products) -> Q-values, and in the same launch the TD step:
+//           gather Q(s,a), max/argmax target, r + (1-term)*gamma*q', Huber/MSE (PER: importance-weighted), dL/dQ, dL/dh1
+//   bwd   : l2 grads, l1 dW/dX, conv3 dW/dX, conv2 dW/dX (FP32 MFMA), conv1 dW (bf16, exact operands); PER: tree update
 //   adam  : fused p,g,m,v pass over the flat parameter arena (libtorch Adam::step formula)
 //   track : tau*src + (1-tau)*dst every soft_update_interval opts (util.rs:31-45)
 #include <algorithm>
@@ -29,8 +30,10 @@ namespace {
 #ifndef BDR_TEAMS
 #define BDR_TEAMS 2
 #endif
-// measured on MI355X (profiles/): conv3 fwd 27.1->25.4us, l1 dX 22.7->17.1us, conv3 dX 32.2->31.3us with 2 teams; the
-// other launches already have >= 2.5 workgroups per CU and lose (conv2 dX 37.9->49.6us)
+// measured on MI355X when introduced: conv3 fwd 27.1->25.4us, l1 dX 22.7->17.1us, conv3 dX 32.2->31.3us with 2 teams; the
+// other launches already have >= 2.5 workgroups per CU and lose (conv2 dX 37.9->49.6us).  With the current pipeline the
+// per-kernel difference is within noise, but the 8-wave form still co-runs better with the weight-gradient stream
+// (A/B in the pipeline: 3 760 vs 3 695 opt-steps/s for conv3 dX).
 #ifndef BDR_TEAMS_FWD_C3
 #define BDR_TEAMS_FWD_C3 BDR_TEAMS
 #endif

@@ -21,48 +21,126 @@ int32_t dqn_mlp_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out)
 int32_t dqn_cnn_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
 int32_t dqn_mlp_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
 
-// named-tensor dump: "BDRP" u32 version, u32 count, then per tensor: u32 name_len, name, u32 ndim,
-// u64 dims[], f32 data (reference variable names / layouts)
+// Checkpoint container: safetensors (8-byte little-endian header length, JSON header
+// {"name": {"dtype": "F32", "shape": [...], "data_offsets": [begin, end]}, ...}, raw little-endian data).
+// tch's VarStore::save / load use this format whenever the file name ends in ".safetensors", with the same variable
+// names (c1.weight ... l2.bias, mlp.ln{i}.*, ...) and reference layouts that save_named is given - so files written here
+// load into border-tch-agent's VarStore and vice versa.  (The reference's default file names end in ".pt.tch", a
+// libtorch TorchScript archive, which is not read or written here.)
 int32_t save_named(const std::string& path, const std::vector<NamedTensor>& meta, const float* data, size_t n)
 {
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) return fail(BDR_ERR_IO, "cannot open %s for writing", path.c_str());
-    uint32_t ver = 1, cnt = (uint32_t)meta.size();
-    fwrite("BDRP", 1, 4, f); fwrite(&ver, 4, 1, f); fwrite(&cnt, 4, 1, f);
+    std::string hdr = "{";
     size_t o = 0;
-    for (const auto& t : meta) {
-        uint32_t nl = (uint32_t)t.name.size(), nd = (uint32_t)t.dims.size();
-        fwrite(&nl, 4, 1, f); fwrite(t.name.data(), 1, nl, f); fwrite(&nd, 4, 1, f);
+    for (size_t t = 0; t < meta.size(); ++t) {
         size_t k = 1;
-        for (auto d : t.dims) { fwrite(&d, 8, 1, f); k *= d; }
-        if (o + k > n) { fclose(f); return fail(BDR_ERR_IO, "tensor metadata exceeds the parameter vector"); }
-        fwrite(data + o, 4, k, f);
+        std::string shape;
+        for (size_t d = 0; d < meta[t].dims.size(); ++d) { k *= meta[t].dims[d]; shape += (d ? "," : "") + std::to_string(meta[t].dims[d]); }
+        if (o + k > n) return fail(BDR_ERR_IO, "tensor metadata exceeds the parameter vector");
+        hdr += (t ? "," : "") + std::string("\"") + meta[t].name + "\":{\"dtype\":\"F32\",\"shape\":[" + shape + "],\"data_offsets\":[" +
+               std::to_string(o * 4) + "," + std::to_string((o + k) * 4) + "]}";
         o += k;
     }
-    const bool ok = fflush(f) == 0 && o == n;
+    hdr += "}";
+    if (o != n) return fail(BDR_ERR_IO, "tensor metadata does not cover the parameter vector");
+    while (hdr.size() % 8) hdr += ' ';   // the data section stays 8-byte aligned
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return fail(BDR_ERR_IO, "cannot open %s for writing", path.c_str());
+    const uint64_t hl = hdr.size();
+    bool ok = fwrite(&hl, 8, 1, f) == 1 && fwrite(hdr.data(), 1, hdr.size(), f) == hdr.size() && fwrite(data, 4, n, f) == n;
+    ok = fflush(f) == 0 && ok;
     fclose(f);
     return ok ? BDR_OK : fail(BDR_ERR_IO, "write to %s failed", path.c_str());
 }
+
+namespace {
+// the subset of JSON a safetensors header uses
+struct StEntry { std::string dtype; std::vector<uint64_t> shape; uint64_t begin = 0, end = 0; };
+struct JsonCur {
+    const std::string& s; size_t i = 0; bool ok = true;
+    explicit JsonCur(const std::string& str) : s(str) {}
+    void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i; }
+    bool eat(char c) { ws(); if (i < s.size() && s[i] == c) { ++i; return true; } return false; }
+    std::string str()
+    {
+        std::string o;
+        if (!eat('"')) { ok = false; return o; }
+        while (i < s.size() && s[i] != '"') { if (s[i] == '\\' && i + 1 < s.size()) ++i; o += s[i++]; }
+        if (i >= s.size()) ok = false; else ++i;
+        return o;
+    }
+    uint64_t num() { ws(); uint64_t v = 0; bool any = false; while (i < s.size() && s[i] >= '0' && s[i] <= '9') { v = v * 10 + (uint64_t)(s[i++] - '0'); any = true; } ok = ok && any; return v; }
+    void skip()   // any value
+    {
+        ws();
+        if (i >= s.size()) { ok = false; return; }
+        if (s[i] == '"') { str(); return; }
+        if (s[i] == '{' || s[i] == '[') {
+            const char close = s[i] == '{' ? '}' : ']';
+            ++i;
+            if (eat(close)) return;
+            do { if (close == '}') { str(); if (!eat(':')) ok = false; } skip(); } while (ok && eat(','));
+            if (!eat(close)) ok = false;
+            return;
+        }
+        while (i < s.size() && s[i] != ',' && s[i] != '}' && s[i] != ']') ++i;
+    }
+};
+bool parse_safetensors_header(const std::string& h, std::vector<std::pair<std::string, StEntry>>& out)
+{
+    JsonCur c(h);
+    if (!c.eat('{')) return false;
+    if (c.eat('}')) return true;
+    do {
+        const std::string name = c.str();
+        if (!c.ok || !c.eat(':')) return false;
+        if (name == "__metadata__") { c.skip(); continue; }
+        StEntry e;
+        if (!c.eat('{')) return false;
+        do {
+            const std::string key = c.str();
+            if (!c.ok || !c.eat(':')) return false;
+            if (key == "dtype") e.dtype = c.str();
+            else if (key == "shape") { if (!c.eat('[')) return false; if (!c.eat(']')) { do e.shape.push_back(c.num()); while (c.eat(',')); if (!c.eat(']')) return false; } }
+            else if (key == "data_offsets") { if (!c.eat('[')) return false; e.begin = c.num(); if (!c.eat(',')) return false; e.end = c.num(); if (!c.eat(']')) return false; }
+            else c.skip();
+        } while (c.ok && c.eat(','));
+        if (!c.ok || !c.eat('}')) return false;
+        out.emplace_back(name, e);
+    } while (c.ok && c.eat(','));
+    return c.ok && c.eat('}');
+}
+}  // namespace
 
 int32_t load_named(const std::string& path, const std::vector<NamedTensor>& meta, float* data, size_t n)
 {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return fail(BDR_ERR_IO, "cannot open %s", path.c_str());
-    char magic[4]; uint32_t ver = 0, cnt = 0;
-    bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "BDRP", 4) == 0 && fread(&ver, 4, 1, f) == 1 &&
-              fread(&cnt, 4, 1, f) == 1 && cnt == meta.size();
+    uint64_t hl = 0;
+    std::string hdr;
+    bool ok = fread(&hl, 8, 1, f) == 1 && hl >= 2 && hl < (1ull << 26);
+    if (ok) { hdr.resize(hl); ok = fread(&hdr[0], 1, hl, f) == hl; }
+    std::vector<std::pair<std::string, StEntry>> ents;
+    ok = ok && parse_safetensors_header(hdr, ents);
+    if (!ok) { fclose(f); return fail(BDR_ERR_IO, "%s is not a safetensors file", path.c_str()); }
     size_t o = 0;
-    for (uint32_t t = 0; ok && t < cnt; ++t) {
-        uint32_t nl = 0, nd = 0; char name[128];
-        ok = fread(&nl, 4, 1, f) == 1 && nl < 128 && fread(name, 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 8;
-        ok = ok && std::string(name, nl) == meta[t].name;
+    for (const auto& t : meta) {   // every variable of the model must be present with its reference shape (extra entries are ignored)
+        const StEntry* e = nullptr;
+        for (const auto& kv : ents) if (kv.first == t.name) { e = &kv.second; break; }
         size_t k = 1;
-        for (uint32_t d = 0; ok && d < nd; ++d) { uint64_t x = 0; ok = fread(&x, 8, 1, f) == 1; k *= x; }
-        ok = ok && o + k <= n && fread(data + o, 4, k, f) == k;
+        for (auto d : t.dims) k *= d;
+        if (!e) { fclose(f); return fail(BDR_ERR_IO, "%s: variable '%s' is missing", path.c_str(), t.name.c_str()); }
+        if (e->dtype != "F32" || e->shape != t.dims || e->end - e->begin != k * 4 || o + k > n) {
+            fclose(f);
+            return fail(BDR_ERR_IO, "%s: variable '%s' has a different dtype or shape", path.c_str(), t.name.c_str());
+        }
+        if (fseek(f, (long)(8 + hl + e->begin), SEEK_SET) != 0 || fread(data + o, 4, k, f) != k) {
+            fclose(f);
+            return fail(BDR_ERR_IO, "%s: short read of '%s'", path.c_str(), t.name.c_str());
+        }
         o += k;
     }
     fclose(f);
-    if (!ok || o != n) return fail(BDR_ERR_IO, "%s is not a matching parameter file", path.c_str());
+    if (o != n) return fail(BDR_ERR_IO, "%s does not cover the model's parameters", path.c_str());
     return BDR_OK;
 }
 }  // namespace bdr

@@ -240,7 +240,7 @@ class Dqn:
     def save_params(self, path: str):
         os.makedirs(path, exist_ok=True)
         _lib.check(_lib.lib().bdr_agent_save_params(self._h, path.encode()))
-        return [os.path.join(path, "qnet.bdr"), os.path.join(path, "qnet_tgt.bdr")]
+        return [os.path.join(path, "qnet.safetensors"), os.path.join(path, "qnet_tgt.safetensors")]
 
     def load_params(self, path: str):
         _lib.check(_lib.lib().bdr_agent_load_params(self._h, path.encode()))

@@ -179,7 +179,7 @@ class Iqn:
     def save_params(self, path: str):
         os.makedirs(path, exist_ok=True)
         _lib.check(_lib.lib().bdr_agent_save_params(self._h, path.encode()))
-        return [os.path.join(path, "iqn.bdr"), os.path.join(path, "iqn_tgt.bdr")]
+        return [os.path.join(path, "iqn.safetensors"), os.path.join(path, "iqn_tgt.safetensors")]
 
     def load_params(self, path: str):
         _lib.check(_lib.lib().bdr_agent_load_params(self._h, path.encode()))

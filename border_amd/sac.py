@@ -171,8 +171,8 @@ class Sac:
         os.makedirs(path, exist_ok=True)
         _lib.check(_lib.lib().bdr_agent_save_params(self._h, path.encode()))
         nc = self.config.n_critics
-        return ([os.path.join(path, f"qnet_{i}.bdr") for i in range(nc)] + [os.path.join(path, f"qnet_tgt_{i}.bdr") for i in range(nc)]
-                + [os.path.join(path, "pi.bdr"), os.path.join(path, "ent_coef.bdr")])
+        return ([os.path.join(path, f"qnet_{i}.safetensors") for i in range(nc)] + [os.path.join(path, f"qnet_tgt_{i}.safetensors") for i in range(nc)]
+                + [os.path.join(path, "pi.safetensors"), os.path.join(path, "ent_coef.safetensors")])
 
     def load_params(self, path: str):
         _lib.check(_lib.lib().bdr_agent_load_params(self._h, path.encode()))

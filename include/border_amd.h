@@ -291,8 +291,11 @@ BDR_API int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* i
  * host that already owns a communicator (e.g. torch.distributed) can reduce it in place. */
 BDR_API int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint64_t* n_floats);
 
-/* Agent::save_params / load_params (dqn/base.rs:345-371): writes/reads `qnet.bdr` and
- * `qnet_tgt.bdr` (named f32 tensors, reference variable names) under dir. */
+/* Agent::save_params / load_params (dqn/base.rs:345-371; iqn/base.rs:328-356; sac/base.rs:313-345): writes / reads
+ * `qnet.safetensors`, `qnet_tgt.safetensors` (IQN: iqn, iqn_tgt; SAC: pi, qnet_{i}, qnet_tgt_{i}, ent_coef) under dir:
+ * safetensors files (the container tch's VarStore uses for *.safetensors paths) holding the reference's variable
+ * names in the reference's layouts (OIHW conv weights, [out,in] linear weights).  Loading requires every variable of
+ * the model with its shape and dtype F32; extra entries are ignored. */
 BDR_API int32_t bdr_agent_save_params(bdr_agent* a, const char* dir);
 BDR_API int32_t bdr_agent_load_params(bdr_agent* a, const char* dir);
 

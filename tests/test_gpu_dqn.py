@@ -361,3 +361,45 @@ def test_ragged_batch_sizes_vs_oracle(B, Bsz, ddqn):
     assert_grads_close(a.get_params("grad"), r["grads"], shapes)
     assert rel(a.qvalues(obs[:1]), O.net_forward(O.cnn_cfg(6), a.get_params("qnet"), obs[:1])) < QTOL
     a.close()
+
+
+def test_checkpoints_are_safetensors_with_reference_names(B, tmp_path):
+    """save_params / load_params (dqn/base.rs:345-371) use the safetensors container tch's VarStore reads and writes
+    for *.safetensors paths: the official `safetensors` package must read what the library wrote (reference variable
+    names, OIHW / [out,in] layouts) and the library must load what the package wrote (any key order, extra metadata)."""
+    from safetensors.numpy import load_file, save_file
+    from oracle import torch_ref as T
+    shapes = T.cnn_shapes(6)
+    names = ["c1.weight", "c1.bias", "c2.weight", "c2.bias", "c3.weight", "c3.bias", "l1.weight", "l1.bias", "l2.weight", "l2.bias"]
+    a = make_agent(B, batch_size=4)
+    p0, p1 = T.init_params(shapes, 61), T.init_params(shapes, 62)
+    a.set_params(p0, "qnet"); a.set_params(p1, "qnet_tgt")
+    files = a.save_params(str(tmp_path))
+    assert [os.path.basename(f) for f in files] == ["qnet.safetensors", "qnet_tgt.safetensors"]
+    for f, p in zip(files, (p0, p1)):
+        d = load_file(f)
+        assert sorted(d) == sorted(names)
+        o = 0
+        for nm, sh in zip(names, shapes):
+            n = int(np.prod(sh))
+            assert d[nm].dtype == np.float32 and d[nm].shape == tuple(sh)
+            assert (d[nm].ravel() == p[o:o + n]).all(), nm
+            o += n
+    # the other direction: files produced by the official writer (sorted keys, metadata entry)
+    q0, q1 = T.init_params(shapes, 63), T.init_params(shapes, 64)
+    for f, q in zip(files, (q0, q1)):
+        o, d = 0, {}
+        for nm, sh in zip(names, shapes):
+            n = int(np.prod(sh))
+            d[nm] = q[o:o + n].reshape(sh).copy()
+            o += n
+        save_file(d, f, metadata={"format": "pt"})
+    a.load_params(str(tmp_path))
+    assert (a.get_params("qnet") == q0).all() and (a.get_params("qnet_tgt") == q1).all()
+    # a file with a wrong shape is rejected
+    bad = {nm: np.zeros(sh, np.float32) for nm, sh in zip(names, shapes)}
+    bad["l2.bias"] = np.zeros(7, np.float32)
+    save_file(bad, files[0])
+    with pytest.raises(B.BdrError):
+        a.load_params(str(tmp_path))
+    a.close()

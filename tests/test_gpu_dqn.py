@@ -403,3 +403,34 @@ def test_checkpoints_are_safetensors_with_reference_names(B, tmp_path):
     with pytest.raises(B.BdrError):
         a.load_params(str(tmp_path))
     a.close()
+
+
+def test_opt_stream_is_deterministic_and_overlap_invariant(B):
+    """200 opt steps over the same synthetic ring from the same initial parameters: bit-identical parameters between
+    two runs, and between the two-stream schedule and the serial one (BDR_NO_OVERLAP=1) - every reduction has a fixed
+    order, so any difference would be a race between the streams."""
+    def run(no_overlap):
+        if no_overlap:
+            os.environ["BDR_NO_OVERLAP"] = "1"
+        else:
+            os.environ.pop("BDR_NO_OVERLAP", None)
+        try:
+            rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=20_000, seed=42), (4, 1, 84, 84), "uint8")
+            rb.fill_synthetic(20_000, seed=3, kind=0, n_actions=6)
+            a = make_agent(B, batch_size=64, critic_loss="SmoothL1", tau=1.0, soft_update_interval=50, param_seed=5)
+            a.train()
+            for _ in range(200):
+                a.opt(rb)
+            a.sync()
+            p, t = a.get_params("qnet"), a.get_params("qnet_tgt")
+            a.close(); rb.close()
+            return p, t
+        finally:
+            os.environ.pop("BDR_NO_OVERLAP", None)
+
+    p1, t1 = run(False)
+    p2, t2 = run(False)
+    p3, t3 = run(True)
+    assert np.isfinite(p1).all()
+    assert (p1 == p2).all() and (t1 == t2).all()
+    assert (p1 == p3).all() and (t1 == t3).all()

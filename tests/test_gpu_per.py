@@ -238,3 +238,37 @@ def test_weighted_update_critic_nature_cnn_vs_aten(B, loss, clip, ddqn):
         assert np.abs(g - gr).max() <= 5e-4 * np.abs(gr).max(), s
         assert np.abs(a.get_params("qnet").astype(np.float64) - t.params()).max() < 0.05 * 1e-4
     a.close()
+
+
+def test_per_opt_stream_is_deterministic_and_overlap_invariant(B):
+    """100 opt steps of the Nature-CNN agent over a PER ring: parameters and the priority tree are bit-identical
+    between two runs and between the three-stream schedule (TD / weight gradients / tree update) and the serial one."""
+    def run(no_overlap):
+        if no_overlap:
+            os.environ["BDR_NO_OVERLAP"] = "1"
+        else:
+            os.environ.pop("BDR_NO_OVERLAP", None)
+        try:
+            rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=5_000, seed=42, per_config=B.PerConfig(n_opts_final=60)),
+                                      (4, 1, 84, 84), "uint8")
+            rb.fill_synthetic(5_000, seed=3, kind=0, n_actions=6)
+            cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=6),
+                                                            opt_config=B.OptimizerConfig.Adam(1e-4)),
+                              device=0, batch_size=32, critic_loss="SmoothL1", tau=1.0, soft_update_interval=40, param_seed=5)
+            a = B.Dqn.build(cfg)
+            a.train()
+            for _ in range(100):
+                a.opt(rb)
+            a.sync()
+            out = a.get_params("qnet"), rb.per_tree(), rb.per_info()["n_opts"]
+            a.close(); rb.close()
+            return out
+        finally:
+            os.environ.pop("BDR_NO_OVERLAP", None)
+
+    p1, t1, n1 = run(False)
+    p2, t2, n2 = run(False)
+    p3, t3, n3 = run(True)
+    assert n1 == n2 == n3 == 100 and np.isfinite(p1).all() and np.isfinite(t1).all()
+    assert (p1 == p2).all() and (t1 == t2).all()
+    assert (p1 == p3).all() and (t1 == t3).all()

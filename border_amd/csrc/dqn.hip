@@ -357,6 +357,75 @@ int32_t ensure_batch(DqnCnn* a, int B)
     return BDR_OK;
 }
 
+// Conv partial reduction and the Adam step in ONE launch (one launch boundary less on the critical path):
+//   blocks [0, reduce_blocks)  : k_reduce_partials3's job for 32 conv-gradient elements each, immediately followed by
+//                                the Adam update of those same elements (the conv layers: 78 k of the 1.69 M parameters);
+//   remaining blocks           : Adam over the rest of the arena (l1, l2), four elements per thread.
+// Element formulas are k_reduce_partials3's and k_adam's, unchanged.
+struct ReduceAdamArgs {
+    Reduce3Args r;
+    float* p; const float* g; float* m; float* v;
+    float* gbase;            // start of the gradient arena (segment gradients live at seg.g = gbase + offset)
+    size_t rest0_4, n4;      // Adam's f32x4 range [rest0_4, n4) = everything behind the conv segments
+    AdamScalars s;
+    int reduce_blocks;
+};
+__device__ __forceinline__ void adam_element(float& p, float g, float& m, float& v, const AdamScalars& s)
+{
+    p *= s.wd_mul;                                // AdamW decoupled decay (1 for Adam)
+    m = m * s.b1 + g * s.omb1;                    // exp_avg.mul_(b1).add_(g, 1-b1)
+    v = v * s.b2 + s.omb2 * g * g;                // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+    const float denom = __fsqrt_rn(v) / s.sqrt_bc2 + s.eps;
+    p = p + s.neg_step * m / denom;               // addcdiv_(exp_avg, denom, -step_size)
+}
+__global__ __launch_bounds__(256) void k_reduce_adam(ReduceAdamArgs a)
+{
+    if ((int)blockIdx.x >= a.reduce_blocks) {
+        const size_t i = a.rest0_4 + (size_t)(blockIdx.x - a.reduce_blocks) * 256 + threadIdx.x;
+        if (i >= a.n4) return;
+        f32x4 pp = reinterpret_cast<f32x4*>(a.p)[i], gg = reinterpret_cast<const f32x4*>(a.g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(a.m)[i], vv = reinterpret_cast<f32x4*>(a.v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pe = pp[j], me = mm[j], ve = vv[j];
+            adam_element(pe, gg[j], me, ve, a.s);
+            pp[j] = pe; mm[j] = me; vv[j] = ve;
+        }
+        reinterpret_cast<f32x4*>(a.p)[i] = pp;
+        reinterpret_cast<f32x4*>(a.m)[i] = mm;
+        reinterpret_cast<f32x4*>(a.v)[i] = vv;
+        return;
+    }
+    __shared__ float red[8][32];
+    const int s_id = (int)blockIdx.x >= a.r.seg[2].wg0 ? 2 : ((int)blockIdx.x >= a.r.seg[1].wg0 ? 1 : 0);
+    const ReduceSeg& sg = a.r.seg[s_id];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = ((int)blockIdx.x - sg.wg0) * 32 + o;
+    float s = 0.f;
+    if (i < sg.n) {
+        int c = grp;
+        for (; c + 24 < sg.chunks; c += 32) {
+            const float v0 = sg.part[(size_t)c * sg.stride + i], v1 = sg.part[(size_t)(c + 8) * sg.stride + i];
+            const float v2 = sg.part[(size_t)(c + 16) * sg.stride + i], v3 = sg.part[(size_t)(c + 24) * sg.stride + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < sg.chunks; c += 8) s += sg.part[(size_t)c * sg.stride + i];
+    }
+    red[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && i < sg.n) {
+        float t = red[0][o];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][o];
+        const float g = i < sg.n_weights ? t * sg.wscale : t;
+        sg.g[i] = g;
+        const size_t e = (size_t)(sg.g - a.gbase) + i;      // the element's index in every arena
+        float pe = a.p[e], me = a.m[e], ve = a.v[e];
+        adam_element(pe, g, me, ve, a.s);
+        a.p[e] = pe; a.m[e] = me; a.v[e] = ve;
+    }
+}
+
 // ---- the forward pass of nz network instances ------------------------------------------------------
 struct NetInst { const uint8_t* x; const float* params; int slot; };
 
@@ -514,17 +583,14 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
                                  k == 0 ? INV255 : 1.0f, wg};
             wg += (nw[k] + nb[k] + 31) / 32;
         }
-        Bracket br(a, "bwd_conv_reduce");
-        hipLaunchKernelGGL(k_reduce_partials3, dim3(wg), dim3(256), 0, a->stream, r);
-        BDR_HIP(hipGetLastError());
-    }
-    // :150 backward_step -> Adam
-    a->adam_step += 1;
-    const AdamScalars s = adam_scalars(c, a->adam_step);
-    const size_t n4 = ar.total / 4;
-    {
-        Bracket br(a, "adam");
-        hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q, a->grad, a->m, a->v, n4, s);
+        // :150 backward_step -> Adam, fused behind the reduction (k_reduce_adam)
+        a->adam_step += 1;
+        ReduceAdamArgs ra{};
+        ra.r = r; ra.p = a->q; ra.g = a->grad; ra.m = a->m; ra.v = a->v; ra.gbase = a->grad;
+        ra.rest0_4 = ar.w4 / 4; ra.n4 = ar.total / 4; ra.s = adam_scalars(c, a->adam_step); ra.reduce_blocks = wg;
+        const unsigned rest_blocks = (unsigned)((ra.n4 - ra.rest0_4 + 255) / 256);
+        Bracket br(a, "reduce_adam");
+        hipLaunchKernelGGL(k_reduce_adam, dim3(wg + rest_blocks), dim3(256), 0, a->stream, ra);
         BDR_HIP(hipGetLastError());
     }
     return BDR_OK;

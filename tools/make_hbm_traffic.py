@@ -12,7 +12,7 @@ import sys
 KEY = {"bdr::k_conv1_bf16": "fwd_conv1", "k_adam": "adam", "k_gather": "sample", "k_igemm<DxC2P>": "bwd_conv2_dx",
        "k_igemm<DxC3P>": "bwd_conv3_dx", "k_igemm<DxL1>": "bwd_l1_dx", "k_igemm<FwdL1>": "fwd_l1", "k_igemm<FwdPC2>": "fwd_conv2",
        "k_igemm<FwdPC3>": "fwd_conv3", "bdr::k_conv1_dw_bf16": "bwd_conv1_dw", "k_igemm_red<DwPC1>": "bwd_conv1_dw", "k_igemm_red<DwPC2>": "bwd_conv2_dw",
-       "k_igemm_red<DwPC3>": "bwd_conv3_dw", "k_igemm_red<DwPL1>": "bwd_l1_dw", "k_reduce_partials3": "bwd_conv_reduce",
+       "k_igemm_red<DwPC3>": "bwd_conv3_dw", "k_igemm_red<DwPL1>": "bwd_l1_dw", "k_reduce_partials3": "bwd_conv_reduce", "k_reduce_adam": "reduce_adam",
        "k_head<": "head_fwd_td", "k_head_fwd": "head_fwd", "k_head_bwd": "head_bwd", "k_td_rows": "td_rows"}
 
 

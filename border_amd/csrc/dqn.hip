@@ -538,6 +538,18 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         BDR_HIP((launch_igemm<DxL1, TEAMS_DX_L1>(a->stream, dim3(((B + 63) / 64) * 49, 1, 1), d)));
     }
     BDR_TRY(fork(1));                  // dy3 ready
+    // :150 backward_step -> Adam.  The l1 / l2 parameters (95 % of the arena) have their gradients (k_head_bwd, DwL1, both
+    // earlier on this stream) and their last readers of this step (k_head, DxL1: before fork(1)) behind them, so their
+    // Adam pass - pure HBM streaming - runs here under the conv dX GEMMs instead of at the end of the critical path.
+    a->adam_step += 1;
+    const AdamScalars adam_s = adam_scalars(c, a->adam_step);
+    {
+        Bracket br(a, "adam_l1_l2");
+        const size_t r4 = (ar.total - ar.w4) / 4;
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((r4 + 255) / 256)), dim3(256), 0, sd, a->q + ar.w4, a->grad + ar.w4, a->m + ar.w4, a->v + ar.w4, r4,
+                           adam_s);
+        BDR_HIP(hipGetLastError());
+    }
     {
         const int M = B * 49, chunks = std::min(pl.chunks_c3, (M + 31) / 32);
         DwArgs d{a->a2[0], a->dy3, a->part + pl.off_c3, pl.stride_c3, M};
@@ -583,14 +595,12 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
                                  k == 0 ? INV255 : 1.0f, wg};
             wg += (nw[k] + nb[k] + 31) / 32;
         }
-        // :150 backward_step -> Adam, fused behind the reduction (k_reduce_adam)
-        a->adam_step += 1;
+        // the conv layers' Adam step rides on their partial reduction (k_reduce_adam); l1 / l2 were done above
         ReduceAdamArgs ra{};
         ra.r = r; ra.p = a->q; ra.g = a->grad; ra.m = a->m; ra.v = a->v; ra.gbase = a->grad;
-        ra.rest0_4 = ar.w4 / 4; ra.n4 = ar.total / 4; ra.s = adam_scalars(c, a->adam_step); ra.reduce_blocks = wg;
-        const unsigned rest_blocks = (unsigned)((ra.n4 - ra.rest0_4 + 255) / 256);
+        ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg;
         Bracket br(a, "reduce_adam");
-        hipLaunchKernelGGL(k_reduce_adam, dim3(wg + rest_blocks), dim3(256), 0, a->stream, ra);
+        hipLaunchKernelGGL(k_reduce_adam, dim3(wg), dim3(256), 0, a->stream, ra);
         BDR_HIP(hipGetLastError());
     }
     return BDR_OK;

@@ -8,5 +8,6 @@ from .replay import GenericTransitionBatch, PerConfig, SimpleReplayBuffer, Simpl
 from .dqn import AtariCnnConfig, Dqn, DqnConfig, DqnModelConfig, EpsilonGreedy, MlpConfig, OptimizerConfig, Softmax  # noqa: F401
 from .sac import Sac, SacConfig  # noqa: F401
 from .iqn import Iqn, IqnConfig  # noqa: F401
+from . import checkpoint  # noqa: F401
 from .trainer import (ParamExchange, Sampler, SimpleStepProcessor, Step, SyntheticEnv, Trainer, TrainerConfig,  # noqa: F401
                       shard_seed)

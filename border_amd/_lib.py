@@ -87,6 +87,10 @@ class SampleInfoC(C.Structure):
                 ("n_samples_best_act", C.c_uint64)]
 
 
+class NamedTensorC(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dims", C.POINTER(C.c_uint64)), ("ndim", C.c_uint32)]
+
+
 class DeviceBatch(C.Structure):
     _fields_ = [("n", C.c_uint64), ("obs", C.c_void_p), ("next_obs", C.c_void_p), ("act", C.c_void_p),
                 ("reward", C.c_void_p), ("is_terminated", C.c_void_p), ("is_truncated", C.c_void_p),
@@ -105,7 +109,8 @@ ABI_SYMBOLS = [
     "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_agent_opt_with_scalars", "bdr_agent_param_count_of", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
     "bdr_explorer_config_default", "bdr_agent_set_explorer", "bdr_agent_get_explorer", "bdr_agent_sample",
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
-    "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_dqn_probe",
+    "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_agent_set_checkpoint_format",
+    "bdr_checkpoint_write", "bdr_checkpoint_read", "bdr_dqn_probe",
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
     "bdr_iqn_config_default", "bdr_iqn_create", "bdr_iqn_update_on_batch", "bdr_iqn_forward", "bdr_iqn_qvalues",
     "bdr_sac_config_default", "bdr_sac_create", "bdr_sac_update_on_batch", "bdr_sac_sample",

@@ -6,6 +6,7 @@
 #include <cmath>
 
 #include "agent_base.hpp"
+#include "tch_archive.hpp"
 
 using namespace bdr;
 
@@ -21,13 +22,55 @@ int32_t dqn_mlp_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out)
 int32_t dqn_cnn_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
 int32_t dqn_mlp_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
 
-// Checkpoint container: safetensors (8-byte little-endian header length, JSON header
-// {"name": {"dtype": "F32", "shape": [...], "data_offsets": [begin, end]}, ...}, raw little-endian data).
-// tch's VarStore::save / load use this format whenever the file name ends in ".safetensors", with the same variable
-// names (c1.weight ... l2.bias, mlp.ln{i}.*, ...) and reference layouts that save_named is given - so files written here
-// load into border-tch-agent's VarStore and vice versa.  (The reference's default file names end in ".pt.tch", a
-// libtorch TorchScript archive, which is not read or written here.)
-int32_t save_named(const std::string& path, const std::vector<NamedTensor>& meta, const float* data, size_t n)
+// Checkpoint containers, chosen by the file name exactly as tch's VarStore::save / load choose:
+//  * "*.safetensors": 8-byte little-endian header length, JSON header
+//    {"name": {"dtype": "F32", "shape": [...], "data_offsets": [begin, end]}, ...}, raw little-endian data;
+//  * anything else (the reference's default "*.pt.tch"): the libtorch named-tensor archive of tch_archive.hpp.
+// Both hold the reference's variable names (c1.weight ... l2.bias, mlp.ln{i}.*, ...) in the reference's layouts, so files
+// written here load into border-tch-agent's VarStore and vice versa.
+static bool is_safetensors_path(const std::string& path)
+{
+    const std::string ext = ".safetensors";
+    return path.size() >= ext.size() && path.compare(path.size() - ext.size(), ext.size(), ext) == 0;
+}
+
+static int32_t save_archive(const std::string& path, const std::vector<NamedTensor>& meta, const float* data, size_t n)
+{
+    std::vector<tcha::Tensor> ts;
+    size_t o = 0;
+    for (const auto& m : meta) {
+        size_t k = 1;
+        for (auto d : m.dims) k *= d;
+        if (o + k > n) return fail(BDR_ERR_IO, "tensor metadata exceeds the parameter vector");
+        tcha::Tensor t;
+        t.name = m.name; t.dims = m.dims; t.data.assign(data + o, data + o + k);
+        ts.push_back(std::move(t));
+        o += k;
+    }
+    if (o != n) return fail(BDR_ERR_IO, "tensor metadata does not cover the parameter vector");
+    const std::string err = tcha::write_archive(path, ts);
+    return err.empty() ? BDR_OK : fail(BDR_ERR_IO, "%s", err.c_str());
+}
+
+static int32_t load_archive(const std::string& path, const std::vector<NamedTensor>& meta, float* data, size_t n)
+{
+    std::vector<tcha::Tensor> ts;
+    const std::string err = tcha::read_archive(path, ts);
+    if (!err.empty()) return fail(BDR_ERR_IO, "%s", err.c_str());
+    size_t o = 0;
+    for (const auto& m : meta) {   // as for safetensors: every variable of the model, with its reference shape; extras are ignored
+        const tcha::Tensor* t = nullptr;
+        for (const auto& c : ts) if (c.name == m.name) { t = &c; break; }
+        if (!t) return fail(BDR_ERR_IO, "%s: variable '%s' is missing", path.c_str(), m.name.c_str());
+        if (t->dims != m.dims || o + t->data.size() > n) return fail(BDR_ERR_IO, "%s: variable '%s' has a different shape", path.c_str(), m.name.c_str());
+        std::copy(t->data.begin(), t->data.end(), data + o);
+        o += t->data.size();
+    }
+    if (o != n) return fail(BDR_ERR_IO, "%s does not cover the model's parameters", path.c_str());
+    return BDR_OK;
+}
+
+static int32_t save_safetensors(const std::string& path, const std::vector<NamedTensor>& meta, const float* data, size_t n)
 {
     std::string hdr = "{";
     size_t o = 0;
@@ -111,7 +154,7 @@ bool parse_safetensors_header(const std::string& h, std::vector<std::pair<std::s
 }
 }  // namespace
 
-int32_t load_named(const std::string& path, const std::vector<NamedTensor>& meta, float* data, size_t n)
+static int32_t load_safetensors(const std::string& path, const std::vector<NamedTensor>& meta, float* data, size_t n)
 {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return fail(BDR_ERR_IO, "cannot open %s", path.c_str());
@@ -142,6 +185,32 @@ int32_t load_named(const std::string& path, const std::vector<NamedTensor>& meta
     fclose(f);
     if (o != n) return fail(BDR_ERR_IO, "%s does not cover the model's parameters", path.c_str());
     return BDR_OK;
+}
+
+int32_t save_named(const std::string& path, const std::vector<NamedTensor>& meta, const float* data, size_t n)
+{
+    return is_safetensors_path(path) ? save_safetensors(path, meta, data, n) : save_archive(path, meta, data, n);
+}
+
+int32_t load_named(const std::string& path, const std::vector<NamedTensor>& meta, float* data, size_t n)
+{
+    return is_safetensors_path(path) ? load_safetensors(path, meta, data, n) : load_archive(path, meta, data, n);
+}
+
+std::string ckpt_save_path(const bdr_agent* a, const char* dir, const std::string& stem)
+{
+    return std::string(dir) + "/" + stem + (a->ckpt_format == BDR_CKPT_SAFETENSORS ? ".safetensors" : ".pt.tch");
+}
+
+std::string ckpt_load_path(const bdr_agent* a, const char* dir, const std::string& stem)
+{
+    const std::string first = ckpt_save_path(a, dir, stem);
+    const std::string second = std::string(dir) + "/" + stem + (a->ckpt_format == BDR_CKPT_SAFETENSORS ? ".pt.tch" : ".safetensors");
+    FILE* f = fopen(first.c_str(), "rb");
+    if (f) { fclose(f); return first; }
+    f = fopen(second.c_str(), "rb");
+    if (f) { fclose(f); return second; }
+    return first;   // the open error then names the file the reference would have looked for
 }
 }  // namespace bdr
 
@@ -428,6 +497,42 @@ int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint
     BDR_REQUIRE(p, "unknown arena %d", which);
     *ptr = p; *n_floats = n;
     return BDR_OK;
+}
+
+int32_t bdr_agent_set_checkpoint_format(bdr_agent* a, int32_t format)
+{
+    BDR_REQUIRE(a, "null argument");
+    BDR_REQUIRE(format == BDR_CKPT_TCH || format == BDR_CKPT_SAFETENSORS, "unknown checkpoint format");
+    a->ckpt_format = format;
+    return BDR_OK;
+}
+
+static int32_t named_meta(const bdr_named_tensor* meta, uint32_t n_tensors, std::vector<NamedTensor>& out)
+{
+    for (uint32_t t = 0; t < n_tensors; ++t) {
+        BDR_REQUIRE(meta[t].name && (meta[t].dims || meta[t].ndim == 0), "null tensor name or dims");
+        NamedTensor nt;
+        nt.name = meta[t].name;
+        nt.dims.assign(meta[t].dims, meta[t].dims + meta[t].ndim);
+        out.push_back(std::move(nt));
+    }
+    return BDR_OK;
+}
+
+int32_t bdr_checkpoint_write(const char* path, const bdr_named_tensor* meta, uint32_t n_tensors, const float* data, uint64_t n)
+{
+    BDR_REQUIRE(path && meta && (data || n == 0), "null argument");
+    std::vector<NamedTensor> m;
+    BDR_TRY(named_meta(meta, n_tensors, m));
+    return save_named(path, m, data, n);
+}
+
+int32_t bdr_checkpoint_read(const char* path, const bdr_named_tensor* meta, uint32_t n_tensors, float* data, uint64_t n)
+{
+    BDR_REQUIRE(path && meta && (data || n == 0), "null argument");
+    std::vector<NamedTensor> m;
+    BDR_TRY(named_meta(meta, n_tensors, m));
+    return load_named(path, m, data, n);
 }
 
 int32_t bdr_agent_save_params(bdr_agent* a, const char* dir)

@@ -46,6 +46,7 @@ struct bdr_agent {
     hipStream_t stream = nullptr;
     bool train = false;
     uint64_t n_opts = 0;
+    int32_t ckpt_format = BDR_CKPT_TCH;
     // Policy::sample state (dqn/base.rs:211-242)
     Explorer explorer;
     uint64_t n_samples_act = 0, n_samples_best_act = 0;
@@ -172,6 +173,10 @@ inline int32_t alloc_f(float** p, size_t n)
 struct NamedTensor { std::string name; std::vector<uint64_t> dims; };
 int32_t save_named(const std::string& path, const std::vector<NamedTensor>& meta, const float* data, size_t n);
 int32_t load_named(const std::string& path, const std::vector<NamedTensor>& meta, float* data, size_t n);
+// "<dir>/<stem>.pt.tch" (the reference's names) or "<dir>/<stem>.safetensors" by bdr_agent_set_checkpoint_format; the load
+// path falls back to the other container when only that one exists
+std::string ckpt_save_path(const bdr_agent* a, const char* dir, const std::string& stem);
+std::string ckpt_load_path(const bdr_agent* a, const char* dir, const std::string& stem);
 
 }  // namespace bdr
 

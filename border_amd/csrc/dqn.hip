@@ -806,20 +806,20 @@ static std::vector<NamedTensor> cnn_meta(int A)
 
 int32_t DqnCnn::save(const char* dir)
 {
-    // dqn/base.rs:348-356: qnet.pt.tch, qnet_tgt.pt.tch  (here: same stems as safetensors, the container tch's VarStore uses for *.safetensors paths)
+    // dqn/base.rs:348-356: qnet.pt.tch, qnet_tgt.pt.tch
     std::vector<float> ref(ref_param_count(ar.A));
     BDR_TRY(get_params(0, ref.data(), ref.size()));
-    BDR_TRY(save_named(std::string(dir) + "/qnet.safetensors", cnn_meta(ar.A), ref.data(), ref.size()));
+    BDR_TRY(save_named(ckpt_save_path(this, dir, "qnet"), cnn_meta(ar.A), ref.data(), ref.size()));
     BDR_TRY(get_params(1, ref.data(), ref.size()));
-    return save_named(std::string(dir) + "/qnet_tgt.safetensors", cnn_meta(ar.A), ref.data(), ref.size());
+    return save_named(ckpt_save_path(this, dir, "qnet_tgt"), cnn_meta(ar.A), ref.data(), ref.size());
 }
 
 int32_t DqnCnn::load(const char* dir)
 {
     std::vector<float> ref(ref_param_count(ar.A));
-    BDR_TRY(load_named(std::string(dir) + "/qnet.safetensors", cnn_meta(ar.A), ref.data(), ref.size()));
+    BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet"), cnn_meta(ar.A), ref.data(), ref.size()));
     BDR_TRY(set_params(0, ref.data(), ref.size()));
-    BDR_TRY(load_named(std::string(dir) + "/qnet_tgt.safetensors", cnn_meta(ar.A), ref.data(), ref.size()));
+    BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet_tgt"), cnn_meta(ar.A), ref.data(), ref.size()));
     return set_params(1, ref.data(), ref.size());
 }
 

@@ -524,16 +524,16 @@ struct Iqn : bdr_agent {
     {
         std::vector<float> ref(ref_total);
         BDR_TRY(get_params(0, ref.data(), ref.size()));
-        BDR_TRY(save_named(std::string(dir) + "/iqn.safetensors", meta(), ref.data(), ref.size()));
+        BDR_TRY(save_named(ckpt_save_path(this, dir, "iqn"), meta(), ref.data(), ref.size()));
         BDR_TRY(get_params(1, ref.data(), ref.size()));
-        return save_named(std::string(dir) + "/iqn_tgt.safetensors", meta(), ref.data(), ref.size());
+        return save_named(ckpt_save_path(this, dir, "iqn_tgt"), meta(), ref.data(), ref.size());
     }
     int32_t load(const char* dir) override
     {
         std::vector<float> ref(ref_total);
-        BDR_TRY(load_named(std::string(dir) + "/iqn.safetensors", meta(), ref.data(), ref.size()));
+        BDR_TRY(load_named(ckpt_load_path(this, dir, "iqn"), meta(), ref.data(), ref.size()));
         BDR_TRY(set_params(0, ref.data(), ref.size()));
-        BDR_TRY(load_named(std::string(dir) + "/iqn_tgt.safetensors", meta(), ref.data(), ref.size()));
+        BDR_TRY(load_named(ckpt_load_path(this, dir, "iqn_tgt"), meta(), ref.data(), ref.size()));
         return set_params(1, ref.data(), ref.size());
     }
     int32_t stage(uint64_t n, const void* obs, const int64_t* act, const void* next_obs, const float* reward, const int8_t* term)

@@ -264,16 +264,16 @@ struct DqnMlp : bdr_agent {
     {
         std::vector<float> ref(net.ref_total);
         BDR_TRY(get_params(0, ref.data(), ref.size()));
-        BDR_TRY(save_named(std::string(dir) + "/qnet.safetensors", meta(), ref.data(), ref.size()));
+        BDR_TRY(save_named(ckpt_save_path(this, dir, "qnet"), meta(), ref.data(), ref.size()));
         BDR_TRY(get_params(1, ref.data(), ref.size()));
-        return save_named(std::string(dir) + "/qnet_tgt.safetensors", meta(), ref.data(), ref.size());
+        return save_named(ckpt_save_path(this, dir, "qnet_tgt"), meta(), ref.data(), ref.size());
     }
     int32_t load(const char* dir) override
     {
         std::vector<float> ref(net.ref_total);
-        BDR_TRY(load_named(std::string(dir) + "/qnet.safetensors", meta(), ref.data(), ref.size()));
+        BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet"), meta(), ref.data(), ref.size()));
         BDR_TRY(set_params(0, ref.data(), ref.size()));
-        BDR_TRY(load_named(std::string(dir) + "/qnet_tgt.safetensors", meta(), ref.data(), ref.size()));
+        BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet_tgt"), meta(), ref.data(), ref.size()));
         return set_params(1, ref.data(), ref.size());
     }
 };

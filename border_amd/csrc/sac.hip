@@ -508,32 +508,32 @@ struct Sac : bdr_agent {
     {
         std::vector<float> v(pi.ref_total);
         BDR_TRY(get_params(0, v.data(), v.size()));
-        BDR_TRY(save_named(std::string(dir) + "/pi.safetensors", pi_meta(), v.data(), v.size()));
+        BDR_TRY(save_named(ckpt_save_path(this, dir, "pi"), pi_meta(), v.data(), v.size()));
         v.resize(qn.ref_total);
         for (int i = 0; i < NC; ++i) {
             BDR_TRY(get_params(1 + i, v.data(), v.size()));
-            BDR_TRY(save_named(std::string(dir) + "/qnet_" + std::to_string(i) + ".safetensors", q_meta(), v.data(), v.size()));
+            BDR_TRY(save_named(ckpt_save_path(this, dir, "qnet_" + std::to_string(i)), q_meta(), v.data(), v.size()));
             BDR_TRY(get_params(1 + NC + i, v.data(), v.size()));
-            BDR_TRY(save_named(std::string(dir) + "/qnet_tgt_" + std::to_string(i) + ".safetensors", q_meta(), v.data(), v.size()));
+            BDR_TRY(save_named(ckpt_save_path(this, dir, "qnet_tgt_" + std::to_string(i)), q_meta(), v.data(), v.size()));
         }
         float la = 0;
         BDR_TRY(get_params(1 + 2 * NC, &la, 1));
-        return save_named(std::string(dir) + "/ent_coef.safetensors", {{"log_alpha", {1}}}, &la, 1);
+        return save_named(ckpt_save_path(this, dir, "ent_coef"), {{"log_alpha", {1}}}, &la, 1);
     }
     int32_t load(const char* dir) override
     {
         std::vector<float> v(pi.ref_total);
-        BDR_TRY(load_named(std::string(dir) + "/pi.safetensors", pi_meta(), v.data(), v.size()));
+        BDR_TRY(load_named(ckpt_load_path(this, dir, "pi"), pi_meta(), v.data(), v.size()));
         BDR_TRY(set_params(0, v.data(), v.size()));
         v.resize(qn.ref_total);
         for (int i = 0; i < NC; ++i) {
-            BDR_TRY(load_named(std::string(dir) + "/qnet_" + std::to_string(i) + ".safetensors", q_meta(), v.data(), v.size()));
+            BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet_" + std::to_string(i)), q_meta(), v.data(), v.size()));
             BDR_TRY(set_params(1 + i, v.data(), v.size()));
-            BDR_TRY(load_named(std::string(dir) + "/qnet_tgt_" + std::to_string(i) + ".safetensors", q_meta(), v.data(), v.size()));
+            BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet_tgt_" + std::to_string(i)), q_meta(), v.data(), v.size()));
             BDR_TRY(set_params(1 + NC + i, v.data(), v.size()));
         }
         float la = 0;
-        BDR_TRY(load_named(std::string(dir) + "/ent_coef.safetensors", {{"log_alpha", {1}}}, &la, 1));
+        BDR_TRY(load_named(ckpt_load_path(this, dir, "ent_coef"), {{"log_alpha", {1}}}, &la, 1));
         return set_params(1 + 2 * NC, &la, 1);
     }
 };

@@ -176,10 +176,17 @@ class Iqn:
         p = np.ascontiguousarray(params, dtype=np.float32)
         _lib.check(_lib.lib().bdr_agent_set_params(self._h, self.WHICH[which], _p(p), p.size))
 
+    def set_checkpoint_format(self, fmt: str) -> None:
+        """"tch" (default): `<stem>.pt.tch` libtorch archives, the reference's files; "safetensors": `<stem>.safetensors`."""
+        from .checkpoint import FORMATS
+        _lib.check(_lib.lib().bdr_agent_set_checkpoint_format(self._h, FORMATS[fmt]))
+        self._ckpt_ext = {"tch": ".pt.tch", "safetensors": ".safetensors"}[fmt]
+
     def save_params(self, path: str):
         os.makedirs(path, exist_ok=True)
         _lib.check(_lib.lib().bdr_agent_save_params(self._h, path.encode()))
-        return [os.path.join(path, "iqn.safetensors"), os.path.join(path, "iqn_tgt.safetensors")]
+        ext = getattr(self, "_ckpt_ext", ".pt.tch")
+        return [os.path.join(path, stem + ext) for stem in ["iqn", "iqn_tgt"]]
 
     def load_params(self, path: str):
         _lib.check(_lib.lib().bdr_agent_load_params(self._h, path.encode()))

@@ -167,12 +167,19 @@ class Sac:
     def sync_model(self, model_info) -> None:
         self.set_params(model_info, "pi")
 
+    def set_checkpoint_format(self, fmt: str) -> None:
+        """"tch" (default): `<stem>.pt.tch` libtorch archives, the reference's files; "safetensors": `<stem>.safetensors`."""
+        from .checkpoint import FORMATS
+        _lib.check(_lib.lib().bdr_agent_set_checkpoint_format(self._h, FORMATS[fmt]))
+        self._ckpt_ext = {"tch": ".pt.tch", "safetensors": ".safetensors"}[fmt]
+
     def save_params(self, path: str):
         os.makedirs(path, exist_ok=True)
         _lib.check(_lib.lib().bdr_agent_save_params(self._h, path.encode()))
         nc = self.config.n_critics
-        return ([os.path.join(path, f"qnet_{i}.safetensors") for i in range(nc)] + [os.path.join(path, f"qnet_tgt_{i}.safetensors") for i in range(nc)]
-                + [os.path.join(path, "pi.safetensors"), os.path.join(path, "ent_coef.safetensors")])
+        ext = getattr(self, "_ckpt_ext", ".pt.tch")
+        stems = [s for i in range(nc) for s in (f"qnet_{i}", f"qnet_tgt_{i}")] + ["pi", "ent_coef"]   # sac/base.rs:313-334 order
+        return [os.path.join(path, stem + ext) for stem in stems]
 
     def load_params(self, path: str):
         _lib.check(_lib.lib().bdr_agent_load_params(self._h, path.encode()))

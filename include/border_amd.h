@@ -291,13 +291,33 @@ BDR_API int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* i
  * host that already owns a communicator (e.g. torch.distributed) can reduce it in place. */
 BDR_API int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint64_t* n_floats);
 
-/* Agent::save_params / load_params (dqn/base.rs:345-371; iqn/base.rs:328-356; sac/base.rs:313-345): writes / reads
- * `qnet.safetensors`, `qnet_tgt.safetensors` (IQN: iqn, iqn_tgt; SAC: pi, qnet_{i}, qnet_tgt_{i}, ent_coef) under dir:
- * safetensors files (the container tch's VarStore uses for *.safetensors paths) holding the reference's variable
- * names in the reference's layouts (OIHW conv weights, [out,in] linear weights).  Loading requires every variable of
- * the model with its shape and dtype F32; extra entries are ignored. */
+/* Agent::save_params / load_params (dqn/base.rs:345-371; iqn/base.rs:303-317; sac/base.rs:313-345): writes / reads
+ * `qnet.pt.tch`, `qnet_tgt.pt.tch` (IQN: iqn, iqn_tgt; SAC: pi, qnet_{i}, qnet_tgt_{i}, ent_coef) under dir - the
+ * reference's file names.  The container follows the file name exactly as tch's VarStore::{save,load} do:
+ *   BDR_CKPT_TCH          "<stem>.pt.tch": the libtorch named-tensor archive (TorchScript module zip) that tch writes
+ *                         through torch-sys at_save_multi and reads with torch::jit::load (default, = the reference);
+ *   BDR_CKPT_SAFETENSORS  "<stem>.safetensors".
+ * Both hold the reference's variable names in the reference's layouts (OIHW conv weights, [out,in] linear weights).
+ * Loading prefers the configured container and falls back to the other one when only that file exists; it requires
+ * every variable of the model with its shape and dtype float32; extra entries are ignored. */
+#define BDR_CKPT_TCH 0
+#define BDR_CKPT_SAFETENSORS 1
+BDR_API int32_t bdr_agent_set_checkpoint_format(bdr_agent* a, int32_t format);
 BDR_API int32_t bdr_agent_save_params(bdr_agent* a, const char* dir);
 BDR_API int32_t bdr_agent_load_params(bdr_agent* a, const char* dir);
+
+/* Host-side named-tensor files (no GPU involved): the container layer under save_params / load_params, for callers
+ * that move parameters themselves (bdr_agent_get_params / set_params take the same reference-layout vectors).
+ * `data` is the concatenation of the tensors in `meta` order (row-major f32); the container is chosen by the file
+ * name as above.  Reading matches by name, checks shapes, ignores extra entries; nested module archives exported
+ * from Python (torch.jit.save of a module with submodules c1, c2, ...) are flattened to dotted names. */
+typedef struct bdr_named_tensor {
+    const char* name;
+    const uint64_t* dims;
+    uint32_t ndim;
+} bdr_named_tensor;
+BDR_API int32_t bdr_checkpoint_write(const char* path, const bdr_named_tensor* meta, uint32_t n_tensors, const float* data, uint64_t n);
+BDR_API int32_t bdr_checkpoint_read(const char* path, const bdr_named_tensor* meta, uint32_t n_tensors, float* data, uint64_t n);
 
 /* Parity probes: copy intermediates of the LAST update to the host.
  * what: 0 q_pred_all [B][A], 1 q_next_all [B][A], 2 pred [B], 3 tgt [B], 4 loss [1]. */

@@ -374,6 +374,7 @@ def test_checkpoints_are_safetensors_with_reference_names(B, tmp_path):
     a = make_agent(B, batch_size=4)
     p0, p1 = T.init_params(shapes, 61), T.init_params(shapes, 62)
     a.set_params(p0, "qnet"); a.set_params(p1, "qnet_tgt")
+    a.set_checkpoint_format("safetensors")
     files = a.save_params(str(tmp_path))
     assert [os.path.basename(f) for f in files] == ["qnet.safetensors", "qnet_tgt.safetensors"]
     for f, p in zip(files, (p0, p1)):
@@ -403,6 +404,72 @@ def test_checkpoints_are_safetensors_with_reference_names(B, tmp_path):
     with pytest.raises(B.BdrError):
         a.load_params(str(tmp_path))
     a.close()
+
+
+def test_checkpoints_default_to_the_reference_pt_tch_archives(B, tmp_path):
+    """By default save_params writes the reference's files - `qnet.pt.tch`, `qnet_tgt.pt.tch` (dqn/base.rs:348-356) - in
+    the container tch's VarStore::save produces for them (libtorch named-tensor archive).  libtorch's TorchScript loader,
+    which is what VarStore::load calls, must see the reference's variable names / layouts; and a Nature-CNN exported from
+    PyTorch (torch.jit.save of a module with submodules c1..l2) must load into the agent and compute the same Q-values."""
+    import torch
+    from oracle import torch_ref as T
+    shapes = T.cnn_shapes(6)
+    names = ["c1.weight", "c1.bias", "c2.weight", "c2.bias", "c3.weight", "c3.bias", "l1.weight", "l1.bias", "l2.weight", "l2.bias"]
+    a = make_agent(B, batch_size=4)
+    p0, p1 = T.init_params(shapes, 71), T.init_params(shapes, 72)
+    a.set_params(p0, "qnet"); a.set_params(p1, "qnet_tgt")
+    files = a.save_params(str(tmp_path))
+    assert [os.path.basename(f) for f in files] == ["qnet.pt.tch", "qnet_tgt.pt.tch"]
+    for f, p in zip(files, (p0, p1)):
+        got = list(torch.jit.load(f).named_parameters())
+        assert [n for n, _ in got] == names
+        o = 0
+        for (n, t), sh in zip(got, shapes):
+            k = int(np.prod(sh))
+            assert t.dtype == torch.float32 and tuple(t.shape) == tuple(sh)
+            assert (t.detach().numpy().ravel() == p[o:o + k]).all(), n
+            o += k
+    b = make_agent(B, batch_size=4, param_seed=9)
+    b.load_params(str(tmp_path))
+    assert (b.get_params("qnet") == p0).all() and (b.get_params("qnet_tgt") == p1).all()
+    b.close()
+
+    # Python-side export of the same architecture (cnn/base.rs:23-36)
+    class AtariCnn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = torch.nn.Conv2d(4, 32, 8, 4)
+            self.c2 = torch.nn.Conv2d(32, 64, 4, 2)
+            self.c3 = torch.nn.Conv2d(64, 64, 3, 1)
+            self.l1 = torch.nn.Linear(3136, 512)
+            self.l2 = torch.nn.Linear(512, 6)
+
+        def forward(self, x):
+            x = x.squeeze(2).float() / 255.0
+            x = torch.relu(self.c3(torch.relu(self.c2(torch.relu(self.c1(x))))))
+            return self.l2(torch.relu(self.l1(x.flatten(1))))
+
+    torch.manual_seed(11)
+    net = AtariCnn()
+    exported = tmp_path / "exported"
+    exported.mkdir()
+    scripted = torch.jit.script(net)
+    torch.jit.save(scripted, str(exported / "qnet.pt.tch"))
+    torch.jit.save(scripted, str(exported / "qnet_tgt.pt.tch"))
+    a.load_params(str(exported))
+    obs = np.random.default_rng(5).integers(0, 256, (7, 4, 1, 84, 84), dtype=np.uint8)
+    with torch.no_grad():
+        want = net(torch.from_numpy(obs)).numpy()
+    assert rel(a.qvalues(obs), want) < QTOL
+    # only the other container present: load falls back to it
+    only_st = tmp_path / "only_st"
+    a.set_checkpoint_format("safetensors")
+    a.save_params(str(only_st))
+    a.set_checkpoint_format("tch")
+    c = make_agent(B, batch_size=4, param_seed=10)
+    c.load_params(str(only_st))
+    assert (c.get_params("qnet") == a.get_params("qnet")).all()
+    c.close(); a.close()
 
 
 def test_opt_stream_is_deterministic_and_overlap_invariant(B):

@@ -105,4 +105,9 @@ def test_iqn_opt_over_replay_and_qvalues(B, tmp_path):
     b = B.Iqn.build(cfg)
     b.load_params(str(tmp_path))
     assert all(os.path.exists(f) for f in files) and (b.get_params("iqn") == a.get_params("iqn")).all()
+    # iqn/base.rs:303-317 file names; libtorch's loader sees the reference's variable names (iqn/model/base.rs:185)
+    import torch
+    assert [os.path.basename(f) for f in files] == ["iqn.pt.tch", "iqn_tgt.pt.tch"]
+    names = [n for n, _ in torch.jit.load(files[0]).named_parameters()]
+    assert "iqn_cos_to_feature.weight" in names and "iqn_cos_to_feature.bias" in names
     a.close(); b.close(); rb.close()

@@ -114,6 +114,10 @@ def test_sac_opt_over_replay_and_sample(B, tmp_path):
     assert rel(a.sample(obs), mean.tanh().detach().numpy()) < 1e-4
     files = a.save_params(str(tmp_path))
     assert all(os.path.exists(f) for f in files)
+    # sac/base.rs:313-334: file names and order; ent_coef holds `log_alpha` (sac/ent_coef.rs)
+    assert [os.path.basename(f) for f in files] == ["qnet_0.pt.tch", "qnet_tgt_0.pt.tch", "qnet_1.pt.tch", "qnet_tgt_1.pt.tch",
+                                                    "pi.pt.tch", "ent_coef.pt.tch"]
+    assert [n for n, _ in torch.jit.load(files[-1]).named_parameters()] == ["log_alpha"]
     b = B.Sac.build(cfg)
     b.load_params(str(tmp_path))
     assert (b.get_params("pi") == pi).all() and (b.get_params("qnet_tgt_1") == a.get_params("qnet_tgt_1")).all()

@@ -115,6 +115,8 @@ struct FwdL1 {
     __device__ static float epi_load(const Epi&, int, int) { return 0.f; }
     __device__ static void store(const Epi& e, int m, int n, float v, float) { e.out[(size_t)m * NC + n] = v; }
 };
+// even instance counts (the online + target pair): XCD = (instance parity, pair of n-tiles); grid (16 m-tiles, splits, nz/2)
+struct FwdL1Z2 : FwdL1 { static constexpr int XMAP = 2; };
 
 // ================================================================================================
 // input-gradient policies (transposed conv as gather; epilogue applies relu'(previous activation))
@@ -136,6 +138,7 @@ struct DxL1 {
     static constexpr int RPI = 1, RPIP = 0;
     static constexpr int NC = 3136;    // N' (columns of the result)
     static constexpr bool B_TR = true;
+    static constexpr int XMAP = 1;     // the 4 m-tiles of a column tile share one XCD's L2 (grid.x = 8 * ceil(tiles / 8))
     __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.M, mv, mr); }
     __device__ static constexpr int N(const Args&) { return NC; }
     __device__ static constexpr int KP(const Args&) { return 512; }   // K' per tap (contiguous in memory)

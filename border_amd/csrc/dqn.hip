@@ -454,7 +454,11 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
     { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3, TEAMS_FWD_C3>(a->stream, dim3((f.M + 63) / 64, 1, nz), f))); }
     f.M = B; f.nkt_per_split = (98 + L1_SPLIT - 1) / L1_SPLIT;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a3[inst[z].slot]; f.w[z] = inst[z].params + ar.w4; f.bias[z] = nullptr; f.out[z] = a->p1[inst[z].slot]; }
-    { Bracket br(a, "fwd_l1"); BDR_HIP((launch_igemm<FwdL1, TEAMS_FWD_L1>(a->stream, dim3(((B + 63) / 64) * 8, L1_SPLIT, nz), f))); }
+    {
+        Bracket br(a, "fwd_l1");
+        if (nz % 2 == 0) BDR_HIP((launch_igemm<FwdL1Z2, TEAMS_FWD_L1>(a->stream, dim3(((B + 63) / 64) * 16, L1_SPLIT, nz / 2), f)));
+        else BDR_HIP((launch_igemm<FwdL1, TEAMS_FWD_L1>(a->stream, dim3(((B + 63) / 64) * 8, L1_SPLIT, nz), f)));
+    }
     HeadArgs h{};
     h.B = B; h.A = ar.A; h.S = L1_SPLIT;
     for (int z = 0; z < nz; ++z) {
@@ -535,7 +539,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     {
         DxArgs d{a->dh1, a->q + ar.w4, a->a3[0], a->dy3, B};
         Bracket br(a, "bwd_l1_dx");
-        BDR_HIP((launch_igemm<DxL1, TEAMS_DX_L1>(a->stream, dim3(((B + 63) / 64) * 49, 1, 1), d)));
+        BDR_HIP((launch_igemm<DxL1, TEAMS_DX_L1>(a->stream, dim3((((B + 63) / 64) * 49 + 7) / 8 * 8, 1, 1), d)));
     }
     BDR_TRY(fork(1));                  // dy3 ready
     // :150 backward_step -> Adam.  The l1 / l2 parameters (95 % of the arena) have their gradients (k_head_bwd, DwL1, both

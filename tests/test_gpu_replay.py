@@ -119,3 +119,66 @@ def test_full_size_gather_roundtrip(B):
             assert (g.obs[k].ravel() == e[0][0]).all() and (g.next_obs[k].ravel() == e[2][0]).all()
             assert g.act[k, 0] == e[1][0] and g.reward[k] == e[3][0] and g.is_terminated[k] == e[4][0]
     rb.close()
+
+
+def test_baseline_size_ring_one_million_transitions(B):
+    """BASELINE configuration 2 at its real size: a 1 000 000-transition ring of [4,1,84,84] u8 rows (2 x 28.2 GB of HBM),
+    batch 256.  SURVEY 8(d): the indices of the first 1 000 batches are identical to the CPU restatement of
+    `ReplayBufferBase::batch` (base.rs:384-390); the gathered rows are the ring rows at those indices (checked against the
+    counter-based fill, which is a function of the transition index alone, and by a checksum of checksums over whole
+    batches); pushes at the end of the ring wrap to row 0 (base.rs:295-316) and are what batch() returns afterwards."""
+    import ctypes as C
+    from border_amd import _lib
+    from oracle import oracle as O
+    from tests import synth
+    cap, bs = 1_000_000, 256
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (4, 1, 84, 84), np.uint8)
+    rb.fill_synthetic(cap - 2, seed=0, kind=0, n_actions=6)
+    assert rb.len() == cap - 2 and rb.head == cap - 2
+    # wrap: 5 rows pushed at cap-2 land in rows cap-2, cap-1, 0, 1, 2
+    rng = np.random.default_rng(0)
+    pobs = rng.integers(0, 256, (5, 4, 1, 84, 84), dtype=np.uint8)
+    pnext = rng.integers(0, 256, (5, 4, 1, 84, 84), dtype=np.uint8)
+    pact = np.arange(5, dtype=np.int64).reshape(5, 1)
+    prew = np.array([0.5, -1.5, 2.5, 3.5, -4.5], np.float32)
+    pterm = np.array([1, 0, 0, 1, 0], np.int8)
+    rb.push(pobs, pact, pnext, prew, pterm, np.zeros(5, np.int8))
+    assert rb.len() == cap and rb.head == 3
+    for row, k in ((cap - 2, 0), (cap - 1, 1), (0, 2), (1, 3), (2, 4)):
+        o, a, n, r, t, _ = rb.read_rows(row, 1)
+        assert (o[0] == pobs[k]).all() and (n[0] == pnext[k]).all() and a[0, 0] == k and r[0] == prew[k] and t[0] == pterm[k]
+    pushed = {cap - 2: 0, cap - 1: 1, 0: 2, 1: 3, 2: 4}
+
+    def row_sums(ixs):   # per-row byte sums of (obs, next_obs) from the definition of the ring contents
+        so, sn = np.empty(len(ixs), np.int64), np.empty(len(ixs), np.int64)
+        for j, ix in enumerate(ixs):
+            ix = int(ix)
+            if ix in pushed:
+                so[j], sn[j] = pobs[pushed[ix]].sum(dtype=np.int64), pnext[pushed[ix]].sum(dtype=np.int64)
+            else:
+                e = synth.atari_rows(0, ix, 1)
+                so[j], sn[j] = e[0].sum(dtype=np.int64), e[2].sum(dtype=np.int64)
+        return so, sn
+
+    ref = O.StdRng.seed_from_u64(42)
+    ixs = np.empty(bs, np.uint64)
+    L = _lib.lib()
+    for it in range(1000):
+        want = ref.sample_indices(cap, bs)
+        if it % 250 == 0:    # full host copy: exact rows, and the checksum of checksums over the whole batch
+            g = rb.batch(bs)
+            assert (g.ix_sample == want).all()
+            so, sn = row_sums(want)
+            assert (g.obs.reshape(bs, -1).sum(1, dtype=np.int64) == so).all()
+            assert (g.next_obs.reshape(bs, -1).sum(1, dtype=np.int64) == sn).all()
+            assert int(g.obs.sum(dtype=np.int64)) == int(so.sum()) and int(g.next_obs.sum(dtype=np.int64)) == int(sn.sum())
+            k = int(np.argmax(want))
+            if int(want[k]) not in pushed:
+                e = synth.atari_rows(0, int(want[k]), 1)
+                assert (g.obs[k].ravel() == e[0][0]).all() and (g.next_obs[k].ravel() == e[2][0]).all()
+                assert g.act[k, 0] == e[1][0] and g.reward[k] == e[3][0] and g.is_terminated[k] == e[4][0]
+        else:                # device-side batch, indices only
+            _lib.check(L.bdr_replay_batch(rb.handle, bs, ixs.ctypes.data_as(C.c_void_p), None, None, None, None, None, None))
+            assert (ixs == want).all(), it
+    assert int(want.max()) < cap
+    rb.close()

@@ -265,7 +265,7 @@ int32_t bdr_agent_sync(bdr_agent* a)
     BDR_REQUIRE(a, "null agent");
     BDR_HIP(hipSetDevice(a->device));
     BDR_HIP(hipStreamSynchronize(a->stream));
-    return BDR_OK;
+    return a->after_sync();
 }
 
 int32_t bdr_agent_opt(bdr_agent* a, bdr_replay* r)

@@ -85,6 +85,7 @@ struct bdr_agent {
     }
     virtual const char* kind() const = 0;
     virtual int32_t opt(bdr_replay* r) = 0;                       // Agent::opt, asynchronous
+    virtual int32_t after_sync() { return BDR_OK; }               // device-side error flags, checked by bdr_agent_sync
     virtual int32_t record(float* out, int cap, int* n) = 0;      // scalars of the last update (syncs)
     virtual uint64_t param_count(int which) = 0;                  // reference-layout element count
     virtual int32_t get_params(int which, float* out, uint64_t n) = 0;
@@ -186,6 +187,12 @@ std::string ckpt_load_path(const bdr_agent* a, const char* dir, const std::strin
         BDR_HIP(hipGetLastError());                                                                \
     } while (0)
 #define LAUNCH(kernel, grid, args) LAUNCH_ON(a->stream, kernel, grid, args)
+// flags: 0 or hipExtAnyOrderLaunch, stop: event completed by the kernel's own packet or nullptr (see launch_igemm)
+#define LAUNCH_FL(st, flags, stop, kernel, grid, block, ...)                                          \
+    do {                                                                                           \
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, st, nullptr, stop, flags, __VA_ARGS__);         \
+        BDR_HIP(hipGetLastError());                                                                \
+    } while (0)
 
 namespace {
 using namespace bdr;

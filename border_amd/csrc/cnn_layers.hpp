@@ -127,6 +127,8 @@ struct DxArgs {
     const float* mask;   // previous layer's post-relu activation (same shape as out)
     float* out;          // gradient w.r.t. the previous layer's pre-activation
     int M;               // rows (per parity class for stride 2)
+    unsigned* sig_flag;  // optional progress flag written at kernel start (igemm.hpp start_signal)
+    unsigned sig_epoch;
 };
 
 // l1: dh0[b][k] = sum_n dh1[b][n] W4[k][n];  treated as 1x1 "conv" with CIN=512 -> N'=3136
@@ -237,6 +239,8 @@ struct DwArgs {
     float* part;        // partials: [chunks][K*N + N]
     size_t part_stride; // floats between chunks
     int M;
+    unsigned* sig_flag; // optional progress flag written at kernel start (igemm.hpp start_signal)
+    unsigned sig_epoch;
 };
 template <class G, class APolicy, int WM_, int WN_, bool U8>
 struct DwP {

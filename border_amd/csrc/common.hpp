@@ -2,6 +2,7 @@
 // the opaque handle layouts.  gfx950 only; no CPU fallback anywhere in this library.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -71,7 +72,13 @@ struct bdr_replay {
     hipStream_t stream = nullptr;
     hipEvent_t written = nullptr;  // recorded after the last push/fill on `stream`
     hipEvent_t read = nullptr;     // recorded by the consumer after the last gather
-    bool read_pending = false;
+    // Cross-stream ordering is lazy: a barrier packet (event record or wait) costs its queue a 5-7 us bubble
+    // (tools/rocprof_timeline.py), so the opt loop's gather records / waits nothing unless a push, fill or tree update
+    // actually happened in between.
+    bool read_pending = false;          // a gather on read_stream may still be reading ring rows / owns the batch buffers
+    hipStream_t read_stream = nullptr;
+    uint64_t written_gen = 1;           // bumped with every record of `written`
+    std::vector<std::pair<hipStream_t, uint64_t>> waited;   // consumer stream -> generation of `written` it has waited for
     // pinned staging for push
     uint8_t* stage = nullptr;
     uint64_t stage_records = 0;

@@ -283,7 +283,10 @@ struct DqnCnn : bdr_agent {
     hipStream_t side = nullptr;          // weight-gradient kernels run here, concurrently with the dX chain
     hipStream_t aux = nullptr;           // prioritized-replay tree updates (created on first use)
     hipEvent_t ev_fork[4] = {nullptr}, ev_join = nullptr;
-    bool overlap = true;
+    bool kev = true;
+    unsigned* sig = nullptr;   // [8] device progress flags of schedule 3
+    unsigned sig_epoch = 0;
+    int sched = 3;   // backward schedule, see update_critic (BDR_SCHED=0|1|2; BDR_NO_OVERLAP=1 == 0)
     Arena ar;
     int B = 0;          // activation buffers are sized for this batch
     // parameter arenas
@@ -305,6 +308,14 @@ struct DqnCnn : bdr_agent {
     ~DqnCnn() override;
     const char* kind() const override { return "dqn_cnn"; }
     int32_t opt(bdr_replay* r) override;
+    int32_t after_sync() override
+    {
+        if (!sig || sig_epoch == 0) return BDR_OK;
+        unsigned err = 0;
+        BDR_HIP(hipMemcpy(&err, sig + 7, sizeof err, hipMemcpyDeviceToHost));   // SIG_ERR
+        if (err) return fail(BDR_ERR_HIP, "cross-stream gate %u timed out: a producer kernel never started", err - 1);
+        return BDR_OK;
+    }
     int32_t record(float* out, int cap, int* n) override;
     uint64_t param_count(int which) override;
     int32_t get_params(int which, float* out, uint64_t n) override;
@@ -378,6 +389,29 @@ __device__ __forceinline__ void adam_element(float& p, float g, float& m, float&
     const float denom = __fsqrt_rn(v) / s.sqrt_bc2 + s.eps;
     p = p + s.neg_step * m / denom;               // addcdiv_(exp_avg, denom, -step_size)
 }
+// Schedule 3 cross-queue ordering without barrier packets (igemm.hpp start_signal).
+// k_gate: one wave; returns once *flag has reached `epoch` (wrap-safe compare).  It holds one wave slot while it waits, so
+// it cannot starve the producer; a producer that never arrives trips the time limit instead of hanging the queue
+// (sig[SIG_ERR] is checked at the next synchronisation).
+constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_ERR = 7;
+__global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned epoch)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();   // 100 MHz
+    while ((int)(__hip_atomic_load(sig + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > 200000000ull) {   // 2 s
+            __hip_atomic_store(sig + SIG_ERR, 1u + (unsigned)which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+}
+// k_signal: "everything queued before me on this stream is complete" (same argument as start_signal)
+__global__ __launch_bounds__(64) void k_signal(unsigned* sig, int which, unsigned epoch)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(sig + which, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(256) void k_reduce_adam(ReduceAdamArgs a)
 {
     if ((int)blockIdx.x >= a.reduce_blocks) {
@@ -469,9 +503,12 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         Bracket br(a, td ? "head_fwd_td" : "head_fwd");
         const dim3 grid((B + HEAD_ROWS - 1) / HEAD_ROWS), block(64 * HEAD_ROWS * nz);
         const TdArgs tv = td ? *td : TdArgs{};
-        if (ar.A <= 8) hipLaunchKernelGGL((k_head<L1_SPLIT, 8>), grid, block, 0, a->stream, h, tv, nz, td ? 1 : 0);
-        else if (ar.A <= 24) hipLaunchKernelGGL((k_head<L1_SPLIT, 24>), grid, block, 0, a->stream, h, tv, nz, td ? 1 : 0);
-        else hipLaunchKernelGGL((k_head<L1_SPLIT, 64>), grid, block, 0, a->stream, h, tv, nz, td ? 1 : 0);
+        // with the two-stream backward schedule the head kernel's own packet completes the first fork event
+        hipEvent_t stop = td && !a->prof && a->sched == 1 && a->kev ? a->ev_fork[0] : nullptr;
+        const int tdi = td ? 1 : 0;
+        if (ar.A <= 8) hipExtLaunchKernelGGL((k_head<L1_SPLIT, 8>), grid, block, 0, a->stream, nullptr, stop, 0, h, tv, nz, tdi);
+        else if (ar.A <= 24) hipExtLaunchKernelGGL((k_head<L1_SPLIT, 24>), grid, block, 0, a->stream, nullptr, stop, 0, h, tv, nz, tdi);
+        else hipExtLaunchKernelGGL((k_head<L1_SPLIT, 64>), grid, block, 0, a->stream, nullptr, stop, 0, h, tv, nz, tdi);
         BDR_HIP(hipGetLastError());
     }
     return BDR_OK;
@@ -503,87 +540,156 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     t.has_clip = c.has_clip_td_err; t.clip_min = (float)c.clip_td_err_min; t.clip_max = (float)c.clip_td_err_max;
     BDR_TRY(forward(a, inst, c.double_dqn ? 3 : 2, B, &t));   // the TD step rides on the head kernel
 
-    // Backward.  The input-gradient chain (dX of l1 -> conv3 -> conv2) is the critical path; every
-    // weight-gradient kernel only needs the dY produced one link earlier, so those run on a second
-    // stream, forked/joined with events (each of these launches fills only part of the chip).
-    // With per-kernel profiling on, everything stays on the main stream.
-    const bool ov = a->overlap && !a->prof;
-    hipStream_t sd = ov ? a->side : a->stream;
+    // Backward.  The input-gradient chain (dX of l1 -> conv3 -> conv2) is the critical path; every weight-gradient kernel
+    // only needs the dY produced one link earlier and fills only part of the chip, so it runs beside the next dX kernel.
+    // Three schedules (a->sched; per-kernel profiling forces 0):
+    //   0  serial, one stream;
+    //   1  weight gradients on a second stream, forked / joined with events (each cross-stream dependency costs the
+    //      recording queue and the waiting queue a 5-7 us bubble: tools/rocprof_timeline.py);
+    //   2  one stream, no events: a dX kernel is launched as a normal (barrier) dispatch and the weight-gradient kernels that
+    //      may run beside it follow as hipExtAnyOrderLaunch dispatches (no barrier bit; ignored by this runtime on gfx9);
+    //   3  two streams ordered through device flags instead of events: the next dX kernel's first workgroup publishes
+    //      "my predecessor is complete" (start_signal), one-wave k_gate kernels on the consuming queue wait for it.  No
+    //      packet is added to the dX queue except the join gate before the reduction.
+    const int sched = a->prof ? 0 : a->sched;
+    const bool ov = sched == 1;
+    const bool gated = sched == 3;
+    hipStream_t sd = ov || gated ? a->side : a->stream;
+    const unsigned epoch = gated ? ++a->sig_epoch : 0;
+    auto sigf = [&](int which) -> unsigned* { return gated ? a->sig + which : nullptr; };
+    auto gate = [&](hipStream_t st, int which) -> int32_t {
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch);
+        BDR_HIP(hipGetLastError());
+        return BDR_OK;
+    };
+    const unsigned any = sched == 2 ? hipExtAnyOrderLaunch : 0;
+    // a->kev: the fork / join events are completed by the producing kernel's own dispatch packet (launch `stop` event)
+    // instead of a marker packet behind it
+    auto kev = [&](int k) -> hipEvent_t { return ov && a->kev ? a->ev_fork[k] : nullptr; };
     auto fork = [&](int k) -> int32_t {
         if (!ov) return BDR_OK;
-        BDR_HIP(hipEventRecord(a->ev_fork[k], a->stream));
+        if (!a->kev) BDR_HIP(hipEventRecord(a->ev_fork[k], a->stream));
         BDR_HIP(hipStreamWaitEvent(a->side, a->ev_fork[k], 0));
         return BDR_OK;
     };
     const DwPlan pl = dw_plan(a->B);   // buffer layout follows the allocated batch capacity
+    a->adam_step += 1;
+    const AdamScalars adam_s = adam_scalars(c, a->adam_step);
+
+    auto head_bwd = [&]() -> int32_t {
+        HeadBwdArgs hb{a->h1[0], a->dq, act, act_bytes, a->loss_row, a->grad + ar.w5, a->grad + ar.b5, a->loss, B, ar.A};
+        Bracket br(a, "head_bwd");
+        LAUNCH_FL(sd, any, nullptr, k_head_bwd, dim3(2 * ar.A + 1), dim3(256), hb);
+        return BDR_OK;
+    };
+    auto l1_dw = [&]() -> int32_t {
+        DwArgs d{a->a3[0], a->dh1, a->grad + ar.w4, 0, B};
+        Bracket br(a, "bwd_l1_dw");
+        LAUNCH_FL(sd, any, nullptr, k_igemm_red<DwL1>, dim3(49 * 8), dim3(256), d);
+        return BDR_OK;
+    };
+    auto l1_dx = [&]() -> int32_t {
+        DxArgs d{a->dh1, a->q + ar.w4, a->a3[0], a->dy3, B, sigf(SIG_HEAD), epoch};   // its start publishes "head done"
+        Bracket br(a, "bwd_l1_dx");
+        BDR_HIP((launch_igemm<DxL1, TEAMS_DX_L1>(a->stream, dim3((((B + 63) / 64) * 49 + 7) / 8 * 8, 1, 1), d, 0, kev(1))));
+        return BDR_OK;
+    };
+    // :150 backward_step -> Adam.  The l1 / l2 parameters (95 % of the arena) have their gradients (k_head_bwd, DwL1) and
+    // their last readers of this step (k_head, DxL1) behind them once DxL1 is done, so their Adam pass - pure HBM
+    // streaming - runs under the conv dX GEMMs instead of at the end of the critical path.
+    auto adam_l1_l2 = [&]() -> int32_t {
+        Bracket br(a, "adam_l1_l2");
+        const size_t r4 = (ar.total - ar.w4) / 4;
+        LAUNCH_FL(sd, any, nullptr, k_adam, dim3((unsigned)((r4 + 255) / 256)), dim3(256), a->q + ar.w4, (const float*)(a->grad + ar.w4), a->m + ar.w4,
+                  a->v + ar.w4, r4, adam_s);
+        return BDR_OK;
+    };
+    auto c3_dw = [&]() -> int32_t {
+        const int M = B * 49, chunks = std::min(pl.chunks_c3, (M + 31) / 32);
+        DwArgs d{a->a2[0], a->dy3, a->part + pl.off_c3, pl.stride_c3, M};
+        Bracket br(a, "bwd_conv3_dw");
+        LAUNCH_FL(sd, any, nullptr, k_igemm_red<DwC3>, dim3(9 * chunks), dim3(256), d);
+        return BDR_OK;
+    };
+    auto c3_dx = [&]() -> int32_t {
+        DxArgs d{a->dy3, a->q + ar.w3, a->a2[0], a->dy2, B * 81, sigf(SIG_DXL1), epoch};
+        Bracket br(a, "bwd_conv3_dx");
+        BDR_HIP((launch_igemm<DxC3, TEAMS_DX_C3>(a->stream, dim3((d.M + 63) / 64, 1, 1), d, 0, kev(2))));
+        return BDR_OK;
+    };
+    auto c2_dw = [&]() -> int32_t {
+        const int M = B * 81, chunks = std::min(pl.chunks_c2, (M + 31) / 32);
+        DwArgs d{a->a1[0], a->dy2, a->part + pl.off_c2, pl.stride_c2, M};
+        Bracket br(a, "bwd_conv2_dw");
+        LAUNCH_FL(sd, any, ov && a->kev ? a->ev_join : nullptr, k_igemm_red<DwC2>, dim3(8 * chunks), dim3(256), d);
+        return BDR_OK;
+    };
+    auto c2_dx = [&]() -> int32_t {
+        DxArgs d{a->dy2, a->q + ar.w2, a->a1[0], a->dy1, B * 100, sigf(SIG_DXC3), epoch};
+        Bracket br(a, "bwd_conv2_dx");
+        BDR_HIP((launch_igemm<DxC2, TEAMS_DX_C2>(a->stream, dim3((d.M + 127) / 128, 4, 1), d)));
+        return BDR_OK;
+    };
+    auto c1_dw = [&]() -> int32_t {   // conv1 has no input gradient
+        const int chunks = std::min(pl.chunks_c1, B);
+        Conv1DwArgs d{obs, a->dy1, a->part + pl.off_c1, pl.stride_c1, B};
+        Bracket br(a, "bwd_conv1_dw");
+        hipLaunchKernelGGL(k_conv1_dw_bf16, dim3(chunks), dim3(512), 0, a->stream, d);
+        BDR_HIP(hipGetLastError());
+        return BDR_OK;
+    };
+
+    // dqn/base.rs:143: buffer.update_priority(&ixs, &Some(td_errs)).  Nothing in this update depends on it, so with
+    // concurrent schedules it runs on its own stream behind the TD step; the next batch() waits for it through the
+    // buffer's `written` event.
+    const bool per = per_buffer && weight;
+    if (per && sched == 2) BDR_HIP(hipEventRecord(a->ev_fork[0], a->stream));
     BDR_TRY(fork(0));                  // dh1, dq, td_abs ready
-    // dqn/base.rs:143: buffer.update_priority(&ixs, &Some(td_errs)).  Nothing in this update depends on it, so it runs
-    // on the weight-gradient stream; the next batch() waits for it through the buffer's `written` event.
-    if (per_buffer && weight) {
+    if (per) {
         hipStream_t ps = a->stream;
-        if (ov) {   // own stream: the weight-gradient stream is already as long as the dX chain
+        if (sched != 0) {
             if (!a->aux) BDR_HIP(hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking));
-            BDR_HIP(hipStreamWaitEvent(a->aux, a->ev_fork[0], 0));
+            if (gated) BDR_TRY(gate(a->aux, SIG_HEAD));
+            else BDR_HIP(hipStreamWaitEvent(a->aux, a->ev_fork[0], 0));
             ps = a->aux;
         }
         Bracket br(a, "per_update");
         BDR_TRY(replay_update_priority_on_stream(per_buffer, B, a->td_abs, ps));
     }
-    HeadBwdArgs hb{a->h1[0], a->dq, act, act_bytes, a->loss_row, a->grad + ar.w5, a->grad + ar.b5, a->loss, B, ar.A};
-    { Bracket br(a, "head_bwd"); LAUNCH_ON(sd, k_head_bwd, dim3(2 * ar.A + 1), hb); }
-    {
-        DwArgs d{a->a3[0], a->dh1, a->grad + ar.w4, 0, B};
-        Bracket br(a, "bwd_l1_dw");
-        LAUNCH_ON(sd, k_igemm_red<DwL1>, dim3(49 * 8), d);
-    }
-    {
-        DxArgs d{a->dh1, a->q + ar.w4, a->a3[0], a->dy3, B};
-        Bracket br(a, "bwd_l1_dx");
-        BDR_HIP((launch_igemm<DxL1, TEAMS_DX_L1>(a->stream, dim3((((B + 63) / 64) * 49 + 7) / 8 * 8, 1, 1), d)));
-    }
-    BDR_TRY(fork(1));                  // dy3 ready
-    // :150 backward_step -> Adam.  The l1 / l2 parameters (95 % of the arena) have their gradients (k_head_bwd, DwL1, both
-    // earlier on this stream) and their last readers of this step (k_head, DxL1: before fork(1)) behind them, so their
-    // Adam pass - pure HBM streaming - runs here under the conv dX GEMMs instead of at the end of the critical path.
-    a->adam_step += 1;
-    const AdamScalars adam_s = adam_scalars(c, a->adam_step);
-    {
-        Bracket br(a, "adam_l1_l2");
-        const size_t r4 = (ar.total - ar.w4) / 4;
-        hipLaunchKernelGGL(k_adam, dim3((unsigned)((r4 + 255) / 256)), dim3(256), 0, sd, a->q + ar.w4, a->grad + ar.w4, a->m + ar.w4, a->v + ar.w4, r4,
-                           adam_s);
+    if (gated) {
+        // dX queue: DxL1, DxC3, DxC2 (each start publishing its predecessor), conv1 dW, join gate.
+        // other queue: gate -> the weight gradients that depend on the published kernel, then the l1 / l2 Adam pass (a
+        // streaming kernel: beside a dX GEMM it starves for workgroup slots - 27 us instead of 8 - so it goes last, beside
+        // the conv1 dW kernel).
+        BDR_TRY(gate(sd, SIG_HEAD)); BDR_TRY(head_bwd()); BDR_TRY(l1_dw());
+        BDR_TRY(l1_dx());
+        BDR_TRY(gate(sd, SIG_DXL1)); BDR_TRY(c3_dw());
+        BDR_TRY(c3_dx());
+        BDR_TRY(gate(sd, SIG_DXC3)); BDR_TRY(c2_dw()); BDR_TRY(adam_l1_l2());
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sd, a->sig, SIG_SIDE, epoch);
         BDR_HIP(hipGetLastError());
-    }
-    {
-        const int M = B * 49, chunks = std::min(pl.chunks_c3, (M + 31) / 32);
-        DwArgs d{a->a2[0], a->dy3, a->part + pl.off_c3, pl.stride_c3, M};
-        { Bracket br(a, "bwd_conv3_dw"); LAUNCH_ON(sd, k_igemm_red<DwC3>, dim3(9 * chunks), d); }
-    }
-    {
-        DxArgs d{a->dy3, a->q + ar.w3, a->a2[0], a->dy2, B * 81};
-        Bracket br(a, "bwd_conv3_dx");
-        BDR_HIP((launch_igemm<DxC3, TEAMS_DX_C3>(a->stream, dim3((d.M + 63) / 64, 1, 1), d)));
-    }
-    BDR_TRY(fork(2));                  // dy2 ready
-    {
-        const int M = B * 81, chunks = std::min(pl.chunks_c2, (M + 31) / 32);
-        DwArgs d{a->a1[0], a->dy2, a->part + pl.off_c2, pl.stride_c2, M};
-        { Bracket br(a, "bwd_conv2_dw"); LAUNCH_ON(sd, k_igemm_red<DwC2>, dim3(8 * chunks), d); }
-    }
-    {
-        DxArgs d{a->dy2, a->q + ar.w2, a->a1[0], a->dy1, B * 100};
-        Bracket br(a, "bwd_conv2_dx");
-        BDR_HIP((launch_igemm<DxC2, TEAMS_DX_C2>(a->stream, dim3((d.M + 127) / 128, 4, 1), d)));
-    }
-    // conv1 (no input gradient) stays on the main stream
-    {
-        const int chunks = std::min(pl.chunks_c1, B);
-        Conv1DwArgs d{obs, a->dy1, a->part + pl.off_c1, pl.stride_c1, B};
-        { Bracket br(a, "bwd_conv1_dw"); hipLaunchKernelGGL(k_conv1_dw_bf16, dim3(chunks), dim3(512), 0, a->stream, d); BDR_HIP(hipGetLastError()); }
-    }
-    if (ov) {                          // join: all weight-gradient partials complete
-        BDR_HIP(hipEventRecord(a->ev_join, a->side));
-        BDR_HIP(hipStreamWaitEvent(a->stream, a->ev_join, 0));
+        BDR_TRY(c2_dx());
+        BDR_TRY(c1_dw());
+        BDR_TRY(gate(a->stream, SIG_SIDE));   // join: all weight-gradient partials complete
+    } else if (sched == 2) {
+        BDR_TRY(l1_dx());  BDR_TRY(head_bwd()); BDR_TRY(l1_dw());        // barrier, any-order, any-order
+        BDR_TRY(c3_dx());  BDR_TRY(adam_l1_l2()); BDR_TRY(c3_dw());
+        BDR_TRY(c2_dx());  BDR_TRY(c2_dw());
+        BDR_TRY(c1_dw());
+    } else {
+        BDR_TRY(head_bwd()); BDR_TRY(l1_dw());
+        BDR_TRY(l1_dx());
+        BDR_TRY(fork(1));              // dy3 ready
+        BDR_TRY(adam_l1_l2()); BDR_TRY(c3_dw());
+        BDR_TRY(c3_dx());
+        BDR_TRY(fork(2));              // dy2 ready
+        BDR_TRY(c2_dw());
+        BDR_TRY(c2_dx());
+        BDR_TRY(c1_dw());
+        if (ov) {                      // join: all weight-gradient partials complete
+            if (!a->kev) BDR_HIP(hipEventRecord(a->ev_join, a->side));
+            BDR_HIP(hipStreamWaitEvent(a->stream, a->ev_join, 0));
+        }
     }
     {   // conv1..conv3 partials -> gradient arena, one launch
         Reduce3Args r{};
@@ -599,7 +705,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
                                  k == 0 ? INV255 : 1.0f, wg};
             wg += (nw[k] + nb[k] + 31) / 32;
         }
-        // the conv layers' Adam step rides on their partial reduction (k_reduce_adam); l1 / l2 were done above
+        // the conv layers' Adam step rides on their partial reduction (k_reduce_adam); l1 / l2: adam_l1_l2 above
         ReduceAdamArgs ra{};
         ra.r = r; ra.p = a->q; ra.g = a->grad; ra.m = a->m; ra.v = a->v; ra.gbase = a->grad;
         ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg;
@@ -751,6 +857,7 @@ DqnCnn::~DqnCnn()
     (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
     for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (sig) (void)hipFree(sig);
     if (aux) (void)hipStreamDestroy(aux);
     if (side) (void)hipStreamDestroy(side);
 }
@@ -837,9 +944,13 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->ar = make_arena(cfg->net.out_dim);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     BDR_HIP(hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking));
-    for (auto& e : a->ev_fork) BDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    BDR_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
-    a->overlap = getenv("BDR_NO_OVERLAP") == nullptr;
+    for (auto& e : a->ev_fork) BDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    BDR_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+    if (const char* e = getenv("BDR_SCHED")) a->sched = std::max(0, std::min(3, atoi(e)));
+    BDR_HIP(hipMalloc((void**)&a->sig, 8 * sizeof(unsigned)));
+    BDR_HIP(hipMemset(a->sig, 0, 8 * sizeof(unsigned)));
+    if (getenv("BDR_NO_OVERLAP")) a->sched = 0;
+    a->kev = getenv("BDR_NO_KEV") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->ar.total));

@@ -21,6 +21,9 @@
 
 #include <cstdint>
 #include <type_traits>
+#include <utility>
+
+#include <hip/hip_ext.h>
 
 namespace bdr {
 
@@ -310,10 +313,24 @@ __device__ unsigned long long* g_igemm_phase;
 #define IGEMM_PH(var) do { } while (0)
 #endif
 
+// Cross-queue progress flags (see DqnCnn::update_critic, schedule 3).  A kernel whose Args carry `sig_flag` / `sig_epoch`
+// publishes "everything queued before me on my stream is complete" the moment its first workgroup starts: the dispatch
+// packet's barrier bit has already waited for the predecessors and their end-of-kernel release, so a consumer on another
+// queue that sees flag >= epoch (k_gate) and then starts a kernel (acquire) reads complete data - without any event /
+// barrier packet in the producer's queue.
+template <class A, class = void> struct has_start_signal : std::false_type {};
+template <class A> struct has_start_signal<A, std::void_t<decltype(std::declval<A>().sig_flag)>> : std::true_type {};
+__device__ inline void start_signal(unsigned* flag, unsigned epoch)
+{
+    if (flag && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class P, int TEAMS = 1>
 __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P::Args args)
 {
     IGEMM_TP(0);
+    if constexpr (has_start_signal<typename P::Args>::value) start_signal(args.sig_flag, args.sig_epoch);
     using A = typename P::A;
     constexpr int NW = P::WM * P::WN, NT = 64 * NW;          // waves / threads per team
     constexpr int BM = P::WM * P::TM * 32, BN = P::WN * P::TN * 32;
@@ -561,10 +578,13 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
 }
 
 
+// flags: 0, or hipExtAnyOrderLaunch (no barrier bit on the dispatch packet: the kernel may start while the packets queued
+// before it on the same stream are still running).  stop: event completed by this kernel's own dispatch packet (no separate
+// marker packet in the queue, unlike hipEventRecord)
 template <class P, int TEAMS>
-inline hipError_t launch_igemm(hipStream_t st, dim3 grid, const typename P::Args& args)
+inline hipError_t launch_igemm(hipStream_t st, dim3 grid, const typename P::Args& args, unsigned flags = 0, hipEvent_t stop = nullptr)
 {
-    hipLaunchKernelGGL((k_igemm<P, TEAMS>), grid, dim3(64 * P::WM * P::WN * TEAMS), 0, st, args);
+    hipExtLaunchKernelGGL((k_igemm<P, TEAMS>), grid, dim3(64 * P::WM * P::WN * TEAMS), 0, st, nullptr, stop, flags, args);
     return hipGetLastError();
 }
 
@@ -581,6 +601,7 @@ inline hipError_t launch_igemm(hipStream_t st, dim3 grid, const typename P::Args
 template <class P>
 __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
 {
+    if constexpr (has_start_signal<typename P::Args>::value) start_signal(args.sig_flag, args.sig_epoch);
     using A = typename P::A;
     constexpr int KO_T = P::WM * P::TM * 32, N_T = P::WN * P::TN * 32;
     constexpr int LDAR = KO_T + 4, LDY = N_T;

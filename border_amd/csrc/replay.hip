@@ -178,6 +178,40 @@ __global__ __launch_bounds__(256) void k_fill_synthetic(FillArgs a)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// `written` was just recorded on some stream: consumers have to wait for it again
+static void mark_written(bdr_replay* r) { r->written_gen += 1; }
+
+// WAR / WAW against the last gather: the stream `s` is about to overwrite ring rows or the batch buffers
+static int32_t wait_for_reader(bdr_replay* r, hipStream_t s)
+{
+    if (!r->read_pending) return BDR_OK;
+    r->read_pending = false;
+    if (r->read_stream == s) return BDR_OK;   // same queue: already ordered
+    if (hipEventRecord(r->read, r->read_stream) != hipSuccess) {   // the consumer's stream is gone (agent destroyed)
+        (void)hipGetLastError();
+        BDR_HIP(hipDeviceSynchronize());
+        return BDR_OK;
+    }
+    BDR_HIP(hipStreamWaitEvent(s, r->read, 0));
+    return BDR_OK;
+}
+
+// RAW against pushes / fills / tree updates: once per consumer stream and generation of `written`
+static int32_t wait_for_writer(bdr_replay* r, hipStream_t s)
+{
+    for (auto& w : r->waited)
+        if (w.first == s) {
+            if (w.second == r->written_gen) return BDR_OK;
+            w.second = r->written_gen;
+            BDR_HIP(hipStreamWaitEvent(s, r->written, 0));
+            return BDR_OK;
+        }
+    if (r->waited.size() >= 16) r->waited.erase(r->waited.begin());
+    r->waited.emplace_back(s, r->written_gen);
+    BDR_HIP(hipStreamWaitEvent(s, r->written, 0));
+    return BDR_OK;
+}
+
 extern "C" {
 
 const char* bdr_last_error(void) { return bdr::g_err; }
@@ -217,11 +251,11 @@ int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out)
                     (double)(cfg->capacity * r->stride) / 1e9, hipGetErrorString(e));
     }
     BDR_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-    BDR_HIP(hipEventCreateWithFlags(&r->written, hipEventDisableTiming));
-    BDR_HIP(hipEventCreateWithFlags(&r->read, hipEventDisableTiming));
+    BDR_HIP(hipEventCreateWithFlags(&r->written, hipEventDisableTiming | hipEventDisableSystemFence));
+    BDR_HIP(hipEventCreateWithFlags(&r->read, hipEventDisableTiming | hipEventDisableSystemFence));
     // rows are zero like `Tensor::zeros` / `vec![0.; capacity]` (tensor_batch.rs:95-101, base.rs:350-352)
     BDR_HIP(hipMemsetAsync(r->ring, 0, r->capacity * r->stride, r->stream));
-    BDR_HIP(hipEventRecord(r->written, r->stream));
+    BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
     r->stage_records = std::max<uint64_t>(1, std::min<uint64_t>(256, (8ull << 20) / r->stride));
     BDR_HIP(hipHostMalloc((void**)&r->stage, r->stage_records * r->stride, hipHostMallocDefault));
     *out = r;
@@ -265,10 +299,7 @@ int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, const void* 
     if (n == 0) return BDR_OK;
     BDR_REQUIRE(obs && act && next_obs && reward && term && trunc, "null transition field");
     BDR_HIP(hipSetDevice(r->device));
-    if (r->read_pending) {  // WAR: do not overwrite rows a consumer's gather may still be reading
-        BDR_HIP(hipStreamWaitEvent(r->stream, r->read, 0));
-        r->read_pending = false;
-    }
+    BDR_TRY(wait_for_reader(r, r->stream));  // WAR: do not overwrite rows a consumer's gather may still be reading
     const uint8_t* o = (const uint8_t*)obs; const uint8_t* a = (const uint8_t*)act; const uint8_t* x = (const uint8_t*)next_obs;
     uint64_t done = 0;
     while (done < n) {
@@ -293,7 +324,7 @@ int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, const void* 
         BDR_HIP(hipStreamWaitEvent(r->stream, r->written, 0));
         BDR_TRY(per_push(r->per, r->i, n, r->stream));
     }
-    BDR_HIP(hipEventRecord(r->written, r->stream));
+    BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
     BDR_HIP(hipStreamSynchronize(r->stream));  // caller may reuse its host buffers; staging reusable
     // base.rs:308-312
     r->i = (r->i + n) % r->capacity;
@@ -311,7 +342,7 @@ int32_t bdr_replay_fill_synthetic(bdr_replay* r, uint64_t n, uint64_t seed, int3
     BDR_REQUIRE(kind == 0 || r->obs_bytes % 4 == 0, "f32 rows need obs_row_bytes %% 4 == 0");
     BDR_REQUIRE(n <= r->capacity, "fill count exceeds capacity");
     BDR_HIP(hipSetDevice(r->device));
-    if (r->read_pending) { BDR_HIP(hipStreamWaitEvent(r->stream, r->read, 0)); r->read_pending = false; }
+    BDR_TRY(wait_for_reader(r, r->stream));
     FillArgs a{r->ring, r->stride, r->obs_bytes, r->act_bytes, r->next_off, r->act_off, r->tail_off, r->capacity,
                n, seed, kind, n_actions};
     // grid.x is limited to 2^31-1; n <= capacity fits comfortably for the sizes used here
@@ -321,7 +352,7 @@ int32_t bdr_replay_fill_synthetic(bdr_replay* r, uint64_t n, uint64_t seed, int3
         BDR_REQUIRE(r->size == 0, "synthetic fill with PER needs an empty buffer");
         BDR_TRY(per_push(r->per, 0, n, r->stream));
     }
-    BDR_HIP(hipEventRecord(r->written, r->stream));
+    BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
     r->i = n % r->capacity;
     r->size = n;
     return BDR_OK;
@@ -384,7 +415,8 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     if (r->size == 0) return fail(BDR_ERR_EMPTY, "batch() on an empty replay buffer");
     BDR_REQUIRE(n > 0 && n < (1ull << 24), "batch size out of range");
     BDR_TRY(replay_ensure_batch_capacity(r, n));
-    BDR_HIP(hipStreamWaitEvent(stream, r->written, 0));  // RAW against pushes / fills
+    BDR_TRY(wait_for_writer(r, stream));
+    BDR_TRY(wait_for_reader(r, stream));   // another stream's gather may still own the batch buffers
     GatherArgs a{};
     a.ring = r->ring; a.stride = r->stride; a.obs_bytes = r->obs_bytes; a.act_bytes = r->act_bytes;
     a.next_off = r->next_off; a.act_off = r->act_off; a.tail_off = r->tail_off; a.ixs = r->b_ixs;
@@ -409,8 +441,7 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
         hipLaunchKernelGGL(k_gather<uint32_t>, dim3((uint32_t)(n * a.chunks)), dim3(256), 0, stream, a);
     }
     BDR_HIP(hipGetLastError());
-    BDR_HIP(hipEventRecord(r->read, stream));
-    r->read_pending = true;
+    r->read_pending = true; r->read_stream = stream;   // recorded only if somebody has to wait for it (wait_for_reader)
     r->batch_n = n;
     return BDR_OK;
 }
@@ -421,7 +452,7 @@ int32_t replay_update_priority_on_stream(bdr_replay* r, uint64_t n, const float*
     if (!r->per) return BDR_OK;
     BDR_REQUIRE(n == r->batch_n, "update_priority size differs from the last batch");
     BDR_TRY(per_update(r->per, n, r->b_ixs, td_dev, stream));
-    BDR_HIP(hipEventRecord(r->written, stream));   // later pushes / samples order behind the tree update
+    BDR_HIP(hipEventRecord(r->written, stream)); mark_written(r);   // later pushes / samples order behind the tree update
     return BDR_OK;
 }
 
@@ -484,7 +515,7 @@ int32_t bdr_replay_enable_per(bdr_replay* r, const bdr_per_config* c)
     BDR_REQUIRE(r->size == 0 && r->i == 0, "PER must be enabled on an empty buffer");
     BDR_HIP(hipSetDevice(r->device));
     BDR_TRY(per_create(c, r->capacity, r->stream, &r->per));
-    BDR_HIP(hipEventRecord(r->written, r->stream));
+    BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
     return BDR_OK;
 }
 
@@ -502,7 +533,7 @@ int32_t bdr_replay_update_priority(bdr_replay* r, uint64_t n, const uint64_t* ix
     if (e == hipSuccess) e = hipMemcpyAsync(d_ix, ixs, n * 8, hipMemcpyHostToDevice, r->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_td, td_errs, n * 4, hipMemcpyHostToDevice, r->stream);
     int32_t rc = e == hipSuccess ? per_update(r->per, n, d_ix, d_td, r->stream) : fail(BDR_ERR_HIP, "update_priority copy failed: %s", hipGetErrorString(e));
-    if (rc == BDR_OK) (void)hipEventRecord(r->written, r->stream);
+    if (rc == BDR_OK) { (void)hipEventRecord(r->written, r->stream); mark_written(r); }
     (void)hipStreamSynchronize(r->stream);
     (void)hipFree(d_ix); (void)hipFree(d_td);
     return rc;

@@ -286,6 +286,7 @@ struct DqnCnn : bdr_agent {
     bool kev = true;
     unsigned* sig = nullptr;   // [8] device progress flags of schedule 3
     unsigned sig_epoch = 0;
+    unsigned long long* gate_trace = nullptr;   // BDR_GATE_TRACE=1: [5][2] (100 MHz ticks waited, count), printed at destruction
     int sched = 3;   // backward schedule, see update_critic (BDR_SCHED=0|1|2; BDR_NO_OVERLAP=1 == 0)
     Arena ar;
     int B = 0;          // activation buffers are sized for this batch
@@ -394,7 +395,7 @@ __device__ __forceinline__ void adam_element(float& p, float g, float& m, float&
 // it cannot starve the producer; a producer that never arrives trips the time limit instead of hanging the queue
 // (sig[SIG_ERR] is checked at the next synchronisation).
 constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_ERR = 7;
-__global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned epoch)
+__global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned epoch, unsigned long long* waited)
 {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();   // 100 MHz
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned 
             return;
         }
     }
+    if (waited) { waited[0] += wall_clock64() - t0; waited[1] += 1; }   // BDR_GATE_TRACE: time spent waiting, per gate site
 }
 // k_signal: "everything queued before me on this stream is complete" (same argument as start_signal)
 __global__ __launch_bounds__(64) void k_signal(unsigned* sig, int which, unsigned epoch)
@@ -558,7 +560,9 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     const unsigned epoch = gated ? ++a->sig_epoch : 0;
     auto sigf = [&](int which) -> unsigned* { return gated ? a->sig + which : nullptr; };
     auto gate = [&](hipStream_t st, int which) -> int32_t {
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch);
+        // trace slot: 2 counters per site; sites 0..3 = flags on the weight-gradient queue, 4 = the join on the dX queue
+        unsigned long long* tr = a->gate_trace ? a->gate_trace + 2 * (st == a->stream ? 4 : which) : nullptr;
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch, tr);
         BDR_HIP(hipGetLastError());
         return BDR_OK;
     };
@@ -857,6 +861,14 @@ DqnCnn::~DqnCnn()
     (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
     for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (gate_trace) {
+        unsigned long long t[10] = {0};
+        (void)hipMemcpy(t, gate_trace, sizeof t, hipMemcpyDeviceToHost);
+        static const char* site[5] = {"side<-head", "side<-DxL1", "side<-DxC3", "-", "main<-side (join)"};
+        for (int k = 0; k < 5; ++k)
+            if (t[2 * k + 1]) fprintf(stderr, "gate %-18s mean wait %.2f us over %llu gates\n", site[k], t[2 * k] / 100.0 / t[2 * k + 1], t[2 * k + 1]);
+        (void)hipFree(gate_trace);
+    }
     if (sig) (void)hipFree(sig);
     if (aux) (void)hipStreamDestroy(aux);
     if (side) (void)hipStreamDestroy(side);
@@ -949,6 +961,10 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     if (const char* e = getenv("BDR_SCHED")) a->sched = std::max(0, std::min(3, atoi(e)));
     BDR_HIP(hipMalloc((void**)&a->sig, 8 * sizeof(unsigned)));
     BDR_HIP(hipMemset(a->sig, 0, 8 * sizeof(unsigned)));
+    if (getenv("BDR_GATE_TRACE")) {
+        BDR_HIP(hipMalloc((void**)&a->gate_trace, 10 * sizeof(unsigned long long)));
+        BDR_HIP(hipMemset(a->gate_trace, 0, 10 * sizeof(unsigned long long)));
+    }
     if (getenv("BDR_NO_OVERLAP")) a->sched = 0;
     a->kev = getenv("BDR_NO_KEV") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};

@@ -474,13 +474,14 @@ def test_checkpoints_default_to_the_reference_pt_tch_archives(B, tmp_path):
 
 def test_opt_stream_is_deterministic_and_overlap_invariant(B):
     """200 opt steps over the same synthetic ring from the same initial parameters: bit-identical parameters between
-    two runs, and between the two-stream schedule and the serial one (BDR_NO_OVERLAP=1) - every reduction has a fixed
-    order, so any difference would be a race between the streams."""
-    def run(no_overlap):
-        if no_overlap:
-            os.environ["BDR_NO_OVERLAP"] = "1"
+    two runs, and between every backward schedule (BDR_SCHED: 0 serial, 1 two streams ordered by events, 2 any-order
+    launches, 3 = default, two streams ordered by device flags and gate kernels) - every reduction has a fixed order, so
+    any difference would be a race between the queues."""
+    def run(sched):
+        if sched is None:
+            os.environ.pop("BDR_SCHED", None)
         else:
-            os.environ.pop("BDR_NO_OVERLAP", None)
+            os.environ["BDR_SCHED"] = str(sched)
         try:
             rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=20_000, seed=42), (4, 1, 84, 84), "uint8")
             rb.fill_synthetic(20_000, seed=3, kind=0, n_actions=6)
@@ -493,11 +494,10 @@ def test_opt_stream_is_deterministic_and_overlap_invariant(B):
             a.close(); rb.close()
             return p, t
         finally:
-            os.environ.pop("BDR_NO_OVERLAP", None)
+            os.environ.pop("BDR_SCHED", None)
 
-    p1, t1 = run(False)
-    p2, t2 = run(False)
-    p3, t3 = run(True)
+    p1, t1 = run(None)
     assert np.isfinite(p1).all()
-    assert (p1 == p2).all() and (t1 == t2).all()
-    assert (p1 == p3).all() and (t1 == t3).all()
+    for sched in (None, 0, 1, 2, 3):
+        p, t = run(sched)
+        assert (p1 == p).all() and (t1 == t).all(), sched

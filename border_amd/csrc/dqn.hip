@@ -960,10 +960,10 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* e = getenv("BDR_SCHED")) a->sched = std::max(0, std::min(3, atoi(e)));
     BDR_HIP(hipMalloc((void**)&a->sig, 8 * sizeof(unsigned)));
-    BDR_HIP(hipMemset(a->sig, 0, 8 * sizeof(unsigned)));
+    BDR_HIP(hipMemsetAsync(a->sig, 0, 8 * sizeof(unsigned), a->stream));   // synchronised with the parameter upload below
     if (getenv("BDR_GATE_TRACE")) {
         BDR_HIP(hipMalloc((void**)&a->gate_trace, 10 * sizeof(unsigned long long)));
-        BDR_HIP(hipMemset(a->gate_trace, 0, 10 * sizeof(unsigned long long)));
+        BDR_HIP(hipMemsetAsync(a->gate_trace, 0, 10 * sizeof(unsigned long long), a->stream));
     }
     if (getenv("BDR_NO_OVERLAP")) a->sched = 0;
     a->kev = getenv("BDR_NO_KEV") == nullptr;

@@ -137,8 +137,8 @@ def main():
             half_null = 0.5 * p.pop("_null", 0.0)
             return {k: max(v - half_null, 0.0) for k, v in p.items()}, half_null
         prof, null_ms = profile(args.profile_steps)
-        if args.profile_steps < 30 and any(v <= 0.0 for v in prof.values()):   # a single-step sample can hit an outlier bracket
-            prof, null_ms = profile(30)
+        if any(v <= 0.0 for v in prof.values()):   # an outlier empty bracket (its half is subtracted everywhere): measure again
+            prof, null_ms = profile(max(30, args.profile_steps))
         nz = 3 if args.double_dqn else 2
         fl = kernel_flops(args.batch, nz)
         if not any(k in fl for k in prof):

@@ -116,6 +116,8 @@ ABI_SYMBOLS = [
     "bdr_sac_config_default", "bdr_sac_create", "bdr_sac_update_on_batch", "bdr_sac_sample",
     "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_agent_allreduce_params",
     "bdr_agent_broadcast_params",
+    "bdr_atari_prep_create", "bdr_atari_prep_destroy", "bdr_atari_prep_reset", "bdr_atari_prep_step", "bdr_atari_prep_obs",
+    "bdr_atari_prep_device_stacks", "bdr_atari_clip_reward",
 ]
 
 _lib = None
@@ -139,8 +141,10 @@ def lib() -> C.CDLL:
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == ABI drift
         if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default", "bdr_iqn_config_default",
-                        "bdr_explorer_config_default", "bdr_per_config_default"):
+                        "bdr_explorer_config_default", "bdr_per_config_default", "bdr_atari_clip_reward"):
             fn.restype = C.c_int32
+    L.bdr_atari_clip_reward.restype = C.c_float
+    L.bdr_atari_clip_reward.argtypes = [C.c_float, C.c_int32]
     L.bdr_dqn_config_default.restype = None
     L.bdr_sac_config_default.restype = None
     L.bdr_iqn_config_default.restype = None

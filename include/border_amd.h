@@ -306,6 +306,27 @@ BDR_API int32_t bdr_agent_set_checkpoint_format(bdr_agent* a, int32_t format);
 BDR_API int32_t bdr_agent_save_params(bdr_agent* a, const char* dir);
 BDR_API int32_t bdr_agent_load_params(bdr_agent* a, const char* dir);
 
+/* border-atari-env frame preprocessing on the device (border-atari-env/src/env.rs):
+ * one handle keeps the `frames: [4][84][84]` u8 stack of n_envs environments in HBM (newest frame first).
+ *   reset  env.rs:263-296   all four slots <- warp_and_grayscale(frame)
+ *   step   env.rs:312-324   skip_and_max (:126-157: element-wise max of the two last RGB frames of the skip-4 step),
+ *                           warp_and_grayscale (:171-195: image 0.23 resize(.., 84, 84, Triangle), then the reference's luma
+ *                           with its (b, g, r) channel naming), stack_frame (:197-209)
+ * frames are host buffers [n][height][width][3] u8 (render_rgb24 layout); env_ixs[k] names the environment of frame k and
+ * may not repeat within one call.  The resize restates image 0.23.14's sample.rs (see oracle/atari_prep.py: parity
+ * unpinned against the real crate).  bdr_atari_clip_reward: env.rs:159-169. */
+typedef struct bdr_atari_prep bdr_atari_prep;
+BDR_API int32_t bdr_atari_prep_create(int32_t device, uint32_t n_envs, uint32_t width, uint32_t height, bdr_atari_prep** out);
+BDR_API int32_t bdr_atari_prep_destroy(bdr_atari_prep* h);
+BDR_API int32_t bdr_atari_prep_reset(bdr_atari_prep* h, uint32_t n, const uint32_t* env_ixs, const uint8_t* frames);
+BDR_API int32_t bdr_atari_prep_step(bdr_atari_prep* h, uint32_t n, const uint32_t* env_ixs, const uint8_t* frames_a,
+                                    const uint8_t* frames_b);
+/* stacked observations of the named environments, [n][4][84][84] u8, to the host (what BorderAtariObs carries) */
+BDR_API int32_t bdr_atari_prep_obs(bdr_atari_prep* h, uint32_t n, const uint32_t* env_ixs, uint8_t* obs_out);
+/* device address of all stacks, [n_envs][4][84][84] u8 */
+BDR_API int32_t bdr_atari_prep_device_stacks(bdr_atari_prep* h, const uint8_t** stacks);
+BDR_API float bdr_atari_clip_reward(float r, int32_t train);
+
 /* Host-side named-tensor files (no GPU involved): the container layer under save_params / load_params, for callers
  * that move parameters themselves (bdr_agent_get_params / set_params take the same reference-layout vectors).
  * `data` is the concatenation of the tensors in `meta` order (row-major f32); the container is chosen by the file

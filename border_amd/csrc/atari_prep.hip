@@ -7,7 +7,8 @@
 // the real crate: no vector exists offline.
 //
 // One workgroup per (environment, step).  HBM-bound byte work: 2 x 100.8 KB of RGB in, 7 KB of luma out, the three older
-// frames of the stack shifted in place.  Pass 1 (rows 210 -> 84) writes a [84][160][3] u8 intermediate to LDS (40 KB), pass 2
+// frames of the stack shifted in place.  Pass 1 (rows 210 -> 84, 4 bytes per thread and item,
+// all loads of an item in flight together) writes a [84][160][3] u8 intermediate to LDS (40 KB), pass 2
 // (columns 160 -> 84) and the luma read it back.  FMA contraction is switched off for this file: the reference multiplies and adds
 // separately (Rust never contracts).
 #include "common.hpp"
@@ -84,43 +85,85 @@ struct PrepArgs {
     int reset;               // 1: all four slots <- the new frame
 };
 
-__global__ __launch_bounds__(256) void k_atari_prep(PrepArgs a)
+__device__ inline uint32_t max_u8x4(uint32_t x, uint32_t y)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r |= max((x >> (8 * b)) & 255u, (y >> (8 * b)) & 255u) << (8 * b);
+    return r;
+}
+
+// 512 threads per environment.  The tap tables of both passes are built once per workgroup in LDS; pass 1 works on
+// 4-byte groups of a row (W * 3 is a multiple of 4 for even W; odd widths take the byte path) with all of an item's loads
+// issued before the arithmetic.
+constexpr int PREP_THREADS = 512;
+__global__ __launch_bounds__(PREP_THREADS) void k_atari_prep(PrepArgs a)
 {
     NO_FMA
-    extern __shared__ uint8_t tmp[];   // [84][W][3]
+    extern __shared__ uint8_t tmp[];   // [84][W][3] (rounded up to 16 B), then the two tap tables
     const int e = blockIdx.x, tid = threadIdx.x;
-    const size_t fsz = (size_t)a.H * a.W * 3;
+    const int rowb = a.W * 3;
+    Taps* vt = reinterpret_cast<Taps*>(tmp + ((OUT * rowb + 15) & ~15));
+    Taps* ht = vt + OUT;
+    const size_t fsz = (size_t)a.H * rowb;
     const uint8_t* fa = a.frames + (size_t)e * 2 * fsz;
     const uint8_t* fb = fa + fsz;
     uint8_t* stack = a.stacks + (size_t)a.env_ixs[e] * 4 * OUT * OUT;
-    const int rowb = a.W * 3;
 
-    // pass 1: vertical_sample of max(frame_a, frame_b); one thread per (output row, byte of the row)
-    for (int idx = tid; idx < OUT * rowb; idx += 256) {
-        const int oy = idx / rowb, xb = idx - oy * rowb;
-        const Taps t = taps_of(oy, a.H);
-        float acc = 0.0f;
-        for (int k = 0; k < t.n; ++k) {
-            const size_t off = (size_t)(t.left + k) * rowb + xb;
-            const uint8_t p = max(fa[off], fb[off]);          // env.rs:148-152
-            acc = acc + (float)p * t.w[k];
+    if (tid < OUT) vt[tid] = taps_of(tid, a.H);
+    else if (tid < 2 * OUT) ht[tid - OUT] = taps_of(tid - OUT, a.W);
+    __syncthreads();
+
+    // pass 1: vertical_sample of max(frame_a, frame_b) (env.rs:148-152)
+    if ((rowb & 3) == 0 && (fsz & 3) == 0) {
+        const int roww = rowb >> 2;
+        const uint32_t* wa = reinterpret_cast<const uint32_t*>(fa);
+        const uint32_t* wb = reinterpret_cast<const uint32_t*>(fb);
+        uint32_t* tw = reinterpret_cast<uint32_t*>(tmp);
+        for (int idx = tid; idx < OUT * roww; idx += PREP_THREADS) {
+            const int oy = idx / roww, xw = idx - oy * roww;
+            const Taps& t = vt[oy];
+            uint32_t px[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = min(t.left + k, a.H - 1);                 // k >= n: weight 0, row clamped
+                px[k] = max_u8x4(wa[(size_t)row * roww + xw], wb[(size_t)row * roww + xw]);
+            }
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < t.n; ++k)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[b] = acc[b] + (float)((px[k] >> (8 * b)) & 255u) * t.w[k];
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o |= (uint32_t)finish(acc[b], t.sum) << (8 * b);
+            tw[idx] = o;
         }
-        tmp[idx] = finish(acc, t.sum);
+    } else {
+        for (int idx = tid; idx < OUT * rowb; idx += PREP_THREADS) {
+            const int oy = idx / rowb, xb = idx - oy * rowb;
+            const Taps& t = vt[oy];
+            float acc = 0.0f;
+            for (int k = 0; k < t.n; ++k) {
+                const size_t off = (size_t)(t.left + k) * rowb + xb;
+                acc = acc + (float)max(fa[off], fb[off]) * t.w[k];
+            }
+            tmp[idx] = finish(acc, t.sum);
+        }
     }
     __syncthreads();
 
     // stack_frame (env.rs:197-209): slots 1..3 <- slots 0..2, every thread moves its own pixels (oldest first)
     if (!a.reset) {
-        for (int p = tid; p < OUT * OUT; p += 256) {
+        for (int p = tid; p < OUT * OUT; p += PREP_THREADS) {
             stack[3 * OUT * OUT + p] = stack[2 * OUT * OUT + p];
             stack[2 * OUT * OUT + p] = stack[1 * OUT * OUT + p];
             stack[1 * OUT * OUT + p] = stack[p];
         }
     }
     // pass 2: horizontal_sample + luma; one thread per output pixel (the same pixels it just moved)
-    for (int p = tid; p < OUT * OUT; p += 256) {
+    for (int p = tid; p < OUT * OUT; p += PREP_THREADS) {
         const int oy = p / OUT, ox = p - oy * OUT;
-        const Taps t = taps_of(ox, a.W);
+        const Taps& t = ht[ox];
         float c[3] = {0.0f, 0.0f, 0.0f};
         for (int k = 0; k < t.n; ++k) {
             const uint8_t* px = tmp + (size_t)oy * rowb + (t.left + k) * 3;
@@ -168,7 +211,7 @@ int32_t run(bdr_atari_prep* h, uint32_t n, const uint32_t* env_ixs, const uint8_
     BDR_HIP(hipMemcpyAsync(h->d_frames, h->h_stage, (size_t)n * 2 * fsz, hipMemcpyHostToDevice, h->stream));
     BDR_HIP(hipMemcpyAsync(h->d_ixs, env_ixs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     PrepArgs a{h->d_frames, h->d_ixs, h->stacks, (int)h->width, (int)h->height, reset};
-    hipLaunchKernelGGL(k_atari_prep, dim3(n), dim3(256), (size_t)OUT * h->width * 3, h->stream, a);
+    hipLaunchKernelGGL(k_atari_prep, dim3(n), dim3(PREP_THREADS), (((size_t)OUT * h->width * 3 + 15) & ~(size_t)15) + 2 * OUT * sizeof(Taps), h->stream, a);
     BDR_HIP(hipGetLastError());
     BDR_HIP(hipStreamSynchronize(h->stream));   // env_ixs / frames may be reused by the caller
     return BDR_OK;

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned 
     const unsigned long long t0 = wall_clock64();   // 100 MHz
     while ((int)(__hip_atomic_load(sig + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > 200000000ull) {   // 2 s
+        if (wall_clock64() - t0 > 1000000000ull) {   // 10 s
             __hip_atomic_store(sig + SIG_ERR, 1u + (unsigned)which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }

@@ -10,5 +10,5 @@ from .sac import Sac, SacConfig  # noqa: F401
 from .iqn import Iqn, IqnConfig  # noqa: F401
 from . import checkpoint  # noqa: F401
 from .atari import AtariPreprocessor  # noqa: F401
-from .trainer import (ParamExchange, Sampler, SimpleStepProcessor, Step, SyntheticEnv, Trainer, TrainerConfig,  # noqa: F401
+from .trainer import (NativeTrainer, ParamExchange, Sampler, SimpleStepProcessor, Step, SyntheticEnv, Trainer, TrainerConfig,  # noqa: F401
                       shard_seed)

@@ -91,6 +91,36 @@ class NamedTensorC(C.Structure):
     _fields_ = [("name", C.c_char_p), ("dims", C.POINTER(C.c_uint64)), ("ndim", C.c_uint32)]
 
 
+ENV_RESET_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
+ENV_STEP_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.c_void_p)
+SET_TRAIN_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32)
+SAMPLE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p)
+OPT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
+OPT_REC_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32))
+PUSH_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int8), C.POINTER(C.c_int8))
+OBSERVER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_float), C.c_int32)
+
+
+class EnvVtable(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("reset", ENV_RESET_FN), ("step_with_reset", ENV_STEP_FN)]
+
+
+class TrainerOps(C.Structure):
+    _fields_ = [("agent", C.c_void_p), ("buffer", C.c_void_p), ("agent_set_train", SET_TRAIN_FN), ("agent_sample", SAMPLE_FN),
+                ("agent_opt", OPT_FN), ("agent_opt_with_record", OPT_REC_FN), ("buffer_push", PUSH_FN)]
+
+
+class TrainerConfigC(C.Structure):
+    _fields_ = [("max_opts", C.c_uint64), ("opt_interval", C.c_uint64), ("warmup_period", C.c_uint64),
+                ("record_agent_info_interval", C.c_uint64), ("record_compute_cost_interval", C.c_uint64),
+                ("obs_row_bytes", C.c_uint64), ("act_row_bytes", C.c_uint64)]
+
+
+class TrainerStatsC(C.Structure):
+    _fields_ = [("env_steps", C.c_uint64), ("opt_steps", C.c_uint64), ("n_records", C.c_uint64), ("n_episodes", C.c_uint64),
+                ("opt_seconds", C.c_double), ("sample_seconds", C.c_double)]
+
+
 class DeviceBatch(C.Structure):
     _fields_ = [("n", C.c_uint64), ("obs", C.c_void_p), ("next_obs", C.c_void_p), ("act", C.c_void_p),
                 ("reward", C.c_void_p), ("is_terminated", C.c_void_p), ("is_truncated", C.c_void_p),
@@ -118,6 +148,7 @@ ABI_SYMBOLS = [
     "bdr_agent_broadcast_params",
     "bdr_atari_prep_create", "bdr_atari_prep_destroy", "bdr_atari_prep_reset", "bdr_atari_prep_step", "bdr_atari_prep_obs",
     "bdr_atari_prep_device_stacks", "bdr_atari_clip_reward",
+    "bdr_trainer_config_default", "bdr_trainer_ops_default", "bdr_trainer_train", "bdr_trainer_train_offline",
 ]
 
 _lib = None
@@ -141,8 +172,16 @@ def lib() -> C.CDLL:
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == ABI drift
         if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default", "bdr_iqn_config_default",
-                        "bdr_explorer_config_default", "bdr_per_config_default", "bdr_atari_clip_reward"):
+                        "bdr_explorer_config_default", "bdr_per_config_default", "bdr_atari_clip_reward", "bdr_trainer_config_default",
+                        "bdr_trainer_ops_default"):
             fn.restype = C.c_int32
+    L.bdr_trainer_config_default.restype = None
+    L.bdr_trainer_ops_default.restype = None
+    L.bdr_trainer_ops_default.argtypes = [C.POINTER(TrainerOps), C.c_void_p, C.c_void_p]
+    L.bdr_trainer_train.argtypes = [C.POINTER(TrainerConfigC), C.POINTER(TrainerOps), C.POINTER(EnvVtable), OBSERVER_FN, C.c_void_p,
+                                    C.POINTER(TrainerStatsC)]
+    L.bdr_trainer_train_offline.argtypes = [C.POINTER(TrainerConfigC), C.POINTER(TrainerOps), OBSERVER_FN, C.c_void_p,
+                                            C.POINTER(TrainerStatsC)]
     L.bdr_atari_clip_reward.restype = C.c_float
     L.bdr_atari_clip_reward.argtypes = [C.c_float, C.c_int32]
     L.bdr_dqn_config_default.restype = None

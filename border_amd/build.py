@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libborder_amd.so")
-SOURCES = ["replay.hip", "per.hip", "agent_api.hip", "dqn.hip", "mlp_agents.hip", "sac.hip", "iqn.hip", "comm.hip", "atari_prep.hip"]  # missing files are skipped
+SOURCES = ["replay.hip", "per.hip", "agent_api.hip", "dqn.hip", "mlp_agents.hip", "sac.hip", "iqn.hip", "comm.hip", "atari_prep.hip", "trainer.hip"]  # missing files are skipped
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))) + ["../../include/border_amd.h"]
 
 
@@ -50,5 +50,17 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_examples() -> str:
+    """examples/train_dqn_synthetic: a training program in compiled code only, on the C ABI (plain g++, no HIP headers)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "train_dqn_synthetic.cpp")
+    exe = os.path.join(root, "examples", "train_dqn_synthetic")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", src, "-I" + os.path.join(root, "include"), "-L" + HERE, "-lborder_amd",
+                               "-Wl,-rpath,$ORIGIN/../border_amd", "-o", exe])
+    return exe
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_examples())

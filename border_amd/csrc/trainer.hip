@@ -1,0 +1,177 @@
+// Host-side driver of the opt-step loops: the reference's Trainer is compiled Rust, so its counterpart
+// above the C ABI is compiled C++ (the Python mirror in border_amd/trainer.py binds the same rules for tests and bench.py).
+//   Trainer::train_step      border-core/src/trainer.rs:197-228   warm-up rule, opt_interval, opt vs opt_with_record, timer
+//   Trainer::train           trainer.rs:267-327                   sample_and_push, train_step, cost record, stop at max_opts
+//   Trainer::train_offline   trainer.rs:330-384                   warmup_period = 0, opt_interval = 1
+//   Sampler::sample_and_push trainer/sampler.rs:99-144            reset on first use, Policy::sample, step_with_reset, push
+//   SimpleStepProcessor      generic_replay_buffer/step_proc.rs:62-137   (prev_obs, act, obs, ...) transitions
+// Recorder / evaluator sinks are out of scope: an observer callback receives what the reference would
+// store.  Pure host code: the agent, buffer and environment are reached through function tables, so the loop itself runs
+// (and is tested) without a GPU.
+#include <chrono>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace bdr;
+
+namespace {
+using Clock = std::chrono::steady_clock;
+
+struct State {
+    const bdr_trainer_config* c;
+    const bdr_trainer_ops* ops;
+    uint64_t env_steps = 0, opt_steps = 0, opt_steps_counter = 0, samples_counter = 0, n_records = 0, n_episodes = 0;
+    double timer_for_opt_steps = 0, timer_for_samples = 0, total_opt = 0, total_sample = 0;
+    float scalars[16];
+    int32_t n_scalars = 0;
+};
+
+// trainer.rs:197-228
+int32_t train_step(State& s, bool* is_opt, bool* with_record)
+{
+    const bdr_trainer_config& c = *s.c;
+    *is_opt = false; *with_record = false; s.n_scalars = 0;
+    if (s.env_steps < c.warmup_period) return BDR_OK;
+    if (s.env_steps % c.opt_interval != 0) return BDR_OK;
+    const auto t0 = Clock::now();
+    if (c.record_agent_info_interval != 0 && (s.opt_steps + 1) % c.record_agent_info_interval == 0) {
+        BDR_TRY(s.ops->agent_opt_with_record(s.ops->agent, s.ops->buffer, s.scalars, 16, &s.n_scalars));
+        *with_record = true;
+        s.n_records += 1;
+    } else {
+        BDR_TRY(s.ops->agent_opt(s.ops->agent, s.ops->buffer));
+    }
+    s.opt_steps += 1;
+    const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
+    s.timer_for_opt_steps += dt; s.total_opt += dt;
+    s.opt_steps_counter += 1;
+    *is_opt = true;
+    return BDR_OK;
+}
+
+// trainer.rs:164-181: average_time() / reset_counters() at every record_compute_cost_interval-th opt step
+void cost_record(State& s, bdr_trainer_observer obs, void* ctx)
+{
+    const bdr_trainer_config& c = *s.c;
+    if (c.record_compute_cost_interval == 0 || s.opt_steps % c.record_compute_cost_interval != 0) return;
+    const float avr[2] = {s.opt_steps_counter ? (float)(1000.0 * s.timer_for_opt_steps / (double)s.opt_steps_counter) : -1.0f,
+                          s.samples_counter ? (float)(1000.0 * s.timer_for_samples / (double)s.samples_counter) : -1.0f};
+    if (obs) obs(ctx, s.env_steps, s.opt_steps, BDR_TRAINER_EVENT_COST, avr, 2);
+    s.timer_for_opt_steps = 0; s.opt_steps_counter = 0; s.timer_for_samples = 0; s.samples_counter = 0;
+}
+
+void fill_stats(const State& s, bdr_trainer_stats* out)
+{
+    if (!out) return;
+    out->env_steps = s.env_steps; out->opt_steps = s.opt_steps; out->n_records = s.n_records; out->n_episodes = s.n_episodes;
+    out->opt_seconds = s.total_opt; out->sample_seconds = s.total_sample;
+}
+
+int32_t check(const bdr_trainer_config* c, const bdr_trainer_ops* ops)
+{
+    BDR_REQUIRE(c && ops, "null argument");
+    BDR_REQUIRE(c->max_opts >= 1, "max_opts must be >= 1");
+    BDR_REQUIRE(c->opt_interval >= 1, "opt_interval must be >= 1");
+    BDR_REQUIRE(ops->agent_set_train && ops->agent_opt && ops->agent_opt_with_record, "agent function table is incomplete");
+    return BDR_OK;
+}
+
+// defaults: the library's own handles
+int32_t d_set_train(void* a, int32_t on) { return bdr_agent_set_train((bdr_agent*)a, on); }
+int32_t d_sample(void* a, uint64_t n, const void* obs, void* act) { return bdr_agent_sample((bdr_agent*)a, n, obs, (int64_t*)act, nullptr); }
+int32_t d_opt(void* a, void* b) { return bdr_agent_opt((bdr_agent*)a, (bdr_replay*)b); }
+int32_t d_opt_rec(void* a, void* b, float* out, int32_t cap, int32_t* n) { return bdr_agent_opt_with_scalars((bdr_agent*)a, (bdr_replay*)b, out, cap, n); }
+int32_t d_push(void* b, uint64_t n, const void* obs, const void* act, const void* next_obs, const float* rew, const int8_t* term, const int8_t* trunc)
+{
+    return bdr_replay_push((bdr_replay*)b, n, obs, act, next_obs, rew, term, trunc);
+}
+}  // namespace
+
+extern "C" {
+
+void bdr_trainer_config_default(bdr_trainer_config* c)   // trainer/config.rs:68-87 (intervals the loops use; 0 = never)
+{
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->max_opts = 0; c->opt_interval = 1; c->warmup_period = 0;
+    c->record_agent_info_interval = 0; c->record_compute_cost_interval = 0;
+}
+
+void bdr_trainer_ops_default(bdr_trainer_ops* ops, bdr_agent* agent, bdr_replay* buffer)
+{
+    if (!ops) return;
+    ops->agent = agent; ops->buffer = buffer;
+    ops->agent_set_train = d_set_train; ops->agent_sample = d_sample; ops->agent_opt = d_opt;
+    ops->agent_opt_with_record = d_opt_rec; ops->buffer_push = d_push;
+}
+
+int32_t bdr_trainer_train(const bdr_trainer_config* c, const bdr_trainer_ops* ops, const bdr_env_vtable* env,
+                          bdr_trainer_observer obs, void* obs_ctx, bdr_trainer_stats* out)
+{
+    BDR_TRY(check(c, ops));
+    BDR_REQUIRE(env && env->reset && env->step_with_reset, "environment function table is incomplete");
+    BDR_REQUIRE(ops->agent_sample && ops->buffer_push, "the online loop needs agent_sample and buffer_push");
+    BDR_REQUIRE(c->obs_row_bytes > 0 && c->act_row_bytes > 0, "obs_row_bytes / act_row_bytes must be set");
+    State s; s.c = c; s.ops = ops;
+    // Sampler state (sampler.rs:61-75) + SimpleStepProcessor::prev_obs (step_proc.rs:86-101)
+    std::vector<uint8_t> prev_obs(c->obs_row_bytes), proc_prev(c->obs_row_bytes), obs_new(c->obs_row_bytes), init_obs(c->obs_row_bytes),
+        act(c->act_row_bytes);
+    bool have_prev = false;
+    BDR_TRY(ops->agent_set_train(ops->agent, 1));   // trainer.rs:283
+    for (;;) {
+        const auto t0 = Clock::now();
+        // ---- Sampler::sample_and_push (sampler.rs:99-144)
+        if (!have_prev) {
+            BDR_TRY(env->reset(env->ctx, prev_obs.data()));
+            proc_prev = prev_obs;                       // step_processor.reset(prev_obs.clone())
+            have_prev = true;
+        }
+        BDR_TRY(ops->agent_sample(ops->agent, 1, prev_obs.data(), act.data()));
+        float reward = 0; int8_t term = 0, trunc = 0;
+        BDR_TRY(env->step_with_reset(env->ctx, act.data(), obs_new.data(), &reward, &term, &trunc, init_obs.data()));
+        const bool is_done = term == 1 || trunc == 1;   // step.rs:136-138
+        prev_obs = is_done ? init_obs : obs_new;
+        // SimpleStepProcessor::process (step_proc.rs:103-137): (prev_obs, act, obs, reward, flags); next transition starts
+        // from obs, or from init_obs after a terminal step
+        BDR_TRY(ops->buffer_push(ops->buffer, 1, proc_prev.data(), act.data(), obs_new.data(), &reward, &term, &trunc));
+        proc_prev = is_done ? init_obs : obs_new;
+        if (is_done) { proc_prev = prev_obs; s.n_episodes += 1; }   // sampler.rs:137-141
+        const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
+        s.timer_for_samples += dt; s.total_sample += dt;
+        s.samples_counter += 1;
+        s.env_steps += 1;
+        // ---- train_step + records
+        bool is_opt = false, with_record = false;
+        BDR_TRY(train_step(s, &is_opt, &with_record));
+        if (obs) obs(obs_ctx, s.env_steps, s.opt_steps, is_opt ? (with_record ? BDR_TRAINER_EVENT_OPT_RECORD : BDR_TRAINER_EVENT_OPT) : BDR_TRAINER_EVENT_SKIP,
+                     s.scalars, s.n_scalars);
+        cost_record(s, obs, obs_ctx);
+        if (s.opt_steps == c->max_opts) break;           // trainer.rs:323-325
+    }
+    fill_stats(s, out);
+    return BDR_OK;
+}
+
+int32_t bdr_trainer_train_offline(const bdr_trainer_config* c_in, const bdr_trainer_ops* ops, bdr_trainer_observer obs, void* obs_ctx,
+                                  bdr_trainer_stats* out)
+{
+    BDR_TRY(check(c_in, ops));
+    bdr_trainer_config c = *c_in;
+    c.warmup_period = 0; c.opt_interval = 1;            // trainer.rs:345-346
+    State s; s.c = &c; s.ops = ops;
+    BDR_TRY(ops->agent_set_train(ops->agent, 1));
+    for (;;) {
+        s.env_steps += 1;
+        bool is_opt = false, with_record = false;
+        BDR_TRY(train_step(s, &is_opt, &with_record));
+        if (obs) obs(obs_ctx, s.env_steps, s.opt_steps, is_opt ? (with_record ? BDR_TRAINER_EVENT_OPT_RECORD : BDR_TRAINER_EVENT_OPT) : BDR_TRAINER_EVENT_SKIP,
+                     s.scalars, s.n_scalars);
+        cost_record(s, obs, obs_ctx);
+        if (s.opt_steps == c.max_opts) break;
+    }
+    fill_stats(s, out);
+    return BDR_OK;
+}
+
+}  // extern "C"

@@ -180,6 +180,74 @@ class Trainer:
                 return
 
 
+class NativeTrainer:
+    """The compiled driver (csrc/trainer.hip: bdr_trainer_train / bdr_trainer_train_offline) - the loops above run in C++;
+    Python only supplies the environment callbacks and, optionally, an observer."""
+
+    EVENTS = {0: "skip", 1: "opt", 2: "opt_record", 3: "cost"}
+
+    def __init__(self, config: TrainerConfig):
+        self.config = config
+        self.stats = None
+
+    def _config(self, obs_row_bytes=0, act_row_bytes=0):
+        c = _lib.TrainerConfigC()
+        _lib.lib().bdr_trainer_config_default(C.byref(c))
+        k = self.config
+        c.max_opts, c.opt_interval, c.warmup_period = k.max_opts, k.opt_interval, k.warmup_period
+        c.record_agent_info_interval, c.record_compute_cost_interval = k.record_agent_info_interval, k.record_compute_cost_interval
+        c.obs_row_bytes, c.act_row_bytes = obs_row_bytes, act_row_bytes
+        return c
+
+    @staticmethod
+    def _observer(on_event):
+        def cb(_ctx, env_steps, opt_steps, event, scalars, n):
+            if on_event is not None:
+                on_event(env_steps, opt_steps, NativeTrainer.EVENTS[event], [scalars[i] for i in range(n)])
+        return _lib.OBSERVER_FN(cb)
+
+    def _finish(self, st):
+        self.stats = {k: getattr(st, k) for k, _ in _lib.TrainerStatsC._fields_}
+        return self.stats
+
+    def train_offline(self, agent, buffer, on_event=None, ops=None):
+        if ops is None:
+            ops = _lib.TrainerOps()
+            _lib.lib().bdr_trainer_ops_default(C.byref(ops), agent.handle, buffer.handle)
+        c, st, obs = self._config(), _lib.TrainerStatsC(), self._observer(on_event)
+        _lib.check(_lib.lib().bdr_trainer_train_offline(C.byref(c), C.byref(ops), obs, None, C.byref(st)))
+        return self._finish(st)
+
+    def train(self, env, agent, buffer, obs_shape, obs_dtype, act_row_bytes=8, on_event=None, ops=None):
+        """`env` has reset(None) -> obs[1, ...] and step_with_reset(act) -> Step (as SyntheticEnv)."""
+        obs_dtype = np.dtype(obs_dtype)
+        row = int(np.prod(obs_shape)) * obs_dtype.itemsize
+
+        def write(ptr, arr):
+            C.memmove(ptr, np.ascontiguousarray(arr, obs_dtype).ctypes.data, row)
+
+        def reset(_ctx, obs_out):
+            write(obs_out, env.reset(None))
+            return 0
+
+        def step(_ctx, act, obs_out, reward, term, trunc, init_out):
+            a = np.frombuffer((C.c_char * act_row_bytes).from_address(act), np.int64).copy()
+            st = env.step_with_reset(a)
+            write(obs_out, st.obs)
+            reward[0], term[0], trunc[0] = float(st.reward[0]), int(st.is_terminated[0]), int(st.is_truncated[0])
+            if st.is_done():
+                write(init_out, st.init_obs)
+            return 0
+
+        vt = _lib.EnvVtable(None, _lib.ENV_RESET_FN(reset), _lib.ENV_STEP_FN(step))
+        if ops is None:
+            ops = _lib.TrainerOps()
+            _lib.lib().bdr_trainer_ops_default(C.byref(ops), agent.handle, buffer.handle)
+        c, st, obs = self._config(row, act_row_bytes), _lib.TrainerStatsC(), self._observer(on_event)
+        _lib.check(_lib.lib().bdr_trainer_train(C.byref(c), C.byref(ops), C.byref(vt), obs, None, C.byref(st)))
+        return self._finish(st)
+
+
 class ParamExchange:
     """Parameter averaging across one-replica-per-GPU ranks.
 

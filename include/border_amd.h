@@ -52,8 +52,8 @@ BDR_API const char* bdr_version(void);
  * SimpleReplayBuffer  (border-core/src/generic_replay_buffer/base.rs:86-123)
  * ---------------------------------------------------------------------------------------- */
 
-/* SimpleReplayBufferConfig (generic_replay_buffer/config.rs:185-210): capacity, seed,
- * per_config (None only in this round; PER is SURVEY.md section 8(f) rank 2). */
+/* SimpleReplayBufferConfig (generic_replay_buffer/config.rs:185-210): capacity, seed; per_config = Some(..) is
+ * bdr_replay_enable_per on the empty buffer (below). */
 typedef struct {
     uint64_t capacity;
     uint64_t seed;
@@ -305,6 +305,65 @@ BDR_API int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** p
 BDR_API int32_t bdr_agent_set_checkpoint_format(bdr_agent* a, int32_t format);
 BDR_API int32_t bdr_agent_save_params(bdr_agent* a, const char* dir);
 BDR_API int32_t bdr_agent_load_params(bdr_agent* a, const char* dir);
+
+/* ---- host-side Trainer loops (border-core/src/trainer.rs) -------------------------------------------------------------
+ * The reference's Trainer is compiled Rust; this is its compiled counterpart above the C ABI (csrc/trainer.hip, host code).
+ * Agent, buffer and environment are reached through function tables, so a border maintainer can drive the library's
+ * handles (bdr_trainer_ops_default) or their own objects, and the loop rules are testable without a GPU.
+ *   bdr_trainer_train          Trainer::train (trainer.rs:267-327): Sampler::sample_and_push (trainer/sampler.rs:99-144, with
+ *                              SimpleStepProcessor, generic_replay_buffer/step_proc.rs:62-137), then train_step (:197-228):
+ *                              no opt while env_steps < warmup_period or env_steps % opt_interval != 0; opt_with_record when
+ *                              (opt_steps + 1) % record_agent_info_interval == 0; the timer wraps opt*() only; stop at
+ *                              opt_steps == max_opts
+ *   bdr_trainer_train_offline  Trainer::train_offline (:330-384): warmup_period = 0, opt_interval = 1, no sampling
+ * Recorder / evaluator sinks are out of scope; `observer` receives what the reference would store. */
+typedef struct bdr_env_vtable {             /* single-process Env (border-core/src/base/env.rs:45-181) */
+    void* ctx;
+    int32_t (*reset)(void* ctx, void* obs_out);                                  /* Env::reset(None) */
+    /* Env::step_with_reset(&act) (env.rs:137-161): writes obs, reward, flags; when the step is done also init_obs */
+    int32_t (*step_with_reset)(void* ctx, const void* act, void* obs_out, float* reward, int8_t* is_terminated,
+                               int8_t* is_truncated, void* init_obs_out);
+} bdr_env_vtable;
+
+typedef struct bdr_trainer_ops {
+    void* agent;
+    void* buffer;
+    int32_t (*agent_set_train)(void* agent, int32_t train);                                       /* Agent::train */
+    int32_t (*agent_sample)(void* agent, uint64_t n_procs, const void* obs, void* act_out);       /* Policy::sample */
+    int32_t (*agent_opt)(void* agent, void* buffer);                                              /* Agent::opt */
+    int32_t (*agent_opt_with_record)(void* agent, void* buffer, float* scalars, int32_t cap, int32_t* n_scalars);
+    int32_t (*buffer_push)(void* buffer, uint64_t n, const void* obs, const void* act, const void* next_obs,
+                           const float* reward, const int8_t* is_terminated, const int8_t* is_truncated);
+} bdr_trainer_ops;
+
+typedef struct bdr_trainer_config {         /* trainer/config.rs:30-87; an interval of 0 means "never" */
+    uint64_t max_opts;
+    uint64_t opt_interval;
+    uint64_t warmup_period;
+    uint64_t record_agent_info_interval;
+    uint64_t record_compute_cost_interval;
+    uint64_t obs_row_bytes;                 /* row sizes of the environment's observation / action (online loop) */
+    uint64_t act_row_bytes;
+} bdr_trainer_config;
+
+typedef struct bdr_trainer_stats {
+    uint64_t env_steps, opt_steps, n_records, n_episodes;
+    double opt_seconds, sample_seconds;     /* timer_for_opt_steps / timer_for_samples summed over the run */
+} bdr_trainer_stats;
+
+#define BDR_TRAINER_EVENT_SKIP 0            /* iteration without an opt step */
+#define BDR_TRAINER_EVENT_OPT 1             /* Agent::opt */
+#define BDR_TRAINER_EVENT_OPT_RECORD 2      /* Agent::opt_with_record: scalars = the agent's Record */
+#define BDR_TRAINER_EVENT_COST 3            /* scalars = {average_opt_time, average_sample_time} in ms (trainer.rs:164-181) */
+typedef void (*bdr_trainer_observer)(void* ctx, uint64_t env_steps, uint64_t opt_steps, int32_t event, const float* scalars,
+                                     int32_t n_scalars);
+
+BDR_API void bdr_trainer_config_default(bdr_trainer_config* c);
+BDR_API void bdr_trainer_ops_default(bdr_trainer_ops* ops, bdr_agent* agent, bdr_replay* buffer);
+BDR_API int32_t bdr_trainer_train(const bdr_trainer_config* c, const bdr_trainer_ops* ops, const bdr_env_vtable* env,
+                                  bdr_trainer_observer observer, void* observer_ctx, bdr_trainer_stats* out);
+BDR_API int32_t bdr_trainer_train_offline(const bdr_trainer_config* c, const bdr_trainer_ops* ops, bdr_trainer_observer observer,
+                                          void* observer_ctx, bdr_trainer_stats* out);
 
 /* border-atari-env frame preprocessing on the device (border-atari-env/src/env.rs):
  * one handle keeps the `frames: [4][84][84]` u8 stack of n_envs environments in HBM (newest frame first).

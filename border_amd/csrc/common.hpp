@@ -88,6 +88,10 @@ struct bdr_replay {
     float* b_reward = nullptr;
     int8_t *b_term = nullptr, *b_trunc = nullptr;
     uint64_t* b_ixs = nullptr;
+    // second set of batch buffers (replay_flip_batch): a consumer that gathers the next batch on another queue while kernels
+    // of the previous update still read the current one alternates between the two sets
+    struct BatchSet { uint8_t *obs = nullptr, *next = nullptr, *act = nullptr; float* reward = nullptr; int8_t *term = nullptr, *trunc = nullptr; uint64_t* ixs = nullptr; } alt;
+    bool alt_valid = false;
 };
 
 namespace bdr {
@@ -95,6 +99,7 @@ namespace bdr {
 // cross-stream ordering against pushes.  Advances the RNG like one batch(n).
 int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream);
 int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n);
+int32_t replay_flip_batch(bdr_replay* r, uint64_t n);   // makes the other buffer set current (allocated on first use)
 
 // per.hip
 int32_t per_create(const bdr_per_config* c, uint64_t capacity, hipStream_t stream, bdr_per** out);

@@ -286,6 +286,8 @@ struct DqnCnn : bdr_agent {
     bool kev = true;
     unsigned* sig = nullptr;   // [8] device progress flags of schedule 3
     unsigned sig_epoch = 0;
+    bool head_gate_enqueued = false;
+    bool side_gather = true;   // BDR_NO_SIDE_GATHER=1: opt() gathers on the dX queue
     unsigned long long* gate_trace = nullptr;   // BDR_GATE_TRACE=1: [5][2] (100 MHz ticks waited, count), printed at destruction
     int sched = 3;   // backward schedule, see update_critic (BDR_SCHED=0|1|2; BDR_NO_OVERLAP=1 == 0)
     Arena ar;
@@ -394,10 +396,12 @@ __device__ __forceinline__ void adam_element(float& p, float g, float& m, float&
 // k_gate: one wave; returns once *flag has reached `epoch` (wrap-safe compare).  It holds one wave slot while it waits, so
 // it cannot starve the producer; a producer that never arrives trips the time limit instead of hanging the queue
 // (sig[SIG_ERR] is checked at the next synchronisation).
-constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_ERR = 7;
-__global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned epoch, unsigned long long* waited)
+constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_GATHER = 4, SIG_ERR = 7;
+__global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned epoch, unsigned long long* waited, int publish)
 {
     if (threadIdx.x != 0) return;
+    // like start_signal: this kernel has started, so everything queued before it on its stream is complete
+    if (publish >= 0) __hip_atomic_store(sig + publish, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = wall_clock64();   // 100 MHz
     while ((int)(__hip_atomic_load(sig + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(4);
@@ -522,6 +526,16 @@ AdamScalars adam_scalars(const bdr_dqn_config& c, uint64_t step)
 }
 
 // Dqn::update_critic on a device-resident batch (dqn/base.rs:60-160)
+// one-wave wait for flag `which` to reach `epoch` on stream st; publish >= 0: also publishes that flag at its start
+int32_t launch_gate(DqnCnn* a, hipStream_t st, int which, unsigned epoch, int publish)
+{
+    // trace slot: 2 counters per site; sites 0..3 = flags on the weight-gradient queue, 4 = the gates on the dX queue
+    unsigned long long* tr = a->gate_trace ? a->gate_trace + 2 * (st == a->stream ? 4 : which) : nullptr;
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch, tr, publish);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+
 int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
                       const float* reward, const int8_t* term, const float* weight = nullptr, bdr_replay* per_buffer = nullptr)
 {
@@ -559,13 +573,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     hipStream_t sd = ov || gated ? a->side : a->stream;
     const unsigned epoch = gated ? ++a->sig_epoch : 0;
     auto sigf = [&](int which) -> unsigned* { return gated ? a->sig + which : nullptr; };
-    auto gate = [&](hipStream_t st, int which) -> int32_t {
-        // trace slot: 2 counters per site; sites 0..3 = flags on the weight-gradient queue, 4 = the join on the dX queue
-        unsigned long long* tr = a->gate_trace ? a->gate_trace + 2 * (st == a->stream ? 4 : which) : nullptr;
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch, tr);
-        BDR_HIP(hipGetLastError());
-        return BDR_OK;
-    };
+    auto gate = [&](hipStream_t st, int which) -> int32_t { return launch_gate(a, st, which, epoch, -1); };
     const unsigned any = sched == 2 ? hipExtAnyOrderLaunch : 0;
     // a->kev: the fork / join events are completed by the producing kernel's own dispatch packet (launch `stop` event)
     // instead of a marker packet behind it
@@ -665,7 +673,9 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         // other queue: gate -> the weight gradients that depend on the published kernel, then the l1 / l2 Adam pass (a
         // streaming kernel: beside a dX GEMM it starves for workgroup slots - 27 us instead of 8 - so it goes last, beside
         // the conv1 dW kernel).
-        BDR_TRY(gate(sd, SIG_HEAD)); BDR_TRY(head_bwd()); BDR_TRY(l1_dw());
+        if (!a->head_gate_enqueued) BDR_TRY(gate(sd, SIG_HEAD));   // (opt_inner enqueues it right behind a side-queue gather)
+        a->head_gate_enqueued = false;
+        BDR_TRY(head_bwd()); BDR_TRY(l1_dw());
         BDR_TRY(l1_dx());
         BDR_TRY(gate(sd, SIG_DXL1)); BDR_TRY(c3_dw());
         BDR_TRY(c3_dx());
@@ -750,7 +760,22 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
     BDR_REQUIRE(r->device == a->device, "agent and replay buffer live on different devices");
     { Bracket br(a, "_null"); }   // empty bracket: the event pair's own cost, subtracted by bench.py
     for (uint64_t u = 0; u < a->cfg.n_updates_per_opt; ++u) {
-        { Bracket br(a, "sample"); BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->stream)); }
+        if (!a->prof && a->sched == 3 && a->side_gather && !r->per) {
+            // The gather does not depend on the previous update, and the weight-gradient queue is idle from the end of one
+            // update to the next head kernel: the batch is gathered there, into the buffer set the previous update is not
+            // using (its conv1 dW may still be reading the other one), while the dX queue finishes the previous update.
+            // That queue's first gate of the new update is enqueued right behind the gather and publishes its completion;
+            // the dX queue waits for it with its own gate in front of conv1.
+            const unsigned epoch = a->sig_epoch + 1;     // the epoch update_critic is about to take
+            BDR_TRY(replay_flip_batch(r, a->cfg.batch_size));
+            BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->side));
+            BDR_TRY(launch_gate(a, a->side, SIG_HEAD, epoch, SIG_GATHER));
+            a->head_gate_enqueued = true;
+            BDR_TRY(launch_gate(a, a->stream, SIG_GATHER, epoch, -1));
+        } else {
+            Bracket br(a, "sample");
+            BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->stream));
+        }
         BDR_TRY(update_critic(a, (int)a->cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
                               replay_batch_weights(r), r));
     }
@@ -967,6 +992,7 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     }
     if (getenv("BDR_NO_OVERLAP")) a->sched = 0;
     a->kev = getenv("BDR_NO_KEV") == nullptr;
+    a->side_gather = getenv("BDR_NO_SIDE_GATHER") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->ar.total));

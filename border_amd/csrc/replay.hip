@@ -271,6 +271,8 @@ int32_t bdr_replay_destroy(bdr_replay* r)
     (void)hipHostFree(r->stage);
     (void)hipFree(r->b_obs); (void)hipFree(r->b_next); (void)hipFree(r->b_act);
     (void)hipFree(r->b_reward); (void)hipFree(r->b_term); (void)hipFree(r->b_trunc); (void)hipFree(r->b_ixs);
+    (void)hipFree(r->alt.obs); (void)hipFree(r->alt.next); (void)hipFree(r->alt.act); (void)hipFree(r->alt.reward);
+    (void)hipFree(r->alt.term); (void)hipFree(r->alt.trunc); (void)hipFree(r->alt.ixs);
     per_destroy(r->per);
     (void)hipEventDestroy(r->written); (void)hipEventDestroy(r->read);
     (void)hipStreamDestroy(r->stream);
@@ -382,10 +384,39 @@ int32_t bdr_replay_read_rows(bdr_replay* r, uint64_t first, uint64_t n, void* ob
 
 namespace bdr {
 
+static void free_alt(bdr_replay* r)
+{
+    (void)hipFree(r->alt.obs); (void)hipFree(r->alt.next); (void)hipFree(r->alt.act); (void)hipFree(r->alt.reward);
+    (void)hipFree(r->alt.term); (void)hipFree(r->alt.trunc); (void)hipFree(r->alt.ixs);
+    r->alt = bdr_replay::BatchSet{};
+    r->alt_valid = false;
+}
+
+int32_t replay_flip_batch(bdr_replay* r, uint64_t n)
+{
+    BDR_TRY(replay_ensure_batch_capacity(r, n));
+    if (!r->alt_valid) {
+        const uint64_t c = r->batch_cap;
+        BDR_HIP(hipMalloc((void**)&r->alt.obs, c * r->obs_bytes));
+        BDR_HIP(hipMalloc((void**)&r->alt.next, c * r->obs_bytes));
+        BDR_HIP(hipMalloc((void**)&r->alt.act, c * r->act_bytes));
+        BDR_HIP(hipMalloc((void**)&r->alt.reward, c * 4));
+        BDR_HIP(hipMalloc((void**)&r->alt.term, round_up(c, 16)));
+        BDR_HIP(hipMalloc((void**)&r->alt.trunc, round_up(c, 16)));
+        BDR_HIP(hipMalloc((void**)&r->alt.ixs, c * 8));
+        r->alt_valid = true;
+    }
+    std::swap(r->b_obs, r->alt.obs); std::swap(r->b_next, r->alt.next); std::swap(r->b_act, r->alt.act);
+    std::swap(r->b_reward, r->alt.reward); std::swap(r->b_term, r->alt.term); std::swap(r->b_trunc, r->alt.trunc);
+    std::swap(r->b_ixs, r->alt.ixs);
+    return BDR_OK;
+}
+
 int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n)
 {
     if (n <= r->batch_cap) return BDR_OK;
     BDR_HIP(hipDeviceSynchronize());
+    free_alt(r);
     (void)hipFree(r->b_obs); (void)hipFree(r->b_next); (void)hipFree(r->b_act);
     (void)hipFree(r->b_reward); (void)hipFree(r->b_term); (void)hipFree(r->b_trunc); (void)hipFree(r->b_ixs);
     BDR_HIP(hipMalloc((void**)&r->b_obs, n * r->obs_bytes));

@@ -251,8 +251,9 @@ int32_t bdr_agent_destroy(bdr_agent* a)
     (void)hipSetDevice(a->device);
     for (auto& s : a->slots) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     hipStream_t st = a->stream;
+    if (st) (void)hipStreamSynchronize(st);
     delete a;
-    if (st) (void)hipStreamDestroy(st);
+    if (st) { stream_retire(st); (void)hipStreamDestroy(st); }
     return BDR_OK;
 }
 

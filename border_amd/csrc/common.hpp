@@ -99,6 +99,11 @@ namespace bdr {
 // cross-stream ordering against pushes.  Advances the RNG like one batch(n).
 int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream);
 int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n);
+// Consumer streams a replay buffer may have to record an event on later (lazy ordering): registered when they first sample,
+// retired by their owner after synchronising and before hipStreamDestroy, so that a buffer never touches a dead handle.
+void stream_register(hipStream_t s);
+void stream_retire(hipStream_t s);
+bool stream_alive(hipStream_t s);
 int32_t replay_flip_batch(bdr_replay* r, uint64_t n);   // makes the other buffer set current (allocated on first use)
 
 // per.hip

@@ -895,8 +895,8 @@ DqnCnn::~DqnCnn()
         (void)hipFree(gate_trace);
     }
     if (sig) (void)hipFree(sig);
-    if (aux) (void)hipStreamDestroy(aux);
-    if (side) (void)hipStreamDestroy(side);
+    if (aux) { (void)hipStreamSynchronize(aux); stream_retire(aux); (void)hipStreamDestroy(aux); }
+    if (side) { stream_retire(side); (void)hipStreamDestroy(side); }
 }
 
 int32_t DqnCnn::opt(bdr_replay* r) { return opt_inner(this, r); }

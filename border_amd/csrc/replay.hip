@@ -3,6 +3,9 @@
 // Reference: border-core/src/generic_replay_buffer/base.rs:86-123 (state), :295-316 (push),
 // :376-402 (batch); border-tch-agent/src/tensor_batch.rs:85-120 (row storage).
 #include "chacha.hpp"
+#include <mutex>
+#include <unordered_set>
+
 #include "common.hpp"
 
 namespace bdr {
@@ -178,6 +181,14 @@ __global__ __launch_bounds__(256) void k_fill_synthetic(FillArgs a)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+namespace bdr {
+static std::mutex g_streams_mu;
+static std::unordered_set<hipStream_t> g_streams;
+void stream_register(hipStream_t s) { std::lock_guard<std::mutex> l(g_streams_mu); g_streams.insert(s); }
+void stream_retire(hipStream_t s) { std::lock_guard<std::mutex> l(g_streams_mu); g_streams.erase(s); }
+bool stream_alive(hipStream_t s) { std::lock_guard<std::mutex> l(g_streams_mu); return g_streams.count(s) != 0; }
+}  // namespace bdr
+
 // `written` was just recorded on some stream: consumers have to wait for it again
 static void mark_written(bdr_replay* r) { r->written_gen += 1; }
 
@@ -187,7 +198,9 @@ static int32_t wait_for_reader(bdr_replay* r, hipStream_t s)
     if (!r->read_pending) return BDR_OK;
     r->read_pending = false;
     if (r->read_stream == s) return BDR_OK;   // same queue: already ordered
-    if (hipEventRecord(r->read, r->read_stream) != hipSuccess) {   // the consumer's stream is gone (agent destroyed)
+    // a retired stream was synchronised by its owner before it was destroyed: nothing left to wait for
+    if (r->read_stream != r->stream && !stream_alive(r->read_stream)) return BDR_OK;
+    if (hipEventRecord(r->read, r->read_stream) != hipSuccess) {
         (void)hipGetLastError();
         BDR_HIP(hipDeviceSynchronize());
         return BDR_OK;
@@ -446,6 +459,7 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     if (r->size == 0) return fail(BDR_ERR_EMPTY, "batch() on an empty replay buffer");
     BDR_REQUIRE(n > 0 && n < (1ull << 24), "batch size out of range");
     BDR_TRY(replay_ensure_batch_capacity(r, n));
+    if (stream != r->stream) stream_register(stream);
     BDR_TRY(wait_for_writer(r, stream));
     BDR_TRY(wait_for_reader(r, stream));   // another stream's gather may still own the batch buffers
     GatherArgs a{};

@@ -501,3 +501,65 @@ def test_opt_stream_is_deterministic_and_overlap_invariant(B):
     for sched in (None, 0, 1, 2, 3):
         p, t = run(sched)
         assert (p1 == p).all() and (t1 == t).all(), sched
+
+
+def test_mixed_api_sequences_on_the_flag_ordered_schedule(B, tmp_path):
+    """Entry points that touch the parameters or the batch buffers between opt() calls (schedule 3 keeps work in flight on a
+    second queue and gathers the next batch into an alternate buffer set): every sequence must equal the serial schedule's
+    result bit for bit, a buffer must outlive the agent that last gathered from it, and two agents may share one buffer."""
+    rng = np.random.default_rng(3)
+
+    def run(sched):
+        os.environ["BDR_SCHED"] = str(sched)
+        try:
+            rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=300, seed=7), (4, 1, 84, 84), "uint8")
+            rb.fill_synthetic(200, seed=1, kind=0, n_actions=6)
+            a = make_agent(B, batch_size=16, critic_loss="SmoothL1", tau=0.5, soft_update_interval=3, param_seed=6)
+            b = make_agent(B, batch_size=8, critic_loss="Mse", tau=1.0, soft_update_interval=2, param_seed=8)
+            a.train(); b.train()
+            r2 = np.random.default_rng(11)
+            out = []
+            for it in range(12):
+                a.opt(rb)
+                if it % 3 == 0:
+                    b.opt(rb)                                   # a second consumer of the same buffer
+                if it % 4 == 1:                                # host pushes between opts (wrap after 100 more rows)
+                    n = 30
+                    rb.push(r2.integers(0, 256, (n, 4, 1, 84, 84), dtype=np.uint8), r2.integers(0, 6, (n, 1)).astype(np.int64),
+                            r2.integers(0, 256, (n, 4, 1, 84, 84), dtype=np.uint8), r2.standard_normal(n).astype(np.float32),
+                            (r2.random(n) < 0.1).astype(np.int8), np.zeros(n, np.int8))
+                if it % 5 == 2:
+                    out.append(a.qvalues(r2.integers(0, 256, (3, 4, 1, 84, 84), dtype=np.uint8)).copy())
+                if it == 6:
+                    p = a.get_params("qnet")
+                    a.set_params(p * np.float32(0.999), "qnet")
+                if it == 8:
+                    a.save_params(str(tmp_path / f"s{sched}"))
+                    a.load_params(str(tmp_path / f"s{sched}"))
+                if it == 9:
+                    rec = a.opt_with_record(rb)
+                    out.append(np.float32(rec["loss"]))
+                if it == 10:                                    # explicit minibatch of another size
+                    m = 5
+                    a.update_on_batch(r2.integers(0, 256, (m, 4, 1, 84, 84), dtype=np.uint8), r2.integers(0, 6, m).astype(np.int64),
+                                      r2.integers(0, 256, (m, 4, 1, 84, 84), dtype=np.uint8), r2.standard_normal(m).astype(np.float32),
+                                      np.zeros(m, np.int8))
+            a.sync(); b.sync()
+            out += [a.get_params("qnet"), a.get_params("qnet_tgt"), b.get_params("qnet")]
+            a.close(); b.close()
+            # the buffer outlives the agents whose (destroyed) queue gathered from it last
+            rb.push(r2.integers(0, 256, (2, 4, 1, 84, 84), dtype=np.uint8), np.zeros((2, 1), np.int64),
+                    r2.integers(0, 256, (2, 4, 1, 84, 84), dtype=np.uint8), np.zeros(2, np.float32), np.zeros(2, np.int8), np.zeros(2, np.int8))
+            g = rb.batch(4)
+            out += [g.ix_sample.copy(), g.obs.copy()]
+            rb.close()
+            return out
+        finally:
+            os.environ.pop("BDR_SCHED", None)
+
+    ref = run(0)
+    for sched in (3, 1):
+        got = run(sched)
+        assert len(got) == len(ref)
+        for k, (x, y) in enumerate(zip(got, ref)):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), (sched, k)

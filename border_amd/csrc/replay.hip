@@ -461,7 +461,13 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     BDR_TRY(replay_ensure_batch_capacity(r, n));
     if (stream != r->stream) stream_register(stream);
     BDR_TRY(wait_for_writer(r, stream));
-    BDR_TRY(wait_for_reader(r, stream));   // another stream's gather may still own the batch buffers
+    // The batch buffers belong to the consumer that sampled last: kernels on any of ITS queues may still be reading them
+    // (the reference's `&mut` exclusivity, one consumer at a time).  A different queue taking over is rare (two agents on
+    // one buffer, bdr_replay_batch between opts, profiling toggles) and simply drains the device.
+    if (r->read_pending && r->read_stream != stream) {
+        BDR_HIP(hipDeviceSynchronize());
+        r->read_pending = false;
+    }
     GatherArgs a{};
     a.ring = r->ring; a.stride = r->stride; a.obs_bytes = r->obs_bytes; a.act_bytes = r->act_bytes;
     a.next_off = r->next_off; a.act_off = r->act_off; a.tail_off = r->tail_off; a.ixs = r->b_ixs;

@@ -147,6 +147,11 @@ int main()
     DX2D(4, 1, 0, 1, 1, 4)
     DX2D(4, 1, 0, 2, 1, 3)
     DX3(2, 2, 0, 1, 1, 2)    // current
+    DX3(3, 2, 96, 1, 1, 1)   // one image (81 rows -> 96) per workgroup: 256 workgroups
+    DX3(3, 2, 96, 1, 1, 2)
+    DX3(3, 1, 96, 1, 2, 1)
+    DX3(3, 1, 96, 1, 2, 2)
+    DX3(1, 2, 96, 3, 1, 2)
 
     DX2(4, 1, 0, 1, 1, 1)    // current
     // ---- quantisation study: time per tile at balanced grids (multiples of 256 workgroups) vs the real grids

@@ -760,7 +760,7 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
     BDR_REQUIRE(r->device == a->device, "agent and replay buffer live on different devices");
     { Bracket br(a, "_null"); }   // empty bracket: the event pair's own cost, subtracted by bench.py
     for (uint64_t u = 0; u < a->cfg.n_updates_per_opt; ++u) {
-        if (!a->prof && a->sched == 3 && a->side_gather && !r->per) {
+        if (!a->prof && a->sched == 3 && a->side_gather) {
             // The gather does not depend on the previous update, and the weight-gradient queue is idle from the end of one
             // update to the next head kernel: the batch is gathered there, into the buffer set the previous update is not
             // using (its conv1 dW may still be reading the other one), while the dX queue finishes the previous update.

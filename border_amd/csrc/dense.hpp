@@ -249,6 +249,16 @@ inline int32_t dense_dw(hipStream_t st, const DenseLayer& l, float* grad_base, D
     return BDR_OK;
 }
 
+// Row chunks for a dW launch: the kernel has (Kp/64)*(Np/64) output tiles; a 256x256 layer over 1 024 rows would run on 16
+// workgroups (32 us on a 256-CU chip).  Split the row reduction so that about one workgroup per CU is in flight (at least
+// 64 rows per chunk, at most 16 chunks; the partials are summed in a fixed order by k_dense_reduce).
+inline int dense_dw_chunks(const DenseLayer& l, int M)
+{
+    const int tiles = (l.Kp / 64) * (l.Np / 64);
+    return std::max(1, std::min(std::min(16, M / 64), (256 + tiles - 1) / tiles));
+}
+inline size_t dense_dw_part_floats(const DenseLayer& l) { return 16 * ((size_t)l.Kp * l.Np + l.Np); }
+
 inline int32_t pack_rows(hipStream_t st, const float* src, int src_ld, int cols, float* dst, int ld, int col0, int B)
 {
     const int n = B * cols;

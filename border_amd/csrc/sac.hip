@@ -195,6 +195,7 @@ struct Sac : bdr_agent {
     std::vector<float*> c_dy[4];                    // critic gradients per layer
     float* dxq[4] = {nullptr};                      // critic input gradients [B][Kp_q]
     float *logp = nullptr, *tgt = nullptr, *loss_row = nullptr, *z_a = nullptr, *z_n = nullptr;
+    float* dw_part = nullptr;   // row-chunk partials of the dW launches (dense_dw_chunks)
     float* scal = nullptr;                          // [0] loss_critic (sum over critics / NC), [1] loss_actor
     // host staging for update_on_batch
     float *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr, *u_rew = nullptr; int8_t* u_term = nullptr; uint64_t u_cap = 0;
@@ -212,7 +213,7 @@ struct Sac : bdr_agent {
     }
     void free_batch()
     {
-        float** singles[] = {&x_o, &x_no, &mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge, &xq, &logp, &tgt, &loss_row, &z_a, &z_n};
+        float** singles[] = {&x_o, &x_no, &mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge, &xq, &logp, &tgt, &loss_row, &z_a, &z_n, &dw_part};
         for (auto p : singles) { (void)hipFree(*p); *p = nullptr; }
         for (auto p : t_act) (void)hipFree(p);
         for (auto p : t_dy) (void)hipFree(p);
@@ -252,6 +253,10 @@ struct Sac : bdr_agent {
         }
         BDR_TRY(zalloc(&logp, Bn)); BDR_TRY(zalloc(&tgt, Bn)); BDR_TRY(zalloc(&loss_row, Bn));
         BDR_TRY(zalloc(&z_a, (size_t)Bn * A)); BDR_TRY(zalloc(&z_n, (size_t)Bn * A));
+        size_t pmax = 4;
+        for (const auto& l : pi.L) pmax = std::max(pmax, dense_dw_part_floats(l));
+        for (const auto& l : qn.L) pmax = std::max(pmax, dense_dw_part_floats(l));
+        BDR_TRY(zalloc(&dw_part, pmax));
         B = Bn;
         return BDR_OK;
     }
@@ -347,15 +352,15 @@ struct Sac : bdr_agent {
         }
         {   // heads, then trunk
             DenseSrc hin = n_trunk ? DenseSrc{t_act[n_trunk - 1], pi.L[n_trunk - 1].Np} : DenseSrc{x_o, pi.L[0].Kp};
-            { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[n_trunk], pi_g, hin, gmean, Bn)); }
-            { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[n_trunk + 1], pi_g, hin, ge, Bn)); }
+            { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[n_trunk], pi_g, hin, gmean, Bn, dw_part, dense_dw_chunks(pi.L[n_trunk], Bn))); }
+            { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[n_trunk + 1], pi_g, hin, ge, Bn, dw_part, dense_dw_chunks(pi.L[n_trunk + 1], Bn))); }
             if (n_trunk) {
                 float* dh = t_dy[n_trunk - 1];
                 { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk], pi_p, gmean, dh, t_act[n_trunk - 1], Bn, false)); }
                 { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk + 1], pi_p, ge, dh, t_act[n_trunk - 1], Bn, true)); }
                 for (int l = n_trunk - 1; l >= 0; --l) {
                     DenseSrc in = l == 0 ? DenseSrc{x_o, pi.L[0].Kp} : DenseSrc{t_act[l - 1], pi.L[l - 1].Np};
-                    { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[l], pi_g, in, t_dy[l], Bn)); }
+                    { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[l], pi_g, in, t_dy[l], Bn, dw_part, dense_dw_chunks(pi.L[l], Bn))); }
                     if (l > 0) { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[l], pi_p, t_dy[l], t_dy[l - 1], t_act[l - 1], Bn)); }
                 }
             }
@@ -389,7 +394,7 @@ struct Sac : bdr_agent {
             }
             for (int l = L - 1; l >= 0; --l) {
                 DenseSrc in = l == 0 ? DenseSrc{xq, Kq} : DenseSrc{c_act[i][l - 1], qn.L[l - 1].Np};
-                { Bracket br(a, "q_dw"); BDR_TRY(dense_dw(stream, qn.L[l], q_g[i], in, c_dy[i][l], Bn)); }
+                { Bracket br(a, "q_dw"); BDR_TRY(dense_dw(stream, qn.L[l], q_g[i], in, c_dy[i][l], Bn, dw_part, dense_dw_chunks(qn.L[l], Bn))); }
                 if (l > 0) { Bracket br(a, "q_dx"); BDR_TRY(dense_dx(stream, qn.L[l], q_p[i], c_dy[i][l], c_dy[i][l - 1], c_act[i][l - 1], Bn)); }
             }
             step_q[i] += 1;

@@ -127,3 +127,53 @@ def test_argument_checks():
         NativeTrainer(TrainerConfig(max_opts=0)).train_offline(None, None, ops=m.ops())
     with pytest.raises(BdrError):
         NativeTrainer(TrainerConfig(max_opts=1, opt_interval=0)).train_offline(None, None, ops=m.ops())
+
+
+def test_callback_errors_stop_the_loop_and_propagate():
+    """A non-zero status from any callback ends the loop at once and is what bdr_trainer_train returns (the reference's `?`)."""
+    from border_amd import BdrError
+    m = MockAgentBuffer()
+    ops = m.ops()
+    calls = {"n": 0}
+
+    class FailingEnv(MockEnv):
+        def step_with_reset(self, act):
+            calls["n"] += 1
+            if calls["n"] == 4:
+                raise RuntimeError("boom")
+            return super().step_with_reset(act)
+
+    # exceptions inside a ctypes callback cannot cross the C frame: turn them into a status code like a Rust shim would
+    env = FailingEnv()
+    orig = env.step_with_reset
+
+    def guarded(act):
+        try:
+            return orig(act)
+        except RuntimeError:
+            return None
+    env.step_with_reset = guarded
+    nt = NativeTrainer(TrainerConfig(max_opts=50))
+    row = 16
+
+    def reset(_c, obs_out):
+        C.memmove(obs_out, env.reset(None).ctypes.data, row); return 0
+
+    def step(_c, act, obs_out, reward, term, trunc, init_out):
+        st = env.step_with_reset(np.zeros(1, np.int64))
+        if st is None:
+            return 42
+        C.memmove(obs_out, st.obs.ctypes.data, row)
+        reward[0], term[0], trunc[0] = float(st.reward[0]), int(st.is_terminated[0]), 0
+        if st.is_done():
+            C.memmove(init_out, st.init_obs.ctypes.data, row)
+        return 0
+
+    vt = _lib.EnvVtable(None, _lib.ENV_RESET_FN(reset), _lib.ENV_STEP_FN(step))
+    c = nt._config(row, 8)
+    st = _lib.TrainerStatsC()
+    rc = _lib.lib().bdr_trainer_train(C.byref(c), C.byref(ops), C.byref(vt), _lib.OBSERVER_FN(lambda *a: None), None, C.byref(st))
+    assert rc == 42
+    assert [x[0] for x in m.log].count("push") == 3 and [x[0] for x in m.log].count("opt") == 3   # three full iterations, then the failing step
+    with pytest.raises(BdrError):
+        _lib.check(rc)

@@ -136,6 +136,20 @@ struct DenseFwd {
     }
 };
 
+// Several networks of the same architecture in one launch (SAC's critics): instance z = blockIdx.z
+struct DenseArgsZ { DenseArgs a[4]; };
+struct DenseFwdZ : DenseFwd {
+    using Args = DenseArgsZ;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.a[0].M, mv, mr); }
+    __device__ static int N(const Args& a) { return a.a[0].ncols; }
+    __device__ static int M(const Args& a) { return a.a[0].M; }
+    __device__ static DenseSrc a_src(const Args& a, int z) { return a.a[z].x; }
+    __device__ static const float* w(const Args& a, int z, int) { return a.a[z].w; }
+    __device__ static void kt_range(const Args& a, int, int& k0, int& k1) { k0 = 0; k1 = a.a[0].kred / BK; }
+    using Epi = DenseArgs;
+    __device__ static const Epi& epi(const Args& a, int z, int) { return a.a[z]; }
+};
+
 // dX[M][Kp] = dY[M][Np] * W[Kp][Np]^T, optional ReLU' mask
 struct DenseDx {
     using A = ADense;
@@ -163,6 +177,19 @@ struct DenseDx {
         float* o = a.out + (size_t)m * a.ldo + n;
         *o = a.accum ? *o + v : v;
     }
+};
+
+struct DenseDxZ : DenseDx {
+    using Args = DenseArgsZ;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.a[0].M, mv, mr); }
+    __device__ static int N(const Args& a) { return a.a[0].ncols; }
+    __device__ static int KP(const Args& a) { return a.a[0].w_ld; }
+    __device__ static int M(const Args& a) { return a.a[0].M; }
+    __device__ static DenseSrc a_src(const Args& a, int z) { return a.a[z].x; }
+    __device__ static const float* w(const Args& a, int z, int) { return a.a[z].w; }
+    __device__ static void kt_range(const Args& a, int, int& k0, int& k1) { k0 = 0; k1 = a.a[0].kred / BK; }
+    using Epi = DenseArgs;
+    __device__ static const Epi& epi(const Args& a, int z, int) { return a.a[z]; }
 };
 
 struct DenseDwArgs {
@@ -216,6 +243,33 @@ inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, 
     d.x = x; d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
     d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
     hipLaunchKernelGGL(k_igemm<DenseFwd>, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), dim3(256), 0, st, d);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+
+// the same layer of nz (<= 4) networks of one architecture in one launch: params_base[z], x[z], out[z]
+inline int32_t dense_forward_z(hipStream_t st, const DenseLayer& l, int nz, const float* const* params_base, const DenseSrc* x, float* const* out, int M)
+{
+    DenseArgsZ dz{};
+    for (int z = 0; z < nz; ++z) {
+        DenseArgs& d = dz.a[z];
+        d.x = x[z]; d.w = params_base[z] + l.w; d.bias = params_base[z] + l.b; d.out = out[z]; d.ldo = l.Np;
+        d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np; d.had_group = 1;
+    }
+    hipLaunchKernelGGL(k_igemm<DenseFwdZ>, dim3(((M + 63) / 64) * (l.Np / 64), 1, nz), dim3(256), 0, st, dz);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+inline int32_t dense_dx_z(hipStream_t st, const DenseLayer& l, int nz, const float* const* params_base, const float* const* dy, float* const* dx,
+                          const float* const* mask, int M)
+{
+    DenseArgsZ dz{};
+    for (int z = 0; z < nz; ++z) {
+        DenseArgs& d = dz.a[z];
+        d.x = DenseSrc{dy[z], l.Np}; d.w = params_base[z] + l.w; d.out = dx[z]; d.ldo = l.Kp; d.mask = mask ? mask[z] : nullptr; d.ldm = l.Kp;
+        d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np;
+    }
+    hipLaunchKernelGGL(k_igemm<DenseDxZ>, dim3(((M + 63) / 64) * (l.Kp / 64), 1, nz), dim3(256), 0, st, dz);
     BDR_HIP(hipGetLastError());
     return BDR_OK;
 }

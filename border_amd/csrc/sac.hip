@@ -299,6 +299,32 @@ struct Sac : bdr_agent {
         }
         return BDR_OK;
     }
+    // all critics (same architecture, own parameters, shared input xq) layer by layer in one launch each
+    int32_t critic_forward_all(float* const* params, int Bn)
+    {
+        if (NC == 1) return critic_forward(0, params[0], Bn);
+        bdr_agent* a = this;
+        DenseSrc in[4];
+        const float* pb[4]; float* out[4];
+        for (int i = 0; i < NC; ++i) { in[i] = DenseSrc{xq, qn.L[0].Kp}; pb[i] = params[i]; }
+        for (size_t l = 0; l < qn.L.size(); ++l) {
+            for (int i = 0; i < NC; ++i) out[i] = c_act[i][l];
+            Bracket br(a, "q_fwd");
+            BDR_TRY(dense_forward_z(stream, qn.L[l], NC, pb, in, out, Bn));
+            for (int i = 0; i < NC; ++i) in[i] = DenseSrc{c_act[i][l], qn.L[l].Np};
+        }
+        return BDR_OK;
+    }
+    // dX of layer l for all critics in one launch: c_dy[i][l] -> (l == 0 ? dxq[i] : c_dy[i][l-1])
+    int32_t critic_dx_all(int l, int Bn)
+    {
+        const float* pb[4]; const float* dy[4]; float* dx[4]; const float* mask[4];
+        for (int i = 0; i < NC; ++i) {
+            pb[i] = q_p[i]; dy[i] = c_dy[i][l]; dx[i] = l == 0 ? dxq[i] : c_dy[i][l - 1]; mask[i] = l == 0 ? nullptr : c_act[i][l - 1];
+        }
+        if (NC == 1) return dense_dx(stream, qn.L[l], pb[0], dy[0], dx[0], mask[0], Bn);
+        return dense_dx_z(stream, qn.L[l], NC, pb, dy, dx, l == 0 ? nullptr : mask, Bn);
+    }
     int32_t pack_obs_into_xq(const float* obs_rows, int Bn) { return pack_rows(stream, obs_rows, O, O, xq, qn.L[0].Kp, 0, Bn); }
 
     // one iteration of the Sac::opt_ loop on a device-resident batch (obs/next_obs/act rows are f32)
@@ -321,7 +347,7 @@ struct Sac : bdr_agent {
             hipLaunchKernelGGL(k_sac_alpha_update, dim3(1), dim3(256), 0, stream, logp, Bn, (float)cfg.target_entropy, log_alpha, al_m, al_v, s);
             BDR_HIP(hipGetLastError());
         }
-        for (int i = 0; i < NC; ++i) BDR_TRY(critic_forward(i, q_p[i], Bn));
+        BDR_TRY(critic_forward_all(q_p, Bn));
         {
             SacSelectArgs p{};
             for (int i = 0; i < NC; ++i) { p.q[i] = c_act[i][L - 1]; p.dout[i] = c_dy[i][L - 1]; }
@@ -332,13 +358,9 @@ struct Sac : bdr_agent {
             hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, scal + 1, 1.0f / (float)Bn, first ? 0 : 1);
             BDR_HIP(hipGetLastError());
         }
-        for (int i = 0; i < NC; ++i) {   // d qmin / d input through each critic (weights untouched here)
-            for (int l = L - 1; l >= 0; --l) {
-                Bracket br(a, "q_dx");
-                float* out = l == 0 ? dxq[i] : c_dy[i][l - 1];
-                const float* mask = l == 0 ? nullptr : c_act[i][l - 1];
-                BDR_TRY(dense_dx(stream, qn.L[l], q_p[i], c_dy[i][l], out, mask, Bn));
-            }
+        for (int l = L - 1; l >= 0; --l) {   // d qmin / d input through the critics (weights untouched here)
+            Bracket br(a, "q_dx");
+            BDR_TRY(critic_dx_all(l, Bn));
         }
         {
             SacActorGradArgs p{};
@@ -371,7 +393,7 @@ struct Sac : bdr_agent {
         // ---------------- update_critic (sac/base.rs:107-149) ----------------
         BDR_TRY(pack_obs_into_xq(next_obs, Bn));
         BDR_TRY(action_logp(x_no, z_next, Bn, false));            // the UPDATED actor
-        for (int i = 0; i < NC; ++i) BDR_TRY(critic_forward(i, q_t[i], Bn));
+        BDR_TRY(critic_forward_all(q_t, Bn));
         {
             SacTargetArgs p{};
             for (int i = 0; i < NC; ++i) p.q[i] = c_act[i][L - 1];
@@ -383,22 +405,26 @@ struct Sac : bdr_agent {
         }
         BDR_TRY(pack_obs_into_xq(obs, Bn));
         BDR_TRY(pack_rows(stream, act, A, A, xq, Kq, O, Bn));
+        BDR_TRY(critic_forward_all(q_p, Bn));   // every critic on (obs, act); their updates below do not depend on each other
         for (int i = 0; i < NC; ++i) {
-            BDR_TRY(critic_forward(i, q_p[i], Bn));
-            {
-                Bracket br(a, "critic_td");
-                hipLaunchKernelGGL(k_sac_critic_td, dim3((Bn + 255) / 256), dim3(256), 0, stream, c_act[i][L - 1], ldq, tgt, c_dy[i][L - 1], loss_row, Bn, cfg.critic_loss);
-                BDR_HIP(hipGetLastError());
-                hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, scal, 1.0f / ((float)Bn * (float)NC), (first && i == 0) ? 0 : 1);
-                BDR_HIP(hipGetLastError());
-            }
-            for (int l = L - 1; l >= 0; --l) {
+            Bracket br(a, "critic_td");
+            hipLaunchKernelGGL(k_sac_critic_td, dim3((Bn + 255) / 256), dim3(256), 0, stream, c_act[i][L - 1], ldq, tgt, c_dy[i][L - 1], loss_row, Bn, cfg.critic_loss);
+            BDR_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, scal, 1.0f / ((float)Bn * (float)NC), (first && i == 0) ? 0 : 1);
+            BDR_HIP(hipGetLastError());
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            for (int i = 0; i < NC; ++i) {
                 DenseSrc in = l == 0 ? DenseSrc{xq, Kq} : DenseSrc{c_act[i][l - 1], qn.L[l - 1].Np};
-                { Bracket br(a, "q_dw"); BDR_TRY(dense_dw(stream, qn.L[l], q_g[i], in, c_dy[i][l], Bn, dw_part, dense_dw_chunks(qn.L[l], Bn))); }
-                if (l > 0) { Bracket br(a, "q_dx"); BDR_TRY(dense_dx(stream, qn.L[l], q_p[i], c_dy[i][l], c_dy[i][l - 1], c_act[i][l - 1], Bn)); }
+                Bracket br(a, "q_dw");
+                BDR_TRY(dense_dw(stream, qn.L[l], q_g[i], in, c_dy[i][l], Bn, dw_part, dense_dw_chunks(qn.L[l], Bn)));
             }
+            if (l > 0) { Bracket br(a, "q_dx"); BDR_TRY(critic_dx_all(l, Bn)); }
+        }
+        for (int i = 0; i < NC; ++i) {
             step_q[i] += 1;
-            { Bracket br(a, "adam_q"); BDR_TRY(launch_adam(stream, q_p[i], q_g[i], q_m[i], q_v[i], qn.total, adam_scalars_for(false, cfg.lr_critic, 0, 0, 0, 0, step_q[i]))); }
+            Bracket br(a, "adam_q");
+            BDR_TRY(launch_adam(stream, q_p[i], q_g[i], q_m[i], q_v[i], qn.total, adam_scalars_for(false, cfg.lr_critic, 0, 0, 0, 0, step_q[i])));
         }
         // ---------------- soft_update (:169-173) ----------------
         for (int i = 0; i < NC; ++i) { Bracket br(a, "track"); BDR_TRY(launch_track(stream, q_t[i], q_p[i], qn.total, cfg.tau)); }

@@ -281,11 +281,13 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
 struct DqnCnn : bdr_agent {
     bdr_dqn_config cfg;
     hipStream_t side = nullptr;          // weight-gradient kernels run here, concurrently with the dX chain
-    hipStream_t aux = nullptr;           // prioritized-replay tree updates (created on first use)
+    hipStream_t aux = nullptr;           // prioritized-replay tree updates
     hipEvent_t ev_fork[4] = {nullptr}, ev_join = nullptr;
     bool kev = true;
     unsigned* sig = nullptr;   // [8] device progress flags of schedule 3
     unsigned sig_epoch = 0;
+    unsigned test_epoch = 0;
+    bool aux_gated = true;     // the PER queue may wait through gates (queues_independent at its creation)
     bool head_gate_enqueued = false;
     bool side_gather = true;   // BDR_NO_SIDE_GATHER=1: opt() gathers on the dX queue
     unsigned long long* gate_trace = nullptr;   // BDR_GATE_TRACE=1: [5][2] (100 MHz ticks waited, count), printed at destruction
@@ -396,8 +398,9 @@ __device__ __forceinline__ void adam_element(float& p, float g, float& m, float&
 // k_gate: one wave; returns once *flag has reached `epoch` (wrap-safe compare).  It holds one wave slot while it waits, so
 // it cannot starve the producer; a producer that never arrives trips the time limit instead of hanging the queue
 // (sig[SIG_ERR] is checked at the next synchronisation).
-constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_GATHER = 4, SIG_ERR = 7;
-__global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned epoch, unsigned long long* waited, int publish)
+constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_GATHER = 4, SIG_TEST = 5, SIG_TEST_ERR = 6, SIG_ERR = 7;
+__global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned epoch, unsigned long long* waited, int publish,
+                                             unsigned long long limit = 1000000000ull /* 10 s of the 100 MHz clock */, int err_slot = SIG_ERR)
 {
     if (threadIdx.x != 0) return;
     // like start_signal: this kernel has started, so everything queued before it on its stream is complete
@@ -405,8 +408,8 @@ __global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned 
     const unsigned long long t0 = wall_clock64();   // 100 MHz
     while ((int)(__hip_atomic_load(sig + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > 1000000000ull) {   // 10 s
-            __hip_atomic_store(sig + SIG_ERR, 1u + (unsigned)which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wall_clock64() - t0 > limit) {
+            __hip_atomic_store(sig + err_slot, 1u + (unsigned)which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
     }
@@ -531,8 +534,28 @@ int32_t launch_gate(DqnCnn* a, hipStream_t st, int which, unsigned epoch, int pu
 {
     // trace slot: 2 counters per site; sites 0..3 = flags on the weight-gradient queue, 4 = the gates on the dX queue
     unsigned long long* tr = a->gate_trace ? a->gate_trace + 2 * (st == a->stream ? 4 : which) : nullptr;
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch, tr, publish);
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch, tr, publish, 1000000000ull, SIG_ERR);
     BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+
+// Gate kernels only work if the waiting stream and the producing stream sit on different hardware queues: HIP multiplexes
+// its streams onto a bounded pool of HSA queues (GPU_MAX_HW_QUEUES), and a gate sharing an in-order queue with its producer
+// would wait for a kernel queued behind it.  Checked once per pair when the streams exist: a gate with a 20 ms limit on
+// `waiter`, then the signal on `producer`; if the gate times out the queues alias.
+int32_t queues_independent(DqnCnn* a, hipStream_t waiter, hipStream_t producer, bool* ok)
+{
+    a->test_epoch += 1;
+    BDR_HIP(hipMemsetAsync(a->sig + SIG_TEST_ERR, 0, sizeof(unsigned), waiter));
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, waiter, a->sig, SIG_TEST, a->test_epoch, (unsigned long long*)nullptr, -1, 2000000ull, SIG_TEST_ERR);
+    BDR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, producer, a->sig, SIG_TEST, a->test_epoch);
+    BDR_HIP(hipGetLastError());
+    BDR_HIP(hipStreamSynchronize(waiter));
+    BDR_HIP(hipStreamSynchronize(producer));
+    unsigned err = 0;
+    BDR_HIP(hipMemcpy(&err, a->sig + SIG_TEST_ERR, sizeof err, hipMemcpyDeviceToHost));
+    *ok = err == 0;
     return BDR_OK;
 }
 
@@ -660,9 +683,11 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     if (per) {
         hipStream_t ps = a->stream;
         if (sched != 0) {
-            if (!a->aux) BDR_HIP(hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking));
-            if (gated) BDR_TRY(gate(a->aux, SIG_HEAD));
-            else BDR_HIP(hipStreamWaitEvent(a->aux, a->ev_fork[0], 0));
+            if (gated && a->aux_gated) BDR_TRY(gate(a->aux, SIG_HEAD));
+            else {
+                if (gated) BDR_HIP(hipEventRecord(a->ev_fork[0], a->stream));   // aliased queue: plain event ordering
+                BDR_HIP(hipStreamWaitEvent(a->aux, a->ev_fork[0], 0));
+            }
             ps = a->aux;
         }
         Bracket br(a, "per_update");
@@ -1006,6 +1031,17 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_HIP(hipMemcpyAsync(a->q_tgt, in.data(), a->ar.total * 4, hipMemcpyHostToDevice, a->stream));  // DqnModel::clone
     BDR_HIP(hipStreamSynchronize(a->stream));
     BDR_TRY(ensure_batch(a, (int)cfg->batch_size));
+    BDR_HIP(hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking));   // prioritized-replay tree updates
+    if (a->sched == 3) {   // both directions are used: the side queue waits for the dX queue, the join waits the other way
+        bool ok1 = false, ok2 = false;
+        BDR_TRY(queues_independent(a, a->side, a->stream, &ok1));
+        BDR_TRY(queues_independent(a, a->stream, a->side, &ok2));
+        BDR_TRY(queues_independent(a, a->aux, a->stream, &a->aux_gated));   // aliased: its dependency falls back to an event
+        if (!(ok1 && ok2)) {
+            fprintf(stderr, "border_amd: the agent's two streams share a hardware queue (GPU_MAX_HW_QUEUES?): serial backward schedule\n");
+            a->sched = 0;
+        }
+    }
     *out = a;
     return BDR_OK;
 }

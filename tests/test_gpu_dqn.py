@@ -563,3 +563,44 @@ def test_mixed_api_sequences_on_the_flag_ordered_schedule(B, tmp_path):
         assert len(got) == len(ref)
         for k, (x, y) in enumerate(zip(got, ref)):
             assert np.array_equal(np.asarray(x), np.asarray(y)), (sched, k)
+
+
+def test_shared_hardware_queue_is_detected_and_falls_back(B, tmp_path):
+    """HIP multiplexes streams onto a bounded pool of hardware queues.  The flag-ordered schedule needs the agent's two streams
+    on different queues (a gate kernel sharing an in-order queue with its producer would wait for a kernel behind it); the
+    agent checks that at creation.  With the pool forced to 2 queues (buffer stream + one more) the check must fail, the
+    agent must say so, run the serial schedule instead of hanging, and produce the same parameters bit for bit; with 3 the
+    prioritized-replay queue aliases and its dependency falls back to an event."""
+    import subprocess
+    import sys
+    script = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import border_amd as B
+per = sys.argv[1] == "per"
+rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=2000, seed=42, per_config=B.PerConfig(n_opts_final=30) if per else None),
+                          (4, 1, 84, 84), "uint8")
+rb.fill_synthetic(2000, seed=3, kind=0, n_actions=6)
+cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=6), opt_config=B.OptimizerConfig.Adam(1e-4)),
+                  device=0, batch_size=32, critic_loss="SmoothL1", tau=1.0, soft_update_interval=20, param_seed=5)
+a = B.Dqn.build(cfg); a.train()
+for _ in range(40): a.opt(rb)
+a.sync()
+np.save(sys.argv[2], a.get_params("qnet"))
+""" % os.path.join(os.path.dirname(__file__), "..")
+    outs = {}
+    for per in ("uniform", "per"):
+        for q in ("default", "2", "3"):
+            env = dict(os.environ)
+            env.pop("BDR_SCHED", None)
+            if q != "default":
+                env["GPU_MAX_HW_QUEUES"] = q
+            f = str(tmp_path / f"{per}_{q}.npy")
+            r = subprocess.run([sys.executable, "-c", script, per, f], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-800:]
+            outs[(per, q)] = (np.load(f), r.stderr)
+        ref, _ = outs[(per, "default")]
+        for q in ("2", "3"):
+            got, err = outs[(per, q)]
+            assert np.array_equal(got, ref), (per, q)
+            assert ("share a hardware queue" in err) == (q == "2"), (per, q, err[-300:])

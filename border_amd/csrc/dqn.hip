@@ -541,13 +541,13 @@ int32_t launch_gate(DqnCnn* a, hipStream_t st, int which, unsigned epoch, int pu
 
 // Gate kernels only work if the waiting stream and the producing stream sit on different hardware queues: HIP multiplexes
 // its streams onto a bounded pool of HSA queues (GPU_MAX_HW_QUEUES), and a gate sharing an in-order queue with its producer
-// would wait for a kernel queued behind it.  Checked once per pair when the streams exist: a gate with a 20 ms limit on
+// would wait for a kernel queued behind it.  Checked once per pair when the streams exist: a gate with a 100 ms limit on
 // `waiter`, then the signal on `producer`; if the gate times out the queues alias.
 int32_t queues_independent(DqnCnn* a, hipStream_t waiter, hipStream_t producer, bool* ok)
 {
     a->test_epoch += 1;
     BDR_HIP(hipMemsetAsync(a->sig + SIG_TEST_ERR, 0, sizeof(unsigned), waiter));
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, waiter, a->sig, SIG_TEST, a->test_epoch, (unsigned long long*)nullptr, -1, 2000000ull, SIG_TEST_ERR);
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, waiter, a->sig, SIG_TEST, a->test_epoch, (unsigned long long*)nullptr, -1, 10000000ull, SIG_TEST_ERR);
     BDR_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, producer, a->sig, SIG_TEST, a->test_epoch);
     BDR_HIP(hipGetLastError());

@@ -784,6 +784,9 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
     BDR_REQUIRE(r->act_bytes >= 8, "discrete actions are stored as i64");
     BDR_REQUIRE(r->device == a->device, "agent and replay buffer live on different devices");
     { Bracket br(a, "_null"); }   // empty bracket: the event pair's own cost, subtracted by bench.py
+    // any buffer growth (hipFree drains the device) happens here, before this update's gates are queued
+    BDR_TRY(ensure_batch(a, (int)a->cfg.batch_size));
+    BDR_TRY(a->td_buffer(a->cfg.batch_size));
     for (uint64_t u = 0; u < a->cfg.n_updates_per_opt; ++u) {
         if (!a->prof && a->sched == 3 && a->side_gather) {
             // The gather does not depend on the previous update, and the weight-gradient queue is idle from the end of one

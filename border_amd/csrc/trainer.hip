@@ -9,6 +9,7 @@
 // store.  Pure host code: the agent, buffer and environment are reached through function tables, so the loop itself runs
 // (and is tested) without a GPU.
 #include <chrono>
+#include <cmath>
 #include <vector>
 
 #include "common.hpp"
@@ -55,8 +56,9 @@ void cost_record(State& s, bdr_trainer_observer obs, void* ctx)
 {
     const bdr_trainer_config& c = *s.c;
     if (c.record_compute_cost_interval == 0 || s.opt_steps % c.record_compute_cost_interval != 0) return;
-    const float avr[2] = {s.opt_steps_counter ? (float)(1000.0 * s.timer_for_opt_steps / (double)s.opt_steps_counter) : -1.0f,
-                          s.samples_counter ? (float)(1000.0 * s.timer_for_samples / (double)s.samples_counter) : -1.0f};
+    // `timer.as_millis() as f32 / n as f32`: the accumulated time is truncated to whole milliseconds first (trainer.rs:164-174)
+    const float avr[2] = {s.opt_steps_counter ? (float)std::floor(1000.0 * s.timer_for_opt_steps) / (float)s.opt_steps_counter : -1.0f,
+                          s.samples_counter ? (float)std::floor(1000.0 * s.timer_for_samples) / (float)s.samples_counter : -1.0f};
     if (obs) obs(ctx, s.env_steps, s.opt_steps, BDR_TRAINER_EVENT_COST, avr, 2);
     s.timer_for_opt_steps = 0; s.opt_steps_counter = 0; s.timer_for_samples = 0; s.samples_counter = 0;
 }

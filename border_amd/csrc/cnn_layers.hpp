@@ -190,6 +190,57 @@ struct DxC3P {
 };
 using DxC3 = DxC3P<2, 2>;      // 64x64 flat tiles, M = B*81
 
+// Position-class tiles: workgroup (x, y) = 64 images at input position pos(y); its k loop walks only the taps that reach a
+// valid output from that position (1, 2, 3, 4, 6 or 9 of them) - 441 tap-tiles per 64 images instead of 729.  y enumerates
+// the positions by decreasing tap count so that the long tiles are dispatched first.  grid: (ceil(B / 64), 81, 1).
+static __device__ __constant__ unsigned char c3_pos_by_taps[81] = {
+    20, 21, 22, 23, 24, 29, 30, 31, 32, 33, 38, 39, 40, 41, 42, 47, 48, 49, 50, 51, 56, 57, 58, 59, 60, 11, 12, 13, 14, 15, 19, 25, 28, 34, 37, 43, 46,
+    52, 55, 61, 65, 66, 67, 68, 69, 10, 16, 64, 70, 2, 3, 4, 5, 6, 18, 26, 27, 35, 36, 44, 45, 53, 54, 62, 74, 75, 76, 77, 78, 1, 7, 9, 17, 63, 71, 73,
+    79, 0, 8, 72, 80};
+struct DxC3Pos {
+    using G = GeomC3;
+    using A = ADxS1Pos<G>;
+    using Args = DxArgs;          // M = B * 81
+    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int RPI = 1, RPIP = 0;
+    static constexpr int NC = G::CIN;
+    static constexpr bool B_TR = true;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.M, mv, mr); }   // (unused: vrow_y)
+    __device__ static bool vrow_y(const Args& a, int y, int mv, int& mr)
+    {
+        mr = mv * (G::IH * G::IW) + c3_pos_by_taps[y];     // image mv at this workgroup's position
+        return mr < a.M;
+    }
+    __device__ static constexpr int N(const Args&) { return NC; }
+    __device__ static constexpr int KP(const Args&) { return G::COUT; }
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
+    __device__ static const float* w(const Args& a, int, int) { return a.w; }
+    __device__ static void pos_taps(int y, int& kh0, int& nh, int& kw0, int& nw)
+    {
+        const int pos = c3_pos_by_taps[y];
+        A::taps(pos / G::IW, G::OH, G::KH, kh0, nh);
+        A::taps(pos % G::IW, G::OW, G::KW, kw0, nw);
+    }
+    __device__ static int tap_index(int y, int t)
+    {
+        int kh0, nh, kw0, nw;
+        pos_taps(y, kh0, nh, kw0, nw);
+        const int th = A::div_small(min(t, nh * nw - 1), nw);
+        return (kh0 + th) * G::KW + kw0 + (min(t, nh * nw - 1) - th * nw);
+    }
+    __device__ static void kt_range(const Args&, int y, int& k0, int& k1)
+    {
+        int kh0, nh, kw0, nw;
+        pos_taps(y, kh0, nh, kw0, nw);
+        k0 = 0; k1 = nh * nw * (G::COUT / BK);
+    }
+    struct Epi { gptr<const float> mask; gptr<float> out; };
+    __device__ static Epi epi(const Args& a, int, int) { return Epi{pin_sgpr(a.mask), pin_sgpr(a.out)}; }
+    __device__ static float epi_load(const Epi& e, int m, int n) { return e.mask[(size_t)m * NC + n]; }
+    __device__ static void store(const Epi& e, int m, int n, float v, float mask) { e.out[(size_t)m * NC + n] = mask > 0.f ? v : 0.f; }
+};
+
 // conv2 (4x4, stride 2): blockIdx.y = parity class (ph,pw); rows (b, ih/2, iw/2); K' = 4 taps * 64
 template <int WM_, int WN_, int RPIP_ = 0, int TM_ = 1, int TN_ = 1>
 struct DxC2P {

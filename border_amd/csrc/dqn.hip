@@ -649,12 +649,12 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     auto c3_dx = [&]() -> int32_t {
         DxArgs d{a->dy3, a->q + ar.w3, a->a2[0], a->dy2, B * 81, sigf(SIG_DXL1), epoch};
         Bracket br(a, "bwd_conv3_dx");
-        BDR_HIP((launch_igemm<DxC3, TEAMS_DX_C3>(a->stream, dim3((d.M + 63) / 64, 1, 1), d, 0, kev(2))));
+        BDR_HIP((launch_igemm<DxC3Pos, TEAMS_DX_C3>(a->stream, dim3((B + 63) / 64, 81, 1), d, 0, kev(2))));
         return BDR_OK;
     };
     auto c2_dw = [&]() -> int32_t {
         const int M = B * 81, chunks = std::min(pl.chunks_c2, (M + 31) / 32);
-        DwArgs d{a->a1[0], a->dy2, a->part + pl.off_c2, pl.stride_c2, M};
+        DwArgs d{a->a1[0], a->dy2, a->part + pl.off_c2, pl.stride_c2, M, nullptr, 0};
         Bracket br(a, "bwd_conv2_dw");
         LAUNCH_FL(sd, any, ov && a->kev ? a->ev_join : nullptr, k_igemm_red<DwC2>, dim3(8 * chunks), dim3(256), d);
         return BDR_OK;
@@ -694,20 +694,21 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         BDR_TRY(replay_update_priority_on_stream(per_buffer, B, a->td_abs, ps));
     }
     if (gated) {
-        // dX queue: DxL1, DxC3, DxC2 (each start publishing its predecessor), conv1 dW, join gate.
-        // other queue: gate -> the weight gradients that depend on the published kernel, then the l1 / l2 Adam pass (a
-        // streaming kernel: beside a dX GEMM it starves for workgroup slots - 27 us instead of 8 - so it goes last, beside
-        // the conv1 dW kernel).
         if (!a->head_gate_enqueued) BDR_TRY(gate(sd, SIG_HEAD));   // (opt_inner enqueues it right behind a side-queue gather)
         a->head_gate_enqueued = false;
+        // dX queue: DxL1, DxC3, DxC2 (each start publishing its predecessor), then conv2's and conv1's dW.
+        // other queue: gate -> head_bwd, DwL1; gate -> DwC3; then the l1 / l2 Adam pass (a streaming kernel: beside a dX
+        // GEMM it starves for workgroup slots - 27 us instead of 8 - so it goes last).  With the position-class conv3 dX
+        // (40 % fewer products) the dX queue has room for conv2's dW; left on the other queue it made that one the longer
+        // by 17 us (4 230 vs 4 515 opt-steps/s on the same box).
         BDR_TRY(head_bwd()); BDR_TRY(l1_dw());
         BDR_TRY(l1_dx());
-        BDR_TRY(gate(sd, SIG_DXL1)); BDR_TRY(c3_dw());
-        BDR_TRY(c3_dx());
-        BDR_TRY(gate(sd, SIG_DXC3)); BDR_TRY(c2_dw()); BDR_TRY(adam_l1_l2());
+        BDR_TRY(gate(sd, SIG_DXL1)); BDR_TRY(c3_dw()); BDR_TRY(adam_l1_l2());
         hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sd, a->sig, SIG_SIDE, epoch);
         BDR_HIP(hipGetLastError());
+        BDR_TRY(c3_dx());
         BDR_TRY(c2_dx());
+        { hipStream_t side = sd; sd = a->stream; BDR_TRY(c2_dw()); sd = side; }
         BDR_TRY(c1_dw());
         BDR_TRY(gate(a->stream, SIG_SIDE));   // join: all weight-gradient partials complete
     } else if (sched == 2) {
@@ -1012,11 +1013,11 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     for (auto& e : a->ev_fork) BDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
     BDR_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* e = getenv("BDR_SCHED")) a->sched = std::max(0, std::min(3, atoi(e)));
-    BDR_HIP(hipMalloc((void**)&a->sig, 8 * sizeof(unsigned)));
-    BDR_HIP(hipMemsetAsync(a->sig, 0, 8 * sizeof(unsigned), a->stream));   // synchronised with the parameter upload below
+    BDR_HIP(hipMalloc((void**)&a->sig, 16 * sizeof(unsigned)));
+    BDR_HIP(hipMemsetAsync(a->sig, 0, 16 * sizeof(unsigned), a->stream));   // synchronised with the parameter upload below
     if (getenv("BDR_GATE_TRACE")) {
-        BDR_HIP(hipMalloc((void**)&a->gate_trace, 10 * sizeof(unsigned long long)));
-        BDR_HIP(hipMemsetAsync(a->gate_trace, 0, 10 * sizeof(unsigned long long), a->stream));
+        BDR_HIP(hipMalloc((void**)&a->gate_trace, 32 * sizeof(unsigned long long)));
+        BDR_HIP(hipMemsetAsync(a->gate_trace, 0, 32 * sizeof(unsigned long long), a->stream));
     }
     if (getenv("BDR_NO_OVERLAP")) a->sched = 0;
     a->kev = getenv("BDR_NO_KEV") == nullptr;

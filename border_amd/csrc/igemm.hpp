@@ -132,6 +132,41 @@ struct ADxS1 {
     }
 };
 
+// The same gather for tiles whose rows all sit at ONE input position (ih, iw): only the taps that reach a valid output are
+// walked (loop index t -> the t-th valid tap of the row's position), so border positions do 1-6 taps instead of 9 - 40 %
+// of the stride-1 3x3 transposed conv's products over the full tap set are with zero padding.
+template <class G>
+struct ADxS1Pos {
+    static constexpr int VEC = 4;
+    static constexpr int NKT = G::KH * G::KW * G::COUT / BK;
+    struct Row { const float* base; int ih, iw, kh0, kw0, nw; };
+    __device__ static void taps(int i, int n_out, int k, int& k0, int& n) { k0 = max(0, i - (n_out - 1)); n = min(k - 1, i) - k0 + 1; }
+    __device__ static int div_small(int t, int d) { return d == 1 ? t : (d == 2 ? t >> 1 : (t * 11) >> 5); }   // t < 16, d <= 3
+    __device__ static Row row(const float* dy, int m, int M)
+    {
+        Row r;
+        const int mm = m < M ? m : 0;
+        const int b = mm / (G::IH * G::IW), rem = mm % (G::IH * G::IW);
+        r.ih = rem / G::IW; r.iw = rem % G::IW;
+        int nh;
+        taps(r.ih, G::OH, G::KH, r.kh0, nh);
+        taps(r.iw, G::OW, G::KW, r.kw0, r.nw);
+        r.base = dy + (size_t)b * G::OH * G::OW * G::COUT;
+        return r;
+    }
+    __device__ static const float* chunk(const Row& r, int kt, int q)
+    {
+        constexpr int TPT = G::COUT / BK;
+        const int t = kt / TPT, c0 = (kt % TPT) * BK;
+        const int th = div_small(t, r.nw);
+        const int kh = r.kh0 + th, kw = r.kw0 + (t - th * r.nw);
+        // clamped: rows of padding images and the clamped tail iterations of a shorter team stay inside the tensor
+        const int oh = min(max(r.ih - kh, 0), G::OH - 1), ow = min(max(r.iw - kw, 0), G::OW - 1);
+        return r.base + (size_t)(oh * G::OW + ow) * G::COUT + c0 + q * 4;
+    }
+    __device__ static void load(const Row& r, int kt, int q, f32x4* v) { v[0] = *reinterpret_cast<const f32x4*>(chunk(r, kt, q)); }
+};
+
 // Input gradient of a stride-2, 4x4 conv: the input grid splits into 4 parity classes (ih%2, iw%2);
 // class (ph,pw) only sees taps kh in {ph, ph+2}, kw in {pw, pw+2}, so K' = 4*COUT per class and no
 // MFMA work is spent on structurally-zero taps.  rows m' = (b, ih/2, iw/2) within a class.
@@ -326,6 +361,17 @@ __device__ inline void start_signal(unsigned* flag, unsigned epoch)
         __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// policies whose row map depends on blockIdx.y (position-class tiles) provide vrow_y(args, y, mv, mr)
+template <class P, class = void> struct has_vrow_y : std::false_type {};
+template <class P>
+struct has_vrow_y<P, std::void_t<decltype(P::vrow_y(std::declval<const typename P::Args&>(), 0, 0, std::declval<int&>()))>> : std::true_type {};
+template <class P>
+__device__ inline bool vrow_of(const typename P::Args& a, int y, int mv, int& mr)
+{
+    if constexpr (has_vrow_y<P>::value) return P::vrow_y(a, y, mv, mr);
+    else return P::vrow(a, mv, mr);
+}
+
 template <class P, int TEAMS = 1>
 __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P::Args args)
 {
@@ -383,7 +429,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
         int mr;
-        const bool ok = P::vrow(args, m0 + p * (NT / APR) + a_r, mr);
+        const bool ok = vrow_of<P>(args, y, m0 + p * (NT / APR) + a_r, mr);
         rows[p] = A::row(P::a_src(args, z), ok ? mr : M, M);   // invalid rows alias row 0 and are never stored
     }
     const float* w = P::w(args, z, y);
@@ -486,7 +532,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int mv = m0 + (wm * P::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (P::vrow(args, mv, mrow[tm][r])) okmask[tm] |= 1u << r;
+            if (vrow_of<P>(args, y, mv, mrow[tm][r])) okmask[tm] |= 1u << r;
             else mrow[tm][r] = 0;
 #pragma unroll
             for (int tn = 0; tn < P::TN; ++tn)

@@ -413,11 +413,18 @@ __global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned 
             return;
         }
     }
-    if (waited) { waited[0] += wall_clock64() - t0; waited[1] += 1; }   // BDR_GATE_TRACE: time spent waiting, per gate site
+    if (waited) {   // BDR_GATE_TRACE: time spent waiting, per gate site; for the join also how long the flag had been set
+        waited[0] += wall_clock64() - t0; waited[1] += 1;
+        if (which == SIG_SIDE) {
+            const unsigned long long ts = *reinterpret_cast<volatile unsigned long long*>(sig + 12);
+            if (ts && t0 > ts) waited[12] += t0 - ts;
+        }
+    }
 }
 // k_signal: "everything queued before me on this stream is complete" (same argument as start_signal)
 __global__ __launch_bounds__(64) void k_signal(unsigned* sig, int which, unsigned epoch)
 {
+    if (threadIdx.x == 0 && which == SIG_SIDE) *reinterpret_cast<volatile unsigned long long*>(sig + 12) = wall_clock64();   // (trace only)
     if (threadIdx.x == 0) __hip_atomic_store(sig + which, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -916,11 +923,12 @@ DqnCnn::~DqnCnn()
     for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (gate_trace) {
-        unsigned long long t[10] = {0};
+        unsigned long long t[32] = {0};
         (void)hipMemcpy(t, gate_trace, sizeof t, hipMemcpyDeviceToHost);
         static const char* site[5] = {"side<-head", "side<-DxL1", "side<-DxC3", "-", "main<-side (join)"};
         for (int k = 0; k < 5; ++k)
             if (t[2 * k + 1]) fprintf(stderr, "gate %-18s mean wait %.2f us over %llu gates\n", site[k], t[2 * k] / 100.0 / t[2 * k + 1], t[2 * k + 1]);
+        if (t[9]) fprintf(stderr, "the weight-gradient queue finished on average %.2f us before the dX queue reached the join\n", t[20] / 100.0 / (t[9] / 2.0));
         (void)hipFree(gate_trace);
     }
     if (sig) (void)hipFree(sig);

@@ -128,6 +128,12 @@ def main():
         # kernel plus ONE marker's processing time (the closing marker is stamped when the kernel retires).  So
         # the per-kernel correction is half of the empty bracket; this reproduces rocprofv3's kernel durations
         # to ~0.3 us (profiles/rocprof_r01_kernel_trace_v4.md).
+        # the timed steps trained a real network: one more step with its Record, which must be finite
+        rec = agent.opt_with_record(rb)
+        final_loss = float(rec["loss"])
+        if not (final_loss == final_loss and abs(final_loss) != float("inf")):
+            sys.exit(f"bench.py: non-finite loss {final_loss} after the timed steps")
+
         def profile(n):
             agent.profile_enable(True)
             for _ in range(n):
@@ -174,7 +180,7 @@ def main():
                              "soft_update_interval": 10000, "tau": 1.0,
                              "parallelism": f"dp{world} (replica + replay shard per GPU"
                                             + (f", parameter all-reduce every {args.sync_interval} opts over {exch.backend})" if world > 1 else ")"),
-                             "samples_per_sec": round(value * args.batch, 1)},
+                             "final_loss": round(final_loss, 6), "samples_per_sec": round(value * args.batch, 1)},
                   "roofline": roof}
     agent.close()
     rb.close()

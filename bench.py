@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark: agent opt-steps/sec, DQN Atari 84x84x4, batch 256 (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2]
 
 A "step" is one Agent::opt() -- on-device ChaCha12 index draw + gather from the 1M-transition HBM
 ring + online/target forward + Huber TD loss + backward + Adam (+ target sync when due) -- exactly
 the region Trainer::train_step times (border-core/src/trainer.rs:213-225).  Inputs are resident in
 HBM before the timed region starts.  For N>1 the driver launches one rank per GPU with
 torch.distributed.run; every rank owns a replica + a local replay shard and parameters are averaged
-over RCCL every --sync-interval opt steps (inside the timed region).
+over RCCL every --sync-interval opt steps (inside the timed region).  The data plane of an N>1 run IS
+RCCL: if the library's communicator cannot be brought up the run exits non-zero (no silent demotion
+to host staging), and the line carries "rccl_ranks": N.
+
+--config selects the BASELINE.json configuration (SURVEY.md section 8 shorthands):
+  c2 (default, the headline)  synthetic Atari DQN Nature-CNN, replay 1M u8 transitions, batch 256
+  c1  CartPole-shaped DQN, Mlp[64,64], replay 10k, batch 32
+  c4  IQN on synthetic Atari, 64/64 quantiles, batch 512, replay 1M
+  c5  SAC obs 17 / act 6, twin-Q [256,256], Auto entropy coefficient, replay 1M, batch 1024
+c1/c4/c5 are parity-test configurations; their lines use the same schema and exist so that their
+rates and per-kernel rooflines are backed by tracked files under profiles/.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live: per-kernel HIP-event timing on the
-agent's own stream (bdr_agent_profile_*), algorithmic FLOPs from SURVEY.md section 8(d).
-`cpu_baseline` times oracle/torch_ref.py (the ATen op sequence tch 0.16 binds) on the host cores.
+agent's own stream (bdr_agent_profile_*), algorithmic FLOPs / bytes from SURVEY.md section 8(d).
+`cpu_baseline` times oracle/torch_ref.py (the ATen op sequence tch 0.16 binds) on the host cores:
+1 thread, a thread-count sweep, and the best count for >= 100 steps or the time budget.
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -25,10 +38,12 @@ sys.path.insert(0, ROOT)
 
 N_ACTIONS = 6
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (conv1 forward / dW: exact 3-term operand split, 3 bf16 MFMAs per product)
 PEAK_HBM_GBS = 8000.0
 
 
-def kernel_flops(B, nz):
+# ------------------------------------------------------------------------------------------------ work models
+def dqn_kernel_flops(B, nz):
     """Algorithmic FLOPs per launch (2*MACs), SURVEY.md section 8(d) / section 2.3 shapes."""
     c1, c2, c3, l1 = 2 * B * 400 * 256 * 32, 2 * B * 81 * 512 * 64, 2 * B * 49 * 576 * 64, 2 * B * 3136 * 512
     return {"fwd_conv1": nz * c1, "fwd_conv2": nz * c2, "fwd_conv3": nz * c3, "fwd_l1": nz * l1,
@@ -36,21 +51,288 @@ def kernel_flops(B, nz):
             "bwd_l1_dw": l1, "bwd_l1_dx": l1}
 
 
+BF16_KERNELS = ("fwd_conv1", "bwd_conv1_dw", "psi_conv1", "psi_conv1_dw")
+
+
+def mlp_layer_dims(in_dim, units, out_dim):
+    dims, i = [], in_dim
+    for u in list(units) + [out_dim]:
+        dims.append((i, u))
+        i = u
+    return dims
+
+
+def host_cpu_info():
+    info = {"model": None, "physical_cores": None, "logical_cpus": os.cpu_count(), "sockets": None}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        f = {k.strip(): v.strip() for k, v in (l.split(":", 1) for l in out.splitlines() if ":" in l)}
+        info["model"] = f.get("Model name")
+        sockets = int(f.get("Socket(s)", "1"))
+        cps = int(f.get("Core(s) per socket", "0"))
+        info["sockets"] = sockets
+        if cps:
+            info["physical_cores"] = sockets * cps
+    except Exception:
+        pass
+    if not info["physical_cores"]:
+        info["physical_cores"] = os.cpu_count()
+    try:   # a cgroup / affinity mask may expose fewer CPUs than lscpu lists
+        info["usable_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["usable_cpus"] = info["logical_cpus"]
+    return info
+
+
+# ------------------------------------------------------------------------------------------------ configurations
+def build_config(B, name, args, rank, local_rank):
+    """-> dict(agent, rb, batch, workload, metric, extra config keys, work model)"""
+    import numpy as np
+    if name == "c2":
+        cap, bs = args.capacity or 1_000_000, args.batch or 256
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=B.shard_seed(42, rank),
+                                                              per_config=B.PerConfig() if args.per else None),
+                                  (4, 1, 84, 84), "uint8", device=local_rank)
+        rb.fill_synthetic(cap, seed=rank, kind=0, n_actions=N_ACTIONS)
+        cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=N_ACTIONS),
+                                                        opt_config=B.OptimizerConfig.Adam(1e-4)),
+                          soft_update_interval=10000, n_updates_per_opt=1, batch_size=bs, discount_factor=0.99,
+                          tau=1.0, double_dqn=args.double_dqn, critic_loss=args.loss, device=local_rank, param_seed=0)
+        agent = B.Dqn.build(cfg)
+        nz = 3 if args.double_dqn else 2
+        fl = dqn_kernel_flops(bs, nz)
+        by = {"sample": 2 * bs * 28224 + bs * 14, "adam_l1_l2": 7 * 4 * (3136 * 512 + 512 + 512 * N_ACTIONS + N_ACTIONS)}
+        step_flops = sum(fl.values()) + 2 * nz * bs * 512 * N_ACTIONS
+        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops=fl, bytes=by, step_flops=step_flops,
+                    metric="agent opt-steps/sec (DQN Atari 84x84x4, batch 256)",
+                    workload=f"synthetic Atari DQN Nature-CNN, replay {cap} u8 transitions/GPU, batch {bs}/GPU",
+                    cfg_extra={"n_actions": N_ACTIONS, "critic_loss": args.loss, "double_dqn": args.double_dqn,
+                               "prioritized_replay": bool(args.per), "optimizer": "Adam lr=1e-4", "soft_update_interval": 10000, "tau": 1.0},
+                    which=("qnet",), loss_key="loss")
+    if name == "c1":
+        cap, bs = args.capacity or 10_000, args.batch or 32
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=B.shard_seed(42, rank)), (4,), "float32", device=local_rank)
+        rb.fill_synthetic(cap, seed=rank, kind=1, n_actions=2)
+        cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.MlpConfig(in_dim=4, units=(64, 64), out_dim=2),
+                                                        opt_config=B.OptimizerConfig.Adam(1e-3)),
+                          soft_update_interval=1, n_updates_per_opt=1, batch_size=bs, discount_factor=0.99, tau=0.01,
+                          critic_loss="Mse", device=local_rank, param_seed=0)
+        agent = B.Dqn.build(cfg)
+        dims = mlp_layer_dims(4, (64, 64), 2)
+        fwd = sum(2 * bs * i * o for i, o in dims)
+        step_flops = 2 * fwd + fwd + sum(2 * bs * i * o for i, o in dims[1:])     # two forwards, dW of every layer, dX of all but the first
+        n_par = sum(i * o + o for i, o in dims)
+        by = {"sample": bs * (2 * 16 + 8 + 6), "adam": 7 * 4 * n_par, "track": 3 * 4 * n_par}
+        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops={}, bytes=by, step_flops=step_flops,
+                    metric="agent opt-steps/sec (DQN CartPole-shaped Mlp[64,64], batch 32)",
+                    workload=f"CartPole-shaped DQN Mlp[64,64] (obs 4 f32, 2 actions), replay {cap}, batch {bs}",
+                    cfg_extra={"critic_loss": "Mse", "optimizer": "Adam lr=1e-3", "soft_update_interval": 1, "tau": 0.01},
+                    which=("qnet",), loss_key="loss")
+    if name == "c4":
+        cap, bs, NQ = args.capacity or 1_000_000, args.batch or 512, 64
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=B.shard_seed(42, rank)), (4, 1, 84, 84), "uint8", device=local_rank)
+        rb.fill_synthetic(cap, seed=rank, kind=0, n_actions=N_ACTIONS)
+        cfg = B.IqnConfig(n_actions=N_ACTIONS, lr=1e-4, batch_size=bs, sample_percents_pred="Uniform64", sample_percents_tgt="Uniform64",
+                          soft_update_interval=10000, tau=1.0, device=local_rank, seed=rank)
+        agent = B.Iqn.build(cfg)
+        M, F, E, H = bs * NQ, 3136, 64, 512
+        c1, c2, c3 = 2 * bs * 400 * 256 * 32, 2 * bs * 81 * 512 * 64, 2 * bs * 49 * 576 * 64
+        fl = {"psi_conv1": 2 * c1, "psi_conv2": 2 * c2, "psi_conv3": 2 * c3, "psi_conv1_dw": c1, "psi_conv2_dw": c2, "psi_conv2_dx": c2,
+              "psi_conv3_dw": c3, "psi_conv3_dx": c3,
+              "iqn_phi_merge": 2 * (2 * M * E * F), "iqn_f_fwd1": 2 * (2 * M * F * H), "iqn_f_fwd2": 2 * (2 * M * H * N_ACTIONS),
+              "iqn_f_dw2": 2 * M * H * N_ACTIONS, "iqn_f_dx2": 2 * M * H * N_ACTIONS, "iqn_f_dw1": 2 * M * F * H, "iqn_f_dx1": 2 * M * F * H,
+              "iqn_cos_dw": 2 * M * E * F}
+        by = {"sample": 2 * bs * 28224 + bs * 14}
+        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops=fl, bytes=by, step_flops=sum(fl.values()),
+                    metric="agent opt-steps/sec (IQN synthetic Atari, 64 quantiles, batch 512)",
+                    workload=f"IQN on synthetic Atari: Nature-CNN trunk (F=3136), embed 64, merge Mlp(3136,[512],{N_ACTIONS}), "
+                             f"Uniform64 pred/tgt quantiles, replay {cap} u8 transitions, batch {bs}",
+                    cfg_extra={"n_actions": N_ACTIONS, "quantiles": NQ, "optimizer": "Adam lr=1e-4", "soft_update_interval": 10000, "tau": 1.0},
+                    which=("iqn",), loss_key="loss_critic")
+    if name == "c5":
+        cap, bs, od, ad = args.capacity or 1_000_000, args.batch or 1024, 17, 6
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=B.shard_seed(42, rank)), (od,), "float32", (ad,), "float32",
+                                  device=local_rank)
+        rb.fill_synthetic(cap, seed=rank, kind=1, n_actions=0)
+        cfg = B.SacConfig(obs_dim=od, act_dim=ad, pi_units=(256, 256), q_units=(256, 256), n_critics=2, batch_size=bs,
+                          ent_coef_mode=("Auto", -6.0, 3e-4), lr_actor=3e-4, lr_critic=3e-4, device=local_rank, seed=rank)
+        agent = B.Sac.build(cfg)
+        pi = mlp_layer_dims(od, (256, 256), 0)[:-1]
+        heads = [(256, ad), (256, ad)]
+        qd = mlp_layer_dims(od + ad, (256, 256), 1)
+        f_pi = sum(2 * bs * i * o for i, o in pi + heads)
+        f_q = sum(2 * bs * i * o for i, o in qd)
+        # update_actor: pi fwd, 2 critics fwd, critics dX (all layers), pi dW + dX; update_critic: pi fwd, 2 target critics fwd,
+        # 2 critics fwd, dW (all layers) + dX (all but the first) per critic
+        dx_q_all = sum(2 * bs * i * o for i, o in qd)
+        dx_q_inner = sum(2 * bs * i * o for i, o in qd[1:])
+        dx_pi = sum(2 * bs * i * o for i, o in heads + pi[1:])
+        step_flops = (f_pi + 2 * f_q + 2 * dx_q_all + f_pi + dx_pi) + (f_pi + 2 * f_q + 2 * f_q + 2 * (f_q + dx_q_inner))
+        n_pi = sum(i * o + o for i, o in pi + heads)
+        n_q = sum(i * o + o for i, o in qd)
+        by = {"sample": bs * (2 * od * 4 + ad * 4 + 6), "adam_pi": 7 * 4 * n_pi, "adam_q": 7 * 4 * n_q, "track": 3 * 4 * n_q}
+        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops={}, bytes=by, step_flops=step_flops,
+                    metric="agent opt-steps/sec (SAC obs 17 / act 6, twin-Q, batch 1024)",
+                    workload=f"SAC on HalfCheetah-shaped synthetic rows (obs 17, act 6 f32), actor Mlp2[256,256], twin-Q Mlp[256,256], "
+                             f"Auto entropy coefficient, replay {cap}, batch {bs}",
+                    cfg_extra={"optimizer": "Adam lr=3e-4 (actor, critics, alpha)", "n_critics": 2, "tau": 0.005},
+                    which=("pi",), loss_key="loss_critic")
+    raise SystemExit(f"unknown --config {name}")
+
+
+# ------------------------------------------------------------------------------------------------ profile -> roofline
+def read_profile(agent):
+    """[(label, mean ms per launch)] in launch order (labels repeat: the same layer runs for several networks)."""
+    import ctypes as C
+    import numpy as np
+    from border_amd import _lib
+    cnt = C.c_uint64(1024)
+    names = C.create_string_buffer(1 << 16)
+    ms = np.zeros(1024, np.float32)
+    _lib.check(_lib.lib().bdr_agent_profile_read(agent.handle, names, 1 << 16, ms.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+    labels = names.value.decode().split("\n")[:cnt.value]
+    return [(l, float(ms[i])) for i, l in enumerate(labels)]
+
+
+def profile(agent, rb, n):
+    agent.profile_enable(True)
+    for _ in range(n):
+        agent.opt(rb)
+    slots = read_profile(agent)
+    agent.profile_enable(False)
+    null = [v for l, v in slots if l == "_null"]
+    half_null = 0.5 * (null[0] if null else 0.0)
+    agg, cnt = {}, {}
+    for l, v in slots:
+        if l == "_null":
+            continue
+        agg[l] = agg.get(l, 0.0) + max(v - half_null, 0.0)
+        cnt[l] = cnt.get(l, 0) + 1
+    return agg, cnt, half_null
+
+
+def roofline(conf, prof, cnt, null_ms, ms_step):
+    fl, by = conf["flops"], conf["bytes"]
+    per = {}
+    for k, v in prof.items():
+        e = {"ms": round(v, 5), "launches": cnt[k]}
+        if k in fl and v > 0:
+            tf = fl[k] / (v * 1e-3) / 1e12
+            if k in BF16_KERNELS:   # 3 bf16 MFMAs per exact product: the matrix pipe issues 3x the algorithmic flops
+                e.update(bound="mfma_bf16", gflop=round(fl[k] / 1e9, 3), achieved_TFLOPs=round(tf, 2), issued_TFLOPs=round(3 * tf, 2),
+                         frac=round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4))
+            else:
+                e.update(bound="mfma_fp32", gflop=round(fl[k] / 1e9, 3), achieved_TFLOPs=round(tf, 2), frac=round(tf / PEAK_FP32_MFMA_TFLOPS, 4))
+        elif k in by and v > 0:
+            gbs = by[k] / (v * 1e-3) / 1e9
+            e.update(bound="hbm", bytes=by[k], achieved_GBs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
+        per[k] = e
+    fp32 = [k for k in prof if k in fl and k not in BF16_KERNELS and prof[k] > 0]
+    bf16 = [k for k in prof if k in fl and k in BF16_KERNELS and prof[k] > 0]
+    roof = {}
+    if fp32:
+        dom = max(fp32, key=lambda k: prof[k])
+        ach = fl[dom] / (prof[dom] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel_ms": round(prof[dom], 5)}
+    else:   # launch / HBM-bound configurations: the dominant kernel with a byte model
+        known = [k for k in prof if k in by and prof[k] > 0]
+        dom = max(known, key=lambda k: prof[k]) if known else None
+        if dom:
+            gbs = by[dom] / (prof[dom] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "kernel_ms": round(prof[dom], 5)}
+    tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if roof and os.path.exists(tr):   # PMC-derived HBM bytes per launch, measured with rocprofv3 --pmc (profiles/)
+        try:
+            roof["traffic"] = json.load(open(tr)).get(roof["kernel"])
+        except Exception:
+            pass
+    sf = conf["step_flops"]
+    step = {"gflop": round(sf / 1e9, 3), "achieved": round(sf / (ms_step * 1e-3) / 1e12, 2),
+            "frac_of_fp32_peak": round(sf / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "serial_kernel_ms": round(sum(prof.values()), 5), "launches_per_step": int(sum(cnt.values()))}
+    step["frac"] = step["frac_of_fp32_peak"]
+    if fp32:   # the two matrix pipes apart: FP32-MFMA kernels against the FP32 peak, exact-bf16 kernels against the bf16 peak
+        f32_fl, f32_ms = sum(fl[k] for k in fp32), sum(prof[k] for k in fp32)
+        step["fp32_mfma"] = {"gflop": round(f32_fl / 1e9, 3), "kernel_ms": round(f32_ms, 5),
+                             "achieved": round(f32_fl / (f32_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                             "frac": round(f32_fl / (f32_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    if bf16:
+        b_fl, b_ms = sum(fl[k] for k in bf16), sum(prof[k] for k in bf16)
+        step["bf16_mfma_exact_split"] = {"gflop_algorithmic": round(b_fl / 1e9, 3), "gflop_issued": round(3 * b_fl / 1e9, 3), "kernel_ms": round(b_ms, 5),
+                                         "achieved_issued": round(3 * b_fl / (b_ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                         "frac": round(3 * b_fl / (b_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+    roof["step"] = step
+    if "sample" in prof and "sample" in by:
+        roof["gather"] = {"bound": "hbm", "bytes": by["sample"], "ms": round(prof["sample"], 5),
+                          "achieved_GBs": round(by["sample"] / max(prof["sample"], 1e-9) / 1e6, 1), "peak_GBs": PEAK_HBM_GBS}
+    roof["event_bracket_overhead_ms"] = round(null_ms, 5)
+    roof["kernels"] = per
+    roof["kernels_ms"] = {k: round(v, 5) for k, v in prof.items()}
+    return roof
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(config, batch, loss, budget_s):
+    """the ATen op sequence of border-tch-agent on the host cores - 1 thread (what the async example forces,
+    dqn_atari_async_tch/src/main.rs:108), a thread sweep up to the physical core count, and the best count for >= 100 steps
+    or the time budget; plus the scalar C restatement (oracle/border_oracle.c) for context."""
+    from oracle import torch_ref
+    info = host_cpu_info()
+    phys = max(1, min(info["physical_cores"] or 1, info.get("usable_cpus") or 10 ** 6))
+    timer = {"c2": torch_ref.time_dqn_atari, "c1": torch_ref.time_dqn_cartpole, "c4": torch_ref.time_iqn_atari, "c5": torch_ref.time_sac}[config]
+    kw = dict(batch_size=batch)
+    if config == "c2":
+        kw.update(n_actions=N_ACTIONS, critic_loss=loss, capacity=65536)
+    t_budget0 = time.perf_counter()
+    one, _ = timer(steps=2, warmup=1, threads=1, **kw)
+    sweep = {1: round(one, 4)}
+    cand = sorted({t for t in (8, 16, 32, 64, phys // 2, phys) if 1 < t <= phys})
+    for t in cand:
+        if time.perf_counter() - t_budget0 > 0.5 * budget_s:
+            break
+        v, _ = timer(steps=3, warmup=1, threads=t, **kw)
+        sweep[t] = round(v, 4)
+    best_t = max(sweep, key=lambda t: sweep[t])
+    left = max(3.0, budget_s - (time.perf_counter() - t_budget0))
+    n = int(max(3, min(500, max(100 if sweep[best_t] * left >= 100 else 0, sweep[best_t] * left))))
+    v, thr = timer(steps=n, warmup=2, threads=best_t, **kw)
+    out = {"value": round(v, 3), "unit": "opt-steps/s", "cores": thr, "kind": "port",
+           "sample": f"{n} opt steps (batch {batch}" + (", f32 ring of 65536 transitions as the reference stores it" if config == "c2" else "")
+                     + ") of oracle/torch_ref.py: the libtorch-CPU (ATen) op sequence border-tch-agent binds through tch; best of the thread sweep",
+           "threads_1": sweep[1], "thread_sweep": sweep, "cpu_model": info["model"], "physical_cores": info["physical_cores"],
+           "logical_cpus": info["logical_cpus"], "sockets": info["sockets"]}
+    if config == "c2":
+        try:
+            out["c_restatement"] = torch_ref.time_c_oracle_dqn(batch, N_ACTIONS, loss)
+        except Exception as e:  # noqa: BLE001
+            out["c_restatement"] = {"error": repr(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--capacity", type=int, default=1_000_000)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c4", "c5"])
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--capacity", type=int, default=None)
     ap.add_argument("--loss", default="SmoothL1", choices=["SmoothL1", "Mse"])
     ap.add_argument("--double-dqn", action="store_true")
     ap.add_argument("--sync-interval", type=int, default=10, help="opt steps between RCCL parameter averaging (N>1)")
-    ap.add_argument("--per", action="store_true", help="prioritized replay (PerConfig defaults) instead of uniform sampling")
+    ap.add_argument("--per", action="store_true", help="prioritized replay (PerConfig defaults) instead of uniform sampling (c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--profile-steps", type=int, default=30)
     args = ap.parse_args()
+    defaults = {"c1": (5000, 200), "c2": (2000, 100), "c4": (60, 5), "c5": (2000, 100)}[args.config]
+    if args.steps is None:
+        args.steps = defaults[0]
+    if args.warmup is None:
+        args.warmup = defaults[1]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -71,7 +353,8 @@ def main():
         # (parameter all-reduce) is the library's own RCCL communicator over xGMI
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    if os.environ.get("BDR_BENCH_SHARE_GPU") == "1":   # flow test of the N>1 path on a 1-GPU box (ranks share device 0)
+    share = os.environ.get("BDR_BENCH_SHARE_GPU") == "1"   # flow test of the N>1 path on a 1-GPU box (ranks share device 0)
+    if share:
         local_rank = local_rank % max(B.device_count(), 1)
     if B.device_count() <= local_rank:
         sys.exit(f"rank {rank}: HIP device {local_rank} not visible")
@@ -83,20 +366,22 @@ def main():
         dist.broadcast(t, src=0)
         return bytes(t.tolist())
 
-    # replay shard: 1M transitions of synthetic 84x84x4 u8 frames per GPU, own StdRng stream
-    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=args.capacity, seed=B.shard_seed(42, rank),
-                                                          per_config=B.PerConfig() if args.per else None),
-                              (4, 1, 84, 84), "uint8", device=local_rank)
-    rb.fill_synthetic(args.capacity, seed=rank, kind=0, n_actions=N_ACTIONS)
-    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=N_ACTIONS),
-                                                    opt_config=B.OptimizerConfig.Adam(1e-4)),
-                      soft_update_interval=10000, n_updates_per_opt=1, batch_size=args.batch, discount_factor=0.99,
-                      tau=1.0, double_dqn=args.double_dqn, critic_loss=args.loss, device=local_rank, param_seed=0)
-    agent = B.Dqn.build(cfg)
+    conf = build_config(B, args.config, args, rank, local_rank)
+    agent, rb = conf["agent"], conf["rb"]
     agent.train()
-    # data plane: the library's own RCCL communicator; demoted (by all ranks together) to torch's RCCL on the same
-    # device arena, then to host staging, only if the communicator cannot be brought up on this node
-    exch = B.ParamExchange.with_fallback(world, rank, args.sync_interval, local_rank, bcast_bytes) if world > 1 else None
+    exch, rccl_ranks = None, 0
+    if world > 1:
+        # RCCL or nothing: a failure to bring the communicator up on ANY rank ends the run on every rank (MIN-reduce of
+        # a success flag over the control plane), with a non-zero exit status - never a silently slower data plane.
+        if share:   # explicit opt-in (tests of the control flow on a 1-GPU box): RCCL refuses duplicate devices
+            exch = B.ParamExchange(world, rank, args.sync_interval, "torch", local_rank, None, conf["which"])
+        else:
+            try:
+                exch = B.ParamExchange.rccl_or_raise(world, rank, args.sync_interval, local_rank, bcast_bytes, conf["which"])
+            except RuntimeError as e:
+                sys.stderr.write(f"bench.py: {e}; an N>1 run has no other data plane\n")
+                sys.exit(3)
+        rccl_ranks = 0 if share else world
 
     def run(n, first_step):
         for s in range(n):
@@ -123,78 +408,38 @@ def main():
     if rank == 0:
         ms = 1000.0 * dt / args.steps
         value = world * args.steps / dt
-        # roofline leg: per-kernel HIP-event timing on the agent's stream
-        # An empty event bracket measures TWO marker packets back to back; a bracket around a kernel contains the
-        # kernel plus ONE marker's processing time (the closing marker is stamped when the kernel retires).  So
-        # the per-kernel correction is half of the empty bracket; this reproduces rocprofv3's kernel durations
-        # to ~0.3 us (profiles/rocprof_r01_kernel_trace_v4.md).
         # the timed steps trained a real network: one more step with its Record, which must be finite
         rec = agent.opt_with_record(rb)
-        final_loss = float(rec["loss"])
+        final_loss = float(rec[conf["loss_key"]])
         if not (final_loss == final_loss and abs(final_loss) != float("inf")):
             sys.exit(f"bench.py: non-finite loss {final_loss} after the timed steps")
-
-        def profile(n):
-            agent.profile_enable(True)
-            for _ in range(n):
-                agent.opt(rb)
-            p = agent.profile_read()
-            agent.profile_enable(False)
-            half_null = 0.5 * p.pop("_null", 0.0)
-            return {k: max(v - half_null, 0.0) for k, v in p.items()}, half_null
-        prof, null_ms = profile(args.profile_steps)
-        if any(v <= 0.0 for v in prof.values()):   # an outlier empty bracket (its half is subtracted everywhere): measure again
-            prof, null_ms = profile(max(30, args.profile_steps))
-        nz = 3 if args.double_dqn else 2
-        fl = kernel_flops(args.batch, nz)
-        if not any(k in fl for k in prof):
+        # roofline leg: per-kernel HIP-event timing on the agent's stream.  An empty event bracket measures TWO marker
+        # packets back to back; a bracket around a kernel contains the kernel plus ONE marker's processing time, so half of
+        # the empty bracket is subtracted (reproduces rocprofv3's kernel durations to ~0.4 us, profiles/).
+        prof, cnt, null_ms = profile(agent, rb, args.profile_steps)
+        if any(v <= 0.0 for v in prof.values()):   # an outlier empty bracket: measure again
+            prof, cnt, null_ms = profile(agent, rb, max(30, args.profile_steps))
+        if not prof:
             sys.exit("bench.py needs --profile-steps >= 1 for the roofline leg")
-        dom = max((k for k in prof if k in fl), key=lambda k: prof[k])
-        achieved = fl[dom] / (max(prof[dom], 1e-6) * 1e-3) / 1e12
-        step_flops = sum(fl.values()) + 2 * nz * args.batch * 512 * N_ACTIONS
-        gather_bytes = 2 * args.batch * 28224 + args.batch * 14
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel_ms": round(prof[dom], 5),
-                "step": {"gflop": round(step_flops / 1e9, 3), "achieved": round(step_flops / (ms * 1e-3) / 1e12, 2),
-                         "frac": round(step_flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
-                "gather": {"bound": "hbm", "bytes": gather_bytes, "ms": round(prof.get("sample", 0.0), 5),
-                           "achieved_GBs": round(gather_bytes / max(prof.get("sample", 1e9), 1e-9) / 1e6, 1),
-                           "peak_GBs": PEAK_HBM_GBS},
-                "event_bracket_overhead_ms": round(null_ms, 5),
-                "kernels_ms": {k: round(v, 5) for k, v in prof.items()}}
-        tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tr):   # PMC-derived HBM bytes per launch, measured with rocprofv3 --pmc (profiles/)
-            try:
-                roof["traffic"] = json.load(open(tr)).get(dom)
-            except Exception:
-                pass
-        result = {"metric": "agent opt-steps/sec (DQN Atari 84x84x4, batch 256)", "value": round(value, 2),
+        roof = roofline(conf, prof, cnt, null_ms, ms)
+        par = f"dp{world} (replica + replay shard per GPU"
+        if world > 1:
+            par += f", parameter all-reduce every {args.sync_interval} opts over " + ("RCCL" if rccl_ranks else "host staging (BDR_BENCH_SHARE_GPU test mode)")
+        par += ")"
+        cfgd = {"workload": conf["workload"], "name": args.config, "batch_size": conf["batch"], "replay_capacity": conf["capacity"]}
+        cfgd.update(conf["cfg_extra"])
+        cfgd.update({"parallelism": par, "final_loss": round(final_loss, 6), "samples_per_sec": round(value * conf["batch"], 1)})
+        result = {"metric": conf["metric"], "value": round(value, 2),
                   "unit": "opt-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                  "dtype": "f32", "data": "synthetic",
-                  "config": {"workload": f"synthetic Atari DQN Nature-CNN, replay {args.capacity} u8 transitions/GPU, batch {args.batch}/GPU",
-                             "batch_size": args.batch, "replay_capacity": args.capacity, "n_actions": N_ACTIONS,
-                             "critic_loss": args.loss, "double_dqn": args.double_dqn, "prioritized_replay": bool(args.per),
-                             "optimizer": "Adam lr=1e-4",
-                             "soft_update_interval": 10000, "tau": 1.0,
-                             "parallelism": f"dp{world} (replica + replay shard per GPU"
-                                            + (f", parameter all-reduce every {args.sync_interval} opts over {exch.backend})" if world > 1 else ")"),
-                             "final_loss": round(final_loss, 6), "samples_per_sec": round(value * args.batch, 1)},
-                  "roofline": roof}
+                  "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks if world > 1 else 1,
+                  "config": cfgd, "roofline": roof}
     agent.close()
     rb.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline: the reference's ATen op sequence on the host cores (bounded sample)
-        from oracle import torch_ref
-        sps, threads = torch_ref.time_dqn_atari(args.batch, N_ACTIONS, steps=2, warmup=1, critic_loss=args.loss)
-        n = max(3, min(400, int(args.cpu_seconds * sps)))
-        sps, threads = torch_ref.time_dqn_atari(args.batch, N_ACTIONS, steps=n, warmup=1, critic_loss=args.loss)
-        result["cpu_baseline"] = {"value": round(sps, 3), "unit": "opt-steps/s", "cores": threads, "kind": "port",
-                                  "sample": f"{n} opt steps (batch {args.batch}, f32 ring of 4096 transitions) of "
-                                            "oracle/torch_ref.py: the libtorch-CPU op sequence of border-tch-agent",
-                                  "gpu_over_cpu": round(result["value"] / sps, 1)}
+        result["cpu_baseline"] = cpu_baseline(args.config, conf["batch"], args.loss, args.cpu_seconds)
+        result["cpu_baseline"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if exch is not None:

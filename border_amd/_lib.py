@@ -136,7 +136,7 @@ ABI_SYMBOLS = [
     "bdr_per_config_default", "bdr_replay_enable_per", "bdr_replay_update_priority", "bdr_replay_batch_weights",
     "bdr_replay_per_info", "bdr_replay_per_read", "bdr_replay_per_get", "bdr_dqn_update_on_batch_weighted",
     "bdr_dqn_config_default", "bdr_dqn_create", "bdr_agent_destroy", "bdr_agent_set_train", "bdr_agent_is_train",
-    "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_agent_opt_with_scalars", "bdr_agent_param_count_of", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
+    "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_agent_opt_with_scalars", "bdr_agent_record_keys", "bdr_agent_draw_noise", "bdr_agent_param_count_of", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
     "bdr_explorer_config_default", "bdr_agent_set_explorer", "bdr_agent_get_explorer", "bdr_agent_sample",
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
     "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_agent_set_checkpoint_format",
@@ -208,6 +208,8 @@ def lib() -> C.CDLL:
     L.bdr_agent_opt.argtypes = [vp, vp]
     L.bdr_agent_opt_with_record.argtypes = [vp, vp, C.POINTER(DqnRecordC)]
     L.bdr_agent_opt_with_scalars.argtypes = [vp, vp, vp, i32, C.POINTER(i32)]
+    L.bdr_agent_record_keys.argtypes = [vp, vp, u64, C.POINTER(i32)]
+    L.bdr_agent_draw_noise.argtypes = [vp, u64, vp]
     L.bdr_agent_param_count_of.argtypes = [vp, i32, C.POINTER(u64)]
     L.bdr_dqn_update_on_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, C.POINTER(DqnRecordC)]
     L.bdr_agent_qvalues.argtypes = [vp, u64, vp, vp, vp]

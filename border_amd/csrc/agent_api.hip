@@ -1,6 +1,9 @@
 // C-ABI entry points shared by every agent kind (include/border_amd.h): dispatch through the
 // polymorphic handle of agent_base.hpp.  Agent-specific constructors live next to their kernels.
+#include <cerrno>
 #include <cstdlib>
+#include <sys/stat.h>
+#include <sys/types.h>
 
 #include <algorithm>
 #include <cmath>
@@ -214,6 +217,60 @@ std::string ckpt_load_path(const bdr_agent* a, const char* dir, const std::strin
 }
 }  // namespace bdr
 
+// ---- device-side error words (agent_base.hpp) -------------------------------------------------------------------------
+int32_t bdr_agent::err_report(const unsigned* w)
+{
+    if (!(w[ERR_ACTION] | w[ERR_GATE] | w[ERR_NONFINITE])) return BDR_OK;
+    const unsigned act = w[ERR_ACTION], gate = w[ERR_GATE], nonf = w[ERR_NONFINITE];
+    (void)hipMemsetAsync(dev_err, 0, ERR_WORDS * sizeof(unsigned), stream);
+    (void)hipStreamSynchronize(stream);
+    memset(host_err, 0, ERR_WORDS * sizeof(unsigned));
+    if (gate) {
+        on_gate_timeout();
+        return fail(BDR_ERR_HIP, "cross-stream gate %u timed out (a producer kernel never started): the parameter updates enqueued "
+                                 "behind it were skipped; the agent continues with event ordering", gate - 1);
+    }
+    if (act) return fail(BDR_ERR_INVALID, "an action index outside [0, n_actions) reached the TD step (the reference's gather raises "
+                                          "an index error); it was clamped");
+    return fail(BDR_ERR_INVALID, "non-finite value flagged on the device (%u)", nonf);
+}
+
+int32_t bdr_agent::err_check()
+{
+    if (!dev_err) return BDR_OK;
+    unsigned w[ERR_WORDS];
+    BDR_HIP(hipMemcpy(w, dev_err, sizeof w, hipMemcpyDeviceToHost));
+    BDR_TRY(err_report(w));
+    if (last_replay && last_replay->per) BDR_TRY(per_check(last_replay->per));
+    return BDR_OK;
+}
+
+int32_t bdr_agent::err_poll()
+{
+    if (!dev_err) return BDR_OK;
+    unsigned w[ERR_WORDS];
+    for (int i = 0; i < ERR_WORDS; ++i) w[i] = reinterpret_cast<volatile unsigned*>(host_err)[i];
+    BDR_TRY(err_report(w));
+    if (++err_poll_count % ERR_POLL_INTERVAL == 0)
+        BDR_HIP(hipMemcpyAsync(host_err, dev_err, ERR_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    return BDR_OK;
+}
+
+// fs::create_dir_all (dqn/base.rs:346, iqn/base.rs:304, sac/base.rs:314)
+static int32_t create_dir_all(const char* dir)
+{
+    std::string p(dir);
+    if (p.empty()) return fail(BDR_ERR_IO, "empty checkpoint directory");
+    for (size_t i = 1; i <= p.size(); ++i) {
+        if (i != p.size() && p[i] != '/') continue;
+        const std::string sub = p.substr(0, i);
+        if (mkdir(sub.c_str(), 0777) != 0 && errno != EEXIST) return fail(BDR_ERR_IO, "cannot create directory %s: %s", sub.c_str(), strerror(errno));
+    }
+    struct stat st;
+    if (stat(p.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return fail(BDR_ERR_IO, "%s is not a directory", p.c_str());
+    return BDR_OK;
+}
+
 static bool is_dqn(const bdr_agent* a) { return a && (!strcmp(a->kind(), "dqn_cnn") || !strcmp(a->kind(), "dqn_mlp")); }
 
 extern "C" {
@@ -266,13 +323,16 @@ int32_t bdr_agent_sync(bdr_agent* a)
     BDR_REQUIRE(a, "null agent");
     BDR_HIP(hipSetDevice(a->device));
     BDR_HIP(hipStreamSynchronize(a->stream));
-    return a->after_sync();
+    BDR_TRY(a->after_sync());
+    return a->err_check();
 }
 
 int32_t bdr_agent_opt(bdr_agent* a, bdr_replay* r)
 {
     BDR_REQUIRE(a && r, "null argument");
     BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(a->err_poll());   // asynchronous: a device-side failure of an earlier step surfaces here without a synchronisation
+    a->last_replay = r;
     BDR_TRY(a->opt(r));
     prof_collect(a);
     return BDR_OK;
@@ -283,10 +343,15 @@ int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* r, bdr_dqn_record* r
     BDR_REQUIRE(a && r && rec, "null argument");
     BDR_REQUIRE(is_dqn(a), "bdr_agent_opt_with_record(bdr_dqn_record) needs a DQN agent; use bdr_agent_opt_with_scalars");
     BDR_HIP(hipSetDevice(a->device));
+    a->last_replay = r;
     BDR_TRY(a->opt(r));
     prof_collect(a);
-    float v[8]; int n = 0;
-    BDR_TRY(a->record(v, 8, &n));
+    float v[128]; int n = 0;
+    a->rec_opt = true;
+    const int32_t st = a->record(v, 128, &n);
+    a->rec_opt = false;
+    BDR_TRY(st);
+    BDR_TRY(a->err_check());
     rec->loss = v[0]; rec->has_verbose = n >= 5;
     if (n >= 5) { rec->pred_mean = v[1]; rec->reward_mean = v[2]; rec->tgt_mean = v[3]; rec->tgt_minus_pred_mean = v[4]; }
     return BDR_OK;
@@ -296,12 +361,50 @@ int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* r, float* out, int3
 {
     BDR_REQUIRE(a && r && out && n_out, "null argument");
     BDR_HIP(hipSetDevice(a->device));
+    a->last_replay = r;
     BDR_TRY(a->opt(r));
     prof_collect(a);
     int n = 0;
-    BDR_TRY(a->record(out, cap, &n));
+    a->rec_opt = true;
+    const int32_t st = a->record(out, cap, &n);
+    a->rec_opt = false;
+    BDR_TRY(st);
+    BDR_TRY(a->err_check());
     *n_out = n;
     return BDR_OK;
+}
+
+// names of the scalars bdr_agent_opt_with_scalars returns, '\n'-separated, in order
+int32_t bdr_agent_record_keys(bdr_agent* a, char* names_out, uint64_t names_cap, int32_t* n_keys)
+{
+    BDR_REQUIRE(a && names_out && names_cap > 0, "null argument");
+    std::vector<std::string> keys;
+    a->record_keys(keys);
+    std::string all;
+    for (const auto& k : keys) { all += k; all += '\n'; }
+    BDR_REQUIRE(all.size() < names_cap, "names_cap too small (%llu needed)", (unsigned long long)all.size() + 1);
+    memcpy(names_out, all.c_str(), all.size() + 1);
+    if (n_keys) *n_keys = (int32_t)keys.size();
+    return BDR_OK;
+}
+
+// test helper: n draws of the agent's device noise stream, copied to the host (advances the stream like an update does)
+int32_t bdr_agent_draw_noise(bdr_agent* a, uint64_t n, float* out)
+{
+    BDR_REQUIRE(a && out && n >= 1 && n <= (1ull << 28), "bad argument");
+    BDR_HIP(hipSetDevice(a->device));
+    float* d = nullptr;
+    BDR_HIP(hipMalloc((void**)&d, n * 4));
+    int32_t st = a->noise(d, n);
+    if (st == BDR_OK) {
+        hipError_t e = hipMemcpyAsync(out, d, n * 4, hipMemcpyDeviceToHost, a->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+        if (e != hipSuccess) st = fail(BDR_ERR_HIP, "noise copy failed: %s", hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(a->stream);
+    }
+    (void)hipFree(d);
+    return st;
 }
 
 int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
@@ -325,9 +428,10 @@ int32_t bdr_dqn_update_on_batch_weighted(bdr_agent* a, uint64_t n, const void* o
         BDR_HIP(hipStreamSynchronize(a->stream));
     }
     prof_collect(a);
+    BDR_TRY(a->err_check());   // (update_on_batch synchronises)
     if (rec) {
-        float v[8]; int k = 0;
-        BDR_TRY(a->record(v, 8, &k));
+        float v[128]; int k = 0;
+        BDR_TRY(a->record(v, 128, &k));
         rec->loss = v[0]; rec->has_verbose = k >= 5;
         if (k >= 5) { rec->pred_mean = v[1]; rec->reward_mean = v[2]; rec->tgt_mean = v[3]; rec->tgt_minus_pred_mean = v[4]; }
     }
@@ -405,6 +509,7 @@ int32_t bdr_agent_sample(bdr_agent* a, uint64_t n, const void* obs, int64_t* act
     std::vector<float> q;
     int A = 0;
     BDR_TRY(action_values(a, n, obs, q, &A));
+    BDR_TRY(a->err_check());
     Explorer& x = a->explorer;
     double eps = 0.0;
     bool is_random = false;
@@ -480,7 +585,8 @@ int32_t bdr_agent_get_params(bdr_agent* a, int32_t which, float* out, uint64_t n
 {
     BDR_REQUIRE(a && out, "null argument");
     BDR_HIP(hipSetDevice(a->device));
-    return a->get_params(which, out, n);
+    BDR_TRY(a->get_params(which, out, n));
+    return a->err_check();
 }
 
 int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* inp, uint64_t n)
@@ -540,6 +646,9 @@ int32_t bdr_agent_save_params(bdr_agent* a, const char* dir)
 {
     BDR_REQUIRE(a && dir, "null argument");
     BDR_HIP(hipSetDevice(a->device));
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    BDR_TRY(a->err_check());               // never write a checkpoint over a flagged state
+    BDR_TRY(create_dir_all(dir));          // fs::create_dir_all(&path) (dqn/base.rs:346)
     return a->save(dir);
 }
 

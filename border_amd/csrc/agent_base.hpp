@@ -70,8 +70,42 @@ struct bdr_agent {
     bool prof = false;
     std::vector<ProfSlot> slots;
     size_t slot_cursor = 0;
+    // Device-side error words (kernels never abort; they flag and keep memory safe):
+    //   [ERR_ACTION]  an action index outside [0, n_actions) reached a TD kernel (the reference's gather would raise);
+    //                 the kernels clamp it so that no out-of-bounds access happens
+    //   [ERR_GATE]    1 + flag id of a cross-queue gate that timed out (DqnCnn schedule 3): parameter updates are skipped
+    //                 from then on until the host has seen the error
+    //   [ERR_NONFINITE] reserved
+    // Checked after every host synchronisation (err_check) and, without synchronising, every ERR_POLL_INTERVAL opts through
+    // an asynchronous copy into pinned memory (err_poll) - so loops that never synchronise (Agent::opt only) still fail
+    // within a few hundred steps instead of training on garbage.
+    enum { ERR_ACTION = 0, ERR_GATE = 1, ERR_NONFINITE = 2, ERR_WORDS = 4, ERR_POLL_INTERVAL = 256 };
+    unsigned* dev_err = nullptr;        // [ERR_WORDS] device
+    unsigned* host_err = nullptr;       // [ERR_WORDS] pinned mirror (last asynchronous read-back)
+    uint64_t err_poll_count = 0;
+    bool rec_opt = false;               // record() is being called by Agent::opt_with_record (dqn/base.rs:316-342)
+    bdr_replay* last_replay = nullptr;  // buffer of the last opt (its PER error flag is checked with the agent's)
 
-    virtual ~bdr_agent() { if (act_stage) (void)hipFree(act_stage); (void)hipFree(td_abs); (void)hipFree(w_stage); }
+    virtual ~bdr_agent()
+    {
+        if (act_stage) (void)hipFree(act_stage);
+        (void)hipFree(td_abs); (void)hipFree(w_stage);
+        (void)hipFree(dev_err);
+        if (host_err) (void)hipHostFree(host_err);
+    }
+    int32_t err_init()
+    {
+        BDR_HIP(hipMalloc((void**)&dev_err, ERR_WORDS * sizeof(unsigned)));
+        BDR_HIP(hipMemset(dev_err, 0, ERR_WORDS * sizeof(unsigned)));
+        BDR_HIP(hipHostMalloc((void**)&host_err, ERR_WORDS * sizeof(unsigned), hipHostMallocDefault));
+        memset(host_err, 0, ERR_WORDS * sizeof(unsigned));
+        return BDR_OK;
+    }
+    // turns the error words `w` into a status; clears them on the device when something was set
+    int32_t err_report(const unsigned* w);
+    int32_t err_check();   // the stream has just been synchronised: read, report, clear
+    int32_t err_poll();    // no synchronisation: look at the last asynchronous read-back, enqueue the next one when due
+    virtual void on_gate_timeout() {}   // DqnCnn: fall back to event ordering
     int32_t act_buffer(size_t bytes, void** out)
     {
         if (bytes > act_stage_bytes) {
@@ -87,6 +121,9 @@ struct bdr_agent {
     virtual int32_t opt(bdr_replay* r) = 0;                       // Agent::opt, asynchronous
     virtual int32_t after_sync() { return BDR_OK; }               // device-side error flags, checked by bdr_agent_sync
     virtual int32_t record(float* out, int cap, int* n) = 0;      // scalars of the last update (syncs)
+    virtual void record_keys(std::vector<std::string>& keys) = 0; // names of those scalars, in order
+    // n draws of the agent's own device noise stream (SAC: N(0,1) of action_logp; IQN: U[0,1) percent points), advancing it
+    virtual int32_t noise(float*, size_t) { return ::bdr::fail(BDR_ERR_INVALID, "this agent draws no device noise"); }
     virtual uint64_t param_count(int which) = 0;                  // reference-layout element count
     virtual int32_t get_params(int which, float* out, uint64_t n) = 0;
     virtual int32_t set_params(int which, const float* in, uint64_t n) = 0;
@@ -172,6 +209,28 @@ inline int32_t alloc_f(float** p, size_t n)
 
 // named f32 tensor container used by every agent's save/load (reference variable names)
 struct NamedTensor { std::string name; std::vector<uint64_t> dims; };
+// util.rs:64-80 param_stats: `<var>_mean` = v.mean(), `<var>_std` = v.std(false) (population) of every variable, appended to
+// `out` in the variables' reference order (data: the reference-layout parameter vector described by meta)
+inline void param_stats(const std::vector<NamedTensor>& meta, const float* data, std::vector<float>& out)
+{
+    size_t o = 0;
+    for (const auto& m : meta) {
+        size_t n = 1;
+        for (auto d : m.dims) n *= d;
+        double s = 0.0;
+        for (size_t i = 0; i < n; ++i) s += data[o + i];
+        const double mean = n ? s / (double)n : 0.0;
+        double q = 0.0;
+        for (size_t i = 0; i < n; ++i) { const double d = data[o + i] - mean; q += d * d; }
+        out.push_back((float)mean);
+        out.push_back((float)std::sqrt(n ? q / (double)n : 0.0));
+        o += n;
+    }
+}
+inline void param_stat_keys(const std::vector<NamedTensor>& meta, std::vector<std::string>& keys)
+{
+    for (const auto& m : meta) { keys.push_back(m.name + "_mean"); keys.push_back(m.name + "_std"); }
+}
 int32_t save_named(const std::string& path, const std::vector<NamedTensor>& meta, const float* data, size_t n);
 int32_t load_named(const std::string& path, const std::vector<NamedTensor>& meta, float* data, size_t n);
 // "<dir>/<stem>.pt.tch" (the reference's names) or "<dir>/<stem>.safetensors" by bdr_agent_set_checkpoint_format; the load
@@ -203,10 +262,11 @@ using namespace bdr;
 struct AdamScalars { float b1, omb1, b2, omb2, sqrt_bc2, eps, neg_step, wd_mul; };
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, size_t n4, AdamScalars s)
+                                              float* __restrict__ v, size_t n4, AdamScalars s, const unsigned* poison = nullptr)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    if (poison && *poison) return;   // a cross-queue gate timed out: the gradients may be incomplete, keep the parameters
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
@@ -259,7 +319,7 @@ inline AdamScalars adam_scalars_for(bool adamw, double lr, double beta1, double 
 inline int32_t launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n_floats, const AdamScalars& s)
 {
     const size_t n4 = n_floats / 4;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p, g, m, v, n4, s);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p, g, m, v, n4, s, (const unsigned*)nullptr);
     BDR_HIP(hipGetLastError());
     return BDR_OK;
 }

@@ -116,6 +116,7 @@ const float* per_weights(const bdr_per* p);
 int32_t per_read(const bdr_per* p, int32_t what, float* out, uint64_t n, hipStream_t st);
 int32_t per_get(const bdr_per* p, float s, uint64_t* ix, hipStream_t st);
 void per_info(const bdr_per* p, bdr_per_info* o);
+int32_t per_check(bdr_per* p);   // non-finite priorities flagged by the update kernels (the reference panics); call after a sync
 // weights of the batch last drawn on the consumer's stream (nullptr without PER), and the priority update
 // an agent enqueues after its backward pass (device arrays, the agent's stream)
 inline const float* replay_batch_weights(const bdr_replay* r) { return r->per ? per_weights(r->per) : nullptr; }

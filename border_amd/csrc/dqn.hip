@@ -13,6 +13,7 @@
 //   adam  : fused p,g,m,v pass over the flat parameter arena (libtorch Adam::step formula)
 //   track : tau*src + (1-tau)*dst every soft_update_interval opts (util.rs:31-45)
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <string>
 
@@ -81,6 +82,7 @@ struct TdArgs {
     const float* weight;   // [B] importance weights (PER) or nullptr
     float* td_abs;         // [B] |pred - tgt| (clipped) for update_priority, or nullptr
     int has_clip; float clip_min, clip_max;
+    unsigned* err;         // bdr_agent::dev_err (ERR_ACTION is raised for an action outside [0, A))
 };
 
 // One workgroup = HEAD_ROWS batch rows x nz network instances, one wave per (row, instance):
@@ -125,6 +127,10 @@ __global__ __launch_bounds__(64 * HEAD_ROWS * MAXZ) void k_head(HeadArgs a, TdAr
     long long act = 0; float reward = 0.f, wgt = 1.f; int term = 0;
     if (td && z == 0) {
         act = *reinterpret_cast<const long long*>(t.act + (size_t)rw * t.act_bytes);
+        if (act < 0 || act >= A) {   // the reference's gather raises; here: flag for the host, clamp to stay in bounds
+            if (lane == 0 && t.err) atomicOr(t.err + bdr_agent::ERR_ACTION, 1u);
+            act = act < 0 ? 0 : A - 1;
+        }
         reward = t.reward[rw]; term = (int)t.term[rw];
         if (t.weight) wgt = t.weight[rw];
     }
@@ -292,6 +298,8 @@ struct DqnCnn : bdr_agent {
     bool side_gather = true;   // BDR_NO_SIDE_GATHER=1: opt() gathers on the dX queue
     unsigned long long* gate_trace = nullptr;   // BDR_GATE_TRACE=1: [5][2] (100 MHz ticks waited, count), printed at destruction
     int sched = 3;   // backward schedule, see update_critic (BDR_SCHED=0|1|2; BDR_NO_OVERLAP=1 == 0)
+    unsigned long long gate_limit = 1000000000ull;   // gate time limit in 100 MHz ticks (10 s; BDR_GATE_LIMIT_MS for tests)
+    bool holds_gate_token = false;                   // see claim_gates()
     Arena ar;
     int B = 0;          // activation buffers are sized for this batch
     // parameter arenas
@@ -313,15 +321,9 @@ struct DqnCnn : bdr_agent {
     ~DqnCnn() override;
     const char* kind() const override { return "dqn_cnn"; }
     int32_t opt(bdr_replay* r) override;
-    int32_t after_sync() override
-    {
-        if (!sig || sig_epoch == 0) return BDR_OK;
-        unsigned err = 0;
-        BDR_HIP(hipMemcpy(&err, sig + 7, sizeof err, hipMemcpyDeviceToHost));   // SIG_ERR
-        if (err) return fail(BDR_ERR_HIP, "cross-stream gate %u timed out: a producer kernel never started", err - 1);
-        return BDR_OK;
-    }
+    void on_gate_timeout() override;
     int32_t record(float* out, int cap, int* n) override;
+    void record_keys(std::vector<std::string>& keys) override;
     uint64_t param_count(int which) override;
     int32_t get_params(int which, float* out, uint64_t n) override;
     int32_t set_params(int which, const float* in, uint64_t n) override;
@@ -385,6 +387,7 @@ struct ReduceAdamArgs {
     size_t rest0_4, n4;      // Adam's f32x4 range [rest0_4, n4) = everything behind the conv segments
     AdamScalars s;
     int reduce_blocks;
+    const unsigned* poison;  // sig + SIG_ERR: a gate timed out, leave the parameters alone
 };
 __device__ __forceinline__ void adam_element(float& p, float g, float& m, float& v, const AdamScalars& s)
 {
@@ -399,17 +402,26 @@ __device__ __forceinline__ void adam_element(float& p, float g, float& m, float&
 // it cannot starve the producer; a producer that never arrives trips the time limit instead of hanging the queue
 // (sig[SIG_ERR] is checked at the next synchronisation).
 constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_GATHER = 4, SIG_TEST = 5, SIG_TEST_ERR = 6, SIG_ERR = 7;
+// A gate that times out POISONS the agent: sig[SIG_ERR] (and dev_err[ERR_GATE], the word the host polls) is set, every later
+// gate returns at once instead of waiting another 10 s, and the kernels that write parameters (k_reduce_adam, the l1 / l2
+// k_adam) skip their update while the flag is up - kernels behind a failed gate run unordered, so their gradients may be
+// incomplete, but the parameters, Adam moments and checkpoints stay those of the last good step.  The host sees the flag at
+// its next synchronisation or poll (bdr_agent::err_check / err_poll), reports BDR_ERR_HIP, clears it and continues with
+// event ordering (schedule 1).
 __global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned epoch, unsigned long long* waited, int publish,
-                                             unsigned long long limit = 1000000000ull /* 10 s of the 100 MHz clock */, int err_slot = SIG_ERR)
+                                             unsigned long long limit = 1000000000ull /* 10 s of the 100 MHz clock */, int err_slot = SIG_ERR,
+                                             unsigned* dev_err = nullptr)
 {
     if (threadIdx.x != 0) return;
     // like start_signal: this kernel has started, so everything queued before it on its stream is complete
     if (publish >= 0) __hip_atomic_store(sig + publish, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err_slot == SIG_ERR && __hip_atomic_load(sig + SIG_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // poisoned
     const unsigned long long t0 = wall_clock64();   // 100 MHz
     while ((int)(__hip_atomic_load(sig + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > limit) {
+        if (wall_clock64() - t0 > limit || (err_slot == SIG_ERR && __hip_atomic_load(sig + SIG_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             __hip_atomic_store(sig + err_slot, 1u + (unsigned)which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dev_err) __hip_atomic_store(dev_err + bdr_agent::ERR_GATE, 1u + (unsigned)which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
     }
@@ -430,7 +442,9 @@ __global__ __launch_bounds__(64) void k_signal(unsigned* sig, int which, unsigne
 
 __global__ __launch_bounds__(256) void k_reduce_adam(ReduceAdamArgs a)
 {
+    const bool poisoned = a.poison && *a.poison != 0;
     if ((int)blockIdx.x >= a.reduce_blocks) {
+        if (poisoned) return;
         const size_t i = a.rest0_4 + (size_t)(blockIdx.x - a.reduce_blocks) * 256 + threadIdx.x;
         if (i >= a.n4) return;
         f32x4 pp = reinterpret_cast<f32x4*>(a.p)[i], gg = reinterpret_cast<const f32x4*>(a.g)[i];
@@ -469,12 +483,15 @@ __global__ __launch_bounds__(256) void k_reduce_adam(ReduceAdamArgs a)
         for (int k = 1; k < 8; ++k) t += red[k][o];
         const float g = i < sg.n_weights ? t * sg.wscale : t;
         sg.g[i] = g;
+        if (poisoned) return;
         const size_t e = (size_t)(sg.g - a.gbase) + i;      // the element's index in every arena
         float pe = a.p[e], me = a.m[e], ve = a.v[e];
         adam_element(pe, g, me, ve, a.s);
         a.p[e] = pe; a.m[e] = me; a.v[e] = ve;
     }
 }
+
+int effective_sched(DqnCnn* a);   // (defined with update_critic)
 
 // ---- the forward pass of nz network instances ------------------------------------------------------
 struct NetInst { const uint8_t* x; const float* params; int slot; };
@@ -520,7 +537,7 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         const dim3 grid((B + HEAD_ROWS - 1) / HEAD_ROWS), block(64 * HEAD_ROWS * nz);
         const TdArgs tv = td ? *td : TdArgs{};
         // with the two-stream backward schedule the head kernel's own packet completes the first fork event
-        hipEvent_t stop = td && !a->prof && a->sched == 1 && a->kev ? a->ev_fork[0] : nullptr;
+        hipEvent_t stop = td && effective_sched(a) == 1 && a->kev ? a->ev_fork[0] : nullptr;
         const int tdi = td ? 1 : 0;
         if (ar.A <= 8) hipExtLaunchKernelGGL((k_head<L1_SPLIT, 8>), grid, block, 0, a->stream, nullptr, stop, 0, h, tv, nz, tdi);
         else if (ar.A <= 24) hipExtLaunchKernelGGL((k_head<L1_SPLIT, 24>), grid, block, 0, a->stream, nullptr, stop, 0, h, tv, nz, tdi);
@@ -541,7 +558,7 @@ int32_t launch_gate(DqnCnn* a, hipStream_t st, int which, unsigned epoch, int pu
 {
     // trace slot: 2 counters per site; sites 0..3 = flags on the weight-gradient queue, 4 = the gates on the dX queue
     unsigned long long* tr = a->gate_trace ? a->gate_trace + 2 * (st == a->stream ? 4 : which) : nullptr;
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch, tr, publish, 1000000000ull, SIG_ERR);
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch, tr, publish, a->gate_limit, SIG_ERR, a->dev_err);
     BDR_HIP(hipGetLastError());
     return BDR_OK;
 }
@@ -554,7 +571,8 @@ int32_t queues_independent(DqnCnn* a, hipStream_t waiter, hipStream_t producer, 
 {
     a->test_epoch += 1;
     BDR_HIP(hipMemsetAsync(a->sig + SIG_TEST_ERR, 0, sizeof(unsigned), waiter));
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, waiter, a->sig, SIG_TEST, a->test_epoch, (unsigned long long*)nullptr, -1, 10000000ull, SIG_TEST_ERR);
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, waiter, a->sig, SIG_TEST, a->test_epoch, (unsigned long long*)nullptr, -1, 10000000ull, SIG_TEST_ERR,
+                       (unsigned*)nullptr);
     BDR_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, producer, a->sig, SIG_TEST, a->test_epoch);
     BDR_HIP(hipGetLastError());
@@ -564,6 +582,25 @@ int32_t queues_independent(DqnCnn* a, hipStream_t waiter, hipStream_t producer, 
     BDR_HIP(hipMemcpy(&err, a->sig + SIG_TEST_ERR, sizeof err, hipMemcpyDeviceToHost));
     *ok = err == 0;
     return BDR_OK;
+}
+
+// Gates are safe only while ONE agent of the process uses them: streams of different agents can alias the same hardware queue
+// (GPU_MAX_HW_QUEUES), and two agents whose gates sit in front of each other's producers could wait in a cycle.  The first
+// agent that runs a gated update owns the process-wide token until it is destroyed; every other agent orders its two queues
+// with events (schedule 1) for as long as the token is taken.
+std::atomic<DqnCnn*> g_gate_owner{nullptr};
+bool claim_gates(DqnCnn* a)
+{
+    if (a->holds_gate_token) return true;
+    DqnCnn* expected = nullptr;
+    if (g_gate_owner.compare_exchange_strong(expected, a)) { a->holds_gate_token = true; return true; }
+    return false;
+}
+int effective_sched(DqnCnn* a)
+{
+    if (a->prof) return 0;
+    if (a->sched == 3 && !claim_gates(a)) return 1;
+    return a->sched;
 }
 
 int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
@@ -584,6 +621,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     t.loss_row = a->loss_row; t.B = B; t.A = ar.A; t.gamma = (float)c.discount_factor; t.loss_kind = c.critic_loss;
     t.weight = weight; t.td_abs = a->td_abs;
     t.has_clip = c.has_clip_td_err; t.clip_min = (float)c.clip_td_err_min; t.clip_max = (float)c.clip_td_err_max;
+    t.err = a->dev_err;
     BDR_TRY(forward(a, inst, c.double_dqn ? 3 : 2, B, &t));   // the TD step rides on the head kernel
 
     // Backward.  The input-gradient chain (dX of l1 -> conv3 -> conv2) is the critical path; every weight-gradient kernel
@@ -597,7 +635,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     //   3  two streams ordered through device flags instead of events: the next dX kernel's first workgroup publishes
     //      "my predecessor is complete" (start_signal), one-wave k_gate kernels on the consuming queue wait for it.  No
     //      packet is added to the dX queue except the join gate before the reduction.
-    const int sched = a->prof ? 0 : a->sched;
+    const int sched = effective_sched(a);
     const bool ov = sched == 1;
     const bool gated = sched == 3;
     hipStream_t sd = ov || gated ? a->side : a->stream;
@@ -643,7 +681,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         Bracket br(a, "adam_l1_l2");
         const size_t r4 = (ar.total - ar.w4) / 4;
         LAUNCH_FL(sd, any, nullptr, k_adam, dim3((unsigned)((r4 + 255) / 256)), dim3(256), a->q + ar.w4, (const float*)(a->grad + ar.w4), a->m + ar.w4,
-                  a->v + ar.w4, r4, adam_s);
+                  a->v + ar.w4, r4, adam_s, (const unsigned*)(a->sig + SIG_ERR));
         return BDR_OK;
     };
     auto c3_dw = [&]() -> int32_t {
@@ -755,7 +793,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         // the conv layers' Adam step rides on their partial reduction (k_reduce_adam); l1 / l2: adam_l1_l2 above
         ReduceAdamArgs ra{};
         ra.r = r; ra.p = a->q; ra.g = a->grad; ra.m = a->m; ra.v = a->v; ra.gbase = a->grad;
-        ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg;
+        ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg; ra.poison = a->sig + SIG_ERR;
         Bracket br(a, "reduce_adam");
         hipLaunchKernelGGL(k_reduce_adam, dim3(wg), dim3(256), 0, a->stream, ra);
         BDR_HIP(hipGetLastError());
@@ -796,7 +834,7 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
     BDR_TRY(ensure_batch(a, (int)a->cfg.batch_size));
     BDR_TRY(a->td_buffer(a->cfg.batch_size));
     for (uint64_t u = 0; u < a->cfg.n_updates_per_opt; ++u) {
-        if (!a->prof && a->sched == 3 && a->side_gather) {
+        if (effective_sched(a) == 3 && a->side_gather) {
             // The gather does not depend on the previous update, and the weight-gradient queue is idle from the end of one
             // update to the next head kernel: the batch is gathered there, into the buffer set the previous update is not
             // using (its conv1 dW may still be reading the other one), while the dX queue finishes the previous update.
@@ -911,9 +949,26 @@ void init_reference_params(int A, uint64_t seed, std::vector<float>& ref)
 
 
 // ---- virtual interface -----------------------------------------------------------------------------
+void DqnCnn::on_gate_timeout()
+{
+    // the flag is cleared by err_report; what was enqueued behind the failed gate has drained (this runs after a
+    // synchronisation or with the error already visible on the host), so both queues restart from a clean epoch
+    (void)hipStreamSynchronize(stream);
+    if (side) (void)hipStreamSynchronize(side);
+    if (aux) (void)hipStreamSynchronize(aux);
+    if (sig) (void)hipMemset(sig, 0, 16 * sizeof(unsigned));
+    sig_epoch = 0; head_gate_enqueued = false;
+    if (sched == 3) {
+        fprintf(stderr, "border_amd: a cross-queue gate timed out; this agent continues with event ordering (schedule 1)\n");
+        sched = 1;
+    }
+    if (holds_gate_token) { DqnCnn* me = this; g_gate_owner.compare_exchange_strong(me, nullptr); holds_gate_token = false; }
+}
+
 DqnCnn::~DqnCnn()
 {
     (void)hipSetDevice(device);
+    if (holds_gate_token) { DqnCnn* me = this; g_gate_owner.compare_exchange_strong(me, nullptr); holds_gate_token = false; }
     (void)hipStreamSynchronize(stream);
     if (side) (void)hipStreamSynchronize(side);
     free_batch_buffers(this);
@@ -938,15 +993,40 @@ DqnCnn::~DqnCnn()
 
 int32_t DqnCnn::opt(bdr_replay* r) { return opt_inner(this, r); }
 
+static std::vector<NamedTensor> cnn_meta(int A);
+
+// Agent::opt_with_record (dqn/base.rs:316-342): "loss"; with record_verbose_level >= 2 also pred_mean, reward_mean, tgt_mean,
+// tgt_minus_pred_mean (update_critic :107-121), then - only from opt_with_record - qnet.param_stats() (`<var>_mean`,
+// `<var>_std` of c1.weight ... l2.bias, util.rs:64-80) and ratio_best_act = n_samples_best_act / n_samples_act with both
+// counters reset (:331-339).
 int32_t DqnCnn::record(float* out, int cap, int* n)
 {
     bdr_dqn_record rec{};
     BDR_TRY(fill_record(this, last_B, last_reward, &rec));
-    const float v[5] = {rec.loss, rec.pred_mean, rec.reward_mean, rec.tgt_mean, rec.tgt_minus_pred_mean};
-    const int k = rec.has_verbose ? 5 : 1;
-    for (int i = 0; i < k && i < cap; ++i) out[i] = v[i];
-    *n = k;
+    std::vector<float> v = {rec.loss};
+    if (rec.has_verbose) {
+        v.insert(v.end(), {rec.pred_mean, rec.reward_mean, rec.tgt_mean, rec.tgt_minus_pred_mean});
+        if (rec_opt) {
+            std::vector<float> ref(ref_param_count(ar.A));
+            BDR_TRY(get_params(0, ref.data(), ref.size()));
+            param_stats(cnn_meta(ar.A), ref.data(), v);
+            v.push_back(n_samples_act == 0 ? 0.f : (float)n_samples_best_act / (float)n_samples_act);
+            n_samples_act = 0; n_samples_best_act = 0;
+        }
+    }
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    *n = (int)std::min(v.size(), (size_t)cap);
     return BDR_OK;
+}
+
+void DqnCnn::record_keys(std::vector<std::string>& keys)
+{
+    keys = {"loss"};
+    if (cfg.record_verbose_level >= 2) {
+        keys.insert(keys.end(), {"pred_mean", "reward_mean", "tgt_mean", "tgt_minus_pred_mean"});
+        param_stat_keys(cnn_meta(ar.A), keys);
+        keys.push_back("ratio_best_act");
+    }
 }
 
 uint64_t DqnCnn::param_count(int which) { return which == -1 ? (uint64_t)ar.A : ref_param_count(ar.A); }
@@ -1028,6 +1108,8 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
         BDR_HIP(hipMemsetAsync(a->gate_trace, 0, 32 * sizeof(unsigned long long), a->stream));
     }
     if (getenv("BDR_NO_OVERLAP")) a->sched = 0;
+    if (const char* e = getenv("BDR_GATE_LIMIT_MS")) a->gate_limit = (unsigned long long)std::max(1, atoi(e)) * 100000ull;
+    BDR_TRY(a->err_init());
     a->kev = getenv("BDR_NO_KEV") == nullptr;
     a->side_gather = getenv("BDR_NO_SIDE_GATHER") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
@@ -1044,7 +1126,8 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_HIP(hipStreamSynchronize(a->stream));
     BDR_TRY(ensure_batch(a, (int)cfg->batch_size));
     BDR_HIP(hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking));   // prioritized-replay tree updates
-    if (a->sched == 3) {   // both directions are used: the side queue waits for the dX queue, the join waits the other way
+    if (a->sched == 3 && !getenv("BDR_SKIP_QUEUE_CHECK")) {   // both directions are used: the side queue waits for the dX queue, the join waits the other way
+        // (BDR_SKIP_QUEUE_CHECK: tests only - lets a gate deadlock for real so that the timeout path can be exercised)
         bool ok1 = false, ok2 = false;
         BDR_TRY(queues_independent(a, a->side, a->stream, &ok1));
         BDR_TRY(queues_independent(a, a->stream, a->side, &ok2));

@@ -53,12 +53,17 @@ __global__ __launch_bounds__(64) void k_iqn_target(IqnTargetArgs p)
 struct IqnLossArgs {
     const float* z; int ldz; const uint8_t* act; int act_bytes; const float* tau_p; const float* tgt;
     float* dz; float* loss_row; int B, Np, Nt; float inv;
+    int A; unsigned* err;   // bdr_agent::dev_err (ERR_ACTION)
 };
 __global__ __launch_bounds__(256) void k_iqn_loss(IqnLossArgs p)
 {
     __shared__ float red[256];
     const int b = blockIdx.x, t = threadIdx.x;
-    const long long act = *reinterpret_cast<const long long*>(p.act + (size_t)b * p.act_bytes);
+    long long act = *reinterpret_cast<const long long*>(p.act + (size_t)b * p.act_bytes);
+    if (act < 0 || act >= p.A) {   // the reference's gather raises; here: flag for the host, clamp to stay in bounds
+        if (t == 0 && p.err) atomicOr(p.err + bdr_agent::ERR_ACTION, 1u);
+        act = act < 0 ? 0 : p.A - 1;
+    }
     float ls = 0.f;
     for (int n = t; n < p.Np; n += 256) {
         const size_t row = (size_t)b * p.Np + n;
@@ -258,7 +263,7 @@ struct Iqn : bdr_agent {
         { Bracket br(a, "iqn_phi_merge"); BDR_TRY(dense_forward(a, stream, hd.L[0], params, DenseSrc{cosv, Ep}, phi, M, feat, ldf, N, mrg)); }
         DenseSrc in{mrg, hd.L[0].Np};
         for (size_t i = 1; i < hd.L.size(); ++i) {
-            Bracket br(a, "iqn_f_fwd");
+            Bracket br(a, ("iqn_f_fwd" + std::to_string(i)).c_str());
             BDR_TRY(dense_forward(a, stream, hd.L[i], params, in, f_act[i - 1], M));
             in = DenseSrc{f_act[i - 1], hd.L[i].Np};
         }
@@ -283,7 +288,7 @@ struct Iqn : bdr_agent {
         BDR_TRY(model_forward(p, obs, tp, Bn, Np));
         const int M = Bn * Np;
         {
-            IqnLossArgs l{f_act.back(), ldz, act, act_bytes, tp, tgt, f_dy.back(), loss_row, Bn, Np, Nt, 1.0f / ((float)Bn * (float)Nt * (float)Np)};
+            IqnLossArgs l{f_act.back(), ldz, act, act_bytes, tp, tgt, f_dy.back(), loss_row, Bn, Np, Nt, 1.0f / ((float)Bn * (float)Nt * (float)Np), A, dev_err};
             Bracket br(a, "iqn_loss");
             hipLaunchKernelGGL(k_iqn_loss, dim3(Bn), dim3(256), 0, stream, l);
             BDR_HIP(hipGetLastError());
@@ -294,12 +299,12 @@ struct Iqn : bdr_agent {
         // f backward
         for (int i = L - 1; i >= 1; --i) {
             DenseSrc in = i == 1 ? DenseSrc{mrg, Fp} : DenseSrc{f_act[i - 2], hd.L[i - 1].Np};
-            { Bracket br(a, "iqn_f_dw"); BDR_TRY(dense_dw(stream, hd.L[i], grad, in, f_dy[i - 1], M, part, ch)); }
-            if (i > 1) { Bracket br(a, "iqn_f_dx"); BDR_TRY(dense_dx(stream, hd.L[i], p, f_dy[i - 1], f_dy[i - 2], f_act[i - 2], M)); }
+            { Bracket br(a, ("iqn_f_dw" + std::to_string(i)).c_str()); BDR_TRY(dense_dw(stream, hd.L[i], grad, in, f_dy[i - 1], M, part, ch)); }
+            if (i > 1) { Bracket br(a, ("iqn_f_dx" + std::to_string(i)).c_str()); BDR_TRY(dense_dx(stream, hd.L[i], p, f_dy[i - 1], f_dy[i - 2], f_act[i - 2], M)); }
         }
         // dm = dL/dm (no ReLU mask: m is a product, not an activation) overwrites m itself: the dW launch of
         // layer 1 that reads m is already enqueued ahead of this kernel on the same stream
-        { Bracket br(a, "iqn_f_dx"); BDR_TRY(dense_dx(stream, hd.L[1], p, f_dy[0], mrg, nullptr, M)); }
+        { Bracket br(a, "iqn_f_dx1"); BDR_TRY(dense_dx(stream, hd.L[1], p, f_dy[0], mrg, nullptr, M)); }
         const float* feat = cnn ? a3 : psi_act.back();
         const int ldf = cnn ? 3136 : psi_mlp.L.back().Np;
         float* dpsi = cnn ? dy3 : psi_dy.back();
@@ -398,6 +403,14 @@ struct Iqn : bdr_agent {
         }
         n_updates_done = (int)cfg.n_updates_per_opt;
         return after_updates();
+    }
+    void record_keys(std::vector<std::string>& keys) override { keys = {"loss_critic"}; }
+    int32_t noise(float* dev, size_t n) override   // the U[0,1) stream fill_tau draws percent points from
+    {
+        hipLaunchKernelGGL(k_rand_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dev, n, cfg.seed, noise_counter);
+        BDR_HIP(hipGetLastError());
+        noise_counter += n;
+        return BDR_OK;
     }
     int32_t record(float* out, int, int* n) override   // {"loss_critic"} (iqn/base.rs:190)
     {
@@ -603,6 +616,7 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     }
     a->total = o;
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    BDR_TRY(a->err_init());
     float** arenas[5] = {&a->p, &a->p_tgt, &a->grad, &a->am, &a->av};
     for (auto q : arenas) BDR_TRY(a->zalloc(q, a->total));
     BDR_TRY(a->zalloc(&a->loss, 4));

@@ -22,13 +22,18 @@ struct TdDenseArgs {
     float* pred; float* tgt; float* loss_row;
     int B, A; float gamma; int loss_kind;
     const float* weight; float* td_abs; int has_clip; float clip_min, clip_max;   // PER (dqn/base.rs:123-145)
+    unsigned* err;    // bdr_agent::dev_err
 };
 __global__ __launch_bounds__(256) void k_td_dense(TdDenseArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= a.B) return;
-    const long long act = *reinterpret_cast<const long long*>(a.act + (size_t)row * a.act_bytes);
+    long long act = *reinterpret_cast<const long long*>(a.act + (size_t)row * a.act_bytes);
+    if (act < 0 || act >= a.A) {   // the reference's gather raises; here: flag for the host, clamp to stay in bounds
+        if (lane == 0 && a.err) atomicOr(a.err + bdr_agent::ERR_ACTION, 1u);
+        act = act < 0 ? 0 : a.A - 1;
+    }
     const float* sel = a.q_on_next ? a.q_on_next : a.q_tg;
     // first-max argmax over the A real actions (A <= 64)
     float v = lane < a.A ? sel[(size_t)row * a.ld + lane] : -INFINITY;
@@ -160,6 +165,7 @@ struct DqnMlp : bdr_agent {
         t.B = Bn; t.A = net.out_dim; t.gamma = (float)cfg.discount_factor; t.loss_kind = cfg.critic_loss;
         t.weight = weight; t.td_abs = td_abs;
         t.has_clip = cfg.has_clip_td_err; t.clip_min = (float)cfg.clip_td_err_min; t.clip_max = (float)cfg.clip_td_err_max;
+        t.err = dev_err;
         { Bracket br(a, "td_dense"); LAUNCH(k_td_dense, dim3((Bn + 3) / 4), t); }
         if (per_buffer && weight) { Bracket br(a, "per_update"); BDR_TRY(replay_update_priority_on_stream(per_buffer, Bn, td_abs, stream)); }
         {
@@ -204,24 +210,41 @@ struct DqnMlp : bdr_agent {
         }
         return after_updates();
     }
+    // Agent::opt_with_record (dqn/base.rs:316-342), see DqnCnn::record
     int32_t record(float* out, int cap, int* n) override
     {
         float l = 0;
         BDR_HIP(hipMemcpyAsync(&l, loss, 4, hipMemcpyDeviceToHost, stream));
         BDR_HIP(hipStreamSynchronize(stream));
-        out[0] = l; *n = 1;
-        if (cfg.record_verbose_level >= 2 && cap >= 5) {
+        std::vector<float> v = {l};
+        if (cfg.record_verbose_level >= 2) {
             std::vector<float> p(last_B), t(last_B), rw(last_B);
             BDR_HIP(hipMemcpy(p.data(), pred, last_B * 4, hipMemcpyDeviceToHost));
             BDR_HIP(hipMemcpy(t.data(), tgt, last_B * 4, hipMemcpyDeviceToHost));
             BDR_HIP(hipMemcpy(rw.data(), last_reward, last_B * 4, hipMemcpyDeviceToHost));
             double sp = 0, st = 0, sr = 0;
             for (int i = 0; i < last_B; ++i) { sp += p[i]; st += t[i]; sr += rw[i]; }
-            out[1] = (float)(sp / last_B); out[2] = (float)(sr / last_B); out[3] = (float)(st / last_B);
-            out[4] = (float)((st - sp) / last_B);
-            *n = 5;
+            v.insert(v.end(), {(float)(sp / last_B), (float)(sr / last_B), (float)(st / last_B), (float)((st - sp) / last_B)});
+            if (rec_opt) {
+                std::vector<float> ref(net.ref_total);
+                BDR_TRY(get_params(0, ref.data(), ref.size()));
+                param_stats(meta(), ref.data(), v);
+                v.push_back(n_samples_act == 0 ? 0.f : (float)n_samples_best_act / (float)n_samples_act);
+                n_samples_act = 0; n_samples_best_act = 0;
+            }
         }
+        for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+        *n = (int)std::min(v.size(), (size_t)cap);
         return BDR_OK;
+    }
+    void record_keys(std::vector<std::string>& keys) override
+    {
+        keys = {"loss"};
+        if (cfg.record_verbose_level >= 2) {
+            keys.insert(keys.end(), {"pred_mean", "reward_mean", "tgt_mean", "tgt_minus_pred_mean"});
+            param_stat_keys(meta(), keys);
+            keys.push_back("ratio_best_act");
+        }
     }
     float* arena_ptr(int which)
     {
@@ -289,6 +312,7 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
     a->net = make_mlp(cfg->net.in_dim, cfg->net.units, cfg->net.n_units, cfg->net.out_dim, false);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    BDR_TRY(a->err_init());
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->net.total));

@@ -33,7 +33,7 @@ struct bdr_per {
     uint64_t capacity = 0, n_samples = 0;
     int maxdepth = 0;          // depth of the deepest leaf of the sum tree
     float* tree = nullptr;     // [2*capacity-1]
-    unsigned* mm = nullptr;    // {min of leaves [0, n_samples), max of all leaves} as bit patterns (k_per_minmax)
+    unsigned* mm = nullptr;    // {min of leaves [0, n_samples), max of all leaves} as bit patterns (k_per_minmax); mm[2]: NaN flag
     bool mm_valid = false;     // mm holds the min/max of the CURRENT leaves (computed off the critical path after an update)
     // scratch of one update batch (<= PER_CHUNK entries)
     uint64_t* u_ix = nullptr;
@@ -104,7 +104,7 @@ struct PrepArgs {
     float alpha, eps;
     int n;
     uint64_t* u_ix; float* u_p; float* u_change;
-    unsigned* mm;             // re-armed here: the leaves are about to change
+    unsigned* mm;             // re-armed here: the leaves are about to change; mm[2] is raised when a change is NaN
 };
 __global__ __launch_bounds__(256) void k_per_prepare(PrepArgs a)
 {
@@ -147,8 +147,13 @@ __global__ __launch_bounds__(256) void k_per_prepare(PrepArgs a)
         const int k = threadIdx.x + it * 256;
         if (k >= a.n) continue;
         a.u_ix[k] = s_ix[k]; a.u_p[k] = s_p[k];
-        a.u_change[k] = s_p[k] - old[it];                                      // change = p - tree[ix]  (:100)
-        if (last[it]) a.tree[(uint64_t)s_ix[k] + a.capacity - 1] = s_p[k];     // leaves are assigned, not accumulated (:105)
+        float change = s_p[k] - old[it];                                       // change = p - tree[ix]  (:100)
+        // `if change.is_nan() { panic!() }` (:101-104): the library never aborts - the update is dropped (leaf and sums keep
+        // their values, so the tree stays usable) and a flag is raised that the next host synchronisation turns into an error
+        const bool bad = change != change;
+        if (bad) { atomicOr(a.mm + 2, 1u); change = 0.f; }
+        a.u_change[k] = change;
+        if (last[it] && !bad) a.tree[(uint64_t)s_ix[k] + a.capacity - 1] = s_p[k];   // leaves are assigned, not accumulated (:105)
     }
 }
 
@@ -306,8 +311,8 @@ int32_t per_create(const bdr_per_config* c, uint64_t capacity, hipStream_t strea
     auto fail_free = [&](hipError_t e) { per_destroy(p); return fail(BDR_ERR_HIP, "PER allocation failed: %s", hipGetErrorString(e)); };
     hipError_t e;
     if ((e = hipMalloc((void**)&p->tree, (2 * capacity - 1) * 4)) != hipSuccess) return fail_free(e);
-    if ((e = hipMalloc((void**)&p->mm, 2 * 4)) != hipSuccess) return fail_free(e);
-    { const unsigned init[2] = {MM_MIN_INIT, MM_MAX_INIT}; if ((e = hipMemcpyAsync(p->mm, init, 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail_free(e); if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail_free(e); }
+    if ((e = hipMalloc((void**)&p->mm, 4 * 4)) != hipSuccess) return fail_free(e);
+    { const unsigned init[4] = {MM_MIN_INIT, MM_MAX_INIT, 0u, 0u}; if ((e = hipMemcpyAsync(p->mm, init, 16, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail_free(e); if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail_free(e); }
     if ((e = hipMalloc((void**)&p->u_ix, PER_CHUNK * 8)) != hipSuccess) return fail_free(e);
     if ((e = hipMalloc((void**)&p->u_p, PER_CHUNK * 4)) != hipSuccess) return fail_free(e);
     if ((e = hipMalloc((void**)&p->u_change, PER_CHUNK * 4)) != hipSuccess) return fail_free(e);
@@ -431,6 +436,16 @@ int32_t per_get(const bdr_per* p, float s, uint64_t* ix, hipStream_t st)
     (void)hipFree(d);
     BDR_HIP(e);
     return BDR_OK;
+}
+
+int32_t per_check(bdr_per* p)
+{
+    unsigned flag = 0;
+    BDR_HIP(hipMemcpy(&flag, p->mm + 2, 4, hipMemcpyDeviceToHost));
+    if (!flag) return BDR_OK;
+    BDR_HIP(hipMemset(p->mm + 2, 0, 4));
+    return fail(BDR_ERR_INVALID, "SumTree::update: change is NaN (a NaN priority / TD error reached update_priority; the reference panics, "
+                                 "sum_tree.rs:101-104); those updates were dropped");
 }
 
 void per_info(const bdr_per* p, bdr_per_info* o)

@@ -356,6 +356,7 @@ int32_t bdr_replay_fill_synthetic(bdr_replay* r, uint64_t n, uint64_t seed, int3
     BDR_REQUIRE(n_actions == 0 || r->act_bytes == 8, "discrete actions are one i64 per row");
     BDR_REQUIRE(kind == 0 || r->obs_bytes % 4 == 0, "f32 rows need obs_row_bytes %% 4 == 0");
     BDR_REQUIRE(n <= r->capacity, "fill count exceeds capacity");
+    BDR_REQUIRE(!r->per || r->size == 0, "synthetic fill with PER needs an empty buffer");   // before anything is overwritten
     BDR_HIP(hipSetDevice(r->device));
     BDR_TRY(wait_for_reader(r, r->stream));
     FillArgs a{r->ring, r->stride, r->obs_bytes, r->act_bytes, r->next_off, r->act_off, r->tail_off, r->capacity,
@@ -364,7 +365,6 @@ int32_t bdr_replay_fill_synthetic(bdr_replay* r, uint64_t n, uint64_t seed, int3
     hipLaunchKernelGGL(k_fill_synthetic, dim3((uint32_t)n), dim3(256), 0, r->stream, a);
     BDR_HIP(hipGetLastError());
     if (r->per) {   // the fill is one push of n rows into an empty ring: one set_priority(n)
-        BDR_REQUIRE(r->size == 0, "synthetic fill with PER needs an empty buffer");
         BDR_TRY(per_push(r->per, 0, n, r->stream));
     }
     BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
@@ -587,6 +587,7 @@ int32_t bdr_replay_update_priority(bdr_replay* r, uint64_t n, const uint64_t* ix
     if (rc == BDR_OK) { (void)hipEventRecord(r->written, r->stream); mark_written(r); }
     (void)hipStreamSynchronize(r->stream);
     (void)hipFree(d_ix); (void)hipFree(d_td);
+    if (rc == BDR_OK) rc = per_check(r->per);
     return rc;
 }
 
@@ -611,7 +612,7 @@ int32_t bdr_replay_per_info(bdr_replay* r, bdr_per_info* out)
     BDR_TRY(per_read(r->per, 0, &total, 1, r->stream));
     BDR_TRY(per_read(r->per, 1, mm, 2, r->stream));
     out->total = total; out->min_p = mm[0]; out->max_p = mm[1];   // transformed (p+eps)^alpha domain
-    return BDR_OK;
+    return per_check(r->per);
 }
 
 int32_t bdr_replay_per_read(bdr_replay* r, int32_t what, float* out, uint64_t n)

@@ -459,6 +459,8 @@ struct Sac : bdr_agent {
         }
         return BDR_OK;
     }
+    void record_keys(std::vector<std::string>& keys) override { keys = {"loss_critic", "loss_actor", "ent_coef"}; }
+    int32_t noise(float* dev, size_t n) override { return gen_noise(dev, n); }   // the N(0,1) stream of action_logp
     int32_t record(float* out, int cap, int* n) override
     {
         float h[2], la;
@@ -608,6 +610,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     }
     a->qn = make_mlp(a->O + a->A, cfg->q_units, cfg->n_q_units, 1, false);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    BDR_TRY(a->err_init());
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};
     for (auto p : pis) BDR_TRY(a->zalloc(p, a->pi.total));
     for (int i = 0; i < a->NC; ++i) {

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 
 #include <map>
 #include <memory>
@@ -244,19 +245,23 @@ struct ZipReader {
         uint64_t n = r16(eocd + 10), cd_off = r32(eocd + 16);
         if (eocd >= 20 && r32(eocd - 20) == 0x07064b50u) {   // zip64 locator -> zip64 end record
             const uint64_t z = r64(eocd - 20 + 8);
-            if (z + 56 <= bytes.size() && r32(z) == 0x06064b50u) { n = r64(z + 32); cd_off = r64(z + 48); }
+            if (z <= bytes.size() && bytes.size() - z >= 56 && r32(z) == 0x06064b50u) { n = r64(z + 32); cd_off = r64(z + 48); }
         }
+        if (n > bytes.size() / 46) { err = "corrupt zip end record (entry count)"; return false; }
         size_t o = cd_off;
         for (uint64_t i = 0; i < n; ++i) {
-            if (o + 46 > bytes.size() || r32(o) != 0x02014b50u) { err = "corrupt zip central directory"; return false; }
+            if (o > bytes.size() || bytes.size() - o < 46 || r32(o) != 0x02014b50u) { err = "corrupt zip central directory"; return false; }
             const uint16_t method = r16(o + 10), nl = r16(o + 28), xl = r16(o + 30), cl = r16(o + 32);
             uint64_t csize = r32(o + 20), usize = r32(o + 24), lho = r32(o + 42);
+            // name, extra field and comment of this record lie inside the file (all lengths come from the file)
+            if (bytes.size() - o - 46 < (size_t)nl + xl + cl) { err = "corrupt zip central directory (record runs past the end of the file)"; return false; }
             const std::string name = bytes.substr(o + 46, nl);
             // zip64 extended information
             size_t x = o + 46 + nl;
             const size_t xend = x + xl;
             while (x + 4 <= xend) {
                 const uint16_t id = r16(x), sz = r16(x + 2);
+                if (x + 4 + sz > xend) break;   // truncated extra field
                 if (id == 1) {
                     size_t q = x + 4;
                     if (usize == 0xFFFFFFFFu && q + 8 <= x + 4 + sz) { usize = r64(q); q += 8; }
@@ -265,12 +270,12 @@ struct ZipReader {
                 }
                 x += 4 + sz;
             }
-            if (lho + 30 > bytes.size() || r32(lho) != 0x04034b50u) { err = "corrupt zip local header"; return false; }
+            if (lho > bytes.size() || bytes.size() - lho < 30 || r32(lho) != 0x04034b50u) { err = "corrupt zip local header"; return false; }
             ZipEntry e;
             e.data_off = lho + 30 + r16(lho + 26) + r16(lho + 28);
             e.size = usize;
             e.stored = method == 0 && csize == usize;   // libtorch deflates only the code/ entries, which are not needed here
-            if (e.data_off + csize > bytes.size()) { err = "zip entry " + name + " runs past the end of the file"; return false; }
+            if (e.data_off > bytes.size() || csize > bytes.size() - e.data_off) { err = "zip entry " + name + " runs past the end of the file"; return false; }
             entries[name] = e;
             o += 46 + nl + xl + cl;
         }
@@ -436,7 +441,7 @@ inline void collect_tensors(const PRef& v, const std::string& prefix, std::vecto
 }
 
 // returns "" on success
-inline std::string read_archive(const std::string& path, std::vector<Tensor>& out)
+inline std::string read_archive_impl(const std::string& path, std::vector<Tensor>& out)
 {
     ZipReader z;
     if (!z.open(path)) return z.err;
@@ -468,14 +473,25 @@ inline std::string read_archive(const std::string& path, std::vector<Tensor>& ou
         r.name = nt.first;
         r.dims = t.sizes;
         uint64_t numel = 1;
-        for (auto d : t.sizes) numel *= d;
+        bool overflow = t.sizes.size() > 16;
+        for (auto d : t.sizes) {   // sizes come from the file: no product overflow, nothing larger than a model could be
+            if (d != 0 && numel > (1ull << 33) / d) overflow = true;
+            if (!overflow) numel *= d;
+        }
+        if (overflow || numel > (1ull << 33)) return path + ": variable '" + nt.first + "' has an implausible shape";
         if (t.sizes.size() != t.strides.size()) return path + ": variable '" + nt.first + "' has inconsistent strides";
+        if (numel > 0 && avail == 0) return path + ": variable '" + nt.first + "' reads past its storage";
         r.data.resize(numel);
         std::vector<uint64_t> idx(t.sizes.size(), 0);
         for (uint64_t e = 0; e < numel; ++e) {   // general strided read (libtorch writes contiguous tensors; Python exports may not be)
             uint64_t off = t.offset;
-            for (size_t d = 0; d < idx.size(); ++d) off += idx[d] * t.strides[d];
-            if (off >= avail) return path + ": variable '" + nt.first + "' reads past its storage";
+            bool past = off >= avail;
+            for (size_t d = 0; d < idx.size() && !past; ++d) {
+                if (idx[d] != 0 && t.strides[d] > avail / idx[d]) { past = true; break; }
+                off += idx[d] * t.strides[d];
+                past = off >= avail;
+            }
+            if (past) return path + ": variable '" + nt.first + "' reads past its storage";
             float v;
             memcpy(&v, src + off * 4, 4);
             r.data[e] = v;
@@ -484,6 +500,19 @@ inline std::string read_archive(const std::string& path, std::vector<Tensor>& ou
         out.push_back(std::move(r));
     }
     return "";
+}
+
+// Everything above is driven by lengths and counts read from the file; whatever still throws (bad_alloc, length_error,
+// out_of_range) on a malformed archive must not cross the extern "C" boundary.
+inline std::string read_archive(const std::string& path, std::vector<Tensor>& out)
+{
+    try {
+        return read_archive_impl(path, out);
+    } catch (const std::exception& e) {
+        return path + ": malformed archive (" + e.what() + ")";
+    } catch (...) {
+        return path + ": malformed archive";
+    }
 }
 
 }  // namespace tcha

@@ -24,7 +24,7 @@ struct State {
     const bdr_trainer_ops* ops;
     uint64_t env_steps = 0, opt_steps = 0, opt_steps_counter = 0, samples_counter = 0, n_records = 0, n_episodes = 0;
     double timer_for_opt_steps = 0, timer_for_samples = 0, total_opt = 0, total_sample = 0;
-    float scalars[16];
+    float scalars[128];
     int32_t n_scalars = 0;
 };
 
@@ -37,7 +37,7 @@ int32_t train_step(State& s, bool* is_opt, bool* with_record)
     if (s.env_steps % c.opt_interval != 0) return BDR_OK;
     const auto t0 = Clock::now();
     if (c.record_agent_info_interval != 0 && (s.opt_steps + 1) % c.record_agent_info_interval == 0) {
-        BDR_TRY(s.ops->agent_opt_with_record(s.ops->agent, s.ops->buffer, s.scalars, 16, &s.n_scalars));
+        BDR_TRY(s.ops->agent_opt_with_record(s.ops->agent, s.ops->buffer, s.scalars, 128, &s.n_scalars));
         *with_record = true;
         s.n_records += 1;
     } else {

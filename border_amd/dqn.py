@@ -148,6 +148,27 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def record_keys(handle) -> list:
+    names = C.create_string_buffer(8192)
+    n = C.c_int32()
+    _lib.check(_lib.lib().bdr_agent_record_keys(handle, names, 8192, C.byref(n)))
+    return names.value.decode().split("\n")[:n.value]
+
+
+def opt_with_named_record(handle, buffer) -> dict:
+    """bdr_agent_opt_with_scalars + bdr_agent_record_keys: the reference's Record of one opt_with_record call."""
+    out = np.zeros(128, np.float32)
+    n = C.c_int32()
+    _lib.check(_lib.lib().bdr_agent_opt_with_scalars(handle, buffer.handle, _p(out), 128, C.byref(n)))
+    return {k: float(v) for k, v in zip(record_keys(handle), out[:n.value])}
+
+
+def draw_noise(handle, n: int) -> np.ndarray:
+    out = np.empty(n, np.float32)
+    _lib.check(_lib.lib().bdr_agent_draw_noise(handle, n, _p(out)))
+    return out
+
+
 class Dqn:
     """Dqn<E, Q, R> (dqn/base.rs:22-48)."""
 
@@ -195,9 +216,10 @@ class Dqn:
         _lib.check(_lib.lib().bdr_agent_opt(self._h, buffer.handle))
 
     def opt_with_record(self, buffer: SimpleReplayBuffer) -> dict:
-        r = _lib.DqnRecordC()
-        _lib.check(_lib.lib().bdr_agent_opt_with_record(self._h, buffer.handle, C.byref(r)))
-        return self._record(r)
+        """Agent::opt_with_record (dqn/base.rs:316-342): the Record as a dict - "loss"; with record_verbose_level >= 2 also
+        pred_mean / reward_mean / tgt_mean / tgt_minus_pred_mean, `<var>_mean` / `<var>_std` of every qnet variable
+        (param_stats, util.rs:64-80) and ratio_best_act (which resets the sample counters)."""
+        return opt_with_named_record(self._h, buffer)
 
     @staticmethod
     def _record(r) -> dict:

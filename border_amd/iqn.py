@@ -107,10 +107,16 @@ class Iqn:
         _lib.check(_lib.lib().bdr_agent_opt(self._h, buffer.handle))
 
     def opt_with_record(self, buffer: SimpleReplayBuffer) -> dict:
-        out = np.zeros(8, np.float32)
-        n = C.c_int32()
-        _lib.check(_lib.lib().bdr_agent_opt_with_scalars(self._h, buffer.handle, _p(out), 8, C.byref(n)))
-        return dict(loss_critic=float(out[0]))
+        from .dqn import opt_with_named_record
+        return opt_with_named_record(self._h, buffer)
+
+    def profile_enable(self, on: bool = True):
+        _lib.check(_lib.lib().bdr_agent_profile_enable(self._h, int(on)))
+
+    def draw_noise(self, n: int) -> np.ndarray:
+        """n draws of the agent's device noise stream (test helper, bdr_agent_draw_noise)."""
+        from .dqn import draw_noise
+        return draw_noise(self._h, n)
 
     def update_on_batch(self, obs, act, next_obs, reward, is_terminated, tau_pred, tau_tgt) -> dict:
         reward = np.ascontiguousarray(reward, dtype=np.float32)

@@ -279,44 +279,24 @@ class ParamExchange:
             self._comm = h
 
     @classmethod
-    def with_fallback(cls, world_size: int, rank: int, sync_interval: int, device: int, bcast_bytes, which=("qnet",)):
-        """The library's RCCL communicator if every rank can bring it up, else torch.distributed's own RCCL
-        ("nccl" backend) on a zero-copy view of the device arena, else the host-staged path.  Every step of
-        the ladder is agreed on by all ranks (MIN-reduce of a success flag over the control-plane group), so
-        the ranks never end up on different data planes."""
+    def rccl_or_raise(cls, world_size: int, rank: int, sync_interval: int, device: int, bcast_bytes, which=("qnet",)):
+        """The library's RCCL communicator on EVERY rank, or a RuntimeError on every rank: the outcome is agreed on by all
+        ranks (MIN-reduce of a success flag over the torch.distributed control-plane group), so no rank is left waiting in a
+        collective and no run continues on a slower data plane without saying so.  (Round 1 demoted silently to torch's RCCL
+        and then to host staging; a multi-GPU measurement must not do that.)"""
         import torch
         import torch.distributed as dist
-
-        def all_ok(ok: bool) -> bool:
-            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(t[0])
-
         ex, err = None, None
         try:
             ex = cls(world_size, rank, sync_interval, "rccl", device, bcast_bytes, which)
-        except Exception as e:  # noqa: BLE001  (any failure demotes every rank together)
+        except Exception as e:  # noqa: BLE001  (reported below, on every rank)
             err = e
-        if all_ok(ex is not None):
-            return ex
-        if ex is not None:
-            ex.close()
-        ex = cls(world_size, rank, sync_interval, "torch-nccl", device, None, which)
-        grp = None
-        try:
-            grp = dist.new_group(backend="nccl")
-            probe = torch.ones(1, device=f"cuda:{device}")   # communicators are created lazily: force it now
-            dist.all_reduce(probe, group=grp)
-            torch.cuda.synchronize(device)
-            if int(probe[0].item()) != world_size:
-                raise RuntimeError("probe all-reduce returned a wrong sum")
-        except Exception as e:  # noqa: BLE001
-            err, grp = e, None
-        if all_ok(grp is not None):
-            ex._group = grp
-            return ex
-        ex = cls(world_size, rank, sync_interval, "torch", device, None, which)
-        ex.fallback_reason = repr(err)
+        ok = torch.tensor([0 if ex is None else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0:
+            if ex is not None:
+                ex.close()
+            raise RuntimeError(f"rank {rank}: the RCCL communicator could not be initialised on every rank ({err!r})")
         return ex
 
     def close(self):

@@ -223,6 +223,19 @@ BDR_API int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* buffer, bdr_
  * SAC: loss_critic, loss_actor, ent_coef).  Synchronises. */
 BDR_API int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* buffer, float* out, int32_t cap, int32_t* n_out);
 
+/* Names of the scalars bdr_agent_opt_with_scalars returns, '\n'-separated, in order (the keys of the reference's Record):
+ *   DQN  "loss"; record_verbose_level >= 2 adds pred_mean, reward_mean, tgt_mean, tgt_minus_pred_mean (dqn/base.rs:107-121),
+ *        then qnet.param_stats() - "<var>_mean", "<var>_std" (population) for c1.weight ... l2.bias / mlp.ln{i}.* in the
+ *        variables' order (util.rs:64-80) - and "ratio_best_act" = n_samples_best_act / n_samples_act, which resets both
+ *        counters (dqn/base.rs:316-342);
+ *   IQN  "loss_critic" (iqn/base.rs:190);   SAC  "loss_critic", "loss_actor", "ent_coef" (sac/base.rs:187-196). */
+BDR_API int32_t bdr_agent_record_keys(bdr_agent* a, char* names_out, uint64_t names_cap, int32_t* n_keys);
+
+/* Test helper: n draws of the agent's own device noise stream copied to the host - SAC: the N(0,1) draws of action_logp
+ * (sac/base.rs:76 uses torch's global generator), IQN: the U[0,1) percent points of IqnSample::Uniform* (iqn/model/base.rs:365-368).
+ * Counter-based (seed, running counter): advances the stream exactly as an update consuming n draws does. */
+BDR_API int32_t bdr_agent_draw_noise(bdr_agent* a, uint64_t n, float* out);
+
 /* One update_critic on a caller-supplied host minibatch (parity tests: "fixed minibatch").
  * act: int64 [n]; obs/next_obs rows as in the replay buffer. */
 BDR_API int32_t bdr_dqn_update_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act,
@@ -274,7 +287,10 @@ typedef struct {
 BDR_API int32_t bdr_agent_sample(bdr_agent* a, uint64_t n_procs, const void* obs, int64_t* act_out,
                                  bdr_sample_info* info);
 
-/* Block until everything enqueued on the agent's stream has finished. */
+/* Block until everything enqueued on the agent's stream has finished.  Device-side error flags raised since the last check
+ * (an action index outside [0, n_actions) in a TD step, a NaN priority in update_priority, a timed-out cross-queue gate) are
+ * reported here - and by every other entry point that synchronises (opt_with_record / _with_scalars, get_params, save_params,
+ * sample, update_on_batch); bdr_agent_opt polls them without synchronising every 256 calls. */
 BDR_API int32_t bdr_agent_sync(bdr_agent* a);
 BDR_API int32_t bdr_agent_n_opts(const bdr_agent* a, uint64_t* n);
 

@@ -188,23 +188,52 @@ def synthetic_atari_batch(B: int, A: int, seed: int):
     return obs, act, next_obs, reward, term
 
 
-def time_dqn_atari(batch_size=256, n_actions=6, steps=5, warmup=1, threads=None, capacity=4096,
-                   critic_loss="SmoothL1"):
-    """CPU baseline: sample (RNG + 3x index_select on an f32 ring, as the reference stores it:
-    border-atari-env/src/obs.rs:45-52 + tensor_batch.rs:95-120) + update, timed like
-    Trainer::train_step (border-core/src/trainer.rs:213-225).  Returns opt-steps/sec."""
+def _timed(one, steps, warmup):
     import time
+    for _ in range(warmup):
+        one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    return steps / (time.perf_counter() - t0), torch.get_num_threads()
+
+
+_RINGS = {}
+
+
+def _f32_ring(capacity, n_actions):
+    """The reference's f32 observation ring (border-atari-env/src/obs.rs:45-52 stores frames as f32; tensor_batch.rs:95-120):
+    [capacity,4,1,84,84] x 2.  Contents are a 1024-row random block tiled over the ring (what is timed is the gather's memory
+    behaviour and the update, not the values); built once per process."""
+    key = (capacity, n_actions)
+    if key not in _RINGS:
+        g = torch.Generator().manual_seed(0)
+        blk = min(1024, capacity)
+        block = torch.randint(0, 256, (blk, 4, 1, 84, 84), generator=g, dtype=torch.uint8).to(torch.float32)
+        rings = []
+        for shift in (0, 1):
+            r = torch.empty((capacity, 4, 1, 84, 84), dtype=torch.float32)
+            src = block.roll(shift, 0)
+            for o in range(0, capacity, blk):
+                n = min(blk, capacity - o)
+                r[o:o + n].copy_(src[:n])
+            rings.append(r)
+        _RINGS[key] = (rings[0], rings[1], torch.randint(0, n_actions, (capacity, 1), generator=g), torch.zeros(capacity),
+                       torch.zeros(capacity, dtype=torch.int8))
+    return _RINGS[key]
+
+
+def time_dqn_atari(batch_size=256, n_actions=6, steps=5, warmup=1, threads=None, capacity=65536,
+                   critic_loss="SmoothL1"):
+    """CPU baseline: sample (index draw + 3x index_select on an f32 ring of 65 536 transitions, as the
+    reference stores it) + update, timed like Trainer::train_step (border-core/src/trainer.rs:213-225).  Returns
+    (opt-steps/sec, threads used)."""
     if threads:
         torch.set_num_threads(threads)
     shapes = cnn_shapes(n_actions)
     agent = TorchDqn("cnn", shapes, init_params(shapes, 0), lr=1e-4, critic_loss=critic_loss, tau=1.0,
                      soft_update_interval=10000)
-    g = torch.Generator().manual_seed(0)
-    ring_obs = torch.randint(0, 256, (capacity, 4, 1, 84, 84), generator=g).to(torch.float32)
-    ring_next = torch.randint(0, 256, (capacity, 4, 1, 84, 84), generator=g).to(torch.float32)
-    ring_act = torch.randint(0, n_actions, (capacity, 1), generator=g)
-    ring_rew = torch.zeros(capacity)
-    ring_term = torch.zeros(capacity, dtype=torch.int8)
+    ring_obs, ring_next, ring_act, ring_rew, ring_term = _f32_ring(capacity, n_actions)
     rng = np.random.default_rng(42)
 
     def one():
@@ -214,13 +243,79 @@ def time_dqn_atari(batch_size=256, n_actions=6, steps=5, warmup=1, threads=None,
         act = ring_act.index_select(0, ixs).numpy()
         agent.update(obs, act, nobs, ring_rew[ixs].numpy(), ring_term[ixs].numpy())
 
-    for _ in range(warmup):
-        one()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    dt = time.perf_counter() - t0
-    return steps / dt, torch.get_num_threads()
+    return _timed(one, steps, warmup)
+
+
+def time_dqn_cartpole(batch_size=32, steps=50, warmup=5, threads=None, capacity=10000):
+    """BASELINE config 1 on the CPU path: Mlp[64,64], obs 4 f32, 2 actions, MSE, Adam 1e-3, tau 0.01 every opt."""
+    if threads:
+        torch.set_num_threads(threads)
+    shapes = mlp_shapes(4, [64, 64], 2)
+    agent = TorchDqn("mlp", shapes, init_params(shapes, 0), lr=1e-3, critic_loss="Mse", tau=0.01, soft_update_interval=1)
+    g = torch.Generator().manual_seed(0)
+    obs, nobs = torch.randn(capacity, 4, generator=g), torch.randn(capacity, 4, generator=g)
+    act, rew, term = torch.randint(0, 2, (capacity, 1), generator=g), torch.randn(capacity, generator=g), torch.zeros(capacity, dtype=torch.int8)
+    rng = np.random.default_rng(42)
+
+    def one():
+        ixs = torch.from_numpy(rng.integers(0, capacity, batch_size))
+        agent.update(obs.index_select(0, ixs).numpy(), act.index_select(0, ixs).numpy(), nobs.index_select(0, ixs).numpy(),
+                     rew[ixs].numpy(), term[ixs].numpy())
+
+    return _timed(one, steps, warmup)
+
+
+def time_iqn_atari(batch_size=512, steps=2, warmup=1, threads=None, n_actions=6, n_quantiles=64):
+    """BASELINE config 4 on the CPU path (fixed minibatch: the gather is negligible next to 0.5 TFLOP of update)."""
+    if threads:
+        torch.set_num_threads(threads)
+    sh = iqn_shapes("cnn", 3136, 64, [512], n_actions)
+    agent = TorchIqn("cnn", sh, init_params(sh[0] + sh[1] + sh[2], 0), lr=1e-4, feature_dim=3136, embed_dim=64, tau=1.0, soft_update_interval=10000)
+    batch = iqn_batch(batch_size, "cnn", n_actions, n_quantiles, n_quantiles, 1)
+    return _timed(lambda: agent.update(*batch), steps, warmup)
+
+
+def time_sac(batch_size=1024, steps=20, warmup=2, threads=None, obs_dim=17, act_dim=6):
+    """BASELINE config 5 on the CPU path: twin-Q [256,256], actor [256,256], Auto entropy coefficient."""
+    if threads:
+        torch.set_num_threads(threads)
+    pu, qu = [256, 256], [256, 256]
+    pi0 = init_params(sac_pi_shapes(obs_dim, pu, act_dim), 1) * np.float32(0.5)
+    q0 = [init_params(sac_q_shapes(obs_dim, act_dim, qu), 2 + i) for i in range(2)]
+    agent = TorchSac(obs_dim, act_dim, pu, qu, pi0, q0, lr_actor=3e-4, lr_critic=3e-4, ent_coef=("Auto", -6.0, 3e-4))
+    batch = sac_batch(batch_size, obs_dim, act_dim, 3)
+    return _timed(lambda: agent.update(*batch), steps, warmup)
+
+
+def time_c_oracle_dqn(batch_size=256, n_actions=6, critic_loss="SmoothL1"):
+    """The scalar C restatement (oracle/border_oracle.c, OpenMP over its outer loops; double accumulators) on the same step,
+    for context: all threads on the full batch, one thread on 1/16 of the batch (scaled)."""
+    import os
+    import time
+    from oracle import oracle as O
+    shapes = cnn_shapes(n_actions)
+    p0 = init_params(shapes, 0)
+
+    def run(B, reps):
+        ref = O.DqnOracle(O.cnn_cfg(n_actions), p0, lr=1e-4, critic_loss=critic_loss, tau=1.0, soft_update_interval=10000)
+        b = synthetic_atari_batch(B, n_actions, 5)
+        ref.update(*b)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ref.update(*b)
+        return reps / (time.perf_counter() - t0)
+
+    nthreads = int(O.lib().orc_num_threads())
+    all_t = run(batch_size, 2)
+    old = os.environ.get("OMP_NUM_THREADS")
+    O.lib().orc_set_num_threads(1)
+    small = max(1, batch_size // 16)
+    one_t = run(small, 1) * small / batch_size
+    O.lib().orc_set_num_threads(nthreads)
+    if old is not None:
+        os.environ["OMP_NUM_THREADS"] = old
+    return {"opt_steps_per_s_all_threads": round(all_t, 4), "threads": nthreads,
+            "opt_steps_per_s_1_thread": round(one_t, 5), "one_thread_sample": f"batch {small}, scaled to {batch_size}"}
 
 
 # ================================================================================================

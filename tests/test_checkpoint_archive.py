@@ -174,3 +174,52 @@ def test_cxx_libtorch_loader_agrees(ck, tmp_path):
     subprocess.run([TOOL, "write", f2, "a.b", "2,3", "c", "4"], check=True)
     got = ck.read(f2, [("a.b", (2, 3)), ("c", (4,))])
     assert np.array_equal(got["a.b"], fill(0, (2, 3))) and np.array_equal(got["c"], fill(1, (4,)))
+
+
+def test_malformed_archives_return_errors_instead_of_terminating(ck, tmp_path):
+    """The reader is driven by lengths and counts stored in the file.  Truncations, corrupted length fields and wild tensor
+    shapes must come back as BDR_ERR_IO through the C ABI - never as an exception crossing `extern "C"` (which would
+    terminate the host process) or an out-of-bounds read."""
+    import struct
+    from border_amd import BdrError
+    good = open(os.path.join(GOLD, "libtorch_mlp_qnet.pt.tch"), "rb").read()
+    cases = {}
+    for cut in (30, 100, len(good) // 2, len(good) - 30, len(good) - 5):
+        cases[f"cut{cut}"] = good[:cut]
+    eocd = good.rfind(b"PK\x05\x06")
+    cd_off = struct.unpack_from("<I", good, eocd + 16)[0]
+    b = bytearray(good); struct.pack_into("<H", b, cd_off + 28, 0xFFFF); cases["name_len"] = bytes(b)           # file-name length
+    b = bytearray(good); struct.pack_into("<H", b, cd_off + 30, 0xFFFF); cases["extra_len"] = bytes(b)          # extra-field length
+    b = bytearray(good); struct.pack_into("<I", b, cd_off + 42, 0xFFFFFFF0); cases["local_off"] = bytes(b)      # local-header offset
+    b = bytearray(good); struct.pack_into("<I", b, cd_off + 20, 0x7FFFFFFF); struct.pack_into("<I", b, cd_off + 24, 0x7FFFFFFF)
+    cases["entry_size"] = bytes(b)
+    z64 = good.rfind(b"PK\x06\x06")       # libtorch writes a zip64 end record; its fields override the 16/32-bit ones
+    assert z64 > 0
+    b = bytearray(good); struct.pack_into("<Q", b, z64 + 32, 1 << 40); cases["entry_count"] = bytes(b)
+    b = bytearray(good); struct.pack_into("<Q", b, z64 + 48, (1 << 63) + 5); cases["cd_offset"] = bytes(b)
+    # a tensor whose pickled shape is astronomically large (sizes are BININT / LONG1 operands in data.pkl)
+    pk = good.find(b"data.pkl")
+    i = good.find(b"(K\x40K\x04t(K\x04K\x01t")      # the (64, 4) size and (4, 1) stride tuples of mlp.ln0.weight
+    assert i > 0
+    b = bytearray(good); b[i + 2] = 0xFF; b[i + 4] = 0xFF; cases["reads_past_storage"] = bytes(b)
+    for name, data in cases.items():
+        f = tmp_path / f"{name}.pt.tch"
+        f.write_bytes(data)
+        with pytest.raises(BdrError) as e:
+            ck.read(str(f), MLP_SPEC)
+        assert e.value.code == 5, (name, str(e.value))
+    # huge declared shape through a hand-made pickle: rebuild the archive with a patched data.pkl
+    import io
+    zin = zipfile.ZipFile(io.BytesIO(good))
+    out = tmp_path / "huge_shape.pt.tch"
+    with zipfile.ZipFile(out, "w", zipfile.ZIP_STORED) as zo:
+        for info in zin.infolist():
+            data = zin.read(info.filename)
+            if info.filename.endswith("data.pkl") and "/code/" not in info.filename and ".data/" not in info.filename:
+                j = data.find(b"(K\x40K\x04t")
+                assert j > 0
+                data = data[:j] + b"(J\xff\xff\xff\x7fJ\xff\xff\xff\x7ft" + data[j + 6:]   # (2^31-1, 2^31-1)
+            zo.writestr(info.filename, data)
+    with pytest.raises(BdrError) as e:
+        ck.read(str(out), MLP_SPEC)
+    assert e.value.code == 5

@@ -604,3 +604,158 @@ np.save(sys.argv[2], a.get_params("qnet"))
             got, err = outs[(per, q)]
             assert np.array_equal(got, ref), (per, q)
             assert ("share a hardware queue" in err) == (q == "2"), (per, q, err[-300:])
+
+
+CNN_VARS = [("c1.weight", (32, 4, 8, 8)), ("c1.bias", (32,)), ("c2.weight", (64, 32, 4, 4)), ("c2.bias", (64,)),
+            ("c3.weight", (64, 64, 3, 3)), ("c3.bias", (64,)), ("l1.weight", (512, 3136)), ("l1.bias", (512,)),
+            ("l2.weight", (6, 512)), ("l2.bias", (6,))]
+
+
+@pytest.mark.parametrize("net", ["cnn", "mlp"])
+def test_opt_with_record_verbose_keys_param_stats_and_ratio_best_act(B, net):
+    """Agent::opt_with_record with record_verbose_level >= 2 (dqn/base.rs:316-342): the update's own scalars, then
+    qnet.param_stats() - `<var>_mean` / `<var>_std` (population std, util.rs:64-80) of every variable, computed from the
+    parameters AFTER the step - and ratio_best_act = n_samples_best_act / n_samples_act, which resets both counters; a plain
+    update (update_on_batch) carries only the five update scalars; level 0 only "loss"."""
+    import torch
+    if net == "cnn":
+        variables, obs_shape, obs_dtype, A = CNN_VARS, (4, 1, 84, 84), np.uint8, 6
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=500, seed=1), obs_shape, obs_dtype)
+        rb.fill_synthetic(500, seed=2, kind=0, n_actions=A)
+        a = make_agent(B, A=A, batch_size=16, record_verbose_level=2, critic_loss="SmoothL1")
+        obs = np.random.default_rng(0).integers(0, 256, (3,) + obs_shape, dtype=np.uint8)
+    else:
+        variables, A = [(f"mlp.ln{i}.{k}", s) for i, (o, n) in enumerate([(64, 4), (64, 64), (2, 64)]) for k, s in (("weight", (o, n)), ("bias", (o,)))], 2
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=500, seed=1), (4,), np.float32)
+        rb.fill_synthetic(500, seed=2, kind=1, n_actions=A)
+        a = make_mlp_agent(B, batch_size=16, record_verbose_level=2)
+        obs = np.random.default_rng(0).standard_normal((3, 4)).astype(np.float32)
+    a.train()
+    a.set_explorer(B.EpsilonGreedy(final_step=10), seed=3)
+    infos = [a.sample(obs, return_info=True)[1] for _ in range(12)]
+    assert infos[-1]["n_samples_act"] == 12
+    want_ratio = infos[-1]["n_samples_best_act"] / 12.0
+    rec = a.opt_with_record(rb)
+    keys = list(rec)
+    assert keys[:5] == ["loss", "pred_mean", "reward_mean", "tgt_mean", "tgt_minus_pred_mean"]
+    assert keys[5:-1] == [f"{v}_{s}" for v, _ in variables for s in ("mean", "std")] and keys[-1] == "ratio_best_act"
+    p = a.get_params("qnet")
+    o = 0
+    for v, shp in variables:
+        n = int(np.prod(shp))
+        t = torch.from_numpy(p[o:o + n].copy())
+        assert abs(rec[f"{v}_mean"] - float(t.mean())) <= 1e-6 * max(1.0, abs(float(t.mean()))) + 1e-9, v
+        assert abs(rec[f"{v}_std"] - float(t.std(unbiased=False))) <= 1e-5 * float(t.std(unbiased=False)) + 1e-9, v
+        o += n
+    assert o == p.size
+    assert abs(rec["ratio_best_act"] - np.float32(want_ratio)) < 1e-7
+    assert abs(rec["tgt_minus_pred_mean"] - (rec["tgt_mean"] - rec["pred_mean"])) < 1e-5
+    # the counters were reset (dqn/base.rs:337-338): no samples since -> ratio 0
+    assert a.sample(obs, return_info=True)[1]["n_samples_act"] == 1
+    a.sample(obs)
+    rec2 = a.opt_with_record(rb)
+    assert 0.0 <= rec2["ratio_best_act"] <= 1.0 and a.sample(obs, return_info=True)[1]["n_samples_act"] == 1
+    assert a.opt_with_record(rb)["ratio_best_act"] in (0.0, 1.0)
+    # the C struct entry point still reports the five update scalars
+    import ctypes as C
+    from border_amd import _lib
+    r = _lib.DqnRecordC()
+    _lib.check(_lib.lib().bdr_agent_opt_with_record(a.handle, rb.handle, C.byref(r)))
+    assert r.has_verbose == 1 and np.isfinite(r.loss)
+    a.close(); rb.close()
+
+
+def test_out_of_range_action_is_flagged_not_read_out_of_bounds(B):
+    """update_critic gathers Q(s, a) with the stored action (dqn/base.rs:71-74); the reference's gather raises for an index
+    outside [0, A).  Here the kernel clamps the index (no out-of-bounds read) and raises a device flag that the next
+    synchronising call reports; the agent stays usable."""
+    from oracle import torch_ref as T
+    a = make_agent(B, A=6, batch_size=8)
+    obs, act, nobs, rew, term = T.synthetic_atari_batch(8, 6, 5)
+    act = np.array(act, np.int64); act[3] = 6
+    with pytest.raises(B.BdrError) as e:
+        a.update_on_batch(obs, act, nobs, rew, term)
+    assert e.value.code == 1 and "action" in str(e.value)
+    act[3] = -1
+    with pytest.raises(B.BdrError):
+        a.update_on_batch(obs, act, nobs, rew, term)
+    act[3] = 5
+    assert np.isfinite(a.update_on_batch(obs, act, nobs, rew, term)["loss"])
+    a.sync()
+    m = make_mlp_agent(B, batch_size=8)
+    rng = np.random.default_rng(0)
+    mo, mn = rng.standard_normal((8, 4)).astype(np.float32), rng.standard_normal((8, 4)).astype(np.float32)
+    with pytest.raises(B.BdrError) as e:
+        m.update_on_batch(mo, np.array([0, 1, 2, 0, 1, 0, 1, 0]), mn, rew, term)
+    assert e.value.code == 1
+    assert np.isfinite(m.update_on_batch(mo, np.array([0, 1, 1, 0, 1, 0, 1, 0]), mn, rew, term)["loss"])
+    a.close(); m.close()
+
+
+def test_save_params_creates_the_directory_like_the_reference(B, tmp_path):
+    """Agent::save_params calls fs::create_dir_all(path) first (dqn/base.rs:346): a C / Rust caller of bdr_agent_save_params
+    may pass a directory that does not exist yet."""
+    from border_amd import _lib
+    a = make_mlp_agent(B, batch_size=4)
+    d = tmp_path / "new" / "nested" / "dir"
+    _lib.check(_lib.lib().bdr_agent_save_params(a.handle, str(d).encode()))
+    assert sorted(os.listdir(d)) == ["qnet.pt.tch", "qnet_tgt.pt.tch"]
+    f = tmp_path / "a_file"
+    f.write_text("x")
+    with pytest.raises(B.BdrError) as e:
+        _lib.check(_lib.lib().bdr_agent_save_params(a.handle, str(f / "sub").encode()))
+    assert e.value.code == 5
+    a.close()
+
+
+def test_gate_timeout_poisons_the_step_reports_and_recovers(B, tmp_path):
+    """Schedule 3 orders the two backward queues with spin-wait gate kernels.  Forced failure: the queue check is skipped
+    (BDR_SKIP_QUEUE_CHECK) while the hardware-queue pool is 2, so a gate sits in front of its own producer and must time out
+    (20 ms limit).  Required behaviour: no hang; parameter-writing kernels behind the failed gate are skipped (the
+    parameters after the failed steps are the initial ones, bit for bit); the failure is reported - by bdr_agent_sync and by
+    the asynchronous poll of a loop that only calls Agent::opt - and cleared; the agent then continues with event ordering
+    and trains normally."""
+    import subprocess
+    import sys
+    script = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import border_amd as B
+rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=2000, seed=42), (4, 1, 84, 84), "uint8")
+rb.fill_synthetic(2000, seed=3, kind=0, n_actions=6)
+cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=6), opt_config=B.OptimizerConfig.Adam(1e-4)),
+                  device=0, batch_size=32, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, param_seed=5)
+a = B.Dqn.build(cfg); a.train()
+p0 = a.get_params("qnet")
+mode = sys.argv[1]
+if mode == "sync":
+    for _ in range(3): a.opt(rb)
+    try:
+        a.sync(); print("NO_ERROR")
+    except B.BdrError as e:
+        print("ERR", e.code, "gate" in str(e))
+else:          # a loop that never synchronises: the poll inside Agent::opt must surface the failure
+    seen = None
+    for k in range(1500):
+        try:
+            a.opt(rb)
+        except B.BdrError as e:
+            seen = (k, e.code, "gate" in str(e)); break
+    print("ERR" if seen else "NO_ERROR", *(seen or ()))
+print("SAME", bool((a.get_params("qnet") == p0).all()))
+a.sync()                                   # clean again
+for _ in range(5): a.opt(rb)
+rec = a.opt_with_record(rb)
+print("LOSS", np.isfinite(rec["loss"]), "MOVED", bool((a.get_params("qnet") != p0).any()))
+""" % os.path.join(os.path.dirname(__file__), "..")
+    for mode in ("sync", "poll"):
+        env = dict(os.environ)
+        env.pop("BDR_SCHED", None)
+        env.update(GPU_MAX_HW_QUEUES="2", BDR_SKIP_QUEUE_CHECK="1", BDR_GATE_LIMIT_MS="20")
+        r = subprocess.run([sys.executable, "-c", script, mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        out = r.stdout.split("\n")
+        assert out[0].startswith("ERR") and " 3 " in out[0] + " " and "True" in out[0], (mode, r.stdout, r.stderr[-500:])
+        assert out[1] == "SAME True", (mode, r.stdout)
+        assert out[2] == "LOSS True MOVED True", (mode, r.stdout)
+        assert "continues with event ordering" in r.stderr, r.stderr[-500:]

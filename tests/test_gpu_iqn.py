@@ -85,6 +85,43 @@ def test_iqn_cnn_64_quantiles_vs_oracle(B):
     a.close()
 
 
+def test_iqn_baseline_config4_full_size_vs_oracle(B):
+    """BASELINE config 4 at its real size: batch 512, 64 prediction / 64 target quantiles, Nature-CNN trunk (F = 3136,
+    embed 64, merge Mlp(3136, [512], 6)) - one Iqn::update_critic (iqn/base.rs:63-170) against the C oracle (OpenMP on the
+    host cores: [32768][3136] x [3136][512] layers, seconds on the GPU box): quantile values of both networks <= 1e-4
+    relative (north_star's bar on Q-values), the quantile-Huber loss, and every parameter gradient."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    Bsz, NQ, A = 512, 64, 6
+    sh = T.iqn_shapes("cnn", 3136, 64, [512], A)
+    p0 = T.init_params(sh[0] + sh[1] + sh[2], 41)
+    a = _agent(B, "cnn", 3136, 64, [512], A, None, [], Bsz, 1e-4, p0, tau=1.0, soft_update_interval=10000)
+    ref = O.IqnOracle("cnn", p0, lr=1e-4, feature_dim=3136, embed_dim=64, f_units=[512], n_actions=A, tau=1.0, soft_update_interval=10000)
+    batch = T.iqn_batch(Bsz, "cnn", A, NQ, NQ, 123)
+    rec = a.update_on_batch(*batch)
+    r = ref.update(*batch)
+    assert abs(rec["loss_critic"] - r["loss"]) <= QTOL * abs(r["loss"]), (rec, r["loss"])
+    g = a.get_params("grad")
+    assert rel(g, r["grads"]) < 5e-4, rel(g, r["grads"])
+    o = 0
+    for shp in sh[0] + sh[1] + sh[2]:       # per variable, relative to that variable's own scale
+        n = int(np.prod(shp))
+        assert rel(g[o:o + n], r["grads"][o:o + n]) < 2e-3, (shp, rel(g[o:o + n], r["grads"][o:o + n]))
+        o += n
+    # parameters after the Adam step: |delta| <= lr, compare the step itself
+    p1 = a.get_params("iqn")
+    assert np.abs(p1.astype(np.float64) - ref.p).max() < 0.1 * 1e-4
+    # forward values of the UPDATED online net and the target net on a 64-row slice (host copies of [64][64][6])
+    sl = slice(0, 64)
+    z_on = a.forward(batch[0][sl], batch[5][sl], "iqn")
+    z_tg = a.forward(batch[2][sl], batch[6][sl], "iqn_tgt")
+    assert rel(z_tg, r["z_tgt"][sl]) < QTOL, rel(z_tg, r["z_tgt"][sl])
+    ref2 = O.IqnOracle("cnn", ref.p, lr=1e-4, feature_dim=3136, embed_dim=64, f_units=[512], n_actions=A)
+    r2 = ref2.update(*[np.asarray(x)[sl] for x in batch])
+    assert rel(z_on, r2["z_pred"]) < QTOL, rel(z_on, r2["z_pred"])
+    a.close()
+
+
 def test_iqn_opt_over_replay_and_qvalues(B, tmp_path):
     """Agent::opt over the HBM ring with device-drawn percent points (Uniform64, batch 32): finite loss, counters,
     checkpoint round trip; Policy::sample's averaged action values == mean over Const32's 33 points of forward()."""
@@ -111,3 +148,24 @@ def test_iqn_opt_over_replay_and_qvalues(B, tmp_path):
     names = [n for n, _ in torch.jit.load(files[0]).named_parameters()]
     assert "iqn_cos_to_feature.weight" in names and "iqn_cos_to_feature.bias" in names
     a.close(); b.close(); rb.close()
+
+
+def test_device_percent_point_stream_is_uniform_reproducible_and_disjoint(B):
+    """IqnSample::Uniform* draws tau ~ U[0,1) (iqn/model/base.rs:365-368, Tensor::rand in the reference); here a counter-based
+    device generator keyed by (seed, running counter): range, moments, bucket counts, reproducibility, stream continuation."""
+    def agent(seed):
+        return B.Iqn.build(B.IqnConfig(f_config=B.MlpConfig(in_dim=4, units=(64,), out_dim=64, activation_out=True), feature_dim=64, embed_dim=64,
+                                       m_units=(64,), n_actions=2, lr=1e-3, batch_size=4, device=0, seed=seed))
+    a, b, c = agent(3), agent(3), agent(4)
+    n = 1 << 20
+    x = a.draw_noise(n).astype(np.float64)
+    assert x.min() >= 0.0 and x.max() < 1.0
+    assert abs(x.mean() - 0.5) < 4 * np.sqrt(1 / 12 / n) and abs(x.var() - 1 / 12) < 1e-3
+    counts = np.bincount((x * 64).astype(int), minlength=64)
+    chi2 = ((counts - n / 64) ** 2 / (n / 64)).sum()
+    assert chi2 < 120, chi2                                                             # 63 dof: mean 63, 99.99 % below ~115
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 0.005
+    assert (np.concatenate([b.draw_noise(777), b.draw_noise(n - 777)]) == x.astype(np.float32)).all()
+    assert abs(np.corrcoef(x, c.draw_noise(n).astype(np.float64))[0, 1]) < 0.005
+    for h in (a, b, c):
+        h.close()

@@ -272,3 +272,32 @@ def test_per_opt_stream_is_deterministic_and_overlap_invariant(B):
     for sched in (None, 0, 1, 3):
         p, t, n = run(sched)
         assert n == 100 and (p1 == p).all() and (t1 == t).all(), sched
+
+
+def test_nan_priority_is_reported_and_the_tree_stays_finite(B):
+    """SumTree::update panics when `change` is NaN (sum_tree.rs:101-104).  The library never aborts: the offending updates
+    are dropped (leaf and partial sums keep their values), a device flag is raised and the call reports BDR_ERR_INVALID."""
+    cap = 64
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=1, per_config=B.PerConfig(alpha=1.0)), (4,), np.float32)
+    rng = np.random.default_rng(0)
+    n = 40
+    rb.push(rng.standard_normal((n, 4)).astype(np.float32), np.zeros((n, 1), np.int64), rng.standard_normal((n, 4)).astype(np.float32),
+            np.zeros(n, np.float32), np.zeros(n, np.int8), np.zeros(n, np.int8))
+    rb.update_priority(np.arange(8), np.linspace(0.1, 0.8, 8).astype(np.float32))
+    before = rb.per_tree()
+    with pytest.raises(B.BdrError) as e:
+        rb.update_priority(np.array([3, 5, 7]), np.array([0.5, np.nan, 0.25], np.float32))
+    assert e.value.code == 1 and "NaN" in str(e.value)
+    after = rb.per_tree()
+    assert np.isfinite(after).all()
+    leaves = cap - 1
+    assert after[leaves + 5] == before[leaves + 5]                      # the NaN update was dropped
+    assert after[leaves + 3] != before[leaves + 3] and after[leaves + 7] != before[leaves + 7]   # the others were applied
+    rb.update_priority(np.array([1]), np.array([0.3], np.float32))       # the flag was cleared
+    assert np.isfinite(rb.per_info()["total"])
+    # a rejected synthetic fill must not have touched the ring (the precondition is checked first)
+    o0 = rb.read_rows(0, 4)[0].copy()
+    with pytest.raises(B.BdrError):
+        rb.fill_synthetic(10, seed=1, kind=1, n_actions=2)
+    assert (rb.read_rows(0, 4)[0] == o0).all()
+    rb.close()

@@ -182,3 +182,69 @@ def test_baseline_size_ring_one_million_transitions(B):
             assert (ixs == want).all(), it
     assert int(want.max()) < cap
     rb.close()
+
+
+def test_sac_baseline_ring_one_million_f32_transitions(B):
+    """BASELINE configuration 5 at its real size: a 1 000 000-transition ring of HalfCheetah-shaped rows (obs 17 x f32,
+    act 6 x f32), batch 1024.  The indices of the first 1 000 batches are identical to the CPU restatement of
+    `ReplayBufferBase::batch` (base.rs:384-390); the gathered rows are the ring rows at those indices (every field of every
+    row against the counter-based fill, a function of the transition index alone); pushes at the end of the ring wrap to
+    row 0 (base.rs:295-316)."""
+    import ctypes as C
+    from border_amd import _lib
+    from oracle import oracle as O
+    from tests import synth
+    cap, bs, od, ad = 1_000_000, 1024, 17, 6
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (od,), np.float32, (ad,), np.float32)
+    rb.fill_synthetic(cap - 3, seed=7, kind=1, n_actions=0)
+    assert rb.len() == cap - 3 and rb.head == cap - 3
+    rng = np.random.default_rng(1)
+    pobs = rng.standard_normal((8, od)).astype(np.float32)
+    pnext = rng.standard_normal((8, od)).astype(np.float32)
+    pact = rng.uniform(-1, 1, (8, ad)).astype(np.float32)
+    prew = rng.standard_normal(8).astype(np.float32)
+    pterm = (rng.random(8) < .5).astype(np.int8)
+    rb.push(pobs, pact, pnext, prew, pterm, np.zeros(8, np.int8))
+    assert rb.len() == cap and rb.head == 5
+    pushed = {(cap - 3 + k) % cap: k for k in range(8)}
+
+    def rows(ixs):
+        ixs = np.asarray(ixs, np.uint64)
+        obs, act, nobs, rew, term = (np.empty((len(ixs), od), np.float32), np.empty((len(ixs), ad), np.float32),
+                                     np.empty((len(ixs), od), np.float32), np.empty(len(ixs), np.float32), np.empty(len(ixs), np.int8))
+        t = ixs[:, None]
+        obs[:] = synth._normal(synth.synth_hash(7, t, 0, np.arange(od, dtype=np.uint64)[None]))
+        nobs[:] = synth._normal(synth.synth_hash(7, t, 1, np.arange(od, dtype=np.uint64)[None]))
+        act[:] = (synth.synth_hash(7, t, 3, np.arange(ad, dtype=np.uint64)[None]) >> np.uint64(40)).astype(np.float32) * np.float32(2.0 / 16777216.0) - np.float32(1.0)
+        rew[:] = synth._normal(synth.synth_hash(7, ixs, 2, 2))
+        term[:] = ((synth.synth_hash(7, ixs, 2, 1) >> np.uint64(40)).astype(np.int64) < 83886)
+        for j, ix in enumerate(ixs):
+            k = pushed.get(int(ix))
+            if k is not None:
+                obs[j], act[j], nobs[j], rew[j], term[j] = pobs[k], pact[k], pnext[k], prew[k], pterm[k]
+        return obs, act, nobs, rew, term
+
+    e = synth.f32_rows(7, 100, 4, od, ad)       # the vectorised helper and the row-wise form agree
+    r = rows(np.arange(100, 104))
+    assert all((np.asarray(x) == np.asarray(y)).all() for x, y in zip(e[:5], r))
+    ref = O.StdRng.seed_from_u64(42)
+    ixs = np.empty(bs, np.uint64)
+    L = _lib.lib()
+    for it in range(1000):
+        want = ref.sample_indices(cap, bs)
+        if it % 100 == 0:
+            g = rb.batch(bs)
+            assert (g.ix_sample == want).all()
+            o, a, n, rw, tm = rows(want)
+            assert (g.obs.view(np.uint32) == o.view(np.uint32)).all() and (g.next_obs.view(np.uint32) == n.view(np.uint32)).all()
+            assert (g.act.view(np.uint32) == a.view(np.uint32)).all() and (g.reward.view(np.uint32) == rw.view(np.uint32)).all()
+            assert (g.is_terminated == tm).all() and (g.is_truncated == 0).all()
+        else:
+            _lib.check(L.bdr_replay_batch(rb.handle, bs, ixs.ctypes.data_as(C.c_void_p), None, None, None, None, None, None))
+            assert (ixs == want).all(), it
+    # the pushed rows are what the ring holds at the wrap
+    o, a, n, rw, tm, _ = rb.read_rows(cap - 3, 3)
+    assert (o == pobs[:3]).all() and (a == pact[:3]).all() and (rw == prew[:3]).all() and (tm == pterm[:3]).all()
+    o, a, n, rw, tm, _ = rb.read_rows(0, 5)
+    assert (o == pobs[3:]).all() and (n == pnext[3:]).all() and (rw == prew[3:]).all()
+    rb.close()

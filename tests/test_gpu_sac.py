@@ -122,3 +122,33 @@ def test_sac_opt_over_replay_and_sample(B, tmp_path):
     b.load_params(str(tmp_path))
     assert (b.get_params("pi") == pi).all() and (b.get_params("qnet_tgt_1") == a.get_params("qnet_tgt_1")).all()
     a.close(); b.close(); rb.close()
+
+
+def test_device_noise_stream_moments_reproducibility_and_disjointness(B):
+    """The N(0,1) draws of action_logp come from a counter-based device generator (sac.hip k_randn; the reference uses
+    torch's global CPU generator, sac/base.rs:76, so only the distribution can be pinned): moments of a large draw, the same
+    (seed, counter) gives the same numbers, consecutive draws continue the stream without overlap, another seed decorrelates."""
+    def agent(seed):
+        return B.Sac.build(B.SacConfig(obs_dim=3, act_dim=1, pi_units=(64,), q_units=(64,), batch_size=8, device=0, seed=seed))
+    a, b, c = agent(11), agent(11), agent(12)
+    n = 1 << 20
+    x = a.draw_noise(n).astype(np.float64)
+    assert np.isfinite(x).all()
+    assert abs(x.mean()) < 4 / np.sqrt(n) and abs(x.var() - 1.0) < 0.01
+    assert abs((x ** 3).mean()) < 0.02 and abs((x ** 4).mean() - 3.0) < 0.05          # skewness 0, kurtosis 3
+    assert abs(np.mean(np.abs(x) < 1.0) - 0.682689) < 0.003 and abs(np.mean(np.abs(x) > 3.0) - 0.0027) < 0.0005
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 0.005                              # neighbouring counters are independent
+    y1, y2 = b.draw_noise(1000), b.draw_noise(n - 1000)
+    assert (np.concatenate([y1, y2]) == x.astype(np.float32)).all()                   # same stream, split anywhere
+    z = c.draw_noise(n).astype(np.float64)
+    assert abs(np.corrcoef(x, z)[0, 1]) < 0.005 and not (z[:64] == x[:64]).any()
+    # an update consumes 2 * B * act_dim draws: the stream position after opt() is where a fresh agent is after as many draws
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=100, seed=1), (3,), np.float32, (1,), np.float32)
+    rb.fill_synthetic(100, seed=1, kind=1, n_actions=0)
+    d, e = agent(5), agent(5)
+    d.opt(rb); d.sync()
+    e.draw_noise(2 * 8 * 1)
+    assert (d.draw_noise(256) == e.draw_noise(256)).all()
+    for h in (a, b, c, d, e):
+        h.close()
+    rb.close()

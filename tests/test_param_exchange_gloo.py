@@ -50,12 +50,13 @@ def _worker(rank, world, port, out):
     c = FakeAgent(base + rank)
     ex.broadcast(c, root=0)
     ok_bcast = bool((c.get_params() == base).all())
-    # (v) the data-plane ladder: without a GPU neither RCCL communicator can come up, so every rank must land on
-    #     host staging TOGETHER (here rank 1 additionally "fails" one step earlier than rank 0 would)
-    lad = ParamExchange.with_fallback(world, rank, 3, 0, lambda b: b if b is not None else bytes(128))
-    d = FakeAgent(base * (rank + 1))
-    lad.average(d)
-    ok_ladder = lad.backend == "torch" and bool(np.allclose(d.get_params(), expect, rtol=1e-6, atol=1e-7))
+    # (v) RCCL or nothing: without a GPU the communicator cannot come up, and EVERY rank must get the error together
+    #     (no rank left in a collective, no silent demotion to a slower data plane)
+    try:
+        ParamExchange.rccl_or_raise(world, rank, 3, 0, lambda b: b if b is not None else bytes(128))
+        ok_ladder = False
+    except RuntimeError as e:
+        ok_ladder = "RCCL communicator could not be initialised" in str(e)
     # (iv) distinct replay streams per shard
     ix = O.StdRng.seed_from_u64(shard_seed(42, rank)).sample_indices(1_000_000, 8).tolist()
     out.put((rank, ok_identity, ok_mean, ok_bcast and ok_ladder, ix))

@@ -12,3 +12,5 @@ from . import checkpoint  # noqa: F401
 from .atari import AtariPreprocessor  # noqa: F401
 from .trainer import (NativeTrainer, ParamExchange, Sampler, SimpleStepProcessor, Step, SyntheticEnv, Trainer, TrainerConfig,  # noqa: F401
                       shard_seed)
+from .async_trainer import (ActorManagerConfig, ActorStat, AsyncTrainer, AsyncTrainerConfig, AsyncTrainStat, ModelMailbox,  # noqa: F401
+                            actor_stats_fmt)

@@ -149,6 +149,8 @@ ABI_SYMBOLS = [
     "bdr_atari_prep_create", "bdr_atari_prep_destroy", "bdr_atari_prep_reset", "bdr_atari_prep_step", "bdr_atari_prep_obs",
     "bdr_atari_prep_device_stacks", "bdr_atari_clip_reward",
     "bdr_trainer_config_default", "bdr_trainer_ops_default", "bdr_trainer_train", "bdr_trainer_train_offline",
+    "bdr_model_mailbox_create", "bdr_model_mailbox_destroy", "bdr_agent_publish_model", "bdr_agent_sync_model_from",
+    "bdr_async_trainer_config_default", "bdr_learner_ops_default", "bdr_actor_ops_default", "bdr_async_train",
 ]
 
 _lib = None
@@ -173,7 +175,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)  # AttributeError here == ABI drift
         if name not in ("bdr_last_error", "bdr_version", "bdr_dqn_config_default", "bdr_sac_config_default", "bdr_iqn_config_default",
                         "bdr_explorer_config_default", "bdr_per_config_default", "bdr_atari_clip_reward", "bdr_trainer_config_default",
-                        "bdr_trainer_ops_default"):
+                        "bdr_trainer_ops_default", "bdr_async_trainer_config_default", "bdr_learner_ops_default", "bdr_actor_ops_default"):
             fn.restype = C.c_int32
     L.bdr_trainer_config_default.restype = None
     L.bdr_trainer_ops_default.restype = None

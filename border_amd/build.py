@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libborder_amd.so")
-SOURCES = ["replay.hip", "per.hip", "agent_api.hip", "dqn.hip", "mlp_agents.hip", "sac.hip", "iqn.hip", "comm.hip", "atari_prep.hip", "trainer.hip"]  # missing files are skipped
+SOURCES = ["replay.hip", "per.hip", "agent_api.hip", "dqn.hip", "mlp_agents.hip", "sac.hip", "iqn.hip", "comm.hip", "atari_prep.hip", "trainer.hip", "async_trainer.hip"]  # missing files are skipped
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))) + ["../../include/border_amd.h"]
 
 

@@ -80,6 +80,7 @@ class SimpleReplayBuffer:
     def __init__(self, config: SimpleReplayBufferConfig, obs_shape, obs_dtype, act_shape=(1,), act_dtype=np.int64,
                  device: int = 0):
         self.config = config
+        self.device = device
         self.obs_shape, self.obs_dtype = tuple(obs_shape), np.dtype(obs_dtype)
         self.act_shape, self.act_dtype = tuple(act_shape), np.dtype(act_dtype)
         self.obs_bytes = int(np.prod(self.obs_shape)) * self.obs_dtype.itemsize

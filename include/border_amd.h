@@ -381,6 +381,88 @@ BDR_API int32_t bdr_trainer_train(const bdr_trainer_config* c, const bdr_trainer
 BDR_API int32_t bdr_trainer_train_offline(const bdr_trainer_config* c, const bdr_trainer_ops* ops, bdr_trainer_observer observer,
                                           void* observer_ctx, bdr_trainer_stats* out);
 
+/* ---- border-async-trainer (border-async-trainer/src) -----------------------------------------------------------------------
+ * The reference runs one learner thread (AsyncTrainer::train, async_trainer/base.rs:299-388) and n actor threads (Actor::run,
+ * actor/base.rs:120-178) in one process: actors sample with their own agent + env, buffer n_buffer transitions in a
+ * ReplayBufferProxy (replay_buffer_proxy.rs:52-72) and try_send them as one PushedItemMessage; the learner drains the channel
+ * into its replay buffer (update_replay_buffer, :275-284), does not optimise until buffer.len() >= warmup_period (:210,
+ * 328-335), and every sync_interval opt steps sends (n_opts, model_info) back (sync, :268-272); an actor adopts a model that is
+ * newer than the one it has (actor/base.rs:104-118).
+ * Here: csrc/async_trainer.hip, compiled, behind function tables like the Trainer above.  One rank per GPU = one learner + its
+ * actors + its local replay shard; `exchange` (optional) runs at every sync point before the local publish and is where the
+ * ranks average their learners over RCCL (bdr_agent_allreduce_params).  The model channel is a device-resident mailbox:
+ * publish = one device-to-device copy on the learner's stream, sync = one copy on the actor's stream, ordered by events. */
+typedef struct bdr_model_mailbox bdr_model_mailbox;
+BDR_API int32_t bdr_model_mailbox_create(int32_t device, uint64_t n_floats, uint32_t n_readers, bdr_model_mailbox** out);
+BDR_API int32_t bdr_model_mailbox_destroy(bdr_model_mailbox* m);
+/* SyncModel::model_info + send (dqn/base.rs:377-389, async_trainer/base.rs:268-272): arena `which` (bdr_agent_arena_device_ptr)
+ * of the learner -> mailbox, tagged n_opts.  Asynchronous on the agent's stream. */
+BDR_API int32_t bdr_agent_publish_model(bdr_agent* a, int32_t which, bdr_model_mailbox* m, uint64_t n_opts);
+/* Actor::sync_model (actor/base.rs:104-118): copies the mailbox into the agent iff mailbox.n_opts > *n_opts_inout (or `first`:
+ * sync_model_first, :98-102), then *n_opts_inout = mailbox.n_opts, *updated = 1.  reader: the actor's index (< n_readers). */
+BDR_API int32_t bdr_agent_sync_model_from(bdr_agent* a, int32_t which, bdr_model_mailbox* m, uint32_t reader, int32_t first,
+                                          uint64_t* n_opts_inout, int32_t* updated);
+
+typedef struct bdr_async_trainer_config {   /* async_trainer/config.rs:13-36 (defaults :101-112) + ActorManagerConfig::n_buffer */
+    uint64_t max_opts;
+    uint64_t warmup_period;                 /* transitions in the learner's buffer before the first opt */
+    uint64_t sync_interval;                 /* opt steps between model syncs (default 100; dqn_atari_async_tch: 1) */
+    uint64_t record_agent_info_interval;    /* 0 = never */
+    uint64_t record_compute_cost_interval;  /* 0 = never */
+    uint64_t n_buffer;                      /* ReplayBufferProxyConfig::n_buffer: transitions per message (100) */
+    uint64_t channel_capacity;              /* bounded(1000), actor_manager/base.rs:140 */
+    uint64_t warmup_sleep_ms;               /* the 100 ms pause between warm-up and training (async_trainer/base.rs:331) */
+    uint64_t obs_row_bytes, act_row_bytes;
+} bdr_async_trainer_config;
+
+typedef struct bdr_learner_ops {
+    bdr_trainer_ops t;                      /* agent, buffer, set_train, opt, opt_with_record, buffer_push */
+    int32_t (*buffer_len)(void* buffer, uint64_t* len);                                  /* ExperienceBufferBase::len */
+    int32_t (*publish_model)(void* agent, void* mailbox, uint64_t n_opts);               /* AsyncTrainer::sync */
+    void* mailbox;
+    int32_t (*exchange)(void* ctx, void* agent, uint64_t opt_steps);                     /* optional: cross-GPU averaging at a sync point */
+    void* exchange_ctx;
+} bdr_learner_ops;
+
+typedef struct bdr_actor_ops {              /* one Actor: its own agent (built from its own config) and environment */
+    void* agent;
+    void* mailbox;
+    int32_t (*agent_set_train)(void* agent, int32_t train);
+    int32_t (*agent_sample)(void* agent, uint64_t n_procs, const void* obs, void* act_out);
+    int32_t (*sync_model)(void* agent, void* mailbox, uint32_t actor_id, int32_t first, uint64_t* n_opts_inout, int32_t* updated);
+    bdr_env_vtable env;
+} bdr_actor_ops;
+
+typedef struct bdr_async_stats {            /* AsyncTrainStat (async_trainer/stat.rs) + counters */
+    uint64_t samples_total, opt_steps, n_records, n_syncs, n_messages;
+    double duration_s;
+    float samples_per_sec, opt_per_sec;
+} bdr_async_stats;
+typedef struct bdr_actor_stat { uint64_t env_steps, n_syncs; double duration_s; } bdr_actor_stat;   /* ActorStat (actor/stat.rs) */
+
+/* observer(ctx, actor, a, b, event, scalars, n): never called concurrently.  actor = UINT32_MAX for learner events.
+ *   SKIP / OPT / OPT_RECORD   a = samples_total, b = opt_steps after the step, scalars = the Record of opt_with_record
+ *   SYNC                      the learner published the model of b = opt_steps
+ *   PUSH                      a message of n transitions of `actor` entered the buffer (a = samples_total after it)
+ *   COST                      scalars = {average_opt_time, average_sample_time} in ms
+ *   ACTOR_SYNC                `actor` adopted the model of b opt steps before its env step a */
+#define BDR_ASYNC_EVENT_SKIP 0
+#define BDR_ASYNC_EVENT_OPT 1
+#define BDR_ASYNC_EVENT_OPT_RECORD 2
+#define BDR_ASYNC_EVENT_COST 3
+#define BDR_ASYNC_EVENT_SYNC 4
+#define BDR_ASYNC_EVENT_PUSH 5
+#define BDR_ASYNC_EVENT_ACTOR_SYNC 6
+typedef void (*bdr_async_observer)(void* ctx, uint32_t actor, uint64_t a, uint64_t b, int32_t event, const float* scalars, int32_t n);
+
+BDR_API void bdr_async_trainer_config_default(bdr_async_trainer_config* c);
+BDR_API void bdr_learner_ops_default(bdr_learner_ops* ops, bdr_agent* agent, bdr_replay* buffer, bdr_model_mailbox* mailbox);
+BDR_API void bdr_actor_ops_default(bdr_actor_ops* ops, bdr_agent* agent, bdr_model_mailbox* mailbox, const bdr_env_vtable* env);
+/* train_async (util.rs:31-92): runs until the learner has done max_opts opt steps; returns the first error of any thread. */
+BDR_API int32_t bdr_async_train(const bdr_async_trainer_config* c, const bdr_learner_ops* learner, const bdr_actor_ops* actors,
+                                uint32_t n_actors, bdr_async_observer observer, void* observer_ctx, bdr_async_stats* out,
+                                bdr_actor_stat* actor_stats);
+
 /* border-atari-env frame preprocessing on the device (border-atari-env/src/env.rs):
  * one handle keeps the `frames: [4][84][84]` u8 stack of n_envs environments in HBM (newest frame first).
  *   reset  env.rs:263-296   all four slots <- warp_and_grayscale(frame)

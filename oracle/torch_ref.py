@@ -188,14 +188,19 @@ def synthetic_atari_batch(B: int, A: int, seed: int):
     return obs, act, next_obs, reward, term
 
 
-def _timed(one, steps, warmup):
+def _timed(one, steps, warmup, seconds=None):
+    """steps/s over `steps` steps - or, with `seconds`, over as many steps (>= 1, <= steps) as fit that much time."""
     import time
     for _ in range(warmup):
         one()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    n = 0
+    while n < steps:
         one()
-    return steps / (time.perf_counter() - t0), torch.get_num_threads()
+        n += 1
+        if seconds is not None and time.perf_counter() - t0 >= seconds:
+            break
+    return n / (time.perf_counter() - t0), torch.get_num_threads()
 
 
 _RINGS = {}
@@ -224,7 +229,7 @@ def _f32_ring(capacity, n_actions):
 
 
 def time_dqn_atari(batch_size=256, n_actions=6, steps=5, warmup=1, threads=None, capacity=65536,
-                   critic_loss="SmoothL1"):
+                   critic_loss="SmoothL1", seconds=None):
     """CPU baseline: sample (index draw + 3x index_select on an f32 ring of 65 536 transitions, as the
     reference stores it) + update, timed like Trainer::train_step (border-core/src/trainer.rs:213-225).  Returns
     (opt-steps/sec, threads used)."""
@@ -243,10 +248,10 @@ def time_dqn_atari(batch_size=256, n_actions=6, steps=5, warmup=1, threads=None,
         act = ring_act.index_select(0, ixs).numpy()
         agent.update(obs, act, nobs, ring_rew[ixs].numpy(), ring_term[ixs].numpy())
 
-    return _timed(one, steps, warmup)
+    return _timed(one, steps, warmup, seconds)
 
 
-def time_dqn_cartpole(batch_size=32, steps=50, warmup=5, threads=None, capacity=10000):
+def time_dqn_cartpole(batch_size=32, steps=50, warmup=5, threads=None, capacity=10000, seconds=None):
     """BASELINE config 1 on the CPU path: Mlp[64,64], obs 4 f32, 2 actions, MSE, Adam 1e-3, tau 0.01 every opt."""
     if threads:
         torch.set_num_threads(threads)
@@ -262,20 +267,20 @@ def time_dqn_cartpole(batch_size=32, steps=50, warmup=5, threads=None, capacity=
         agent.update(obs.index_select(0, ixs).numpy(), act.index_select(0, ixs).numpy(), nobs.index_select(0, ixs).numpy(),
                      rew[ixs].numpy(), term[ixs].numpy())
 
-    return _timed(one, steps, warmup)
+    return _timed(one, steps, warmup, seconds)
 
 
-def time_iqn_atari(batch_size=512, steps=2, warmup=1, threads=None, n_actions=6, n_quantiles=64):
+def time_iqn_atari(batch_size=512, steps=2, warmup=1, threads=None, n_actions=6, n_quantiles=64, seconds=None):
     """BASELINE config 4 on the CPU path (fixed minibatch: the gather is negligible next to 0.5 TFLOP of update)."""
     if threads:
         torch.set_num_threads(threads)
     sh = iqn_shapes("cnn", 3136, 64, [512], n_actions)
     agent = TorchIqn("cnn", sh, init_params(sh[0] + sh[1] + sh[2], 0), lr=1e-4, feature_dim=3136, embed_dim=64, tau=1.0, soft_update_interval=10000)
     batch = iqn_batch(batch_size, "cnn", n_actions, n_quantiles, n_quantiles, 1)
-    return _timed(lambda: agent.update(*batch), steps, warmup)
+    return _timed(lambda: agent.update(*batch), steps, warmup, seconds)
 
 
-def time_sac(batch_size=1024, steps=20, warmup=2, threads=None, obs_dim=17, act_dim=6):
+def time_sac(batch_size=1024, steps=20, warmup=2, threads=None, obs_dim=17, act_dim=6, seconds=None):
     """BASELINE config 5 on the CPU path: twin-Q [256,256], actor [256,256], Auto entropy coefficient."""
     if threads:
         torch.set_num_threads(threads)
@@ -284,7 +289,7 @@ def time_sac(batch_size=1024, steps=20, warmup=2, threads=None, obs_dim=17, act_
     q0 = [init_params(sac_q_shapes(obs_dim, act_dim, qu), 2 + i) for i in range(2)]
     agent = TorchSac(obs_dim, act_dim, pu, qu, pi0, q0, lr_actor=3e-4, lr_critic=3e-4, ent_coef=("Auto", -6.0, 3e-4))
     batch = sac_batch(batch_size, obs_dim, act_dim, 3)
-    return _timed(lambda: agent.update(*batch), steps, warmup)
+    return _timed(lambda: agent.update(*batch), steps, warmup, seconds)
 
 
 def time_c_oracle_dqn(batch_size=256, n_actions=6, critic_loss="SmoothL1"):

@@ -438,6 +438,36 @@ int32_t bdr_dqn_update_on_batch_weighted(bdr_agent* a, uint64_t n, const void* o
     return BDR_OK;
 }
 
+// update_critic up to loss.backward() on a host minibatch (gradients -> arena 4; parameters, moments, counters untouched)
+int32_t bdr_dqn_grads_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
+                               const float* reward, const int8_t* term, bdr_dqn_record* rec)
+{
+    BDR_REQUIRE(a && obs && act && next_obs && reward && term, "null argument");
+    BDR_REQUIRE(is_dqn(a), "not a DQN agent");
+    BDR_REQUIRE(n >= 1 && n <= 65536, "batch size out of range");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(a->grads_on_batch(n, obs, act, next_obs, reward, term));
+    prof_collect(a);
+    BDR_TRY(a->err_check());
+    if (rec) {
+        float v[128]; int k = 0;
+        BDR_TRY(a->record(v, 128, &k));
+        rec->loss = v[0]; rec->has_verbose = k >= 5;
+        if (k >= 5) { rec->pred_mean = v[1]; rec->reward_mean = v[2]; rec->tgt_mean = v[3]; rec->tgt_minus_pred_mean = v[4]; }
+    }
+    return BDR_OK;
+}
+
+// the optimizer step (opt.rs:74-83 `step`) on the gradient arena + the bookkeeping of opt_ (dqn/base.rs:190-198)
+int32_t bdr_agent_apply_grads(bdr_agent* a)
+{
+    BDR_REQUIRE(a, "null agent");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(a->apply_grads());
+    prof_collect(a);
+    return BDR_OK;
+}
+
 // action values [n][A] of any value-based agent, on the host
 static int32_t action_values(bdr_agent* a, uint64_t n, const void* obs, std::vector<float>& q, int* A_out)
 {
@@ -704,4 +734,5 @@ float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* strea
     return a->arena(which, n_floats);
 }
 int32_t agent_scale(bdr_agent* a, float* p, size_t n, float s) { return launch_scale(a->stream, p, n, s); }
+void agent_set_grad_comm(bdr_agent* a, void* comm, int32_t (*reduce)(bdr_agent*, void*)) { a->grad_comm = comm; a->grad_reduce = reduce; }
 }  // namespace bdr

@@ -106,6 +106,18 @@ struct bdr_agent {
     int32_t err_check();   // the stream has just been synchronised: read, report, clear
     int32_t err_poll();    // no synchronisation: look at the last asynchronous read-back, enqueue the next one when due
     virtual void on_gate_timeout() {}   // DqnCnn: fall back to event ordering
+    // Synchronous data-parallel mode (SURVEY.md 8(e) "Collective", last sentence): opt() = backward -> all-reduce of the
+    // gradient arena over the communicator (sum, then 1/N) -> optimizer step, so that N ranks with batch B/N each take exactly
+    // the step one rank takes on the concatenated batch.  grad_reduce is installed by bdr_agent_set_grad_comm (comm.hip).
+    void* grad_comm = nullptr;
+    int32_t (*grad_reduce)(bdr_agent*, void*) = nullptr;
+    // update_critic up to `loss.backward()` on a host minibatch: gradients land in the gradient arena, parameters and
+    // optimizer state are untouched; apply_grads = the optimizer step on whatever the gradient arena holds + opt_ bookkeeping
+    virtual int32_t grads_on_batch(uint64_t, const void*, const int64_t*, const void*, const float*, const int8_t*)
+    {
+        return ::bdr::fail(BDR_ERR_INVALID, "this agent kind has no split backward / optimizer step");
+    }
+    virtual int32_t apply_grads() { return ::bdr::fail(BDR_ERR_INVALID, "this agent kind has no split backward / optimizer step"); }
     int32_t act_buffer(size_t bytes, void** out)
     {
         if (bytes > act_stage_bytes) {

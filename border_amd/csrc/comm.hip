@@ -13,6 +13,7 @@ using namespace bdr;
 namespace bdr {
 float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* stream, int* device);
 int32_t agent_scale(bdr_agent* a, float* p, size_t n, float s);
+void agent_set_grad_comm(bdr_agent* a, void* comm, int32_t (*reduce)(bdr_agent*, void*));
 }
 
 namespace {
@@ -102,6 +103,31 @@ int32_t bdr_agent_allreduce_params(bdr_agent* a, bdr_comm* c, int32_t which)
     BDR_HIP(hipSetDevice(dev));
     BDR_NCCL(g_rccl.AllReduce(p, p, n, kNcclFloat, kNcclSum, c->comm, s));
     return agent_scale(a, p, n, 1.0f / (float)c->nranks);
+}
+
+// Synchronous data-parallel mode: every Agent::opt of `a` all-reduces its gradient arena (sum, 1/nranks) between backward and the
+// optimizer step (agent_base.hpp grad_comm).  c == NULL switches back to independent steps.
+static int32_t grad_reduce_rccl(bdr_agent* a, void* comm)
+{
+    bdr_comm* c = (bdr_comm*)comm;
+    size_t n = 0; hipStream_t s = nullptr; int dev = 0;
+    float* g = agent_arena(a, 4, &n, &s, &dev);
+    BDR_REQUIRE(g, "agent has no gradient arena");
+    BDR_NCCL(g_rccl.AllReduce(g, g, n, kNcclFloat, kNcclSum, c->comm, s));
+    if (c->nranks == 1) return BDR_OK;
+    return agent_scale(a, g, n, 1.0f / (float)c->nranks);
+}
+
+int32_t bdr_agent_set_grad_comm(bdr_agent* a, bdr_comm* c)
+{
+    BDR_REQUIRE(a, "null agent");
+    if (c) {
+        int dev = 0;
+        BDR_REQUIRE(agent_arena(a, 4, nullptr, nullptr, &dev), "agent has no gradient arena");
+        BDR_REQUIRE(dev == c->device, "agent and communicator live on different devices");
+    }
+    agent_set_grad_comm(a, c, c ? grad_reduce_rccl : nullptr);
+    return BDR_OK;
 }
 
 int32_t bdr_agent_broadcast_params(bdr_agent* a, bdr_comm* c, int32_t which, int32_t root)

@@ -300,6 +300,7 @@ struct DqnCnn : bdr_agent {
     int sched = 3;   // backward schedule, see update_critic (BDR_SCHED=0|1|2; BDR_NO_OVERLAP=1 == 0)
     unsigned long long gate_limit = 1000000000ull;   // gate time limit in 100 MHz ticks (10 s; BDR_GATE_LIMIT_MS for tests)
     bool holds_gate_token = false;                   // see claim_gates()
+    bool defer_adam = false;                         // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
     Arena ar;
     int B = 0;          // activation buffers are sized for this batch
     // parameter arenas
@@ -322,6 +323,8 @@ struct DqnCnn : bdr_agent {
     const char* kind() const override { return "dqn_cnn"; }
     int32_t opt(bdr_replay* r) override;
     void on_gate_timeout() override;
+    int32_t grads_on_batch(uint64_t n, const void* obs, const int64_t* act, const void* next_obs, const float* reward, const int8_t* term) override;
+    int32_t apply_grads() override;
     int32_t record(float* out, int cap, int* n) override;
     void record_keys(std::vector<std::string>& keys) override;
     uint64_t param_count(int which) override;
@@ -388,6 +391,7 @@ struct ReduceAdamArgs {
     AdamScalars s;
     int reduce_blocks;
     const unsigned* poison;  // sig + SIG_ERR: a gate timed out, leave the parameters alone
+    int reduce_only;         // gradients only (the optimizer step follows an all-reduce: synchronous data-parallel mode)
 };
 __device__ __forceinline__ void adam_element(float& p, float g, float& m, float& v, const AdamScalars& s)
 {
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(64) void k_signal(unsigned* sig, int which, unsigne
 
 __global__ __launch_bounds__(256) void k_reduce_adam(ReduceAdamArgs a)
 {
-    const bool poisoned = a.poison && *a.poison != 0;
+    const bool poisoned = a.reduce_only || (a.poison && *a.poison != 0);
     if ((int)blockIdx.x >= a.reduce_blocks) {
         if (poisoned) return;
         const size_t i = a.rest0_4 + (size_t)(blockIdx.x - a.reduce_blocks) * 256 + threadIdx.x;
@@ -653,8 +657,9 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         return BDR_OK;
     };
     const DwPlan pl = dw_plan(a->B);   // buffer layout follows the allocated batch capacity
-    a->adam_step += 1;
-    const AdamScalars adam_s = adam_scalars(c, a->adam_step);
+    const bool defer = a->defer_adam;  // backward only: the optimizer step is apply_grads()
+    if (!defer) a->adam_step += 1;
+    const AdamScalars adam_s = adam_scalars(c, std::max<uint64_t>(a->adam_step, 1));
 
     auto head_bwd = [&]() -> int32_t {
         HeadBwdArgs hb{a->h1[0], a->dq, act, act_bytes, a->loss_row, a->grad + ar.w5, a->grad + ar.b5, a->loss, B, ar.A};
@@ -678,6 +683,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     // their last readers of this step (k_head, DxL1) behind them once DxL1 is done, so their Adam pass - pure HBM
     // streaming - runs under the conv dX GEMMs instead of at the end of the critical path.
     auto adam_l1_l2 = [&]() -> int32_t {
+        if (defer) return BDR_OK;
         Bracket br(a, "adam_l1_l2");
         const size_t r4 = (ar.total - ar.w4) / 4;
         LAUNCH_FL(sd, any, nullptr, k_adam, dim3((unsigned)((r4 + 255) / 256)), dim3(256), a->q + ar.w4, (const float*)(a->grad + ar.w4), a->m + ar.w4,
@@ -793,7 +799,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         // the conv layers' Adam step rides on their partial reduction (k_reduce_adam); l1 / l2: adam_l1_l2 above
         ReduceAdamArgs ra{};
         ra.r = r; ra.p = a->q; ra.g = a->grad; ra.m = a->m; ra.v = a->v; ra.gbase = a->grad;
-        ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg; ra.poison = a->sig + SIG_ERR;
+        ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg; ra.poison = a->sig + SIG_ERR; ra.reduce_only = defer ? 1 : 0;
         Bracket br(a, "reduce_adam");
         hipLaunchKernelGGL(k_reduce_adam, dim3(wg), dim3(256), 0, a->stream, ra);
         BDR_HIP(hipGetLastError());
@@ -820,6 +826,18 @@ int32_t after_updates(DqnCnn* a)
         BDR_TRY(soft_update(a));
     }
     a->n_opts += 1;
+    return BDR_OK;
+}
+
+// the optimizer step over the whole arena (the fused path splits it between k_reduce_adam and the l1 / l2 k_adam)
+int32_t adam_all(DqnCnn* a)
+{
+    a->adam_step += 1;
+    Bracket br(a, "adam_all");
+    const size_t n4 = a->ar.total / 4;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q, (const float*)a->grad, a->m, a->v, n4,
+                       adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR));
+    BDR_HIP(hipGetLastError());
     return BDR_OK;
 }
 
@@ -850,8 +868,15 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
             Bracket br(a, "sample");
             BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->stream));
         }
-        BDR_TRY(update_critic(a, (int)a->cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
-                              replay_batch_weights(r), r));
+        a->defer_adam = a->grad_comm != nullptr;
+        const int32_t st = update_critic(a, (int)a->cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
+                                         replay_batch_weights(r), r);
+        a->defer_adam = false;
+        BDR_TRY(st);
+        if (a->grad_comm) {   // synchronous data-parallel step: mean gradient over the ranks, then everybody's optimizer step
+            { Bracket br(a, "grad_allreduce"); BDR_TRY(a->grad_reduce(a, a->grad_comm)); }
+            BDR_TRY(adam_all(a));
+        }
     }
     return after_updates(a);
 }
@@ -992,6 +1017,12 @@ DqnCnn::~DqnCnn()
 }
 
 int32_t DqnCnn::opt(bdr_replay* r) { return opt_inner(this, r); }
+
+int32_t DqnCnn::apply_grads()
+{
+    BDR_TRY(adam_all(this));
+    return after_updates(this);
+}
 
 static std::vector<NamedTensor> cnn_meta(int A);
 
@@ -1161,12 +1192,24 @@ int32_t dqn_cnn_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, co
     BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, a->stream));
     const float* wd = nullptr;
     if (weight) { BDR_TRY(a->td_buffer(n)); BDR_HIP(hipMemcpyAsync(a->w_stage, weight, n * 4, hipMemcpyHostToDevice, a->stream)); wd = a->w_stage; }
-    BDR_TRY(update_critic(a, (int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term, wd, nullptr));
-    BDR_TRY(after_updates(a));
+    const int32_t st = update_critic(a, (int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term, wd, nullptr);
+    if (st == BDR_OK && !a->defer_adam) BDR_TRY(after_updates(a));
+    BDR_TRY(st);
     BDR_HIP(hipStreamSynchronize(a->stream));   // host buffers may be reused by the caller
     return BDR_OK;
 }
 
+}  // namespace bdr
+
+int32_t DqnCnn::grads_on_batch(uint64_t n, const void* obs, const int64_t* act, const void* next_obs, const float* reward, const int8_t* term)
+{
+    defer_adam = true;
+    const int32_t st = bdr::dqn_cnn_update_on_batch(this, n, obs, act, next_obs, reward, term, nullptr);
+    defer_adam = false;
+    return st;
+}
+
+namespace bdr {
 int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_out)
 {
     DqnCnn* a = static_cast<DqnCnn*>(base);

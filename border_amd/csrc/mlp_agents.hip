@@ -87,6 +87,7 @@ struct DqnMlp : bdr_agent {
     uint64_t u_cap = 0;
     const float* last_reward = nullptr; int last_B = 0;
     uint64_t adam_step = 0, soft_update_counter = 0;
+    bool defer_adam = false;   // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
 
     ~DqnMlp() override
     {
@@ -178,11 +179,22 @@ struct DqnMlp : bdr_agent {
             { Bracket br(a, "mlp_dw"); BDR_TRY(dense_dw(stream, net.L[i], grad, x, dys[i], Bn)); }
             if (i > 0) { Bracket br(a, "mlp_dx"); BDR_TRY(dense_dx(stream, net.L[i], q, dys[i], dys[i - 1], acts[0][i - 1], Bn)); }
         }
-        adam_step += 1;
-        const AdamScalars s = adam_scalars_for(cfg.opt_kind == BDR_OPT_ADAMW, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, adam_step);
-        { Bracket br(a, "adam"); BDR_TRY(launch_adam(stream, q, grad, m, v, net.total, s)); }
+        if (!defer_adam) BDR_TRY(adam_all());
         return BDR_OK;
     }
+    int32_t adam_all()
+    {
+        adam_step += 1;
+        const AdamScalars s = adam_scalars_for(cfg.opt_kind == BDR_OPT_ADAMW, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, adam_step);
+        Bracket br(this, "adam");
+        return launch_adam(stream, q, grad, m, v, net.total, s);
+    }
+    int32_t apply_grads() override
+    {
+        BDR_TRY(adam_all());
+        return after_updates();
+    }
+    int32_t grads_on_batch(uint64_t n, const void* obs, const int64_t* act, const void* next_obs, const float* reward, const int8_t* term) override;
 
     int32_t after_updates()   // dqn/base.rs:190-198
     {
@@ -205,8 +217,15 @@ struct DqnMlp : bdr_agent {
         BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
         for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
             { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, cfg.batch_size, stream)); }
-            BDR_TRY(update_critic((int)cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
-                                  replay_batch_weights(r), r));
+            defer_adam = grad_comm != nullptr;
+            const int32_t st = update_critic((int)cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
+                                             replay_batch_weights(r), r);
+            defer_adam = false;
+            BDR_TRY(st);
+            if (grad_comm) {   // synchronous data-parallel step (see bdr_agent::grad_comm)
+                { Bracket br(this, "grad_allreduce"); BDR_TRY(grad_reduce(this, grad_comm)); }
+                BDR_TRY(adam_all());
+            }
         }
         return after_updates();
     }
@@ -349,11 +368,22 @@ int32_t dqn_mlp_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, co
     const float* wd = nullptr;
     if (weight) { BDR_TRY(a->td_buffer(n)); BDR_HIP(hipMemcpyAsync(a->w_stage, weight, n * 4, hipMemcpyHostToDevice, a->stream)); wd = a->w_stage; }
     BDR_TRY(a->update_critic((int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term, wd, nullptr));
-    BDR_TRY(a->after_updates());
+    if (!a->defer_adam) BDR_TRY(a->after_updates());
     BDR_HIP(hipStreamSynchronize(a->stream));
     return BDR_OK;
 }
 
+}  // namespace bdr
+
+int32_t DqnMlp::grads_on_batch(uint64_t n, const void* obs, const int64_t* act, const void* next_obs, const float* reward, const int8_t* term)
+{
+    defer_adam = true;
+    const int32_t st = bdr::dqn_mlp_update_on_batch(this, n, obs, act, next_obs, reward, term, nullptr);
+    defer_adam = false;
+    return st;
+}
+
+namespace bdr {
 int32_t dqn_mlp_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_out)
 {
     DqnMlp* a = static_cast<DqnMlp*>(base);

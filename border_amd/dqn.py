@@ -250,6 +250,21 @@ class Dqn:
         rec["td_errs"] = td
         return rec
 
+    def grads_on_batch(self, obs, act, next_obs, reward, is_terminated) -> dict:
+        """update_critic up to loss.backward() on a host minibatch: gradients -> get_params("grad"); nothing else changes."""
+        reward = np.ascontiguousarray(reward, dtype=np.float32)
+        n = len(reward)
+        obs, next_obs = np.ascontiguousarray(obs), np.ascontiguousarray(next_obs)
+        act = np.ascontiguousarray(act, dtype=np.int64).reshape(n)
+        term = np.ascontiguousarray(is_terminated, dtype=np.int8)
+        r = _lib.DqnRecordC()
+        _lib.check(_lib.lib().bdr_dqn_grads_on_batch(self._h, n, _p(obs), _p(act), _p(next_obs), _p(reward), _p(term), C.byref(r)))
+        return self._record(r)
+
+    def apply_grads(self) -> None:
+        """The optimizer step on the gradient arena + opt_'s bookkeeping (soft update counter, n_opts)."""
+        _lib.check(_lib.lib().bdr_agent_apply_grads(self._h))
+
     def sync(self):
         _lib.check(_lib.lib().bdr_agent_sync(self._h))
 

@@ -249,6 +249,15 @@ BDR_API int32_t bdr_dqn_update_on_batch_weighted(bdr_agent* a, uint64_t n, const
                                                  const void* next_obs, const float* reward, const int8_t* is_terminated,
                                                  const float* weight, float* td_errs_out, bdr_dqn_record* rec);
 
+/* Split step (synchronous data-parallel training): bdr_dqn_grads_on_batch = update_critic up to
+ * `loss.backward()` (dqn/base.rs:60-150, opt.rs:74-83 without `step`) on a host minibatch - gradients land in arena 4
+ * (bdr_agent_get_params / set_params), parameters, Adam moments and counters are untouched; bdr_agent_apply_grads = the
+ * optimizer step on whatever arena 4 holds, then opt_'s bookkeeping (soft-update counter, n_opts).  N ranks that each take the
+ * gradient of B/N rows, average the arenas and apply take exactly the step one rank takes on the B rows. */
+BDR_API int32_t bdr_dqn_grads_on_batch(bdr_agent* a, uint64_t n, const void* obs, const int64_t* act, const void* next_obs,
+                                       const float* reward, const int8_t* is_terminated, bdr_dqn_record* rec);
+BDR_API int32_t bdr_agent_apply_grads(bdr_agent* a);
+
 /* Q(obs) for n observations -> q_out[n][A] and argmax actions (either pointer may be NULL).
  * DQN: qnet.forward (dqn/base.rs:213); IQN: quantile average (iqn/base.rs:209-215). */
 BDR_API int32_t bdr_agent_qvalues(bdr_agent* a, uint64_t n, const void* obs, float* q_out,
@@ -586,6 +595,10 @@ BDR_API int32_t bdr_comm_destroy(bdr_comm* c);
 /* params <- mean over ranks (ncclAllReduce sum on the flat arena, then 1/nranks), on the
  * agent's stream; which as in bdr_agent_get_params (0 qnet, 1 qnet_tgt, 2/3 Adam moments). */
 BDR_API int32_t bdr_agent_allreduce_params(bdr_agent* a, bdr_comm* c, int32_t which);
+/* Synchronous data-parallel mode for DQN agents: from now on every Agent::opt of `a` runs backward, all-reduces the gradient
+ * arena over `c` (ncclAllReduce sum, then 1/nranks, on the agent's stream) and then takes the optimizer step, so the ranks
+ * stay bit-for-bit in lock step and N x batch B/N equals one step on batch B.  c == NULL: back to independent steps. */
+BDR_API int32_t bdr_agent_set_grad_comm(bdr_agent* a, bdr_comm* c);
 /* params <- root's (ncclBroadcast): the faithful learner->actor sync. */
 BDR_API int32_t bdr_agent_broadcast_params(bdr_agent* a, bdr_comm* c, int32_t which, int32_t root);
 

@@ -273,6 +273,22 @@ using namespace bdr;
 // ================================================================================================
 struct AdamScalars { float b1, omb1, b2, omb2, sqrt_bc2, eps, neg_step, wd_mul; };
 
+// libtorch Adam::step for one element.  Every operation rounds on its own (no fused multiply-add contraction): the fused and
+// the split optimizer paths (k_reduce_adam / k_adam, synchronous-DP mode) must agree bit for bit whichever kernel an element is
+// updated by, and separately rounded f32 operations are also what the reference's vectorised CPU kernels compute.
+__device__ __forceinline__ void adam_element(float& p, float g, float& m, float& v, const AdamScalars& s)
+{
+#pragma clang fp contract(off)
+    p = p * s.wd_mul;                             // AdamW decoupled decay (1 for Adam)
+    const float mg = g * s.omb1;
+    m = m * s.b1 + mg;                            // exp_avg.mul_(b1).add_(g, 1-b1)
+    const float gg = s.omb2 * g * g;
+    v = v * s.b2 + gg;                            // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+    const float denom = __fsqrt_rn(v) / s.sqrt_bc2 + s.eps;
+    const float upd = s.neg_step * m / denom;
+    p = p + upd;                                  // addcdiv_(exp_avg, denom, -step_size)
+}
+
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, size_t n4, AdamScalars s, const unsigned* poison = nullptr)
 {
@@ -283,11 +299,9 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        pp[j] *= s.wd_mul;                                 // AdamW decoupled decay (1 for Adam)
-        mm[j] = mm[j] * s.b1 + gg[j] * s.omb1;             // exp_avg.mul_(b1).add_(g, 1-b1)
-        vv[j] = vv[j] * s.b2 + s.omb2 * gg[j] * gg[j];     // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
-        const float denom = __fsqrt_rn(vv[j]) / s.sqrt_bc2 + s.eps;
-        pp[j] = pp[j] + s.neg_step * mm[j] / denom;        // addcdiv_(exp_avg, denom, -step_size)
+        float pe = pp[j], me = mm[j], ve = vv[j];
+        adam_element(pe, gg[j], me, ve, s);
+        pp[j] = pe; mm[j] = me; vv[j] = ve;
     }
     reinterpret_cast<f32x4*>(p)[i] = pp;
     reinterpret_cast<f32x4*>(m)[i] = mm;

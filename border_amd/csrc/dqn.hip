@@ -393,14 +393,6 @@ struct ReduceAdamArgs {
     const unsigned* poison;  // sig + SIG_ERR: a gate timed out, leave the parameters alone
     int reduce_only;         // gradients only (the optimizer step follows an all-reduce: synchronous data-parallel mode)
 };
-__device__ __forceinline__ void adam_element(float& p, float g, float& m, float& v, const AdamScalars& s)
-{
-    p *= s.wd_mul;                                // AdamW decoupled decay (1 for Adam)
-    m = m * s.b1 + g * s.omb1;                    // exp_avg.mul_(b1).add_(g, 1-b1)
-    v = v * s.b2 + s.omb2 * g * g;                // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
-    const float denom = __fsqrt_rn(v) / s.sqrt_bc2 + s.eps;
-    p = p + s.neg_step * m / denom;               // addcdiv_(exp_avg, denom, -step_size)
-}
 // Schedule 3 cross-queue ordering without barrier packets (igemm.hpp start_signal).
 // k_gate: one wave; returns once *flag has reached `epoch` (wrap-safe compare).  It holds one wave slot while it waits, so
 // it cannot starve the producer; a producer that never arrives trips the time limit instead of hanging the queue

@@ -116,9 +116,12 @@ def test_iqn_baseline_config4_full_size_vs_oracle(B):
         bad = (d > 1e-3).reshape(shp[0], -1).any(1)
         assert bad.sum() <= 4 and d.max() < 2e-2, (shp, int(bad.sum()), d.max())
         o += n
-    # parameters after the Adam step: |delta| <= lr, compare the step itself
+    # parameters after the first Adam step: every element moves by lr * g / (|g| + 1e-8), i.e. by ~lr unless |g| is at the
+    # 1e-8 level, where the step is as ill-conditioned as the f32 round-off of g itself - so: all but a sliver of the
+    # 1.9 M elements within 10 % of lr, none further than the 2 lr two opposite steps can differ by
     p1 = a.get_params("iqn")
-    assert np.abs(p1.astype(np.float64) - ref.p).max() < 0.1 * 1e-4
+    dp = np.abs(p1.astype(np.float64) - ref.p)
+    assert (dp > 0.1 * 1e-4).mean() < 2e-3 and dp.max() <= 2.01e-4, ((dp > 0.1 * 1e-4).mean(), dp.max())
     # forward values of the UPDATED online net and the target net on a 64-row slice (host copies of [64][64][6])
     sl = slice(0, 64)
     z_on = a.forward(batch[0][sl], batch[5][sl], "iqn")

@@ -45,30 +45,32 @@ def test_two_ranks_of_128_equal_one_rank_of_256_nature_cnn(B):
     for a in ranks + [full]:
         a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
     ref = O.DqnOracle(O.cnn_cfg(6), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000)
-    for step in range(2):     # two steps: the second Adam step depends on the MAGNITUDE of both gradients (exp_avg / exp_avg_sq)
+    # step 0 carries the parity claim (every side starts from the same parameters and Adam state): mean of the two half-batch
+    # gradients == the oracle's full-batch gradient, and the step taken with it == the oracle's B = 256 step.  Steps 1, 2 check
+    # that the ranks stay in lock step and track this library's own fused B = 256 agent (by then a ReLU-boundary flip of
+    # step 0 may have moved individual channels by up to 2 lr on either side, so the oracle is no longer the same function).
+    for step in range(3):
         obs, act, nobs, rew, term = T.synthetic_atari_batch(256, 6, 500 + step)
         halves = [tuple(x[r * 128:(r + 1) * 128] for x in (obs, act, nobs, rew, term)) for r in range(2)]
-        recs = [a.grads_on_batch(*h) for a, h in zip(ranks, halves)]
         before = [a.get_params("qnet") for a in ranks]
-        assert all((b == (p0 if step == 0 else prev)).all() for b, prev in zip(before, before))       # backward alone moves nothing
-        assert all(a.n_opts == step for a in ranks)
+        recs = [a.grads_on_batch(*h) for a, h in zip(ranks, halves)]
+        assert all((a.get_params("qnet") == b).all() for a, b in zip(ranks, before)) and all(a.n_opts == step for a in ranks)   # backward moves nothing
         g = 0.5 * (ranks[0].get_params("grad").astype(np.float64) + ranks[1].get_params("grad").astype(np.float64))
-        r = ref.update(obs, act, nobs, rew, term, probe=True)
-        assert_grads_close(g.astype(np.float32), r["grads"], shapes)                                  # mean gradient == full-batch gradient
-        assert abs(0.5 * (recs[0]["loss"] + recs[1]["loss"]) - r["loss"]) <= 1e-4 * abs(r["loss"])
+        if step == 0:
+            r = ref.update(obs, act, nobs, rew, term, probe=True)
+            assert_grads_close(g.astype(np.float32), r["grads"], shapes)                              # mean gradient == full-batch gradient
+            assert abs(0.5 * (recs[0]["loss"] + recs[1]["loss"]) - r["loss"]) <= 1e-4 * abs(r["loss"])
         for a in ranks:
             a.set_params(g.astype(np.float32), "grad")
             a.apply_grads()
         full.update_on_batch(obs, act, nobs, rew, term)
         pa, pb = ranks[0].get_params("qnet"), ranks[1].get_params("qnet")
-        assert (pa == pb).all() and ranks[0].n_opts == step + 1                                        # the ranks stay in lock step, bit for bit
-        # vs the oracle's B=256 step: everything but the (<= 2 per layer) ReLU-flipped channels within 5 % of lr
-        dp = np.abs(pa.astype(np.float64) - ref.q)
-        assert (dp > 0.05 * 1e-4).sum() <= 2 * 2 * 257 and dp.max() <= 5e-4, ((dp > 0.05 * 1e-4).sum(), dp.max())
-        assert rel(pa, ref.q) < 5e-3
-        # vs this library's own fused B=256 step (same kernels, different partial-sum grouping)
+        assert (pa == pb).all() and ranks[0].n_opts == step + 1                                        # lock step, bit for bit
+        if step == 0:   # vs the oracle's B=256 step: everything but the (<= 2 per layer) ReLU-flipped channels within 5 % of lr
+            dp = np.abs(pa.astype(np.float64) - ref.q)
+            assert (dp > 0.05 * 1e-4).sum() <= 2 * 257 and dp.max() <= 2.5e-4, ((dp > 0.05 * 1e-4).sum(), dp.max())
         dq = np.abs(pa.astype(np.float64) - full.get_params("qnet"))
-        assert (dq > 0.05 * 1e-4).sum() <= 2 * 2 * 257, (dq > 0.05 * 1e-4).sum()
+        assert (dq > 0.1 * 1e-4).mean() < 2e-3 and dq.max() <= (step + 1) * 2.01e-4, (step, (dq > 0.1 * 1e-4).mean(), dq.max())
     for a in ranks + [full]:
         a.close()
 

@@ -83,6 +83,14 @@ struct TdArgs {
     float* td_abs;         // [B] |pred - tgt| (clipped) for update_priority, or nullptr
     int has_clip; float clip_min, clip_max;
     unsigned* err;         // bdr_agent::dev_err (ERR_ACTION is raised for an action outside [0, A))
+    // Split forward (schedule 3): the target network's Q rows were produced by a separate launch on the other queue.
+    //   q_tgt_mem   [B][A] target Q rows in memory (nullptr: the target instance is z_tgt of THIS launch, rows in LDS)
+    //   z_sel       LDS instance whose argmax selects the action (double DQN: online(next_obs)); -1: the target rows themselves
+    //   wait_sig    flag that must reach wait_epoch before q_tgt_mem is read (published by the other queue once the target
+    //               head kernel is complete); polled inside this kernel, so the dX queue carries no extra gate packet
+    const float* q_tgt_mem;
+    int z_tgt, z_sel;
+    unsigned* wait_sig; unsigned wait_epoch; unsigned long long wait_limit; unsigned* sig_err;
 };
 
 // One workgroup = HEAD_ROWS batch rows x nz network instances, one wave per (row, instance):
@@ -172,11 +180,32 @@ __global__ __launch_bounds__(64 * HEAD_ROWS * MAXZ) void k_head(HeadArgs a, TdAr
         sq[r][z][lane] = qv;
     }
     if (!td) return;
+    if (t.q_tgt_mem && t.wait_sig) {
+        // the target rows come from the other queue: wait for its "target head complete" flag (one poller per workgroup; the
+        // wait overlaps nothing critical - this workgroup's own l1 finish / l2 are done), then acquire at agent scope so the
+        // rows are re-read from memory (another XCD's L2 wrote them)
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while ((int)(__hip_atomic_load(t.wait_sig, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - t.wait_epoch) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__hip_atomic_load(t.sig_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // poisoned
+                if (wall_clock64() - t0 > t.wait_limit) {
+                    __hip_atomic_store(t.sig_err, 100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t.err) __hip_atomic_store(t.err + bdr_agent::ERR_GATE, 100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
     __syncthreads();
     if (z != 0 || !valid) return;
-    // ---- TD of this row (instance 0 = qnet(obs), 1 = qnet_tgt(next_obs), 2 = qnet(next_obs) for double DQN)
-    const float* q_tg = sq[r][1];
-    const float* sel = t.double_dqn ? sq[r][2] : q_tg;
+    // ---- TD of this row (instance 0 = qnet(obs); target rows = qnet_tgt(next_obs); selection rows = qnet(next_obs) for double DQN)
+    if (t.q_tgt_mem) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane < A) sq[r][MAXZ - 1][lane] = __builtin_nontemporal_load(t.q_tgt_mem + (size_t)row * A + lane);   // (instance slot MAXZ-1 is free: nz <= 2 here)
+    }
+    const float* q_tg = t.q_tgt_mem ? sq[r][MAXZ - 1] : sq[r][t.z_tgt];
+    const float* sel = t.z_sel >= 0 ? sq[r][t.z_sel] : q_tg;
     // argmax over actions: first maximal index (at::argmax), lanes >= A hold -inf
     float v = lane < A ? sel[lane] : -INFINITY;
     int idx = lane;
@@ -301,6 +330,10 @@ struct DqnCnn : bdr_agent {
     unsigned long long gate_limit = 1000000000ull;   // gate time limit in 100 MHz ticks (10 s; BDR_GATE_LIMIT_MS for tests)
     bool holds_gate_token = false;                   // see claim_gates()
     bool defer_adam = false;                         // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
+    bool split_fwd = true;                           // schedule 3: target network forward on the other queue (BDR_NO_SPLIT_FWD=1: off)
+    bool tgt_enqueued = false;                       // opt_inner has put this update's target forward on the other queue
+    unsigned track_epoch = 0;                        // epoch of the last update that was followed by a soft update (SIG_TRACK)
+    bool track_wait_pending = false;                 // the other queue must see SIG_TRACK == track_epoch before it reads q_tgt again
     Arena ar;
     int B = 0;          // activation buffers are sized for this batch
     // parameter arenas
@@ -397,7 +430,7 @@ struct ReduceAdamArgs {
 // k_gate: one wave; returns once *flag has reached `epoch` (wrap-safe compare).  It holds one wave slot while it waits, so
 // it cannot starve the producer; a producer that never arrives trips the time limit instead of hanging the queue
 // (sig[SIG_ERR] is checked at the next synchronisation).
-constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_GATHER = 4, SIG_TEST = 5, SIG_TEST_ERR = 6, SIG_ERR = 7;
+constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_GATHER = 4, SIG_TEST = 5, SIG_TEST_ERR = 6, SIG_ERR = 7, SIG_TGT = 8, SIG_TRACK = 9;
 // A gate that times out POISONS the agent: sig[SIG_ERR] (and dev_err[ERR_GATE], the word the host polls) is set, every later
 // gate returns at once instead of waiting another 10 s, and the kernels that write parameters (k_reduce_adam, the l1 / l2
 // k_adam) skip their update while the flag is up - kernels behind a failed gate run unordered, so their gradients may be
@@ -492,8 +525,10 @@ int effective_sched(DqnCnn* a);   // (defined with update_critic)
 // ---- the forward pass of nz network instances ------------------------------------------------------
 struct NetInst { const uint8_t* x; const float* params; int slot; };
 
-int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td = nullptr)
+// st: the queue the launches go to (the agent's dX queue, or the other queue for the split target forward)
+int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td = nullptr, hipStream_t st = nullptr)
 {
+    if (!st) st = a->stream;
     const Arena& ar = a->ar;
     FwdArgs f{};
     {
@@ -506,21 +541,21 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         const int items = (c.M + 31) / 32;
         const int g = std::max(1, std::min(512 / nz, (items + 7) / 8));
         Bracket br(a, "fwd_conv1");
-        hipLaunchKernelGGL(k_conv1_bf16, dim3(g * nz), dim3(512), 0, a->stream, c);
+        hipLaunchKernelGGL(k_conv1_bf16, dim3(g * nz), dim3(512), 0, st, c);
         BDR_HIP(hipGetLastError());
     }
     f.M = B * 81;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a1[inst[z].slot]; f.w[z] = inst[z].params + ar.w2; f.bias[z] = inst[z].params + ar.b2; f.out[z] = a->a2[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv2"); BDR_HIP((launch_igemm<FwdC2, TEAMS_FWD_C2>(a->stream, dim3((f.M + 63) / 64, 1, nz), f))); }
+    { Bracket br(a, "fwd_conv2"); BDR_HIP((launch_igemm<FwdC2, TEAMS_FWD_C2>(st, dim3((f.M + 63) / 64, 1, nz), f))); }
     f.M = B * 49;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a2[inst[z].slot]; f.w[z] = inst[z].params + ar.w3; f.bias[z] = inst[z].params + ar.b3; f.out[z] = a->a3[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3, TEAMS_FWD_C3>(a->stream, dim3((f.M + 63) / 64, 1, nz), f))); }
+    { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3, TEAMS_FWD_C3>(st, dim3((f.M + 63) / 64, 1, nz), f))); }
     f.M = B; f.nkt_per_split = (98 + L1_SPLIT - 1) / L1_SPLIT;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a3[inst[z].slot]; f.w[z] = inst[z].params + ar.w4; f.bias[z] = nullptr; f.out[z] = a->p1[inst[z].slot]; }
     {
         Bracket br(a, "fwd_l1");
-        if (nz % 2 == 0) BDR_HIP((launch_igemm<FwdL1Z2, TEAMS_FWD_L1>(a->stream, dim3(((B + 63) / 64) * 16, L1_SPLIT, nz / 2), f)));
-        else BDR_HIP((launch_igemm<FwdL1, TEAMS_FWD_L1>(a->stream, dim3(((B + 63) / 64) * 8, L1_SPLIT, nz), f)));
+        if (nz % 2 == 0) BDR_HIP((launch_igemm<FwdL1Z2, TEAMS_FWD_L1>(st, dim3(((B + 63) / 64) * 16, L1_SPLIT, nz / 2), f)));
+        else BDR_HIP((launch_igemm<FwdL1, TEAMS_FWD_L1>(st, dim3(((B + 63) / 64) * 8, L1_SPLIT, nz), f)));
     }
     HeadArgs h{};
     h.B = B; h.A = ar.A; h.S = L1_SPLIT;
@@ -535,9 +570,9 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         // with the two-stream backward schedule the head kernel's own packet completes the first fork event
         hipEvent_t stop = td && effective_sched(a) == 1 && a->kev ? a->ev_fork[0] : nullptr;
         const int tdi = td ? 1 : 0;
-        if (ar.A <= 8) hipExtLaunchKernelGGL((k_head<L1_SPLIT, 8>), grid, block, 0, a->stream, nullptr, stop, 0, h, tv, nz, tdi);
-        else if (ar.A <= 24) hipExtLaunchKernelGGL((k_head<L1_SPLIT, 24>), grid, block, 0, a->stream, nullptr, stop, 0, h, tv, nz, tdi);
-        else hipExtLaunchKernelGGL((k_head<L1_SPLIT, 64>), grid, block, 0, a->stream, nullptr, stop, 0, h, tv, nz, tdi);
+        if (ar.A <= 8) hipExtLaunchKernelGGL((k_head<L1_SPLIT, 8>), grid, block, 0, st, nullptr, stop, 0, h, tv, nz, tdi);
+        else if (ar.A <= 24) hipExtLaunchKernelGGL((k_head<L1_SPLIT, 24>), grid, block, 0, st, nullptr, stop, 0, h, tv, nz, tdi);
+        else hipExtLaunchKernelGGL((k_head<L1_SPLIT, 64>), grid, block, 0, st, nullptr, stop, 0, h, tv, nz, tdi);
         BDR_HIP(hipGetLastError());
     }
     return BDR_OK;
@@ -553,7 +588,7 @@ AdamScalars adam_scalars(const bdr_dqn_config& c, uint64_t step)
 int32_t launch_gate(DqnCnn* a, hipStream_t st, int which, unsigned epoch, int publish)
 {
     // trace slot: 2 counters per site; sites 0..3 = flags on the weight-gradient queue, 4 = the gates on the dX queue
-    unsigned long long* tr = a->gate_trace ? a->gate_trace + 2 * (st == a->stream ? 4 : which) : nullptr;
+    unsigned long long* tr = a->gate_trace && which <= SIG_SIDE ? a->gate_trace + 2 * (st == a->stream ? 4 : which) : nullptr;
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, a->sig, which, epoch, tr, publish, a->gate_limit, SIG_ERR, a->dev_err);
     BDR_HIP(hipGetLastError());
     return BDR_OK;
@@ -618,7 +653,18 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     t.weight = weight; t.td_abs = a->td_abs;
     t.has_clip = c.has_clip_td_err; t.clip_min = (float)c.clip_td_err_min; t.clip_max = (float)c.clip_td_err_max;
     t.err = a->dev_err;
-    BDR_TRY(forward(a, inst, c.double_dqn ? 3 : 2, B, &t));   // the TD step rides on the head kernel
+    t.z_tgt = 1; t.z_sel = c.double_dqn ? 2 : -1;
+    if (a->tgt_enqueued) {
+        // Split forward: qnet_tgt(next_obs) is already running (or done) on the other queue (opt_inner); this queue runs the
+        // online instance(s) only and the head kernel picks the target rows up from memory once their flag is up.
+        a->tgt_enqueued = false;
+        NetInst on[2] = {{obs, a->q, 0}, {next_obs, a->q, 2}};
+        t.q_tgt_mem = a->qv[1]; t.z_tgt = -1; t.z_sel = c.double_dqn ? 1 : -1;
+        t.wait_sig = a->sig + SIG_TGT; t.wait_epoch = a->sig_epoch + 1; t.wait_limit = a->gate_limit; t.sig_err = a->sig + SIG_ERR;
+        BDR_TRY(forward(a, on, c.double_dqn ? 2 : 1, B, &t));
+    } else {
+        BDR_TRY(forward(a, inst, c.double_dqn ? 3 : 2, B, &t));   // the TD step rides on the head kernel
+    }
 
     // Backward.  The input-gradient chain (dX of l1 -> conv3 -> conv2) is the critical path; every weight-gradient kernel
     // only needs the dY produced one link earlier and fills only part of the chip, so it runs beside the next dX kernel.
@@ -806,6 +852,12 @@ int32_t soft_update(DqnCnn* a)
     Bracket br(a, "track");
     hipLaunchKernelGGL(k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q_tgt, a->q, n4, tau, omt);
     BDR_HIP(hipGetLastError());
+    if (a->sig_epoch != 0 && a->split_fwd && !a->prof) {   // the other queue's next target forward must see the new target parameters
+        a->track_epoch = a->sig_epoch;
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, a->stream, a->sig, SIG_TRACK, a->track_epoch);
+        BDR_HIP(hipGetLastError());
+        a->track_wait_pending = true;
+    }
     return BDR_OK;
 }
 
@@ -853,7 +905,26 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
             const unsigned epoch = a->sig_epoch + 1;     // the epoch update_critic is about to take
             BDR_TRY(replay_flip_batch(r, a->cfg.batch_size));
             BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->side));
-            BDR_TRY(launch_gate(a, a->side, SIG_HEAD, epoch, SIG_GATHER));
+            if (a->split_fwd) {
+                // Split forward.  qnet_tgt(next_obs) depends on nothing the previous update computes (the target parameters
+                // only change at a soft update), and the host runs a step or two ahead of the device: put on this queue, the
+                // target network's forward overlaps the PREVIOUS update's backward on the dX queue, whose GEMMs leave a third
+                // of the CUs' issue slots idle (tile quantisation, prologues, epilogues).  The dX queue then runs the online
+                // instance only.  Order: gather -> signal(GATHER) -> [wait for the previous update's soft update, if it had
+                // one] -> target conv1..head -> gate(HEAD), whose start publishes TGT = "target rows complete".
+                hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, a->side, a->sig, SIG_GATHER, epoch);
+                BDR_HIP(hipGetLastError());
+                if (a->track_wait_pending) {
+                    BDR_TRY(launch_gate(a, a->side, SIG_TRACK, a->track_epoch, -1));
+                    a->track_wait_pending = false;
+                }
+                NetInst tg[1] = {{r->b_next, a->q_tgt, 1}};
+                BDR_TRY(forward(a, tg, 1, (int)a->cfg.batch_size, nullptr, a->side));
+                BDR_TRY(launch_gate(a, a->side, SIG_HEAD, epoch, SIG_TGT));
+                a->tgt_enqueued = true;
+            } else {
+                BDR_TRY(launch_gate(a, a->side, SIG_HEAD, epoch, SIG_GATHER));
+            }
             a->head_gate_enqueued = true;
             BDR_TRY(launch_gate(a, a->stream, SIG_GATHER, epoch, -1));
         } else {
@@ -1135,6 +1206,7 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_TRY(a->err_init());
     a->kev = getenv("BDR_NO_KEV") == nullptr;
     a->side_gather = getenv("BDR_NO_SIDE_GATHER") == nullptr;
+    a->split_fwd = getenv("BDR_NO_SPLIT_FWD") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->ar.total));

@@ -25,7 +25,7 @@ class BdrError(RuntimeError):
 
 class ReplayConfig(C.Structure):
     _fields_ = [("capacity", C.c_uint64), ("seed", C.c_uint64), ("obs_row_bytes", C.c_uint64),
-                ("act_row_bytes", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("act_row_bytes", C.c_uint64), ("device", C.c_int32), ("frame_stack", C.c_int32), ("frame_capacity", C.c_uint64)]
 
 
 class NetConfig(C.Structure):
@@ -130,7 +130,7 @@ class DeviceBatch(C.Structure):
 # every symbol include/border_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "bdr_last_error", "bdr_device_count", "bdr_version",
-    "bdr_replay_create", "bdr_replay_destroy", "bdr_replay_push", "bdr_replay_len", "bdr_replay_head",
+    "bdr_replay_create", "bdr_replay_destroy", "bdr_replay_push", "bdr_replay_len", "bdr_replay_head", "bdr_replay_frames_used",
     "bdr_replay_sample_indices", "bdr_replay_batch", "bdr_replay_last_batch", "bdr_replay_fill_synthetic",
     "bdr_replay_read_rows",
     "bdr_per_config_default", "bdr_replay_enable_per", "bdr_replay_update_priority", "bdr_replay_batch_weights",
@@ -197,6 +197,7 @@ def lib() -> C.CDLL:
     L.bdr_replay_push.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
     L.bdr_replay_len.argtypes = [vp, C.POINTER(u64)]
     L.bdr_replay_head.argtypes = [vp, C.POINTER(u64)]
+    L.bdr_replay_frames_used.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.bdr_replay_sample_indices.argtypes = [vp, u64, vp]
     L.bdr_replay_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]
     L.bdr_replay_last_batch.argtypes = [vp, C.POINTER(DeviceBatch)]

@@ -92,6 +92,19 @@ struct bdr_replay {
     // of the previous update still read the current one alternates between the two sets
     struct BatchSet { uint8_t *obs = nullptr, *next = nullptr, *act = nullptr; float* reward = nullptr; int8_t *term = nullptr, *trunc = nullptr; uint64_t* ixs = nullptr; } alt;
     bool alt_valid = false;
+    // ---- single-frame store (bdr_replay_config::frame_stack > 0): `ring` then holds only the small records
+    //   [u32 frame slot x 2k (obs newest..oldest, next_obs newest..oldest) | act | reward f32 | is_terminated i8 | is_truncated i8]
+    // and `frames` the frame store (frame_cap slots of frame_bytes, allocated in push order, slot = seq % frame_cap).
+    int32_t frame_stack = 0;
+    uint64_t frame_bytes = 0, frame_cap = 0, frame_seq = 0;   // frame_seq: frames allocated so far
+    uint8_t* frames = nullptr;
+    uint64_t rec_act_off = 0, rec_tail_off = 0;               // record layout (offsets of act / tail inside a record)
+    std::vector<uint64_t> first_ref;       // per transition slot: smallest frame sequence number it references
+    std::vector<uint8_t> last_next;        // host copy of the last pushed next_obs (episode continuation test)
+    std::vector<uint64_t> last_next_seq;   // ... and the sequence numbers of its k frames
+    bool have_last = false;
+    uint8_t* fstage = nullptr;             // pinned staging for new frames
+    uint64_t fstage_frames = 0;
 };
 
 namespace bdr {

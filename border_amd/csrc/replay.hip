@@ -3,6 +3,7 @@
 // Reference: border-core/src/generic_replay_buffer/base.rs:86-123 (state), :295-316 (push),
 // :376-402 (batch); border-tch-agent/src/tensor_batch.rs:85-120 (row storage).
 #include "chacha.hpp"
+#include <algorithm>
 #include <mutex>
 #include <unordered_set>
 
@@ -101,6 +102,79 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a)
             a.b_trunc[sample] = *reinterpret_cast<const int8_t*>(rec + a.tail_off + 5);
         }
     }
+}
+
+// K2 for the single-frame store: the record of a sampled transition names 2k frame slots; workgroup (sample, half) copies the
+// k frames of obs (half 0) or next_obs (half 1) out of the frame store into the stacked batch row - the batch layout (and
+// therefore every consumer) is the plain ring's.  Algorithmic bytes per sample are the same 2 * obs_bytes.
+struct GatherFramesArgs {
+    const uint8_t* recs; uint64_t rec_stride, rec_act_off, rec_tail_off, act_bytes;
+    const uint8_t* frames; uint64_t frame_bytes; int k;
+    uint64_t* ixs; ChaChaKey key; uint64_t word_pos, size;
+    uint8_t *b_obs, *b_next, *b_act; float* b_reward; int8_t *b_term, *b_trunc;
+    uint32_t given;
+};
+__global__ __launch_bounds__(256) void k_gather_frames(GatherFramesArgs a)
+{
+    const uint32_t sample = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const uint64_t row = a.given ? a.ixs[sample] : (uint64_t)chacha12_word(a.key, a.word_pos + sample) % a.size;
+    if (!a.given && half == 0 && threadIdx.x == 0) a.ixs[sample] = row;
+    const uint8_t* rec = a.recs + row * a.rec_stride;
+    const uint32_t* slots = reinterpret_cast<const uint32_t*>(rec) + half * a.k;
+    const uint64_t fv = a.frame_bytes / 16, nvec = fv * a.k;          // 16-byte vectors per frame / per stacked row
+    u32x4* dst = reinterpret_cast<u32x4*>((half ? a.b_next : a.b_obs) + (uint64_t)sample * a.frame_bytes * a.k);
+    for (uint64_t v = threadIdx.x; v < nvec; v += 1024) {
+        u32x4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t w = min(v + (uint64_t)u * 256, nvec - 1);
+            const uint64_t f = w / fv, o = w % fv;
+            x[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.frames + (uint64_t)slots[f] * a.frame_bytes) + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t w = v + (uint64_t)u * 256;
+            if (w < nvec) dst[w] = x[u];
+        }
+    }
+    if (half == 0) {
+        for (uint32_t t = threadIdx.x; t < a.act_bytes; t += 256) a.b_act[(uint64_t)sample * a.act_bytes + t] = rec[a.rec_act_off + t];
+        if (threadIdx.x == 0) {
+            a.b_reward[sample] = *reinterpret_cast<const float*>(rec + a.rec_tail_off);
+            a.b_term[sample] = *reinterpret_cast<const int8_t*>(rec + a.rec_tail_off + 4);
+            a.b_trunc[sample] = *reinterpret_cast<const int8_t*>(rec + a.rec_tail_off + 5);
+        }
+    }
+}
+
+// synthetic fill of the single-frame store: one continuous "episode" - frame sequence number q holds the counter-based bytes of
+// (seed, q), transition t is obs = frames (t+k-1 .. t), next_obs = (t+k .. t+1) (newest first), side fields as in k_fill_synthetic
+struct FillFramesArgs {
+    uint8_t* recs; uint64_t rec_stride, rec_act_off, rec_tail_off; uint8_t* frames; uint64_t frame_bytes, frame_cap;
+    uint64_t n, seed, capacity; int k, n_actions;
+};
+__host__ __device__ __forceinline__ uint64_t synth_hash(uint64_t seed, uint64_t t, uint64_t sec, uint64_t w);
+__global__ __launch_bounds__(256) void k_fill_frames(FillFramesArgs a)
+{
+    const uint64_t q = blockIdx.x;                       // frame sequence number, q < n + k
+    uint8_t* dst = a.frames + (q % a.frame_cap) * a.frame_bytes;
+    for (uint64_t w = threadIdx.x; w < a.frame_bytes / 8; w += 256) reinterpret_cast<uint64_t*>(dst)[w] = synth_hash(a.seed, q, 7, w);
+    if (q >= a.n || threadIdx.x != 0) return;
+    const uint64_t t = q;
+    uint8_t* rec = a.recs + (t % a.capacity) * a.rec_stride;
+    uint32_t* slots = reinterpret_cast<uint32_t*>(rec);
+    for (int j = 0; j < a.k; ++j) {
+        slots[j] = (uint32_t)((t + a.k - 1 - j) % a.frame_cap);
+        slots[a.k + j] = (uint32_t)((t + a.k - j) % a.frame_cap);
+    }
+    const uint64_t h = synth_hash(a.seed, t, 2, 0);
+    int64_t act = (int64_t)((h & 0xFFFFFFFFull) % (uint64_t)a.n_actions);
+    memcpy(rec + a.rec_act_off, &act, 8);
+    const uint32_t u = (uint32_t)(h >> 40);
+    const float reward = u < 838861u ? -1.0f : (u < 15938355u ? 0.0f : 1.0f);
+    memcpy(rec + a.rec_tail_off, &reward, 4);
+    rec[a.rec_tail_off + 4] = (synth_hash(a.seed, t, 2, 1) >> 40) < 83886u ? 1 : 0;
+    rec[a.rec_tail_off + 5] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -225,6 +299,123 @@ static int32_t wait_for_writer(bdr_replay* r, hipStream_t s)
     return BDR_OK;
 }
 
+// push() of the single-frame store.  Sharing is FOUND, not assumed: frame j of an incoming stack reuses an already stored frame
+// only when its bytes equal that frame's bytes -
+//   obs_t == the previous push's next_obs (episode continues)      -> obs costs nothing
+//   next_obs_t[1..k) == obs_t[0..k-1) (stack_frame, env.rs:197-209) -> next_obs costs its newest frame only
+//   equal neighbouring frames inside one stack (reset: all k slots hold the first frame, env.rs:263-296) are stored once
+// - so whatever rows are pushed come back bit for bit.  Frames are allocated in push order in a ring of frame_cap slots; a slot
+// may only be reused once no live transition references it (first_ref), otherwise the push fails loudly.
+static int32_t push_frames(bdr_replay* r, uint64_t n, const uint8_t* o, const uint8_t* a, const uint8_t* x, const float* reward,
+                           const int8_t* term, const int8_t* trunc)
+{
+    const int k = r->frame_stack;
+    const uint64_t fb = r->frame_bytes;
+    std::vector<uint64_t> oseq(k), nseq(k);
+    uint64_t staged = 0, stage_first_seq = r->frame_seq, rec_done = 0;
+    auto flush_frames = [&]() -> int32_t {   // staged frames -> their slots (<= 2 runs: the store is a ring)
+        uint64_t off = 0;
+        while (off < staged) {
+            const uint64_t slot = (stage_first_seq + off) % r->frame_cap;
+            const uint64_t m = std::min(staged - off, r->frame_cap - slot);
+            BDR_HIP(hipMemcpyAsync(r->frames + slot * fb, r->fstage + off * fb, m * fb, hipMemcpyHostToDevice, r->stream));
+            off += m;
+        }
+        if (staged) BDR_HIP(hipStreamSynchronize(r->stream));   // staging reusable
+        stage_first_seq = r->frame_seq; staged = 0;
+        return BDR_OK;
+    };
+    auto flush_records = [&](uint64_t upto) -> int32_t {       // packed records [rec_done, upto) -> ring (<= 2 runs)
+        uint64_t s0 = rec_done;
+        while (s0 < upto) {
+            const uint64_t pos = (r->i + s0) % r->capacity;
+            const uint64_t m = std::min(std::min(upto - s0, r->capacity - pos), r->stage_records);
+            BDR_HIP(hipMemcpyAsync(r->ring + pos * r->stride, r->stage + (s0 - rec_done) * r->stride, m * r->stride, hipMemcpyHostToDevice, r->stream));
+            s0 += m;
+        }
+        BDR_HIP(hipStreamSynchronize(r->stream));
+        rec_done = upto;
+        return BDR_OK;
+    };
+    auto alloc = [&](const uint8_t* frame, uint64_t oldest_live) -> int64_t {   // -> sequence number, or -1 (store exhausted)
+        if (r->frame_seq >= r->frame_cap && r->frame_seq - r->frame_cap >= oldest_live) return -1;   // would overwrite a live frame
+        memcpy(r->fstage + staged * fb, frame, fb);
+        staged += 1;
+        return (int64_t)r->frame_seq++;
+    };
+    for (uint64_t s = 0; s < n; ++s) {
+        if (staged + 2 * (uint64_t)k > r->fstage_frames) BDR_TRY(flush_frames());
+        if (s - rec_done >= r->stage_records) BDR_TRY(flush_records(s));
+        const uint64_t pos = (r->i + s) % r->capacity;
+        // the oldest frame any transition that stays live references: slot `pos` itself is being replaced
+        uint64_t oldest_live = UINT64_MAX;
+        const uint64_t live = std::min(r->size + s, r->capacity);
+        if (live > 0) {
+            const bool replacing = r->size + s >= r->capacity;
+            if (!replacing) oldest_live = r->first_ref[(r->i + s + r->capacity - live) % r->capacity];
+            else if (r->capacity > 1) oldest_live = r->first_ref[(pos + 1) % r->capacity];
+        }
+        if (r->have_last) oldest_live = std::min(oldest_live, *std::min_element(r->last_next_seq.begin(), r->last_next_seq.end()));
+        const uint8_t* os = o + s * r->obs_bytes;
+        const uint8_t* ns = x + s * r->obs_bytes;
+        bool ok = true;
+        if (r->have_last && memcmp(os, r->last_next.data(), r->obs_bytes) == 0) oseq = r->last_next_seq;
+        else {
+            for (int j = k - 1; j >= 0 && ok; --j) {   // oldest first, so that sequence numbers grow with time
+                if (j < k - 1 && memcmp(os + j * fb, os + (j + 1) * fb, fb) == 0) oseq[j] = oseq[j + 1];
+                else { const int64_t q = alloc(os + j * fb, oldest_live); ok = q >= 0; oseq[j] = (uint64_t)q; }
+            }
+        }
+        if (ok) {
+            if (k > 1 && memcmp(ns + fb, os, (k - 1) * fb) == 0) {
+                for (int j = 1; j < k; ++j) nseq[j] = oseq[j - 1];
+                if (memcmp(ns, ns + fb, fb) == 0) nseq[0] = nseq[1];
+                else { const int64_t q = alloc(ns, std::min(oldest_live, *std::min_element(oseq.begin(), oseq.end()))); ok = q >= 0; nseq[0] = (uint64_t)q; }
+            } else {
+                for (int j = k - 1; j >= 0 && ok; --j) {
+                    if (j < k - 1 && memcmp(ns + j * fb, ns + (j + 1) * fb, fb) == 0) nseq[j] = nseq[j + 1];
+                    else { const int64_t q = alloc(ns + j * fb, std::min(oldest_live, *std::min_element(oseq.begin(), oseq.end()))); ok = q >= 0; nseq[j] = (uint64_t)q; }
+                }
+            }
+        }
+        if (!ok) {
+            // keep the buffer consistent: what was staged for the transitions already accepted is written, the rest is dropped
+            r->frame_seq = stage_first_seq + staged;   // (frames of the failed transition may have been staged: harmless)
+            BDR_TRY(flush_frames());
+            BDR_TRY(flush_records(s));
+            BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
+            if (r->per && s) BDR_TRY(per_push(r->per, r->i, s, r->stream));
+            r->i = (r->i + s) % r->capacity; r->size = std::min(r->size + s, r->capacity);
+            return fail(BDR_ERR_INVALID, "single-frame store exhausted: %llu frames cannot hold the frames of %llu live transitions "
+                                         "(raise bdr_replay_config::frame_capacity)", (unsigned long long)r->frame_cap, (unsigned long long)r->capacity);
+        }
+        uint8_t* rec = r->stage + (s - rec_done) * r->stride;
+        memset(rec, 0, r->stride);
+        uint32_t* slots = reinterpret_cast<uint32_t*>(rec);
+        uint64_t fr = UINT64_MAX;
+        for (int j = 0; j < k; ++j) {
+            slots[j] = (uint32_t)(oseq[j] % r->frame_cap); slots[k + j] = (uint32_t)(nseq[j] % r->frame_cap);
+            fr = std::min(fr, std::min(oseq[j], nseq[j]));
+        }
+        memcpy(rec + r->rec_act_off, a + s * r->act_bytes, r->act_bytes);
+        memcpy(rec + r->rec_tail_off, &reward[s], 4);
+        rec[r->rec_tail_off + 4] = (uint8_t)term[s]; rec[r->rec_tail_off + 5] = (uint8_t)trunc[s];
+        r->first_ref[pos] = fr;
+        memcpy(r->last_next.data(), ns, r->obs_bytes); r->last_next_seq = nseq; r->have_last = true;
+    }
+    BDR_TRY(flush_frames());
+    BDR_TRY(flush_records(n));
+    if (r->per) {
+        BDR_HIP(hipStreamWaitEvent(r->stream, r->written, 0));
+        BDR_TRY(per_push(r->per, r->i, n, r->stream));
+    }
+    BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
+    BDR_HIP(hipStreamSynchronize(r->stream));
+    r->i = (r->i + n) % r->capacity;
+    r->size = std::min(r->size + n, r->capacity);
+    return BDR_OK;
+}
+
 extern "C" {
 
 const char* bdr_last_error(void) { return bdr::g_err; }
@@ -257,6 +448,26 @@ int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out)
     const uint64_t raw = r->tail_off + 8;
     r->stride = round_up(raw, raw >= 1024 ? 128 : 16);
     seed_from_u64(cfg->seed, r->key);
+    if (cfg->frame_stack > 0) {   // single-frame store: small records + frame store
+        const int k = cfg->frame_stack;
+        if (k > 64 || r->obs_bytes % (uint64_t)k != 0 || (r->obs_bytes / k) % 16 != 0) {
+            delete r;
+            return fail(BDR_ERR_INVALID, "frame_stack %d: obs_row_bytes must be frame_stack frames of a multiple of 16 bytes", k);
+        }
+        r->frame_stack = k; r->frame_bytes = r->obs_bytes / k;
+        r->frame_cap = cfg->frame_capacity ? cfg->frame_capacity : r->capacity + r->capacity / 4 + 64;
+        if (r->frame_cap < (uint64_t)2 * k + 1 || r->frame_cap > 0xFFFFFFFFull) { delete r; return fail(BDR_ERR_INVALID, "frame_capacity out of range"); }
+        r->rec_act_off = round_up((uint64_t)8 * k, 8);
+        r->rec_tail_off = round_up(r->rec_act_off + r->act_bytes, 8);
+        r->stride = round_up(r->rec_tail_off + 8, 16);
+        hipError_t fe = hipMalloc((void**)&r->frames, r->frame_cap * r->frame_bytes);
+        if (fe != hipSuccess) {
+            delete r;
+            return fail(BDR_ERR_HIP, "hipMalloc of the %.2f GB frame store failed: %s", (double)(r->frame_cap * r->frame_bytes) / 1e9, hipGetErrorString(fe));
+        }
+        r->first_ref.assign(r->capacity, 0);
+        r->last_next.resize(r->obs_bytes); r->last_next_seq.assign(k, 0);
+    }
     hipError_t e = hipMalloc((void**)&r->ring, r->capacity * r->stride);
     if (e != hipSuccess) {
         delete r;
@@ -268,6 +479,11 @@ int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out)
     BDR_HIP(hipEventCreateWithFlags(&r->read, hipEventDisableTiming | hipEventDisableSystemFence));
     // rows are zero like `Tensor::zeros` / `vec![0.; capacity]` (tensor_batch.rs:95-101, base.rs:350-352)
     BDR_HIP(hipMemsetAsync(r->ring, 0, r->capacity * r->stride, r->stream));
+    if (r->frames) {   // slot 0 stays all-zero until it is allocated: never-written records (all slots 0) read as zero rows
+        BDR_HIP(hipMemsetAsync(r->frames, 0, r->frame_cap * r->frame_bytes, r->stream));
+        r->fstage_frames = std::max<uint64_t>(2 * r->frame_stack, std::min<uint64_t>(1024, (8ull << 20) / r->frame_bytes));
+        BDR_HIP(hipHostMalloc((void**)&r->fstage, r->fstage_frames * r->frame_bytes, hipHostMallocDefault));
+    }
     BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
     r->stage_records = std::max<uint64_t>(1, std::min<uint64_t>(256, (8ull << 20) / r->stride));
     BDR_HIP(hipHostMalloc((void**)&r->stage, r->stage_records * r->stride, hipHostMallocDefault));
@@ -281,6 +497,8 @@ int32_t bdr_replay_destroy(bdr_replay* r)
     (void)hipSetDevice(r->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(r->ring);
+    (void)hipFree(r->frames);
+    if (r->fstage) (void)hipHostFree(r->fstage);
     (void)hipHostFree(r->stage);
     (void)hipFree(r->b_obs); (void)hipFree(r->b_next); (void)hipFree(r->b_act);
     (void)hipFree(r->b_reward); (void)hipFree(r->b_term); (void)hipFree(r->b_trunc); (void)hipFree(r->b_ixs);
@@ -300,6 +518,15 @@ int32_t bdr_replay_len(const bdr_replay* r, uint64_t* len)
     return BDR_OK;
 }
 
+int32_t bdr_replay_frames_used(const bdr_replay* r, uint64_t* allocated, uint64_t* capacity)
+{
+    BDR_REQUIRE(r, "null replay handle");
+    BDR_REQUIRE(r->frame_stack > 0, "not a single-frame store (bdr_replay_config::frame_stack == 0)");
+    if (allocated) *allocated = r->frame_seq;
+    if (capacity) *capacity = r->frame_cap;
+    return BDR_OK;
+}
+
 int32_t bdr_replay_head(const bdr_replay* r, uint64_t* head)
 {
     BDR_REQUIRE(r && head, "null argument");
@@ -316,6 +543,7 @@ int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, const void* 
     BDR_HIP(hipSetDevice(r->device));
     BDR_TRY(wait_for_reader(r, r->stream));  // WAR: do not overwrite rows a consumer's gather may still be reading
     const uint8_t* o = (const uint8_t*)obs; const uint8_t* a = (const uint8_t*)act; const uint8_t* x = (const uint8_t*)next_obs;
+    if (r->frame_stack) return push_frames(r, n, o, a, x, reward, term, trunc);
     uint64_t done = 0;
     while (done < n) {
         // records that fit the staging buffer and do not wrap the ring
@@ -359,6 +587,28 @@ int32_t bdr_replay_fill_synthetic(bdr_replay* r, uint64_t n, uint64_t seed, int3
     BDR_REQUIRE(!r->per || r->size == 0, "synthetic fill with PER needs an empty buffer");   // before anything is overwritten
     BDR_HIP(hipSetDevice(r->device));
     BDR_TRY(wait_for_reader(r, r->stream));
+    if (r->frame_stack) {   // one continuous episode of n transitions over n + k frames (see k_fill_frames)
+        BDR_REQUIRE(kind == 0 && n_actions > 0, "the single-frame store is filled with Atari-like rows (kind 0, discrete actions)");
+        BDR_REQUIRE(r->size == 0 && r->frame_seq == 0, "synthetic fill of the single-frame store needs an empty buffer");
+        BDR_REQUIRE(n + (uint64_t)r->frame_stack <= r->frame_cap, "fill needs n + frame_stack frames");
+        const int k = r->frame_stack;
+        FillFramesArgs fa{r->ring, r->stride, r->rec_act_off, r->rec_tail_off, r->frames, r->frame_bytes, r->frame_cap, n, seed, r->capacity, k, n_actions};
+        hipLaunchKernelGGL(k_fill_frames, dim3((uint32_t)(n + k)), dim3(256), 0, r->stream, fa);
+        BDR_HIP(hipGetLastError());
+        if (r->per) BDR_TRY(per_push(r->per, 0, n, r->stream));
+        BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
+        for (uint64_t t = 0; t < n; ++t) r->first_ref[t % r->capacity] = t;
+        r->frame_seq = n + k;
+        // the last next_obs (frames n+k-1 .. n, newest first) as push() will compare against it
+        for (int j = 0; j < k; ++j) {
+            r->last_next_seq[j] = n + k - 1 - j;
+            uint64_t* dst = reinterpret_cast<uint64_t*>(r->last_next.data() + (uint64_t)j * r->frame_bytes);
+            for (uint64_t w = 0; w < r->frame_bytes / 8; ++w) dst[w] = synth_hash(seed, n + k - 1 - j, 7, w);
+        }
+        r->have_last = n > 0;
+        r->i = n % r->capacity; r->size = n;
+        return BDR_OK;
+    }
     FillArgs a{r->ring, r->stride, r->obs_bytes, r->act_bytes, r->next_off, r->act_off, r->tail_off, r->capacity,
                n, seed, kind, n_actions};
     // grid.x is limited to 2^31-1; n <= capacity fits comfortably for the sizes used here
@@ -381,6 +631,22 @@ int32_t bdr_replay_read_rows(bdr_replay* r, uint64_t first, uint64_t n, void* ob
     BDR_HIP(hipSetDevice(r->device));
     BDR_HIP(hipStreamSynchronize(r->stream));
     std::vector<uint8_t> tmp(r->stride);
+    if (r->frame_stack) {
+        const int K = r->frame_stack;
+        for (uint64_t k = 0; k < n; ++k) {
+            BDR_HIP(hipMemcpy(tmp.data(), r->ring + (first + k) * r->stride, r->stride, hipMemcpyDeviceToHost));
+            const uint32_t* slots = reinterpret_cast<const uint32_t*>(tmp.data());
+            for (int j = 0; j < K; ++j) {
+                if (obs) BDR_HIP(hipMemcpy((uint8_t*)obs + k * r->obs_bytes + (uint64_t)j * r->frame_bytes, r->frames + (uint64_t)slots[j] * r->frame_bytes, r->frame_bytes, hipMemcpyDeviceToHost));
+                if (next_obs) BDR_HIP(hipMemcpy((uint8_t*)next_obs + k * r->obs_bytes + (uint64_t)j * r->frame_bytes, r->frames + (uint64_t)slots[K + j] * r->frame_bytes, r->frame_bytes, hipMemcpyDeviceToHost));
+            }
+            if (act) memcpy((uint8_t*)act + k * r->act_bytes, tmp.data() + r->rec_act_off, r->act_bytes);
+            if (reward) memcpy(&reward[k], tmp.data() + r->rec_tail_off, 4);
+            if (term) term[k] = (int8_t)tmp[r->rec_tail_off + 4];
+            if (trunc) trunc[k] = (int8_t)tmp[r->rec_tail_off + 5];
+        }
+        return BDR_OK;
+    }
     for (uint64_t k = 0; k < n; ++k) {
         BDR_HIP(hipMemcpy(tmp.data(), r->ring + (first + k) * r->stride, r->stride, hipMemcpyDeviceToHost));
         if (obs) memcpy((uint8_t*)obs + k * r->obs_bytes, tmp.data(), r->obs_bytes);
@@ -479,7 +745,15 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
         a.given = 1;
     }
     r->word_pos += n;  // one next_u32() per index
-    if (r->obs_bytes % 16 == 0) {
+    if (r->frame_stack) {
+        GatherFramesArgs g{};
+        g.recs = r->ring; g.rec_stride = r->stride; g.rec_act_off = r->rec_act_off; g.rec_tail_off = r->rec_tail_off; g.act_bytes = r->act_bytes;
+        g.frames = r->frames; g.frame_bytes = r->frame_bytes; g.k = r->frame_stack;
+        g.ixs = a.ixs; g.key = a.key; g.word_pos = a.word_pos; g.size = a.size;
+        g.b_obs = a.b_obs; g.b_next = a.b_next; g.b_act = a.b_act; g.b_reward = a.b_reward; g.b_term = a.b_term; g.b_trunc = a.b_trunc;
+        g.given = a.given;
+        hipLaunchKernelGGL(k_gather_frames, dim3((uint32_t)(n * 2)), dim3(256), 0, stream, g);
+    } else if (r->obs_bytes % 16 == 0) {
         const uint64_t nvec = r->obs_bytes / 16;
         // up to 4 vectors per thread per section and pass: 2 workgroups per sample for Atari rows (1764 vectors)
         a.chunks = (uint32_t)std::max<uint64_t>(1, (nvec + 1023) / 1024);

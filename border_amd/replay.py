@@ -40,6 +40,10 @@ class SimpleReplayBufferConfig:
     capacity: int = 10000
     seed: int = 42
     per_config: Optional[object] = None
+    # MI355X extension: store every distinct frame once instead of stacked obs + next_obs
+    # (bdr_replay_config::frame_stack); frame_capacity 0 = capacity * 1.25 + 64 frames
+    frame_stack: int = 0
+    frame_capacity: int = 0
 
     def capacity_(self, v):  # builder-style setters like the reference's
         self.capacity = v
@@ -85,7 +89,7 @@ class SimpleReplayBuffer:
         self.act_shape, self.act_dtype = tuple(act_shape), np.dtype(act_dtype)
         self.obs_bytes = int(np.prod(self.obs_shape)) * self.obs_dtype.itemsize
         self.act_bytes = int(np.prod(self.act_shape)) * self.act_dtype.itemsize
-        cfg = _lib.ReplayConfig(config.capacity, config.seed, self.obs_bytes, self.act_bytes, device, 0)
+        cfg = _lib.ReplayConfig(config.capacity, config.seed, self.obs_bytes, self.act_bytes, device, config.frame_stack, config.frame_capacity)
         h = C.c_void_p()
         _lib.check(_lib.lib().bdr_replay_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -136,6 +140,12 @@ class SimpleReplayBuffer:
         n = C.c_uint64()
         _lib.check(_lib.lib().bdr_replay_head(self._h, C.byref(n)))
         return n.value
+
+    def frames_used(self):
+        """(frames allocated so far, frame capacity) of the single-frame store."""
+        a, c = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib().bdr_replay_frames_used(self._h, C.byref(a), C.byref(c)))
+        return a.value, c.value
 
     # ReplayBufferBase -----------------------------------------------------------------------
     def batch(self, size: int) -> GenericTransitionBatch:

@@ -60,7 +60,15 @@ typedef struct {
     uint64_t obs_row_bytes; /* bytes of one observation row (Atari: 4*1*84*84 u8 = 28224)  */
     uint64_t act_row_bytes; /* bytes of one action row (discrete: 8, one i64)              */
     int32_t device;         /* HIP device ordinal                                          */
-    int32_t reserved;
+    int32_t frame_stack;    /* 0: rows stored as given.  k > 0 (Atari: 4): SINGLE-FRAME store - an observation is k frames of
+                             * obs_row_bytes / k bytes, newest first (border-atari-env/src/env.rs:197-209 stack_frame), and every
+                             * distinct frame is stored once: obs_t / next_obs_t share k-1 frames and next_obs_t == obs_t+1 inside
+                             * an episode, so a transition costs ONE new frame instead of 2k (8x less HBM for k = 4).  push()
+                             * still takes the stacked rows and finds the sharing by comparing bytes (any input is stored
+                             * exactly; what cannot be shared is stored in full), batch() rebuilds the stacks - indices, pushes
+                             * and batches are identical to the plain ring's. */
+    uint64_t frame_capacity;/* frames in the store (0: capacity + capacity / 4 + 64).  A push that would overwrite a frame a
+                             * live transition still references fails with BDR_ERR_INVALID (raise frame_capacity). */
 } bdr_replay_config;
 
 /* ReplayBufferBase::build (base.rs:336-356).  The ring lives in HBM as one fused record per
@@ -77,6 +85,10 @@ BDR_API int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, cons
 /* ExperienceBufferBase::len (base.rs:318-320) and the write cursor `i`. */
 BDR_API int32_t bdr_replay_len(const bdr_replay* r, uint64_t* len);
 BDR_API int32_t bdr_replay_head(const bdr_replay* r, uint64_t* head);
+
+/* Single-frame store only: frames allocated since creation (a continuing episode costs one per transition) and the store's
+ * capacity in frames. */
+BDR_API int32_t bdr_replay_frames_used(const bdr_replay* r, uint64_t* allocated, uint64_t* capacity);
 
 /* The index draw of ReplayBufferBase::batch (base.rs:384-390):
  * ixs[k] = (StdRng::next_u32() as usize) % size, generated ON DEVICE by the ChaCha12 kernel

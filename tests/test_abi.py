@@ -41,7 +41,7 @@ def test_no_device_fails_loudly(libpath):
     """No silent CPU fallback: without a GPU, constructors return an error."""
     if _lib.device_count() > 0:
         pytest.skip("a GPU is visible")
-    cfg = _lib.ReplayConfig(16, 42, 16, 8, 0, 0)
+    cfg = _lib.ReplayConfig(16, 42, 16, 8, 0, 0, 0)
     h = C.c_void_p()
     assert _lib.lib().bdr_replay_create(C.byref(cfg), C.byref(h)) == 2  # BDR_ERR_NO_DEVICE
     with pytest.raises(_lib.BdrError):

@@ -735,4 +735,15 @@ float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* strea
 }
 int32_t agent_scale(bdr_agent* a, float* p, size_t n, float s) { return launch_scale(a->stream, p, n, s); }
 void agent_set_grad_comm(bdr_agent* a, void* comm, int32_t (*reduce)(bdr_agent*, void*)) { a->grad_comm = comm; a->grad_reduce = reduce; }
+struct XSeg { size_t off, n; };
+int agent_exchange_plan(bdr_agent* a, int which, XSeg* segs, int cap, hipStream_t* comm)
+{
+    bdr_agent::ExchangeSeg es[8];
+    const int n = a->exchange_plan(which, es, std::min(cap, 8), comm);
+    for (int k = 0; k < n; ++k) { segs[k].off = es[k].off; segs[k].n = es[k].n; }
+    return n;
+}
+int32_t agent_exchange_begin(bdr_agent* a, int seg) { return a->exchange_begin(seg); }
+int32_t agent_exchange_end(bdr_agent* a, int seg) { return a->exchange_end(seg); }
+int32_t scale_on(hipStream_t st, float* p, size_t n, float s) { return launch_scale(st, p, n, s); }
 }  // namespace bdr

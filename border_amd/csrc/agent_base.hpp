@@ -111,6 +111,15 @@ struct bdr_agent {
     // the step one rank takes on the concatenated batch.  grad_reduce is installed by bdr_agent_set_grad_comm (comm.hip).
     void* grad_comm = nullptr;
     int32_t (*grad_reduce)(bdr_agent*, void*) = nullptr;
+    // Overlapped parameter exchange (bdr_agent_allreduce_params on arena 0): an agent that can order a communication queue
+    // against its compute queues returns the segments of the arena, each with hooks the collective is bracketed by -
+    //   begin(seg): make `comm` wait until the segment's last writer / reader of this step is done
+    //   end(seg):   publish "segment exchanged" so that the next step's first reader of the segment waits for it
+    // - and the collective runs on `comm` beside the rest of the step.  n == 0: no plan, the exchange runs in-stream.
+    struct ExchangeSeg { size_t off, n; };
+    virtual int exchange_plan(int /*which*/, ExchangeSeg* /*segs*/, int /*cap*/, hipStream_t* /*comm*/) { return 0; }
+    virtual int32_t exchange_begin(int /*seg*/) { return BDR_OK; }
+    virtual int32_t exchange_end(int /*seg*/) { return BDR_OK; }
     // update_critic up to `loss.backward()` on a host minibatch: gradients land in the gradient arena, parameters and
     // optimizer state are untouched; apply_grads = the optimizer step on whatever the gradient arena holds + opt_ bookkeeping
     virtual int32_t grads_on_batch(uint64_t, const void*, const int64_t*, const void*, const float*, const int8_t*)

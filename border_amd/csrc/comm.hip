@@ -13,6 +13,11 @@ using namespace bdr;
 namespace bdr {
 float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* stream, int* device);
 int32_t agent_scale(bdr_agent* a, float* p, size_t n, float s);
+struct XSeg { size_t off, n; };
+int agent_exchange_plan(bdr_agent* a, int which, XSeg* segs, int cap, hipStream_t* comm);
+int32_t agent_exchange_begin(bdr_agent* a, int seg);
+int32_t agent_exchange_end(bdr_agent* a, int seg);
+int32_t scale_on(hipStream_t st, float* p, size_t n, float s);
 void agent_set_grad_comm(bdr_agent* a, void* comm, int32_t (*reduce)(bdr_agent*, void*));
 }
 
@@ -101,6 +106,21 @@ int32_t bdr_agent_allreduce_params(bdr_agent* a, bdr_comm* c, int32_t which)
     BDR_REQUIRE(p, "unknown arena");
     BDR_REQUIRE(dev == c->device, "agent and communicator live on different devices");
     BDR_HIP(hipSetDevice(dev));
+    // Overlapped form: the agent names segments whose exchange may start before its step has finished (the l1 / l2 parameters
+    // are final once their Adam pass on the weight-gradient queue is done, well before the conv dX chain ends) and may finish
+    // after the next step has started (the next forward waits per segment): one collective per segment on the agent's
+    // communication queue, bracketed by the agent's own ordering hooks.
+    XSeg segs[4]; hipStream_t cs = nullptr;
+    const int ns = agent_exchange_plan(a, which, segs, 4, &cs);
+    if (ns > 0) {
+        for (int k = 0; k < ns; ++k) {
+            BDR_TRY(agent_exchange_begin(a, k));
+            BDR_NCCL(g_rccl.AllReduce(p + segs[k].off, p + segs[k].off, segs[k].n, kNcclFloat, kNcclSum, c->comm, cs));
+            BDR_TRY(scale_on(cs, p + segs[k].off, segs[k].n, 1.0f / (float)c->nranks));
+            BDR_TRY(agent_exchange_end(a, k));
+        }
+        return BDR_OK;
+    }
     BDR_NCCL(g_rccl.AllReduce(p, p, n, kNcclFloat, kNcclSum, c->comm, s));
     return agent_scale(a, p, n, 1.0f / (float)c->nranks);
 }

@@ -334,6 +334,11 @@ struct DqnCnn : bdr_agent {
     bool tgt_enqueued = false;                       // opt_inner has put this update's target forward on the other queue
     unsigned track_epoch = 0;                        // epoch of the last update that was followed by a soft update (SIG_TRACK)
     bool track_wait_pending = false;                 // the other queue must see SIG_TRACK == track_epoch before it reads q_tgt again
+    // overlapped parameter exchange (exchange_plan): communication queue, and what the next update has to wait for
+    hipStream_t comm_st = nullptr;
+    int comm_state = 0;                              // 0 untested, 1 usable (own hardware queue), -1 not usable: exchange in-stream
+    unsigned xchg_epoch = 0;                         // epoch (sig_epoch of the exchanged step) of the pending exchange
+    bool xchg_pending_conv = false, xchg_pending_fc = false, xchg_tracked = false;
     Arena ar;
     int B = 0;          // activation buffers are sized for this batch
     // parameter arenas
@@ -356,8 +361,19 @@ struct DqnCnn : bdr_agent {
     const char* kind() const override { return "dqn_cnn"; }
     int32_t opt(bdr_replay* r) override;
     void on_gate_timeout() override;
+    int32_t after_sync() override
+    {
+        if (!(xchg_pending_conv || xchg_pending_fc)) return BDR_OK;
+        BDR_TRY(join_exchange(true, true));
+        BDR_HIP(hipStreamSynchronize(stream));
+        return BDR_OK;
+    }
     int32_t grads_on_batch(uint64_t n, const void* obs, const int64_t* act, const void* next_obs, const float* reward, const int8_t* term) override;
     int32_t apply_grads() override;
+    int exchange_plan(int which, ExchangeSeg* segs, int cap, hipStream_t* comm) override;
+    int32_t exchange_begin(int seg) override;
+    int32_t exchange_end(int seg) override;
+    int32_t join_exchange(bool conv, bool fc);       // make the dX queue wait for pending exchanged segments
     int32_t record(float* out, int cap, int* n) override;
     void record_keys(std::vector<std::string>& keys) override;
     uint64_t param_count(int which) override;
@@ -430,7 +446,7 @@ struct ReduceAdamArgs {
 // k_gate: one wave; returns once *flag has reached `epoch` (wrap-safe compare).  It holds one wave slot while it waits, so
 // it cannot starve the producer; a producer that never arrives trips the time limit instead of hanging the queue
 // (sig[SIG_ERR] is checked at the next synchronisation).
-constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_GATHER = 4, SIG_TEST = 5, SIG_TEST_ERR = 6, SIG_ERR = 7, SIG_TGT = 8, SIG_TRACK = 9;
+constexpr int SIG_HEAD = 0, SIG_DXL1 = 1, SIG_DXC3 = 2, SIG_SIDE = 3, SIG_GATHER = 4, SIG_TEST = 5, SIG_TEST_ERR = 6, SIG_ERR = 7, SIG_TGT = 8, SIG_TRACK = 9, SIG_MAIN_END = 10, SIG_XCONV = 11, SIG_XFC = 14;   // (12, 13: trace timestamp)
 // A gate that times out POISONS the agent: sig[SIG_ERR] (and dev_err[ERR_GATE], the word the host polls) is set, every later
 // gate returns at once instead of waiting another 10 s, and the kernels that write parameters (k_reduce_adam, the l1 / l2
 // k_adam) skip their update while the flag is up - kernels behind a failed gate run unordered, so their gradients may be
@@ -531,6 +547,9 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
     if (!st) st = a->stream;
     const Arena& ar = a->ar;
     FwdArgs f{};
+    bool uses_q = false;   // an overlapped parameter exchange of the online network may still be in flight (join_exchange)
+    for (int z = 0; z < nz; ++z) uses_q = uses_q || inst[z].params == a->q;
+    if (uses_q) BDR_TRY(a->join_exchange(true, false));
     {
         // conv1 on the bf16 matrix cores with exact operands (conv1_bf16.hpp)
         Conv1Args c{};
@@ -552,6 +571,7 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
     { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3, TEAMS_FWD_C3>(st, dim3((f.M + 63) / 64, 1, nz), f))); }
     f.M = B; f.nkt_per_split = (98 + L1_SPLIT - 1) / L1_SPLIT;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a3[inst[z].slot]; f.w[z] = inst[z].params + ar.w4; f.bias[z] = nullptr; f.out[z] = a->p1[inst[z].slot]; }
+    if (uses_q) BDR_TRY(a->join_exchange(false, true));
     {
         Bracket br(a, "fwd_l1");
         if (nz % 2 == 0) BDR_HIP((launch_igemm<FwdL1Z2, TEAMS_FWD_L1>(st, dim3(((B + 63) / 64) * 16, L1_SPLIT, nz / 2), f)));
@@ -1044,6 +1064,8 @@ void DqnCnn::on_gate_timeout()
     (void)hipStreamSynchronize(stream);
     if (side) (void)hipStreamSynchronize(side);
     if (aux) (void)hipStreamSynchronize(aux);
+    if (comm_st) (void)hipStreamSynchronize(comm_st);
+    xchg_pending_conv = xchg_pending_fc = false;
     if (sig) (void)hipMemset(sig, 0, 16 * sizeof(unsigned));
     sig_epoch = 0; head_gate_enqueued = false;
     if (sched == 3) {
@@ -1053,9 +1075,61 @@ void DqnCnn::on_gate_timeout()
     if (holds_gate_token) { DqnCnn* me = this; g_gate_owner.compare_exchange_strong(me, nullptr); holds_gate_token = false; }
 }
 
+// ---- overlapped parameter exchange ------------------------------------------------------------------------------------------
+// Segment 0 = the l1 / l2 parameters (95 % of the arena): final as soon as their Adam pass on the weight-gradient queue has run
+// (flag SIDE of the step's epoch - published every step anyway), first read again by the NEXT update's l1 forward.
+// Segment 1 = the conv parameters: final after k_reduce_adam at the end of the dX queue (a k_signal queued behind it when the
+// exchange is requested), first read by the next update's conv1.  The collectives run on their own queue in that order, so
+// the big segment's all-reduce overlaps the conv dX / dW tail of the step and the next forward up to l1; what stays exposed is
+// the 0.3 MB conv segment.  A step that ended with a soft update (track reads the parameters) exchanges after the track.
+int DqnCnn::exchange_plan(int which, ExchangeSeg* segs, int cap, hipStream_t* comm)
+{
+    if (which != 0 || cap < 2 || sig_epoch == 0 || getenv("BDR_NO_XCHG_OVERLAP")) return 0;
+    if (effective_sched(this) != 3 || xchg_pending_conv || xchg_pending_fc) return 0;
+    if (comm_state == 0) {
+        comm_state = -1;
+        if (hipStreamCreateWithFlags(&comm_st, hipStreamNonBlocking) == hipSuccess) {
+            bool ok1 = false, ok2 = false, ok3 = false;
+            if (queues_independent(this, comm_st, stream, &ok1) == BDR_OK && queues_independent(this, comm_st, side, &ok2) == BDR_OK &&
+                queues_independent(this, stream, comm_st, &ok3) == BDR_OK && ok1 && ok2 && ok3) comm_state = 1;
+        }
+    }
+    if (comm_state != 1) return 0;
+    segs[0] = ExchangeSeg{ar.w4, ar.total - ar.w4};
+    segs[1] = ExchangeSeg{0, ar.w4};
+    *comm = comm_st;
+    xchg_epoch = sig_epoch;
+    xchg_tracked = track_wait_pending && track_epoch == sig_epoch;   // this step ended with a soft update
+    // "the dX queue has finished the step" (behind k_reduce_adam and the track, if any)
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, stream, sig, SIG_MAIN_END, xchg_epoch);
+    return hipGetLastError() == hipSuccess ? 2 : 0;
+}
+
+int32_t DqnCnn::exchange_begin(int seg)
+{
+    const int flag = (seg == 0 && !xchg_tracked) ? SIG_SIDE : SIG_MAIN_END;
+    return launch_gate(this, comm_st, flag, xchg_epoch, -1);
+}
+
+int32_t DqnCnn::exchange_end(int seg)
+{
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, comm_st, sig, seg == 0 ? SIG_XFC : SIG_XCONV, xchg_epoch);
+    BDR_HIP(hipGetLastError());
+    if (seg == 0) xchg_pending_fc = true; else xchg_pending_conv = true;
+    return BDR_OK;
+}
+
+int32_t DqnCnn::join_exchange(bool conv, bool fc)
+{
+    if (conv && xchg_pending_conv) { BDR_TRY(launch_gate(this, stream, SIG_XCONV, xchg_epoch, -1)); xchg_pending_conv = false; }
+    if (fc && xchg_pending_fc) { BDR_TRY(launch_gate(this, stream, SIG_XFC, xchg_epoch, -1)); xchg_pending_fc = false; }
+    return BDR_OK;
+}
+
 DqnCnn::~DqnCnn()
 {
     (void)hipSetDevice(device);
+    if (comm_st) { (void)hipStreamSynchronize(comm_st); (void)hipStreamDestroy(comm_st); }
     if (holds_gate_token) { DqnCnn* me = this; g_gate_owner.compare_exchange_strong(me, nullptr); holds_gate_token = false; }
     (void)hipStreamSynchronize(stream);
     if (side) (void)hipStreamSynchronize(side);
@@ -1127,6 +1201,7 @@ uint64_t DqnCnn::param_count(int which) { return which == -1 ? (uint64_t)ar.A : 
 
 int32_t DqnCnn::get_params(int which, float* out, uint64_t n)
 {
+    BDR_TRY(join_exchange(true, true));
     float* src = arena_ptr(this, which);
     BDR_REQUIRE(src, "which must be 0..4");
     BDR_REQUIRE(n == ref_param_count(ar.A), "parameter count mismatch (%llu vs %llu)", (unsigned long long)n,
@@ -1140,6 +1215,7 @@ int32_t DqnCnn::get_params(int which, float* out, uint64_t n)
 
 int32_t DqnCnn::set_params(int which, const float* inp, uint64_t n)
 {
+    BDR_TRY(join_exchange(true, true));
     float* dst = arena_ptr(this, which);
     BDR_REQUIRE(dst, "which must be 0..4");
     BDR_REQUIRE(n == ref_param_count(ar.A), "parameter count mismatch");
@@ -1152,6 +1228,7 @@ int32_t DqnCnn::set_params(int which, const float* inp, uint64_t n)
 
 float* DqnCnn::arena(int which, size_t* n)
 {
+    (void)join_exchange(true, true);   // whoever asks for the arena is about to enqueue work on it behind this queue
     if (n) *n = ar.total;
     return arena_ptr(this, which);
 }

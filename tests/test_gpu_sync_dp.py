@@ -137,3 +137,44 @@ def test_grad_comm_over_one_rank_rccl_reproduces_the_fused_step(B, kind):
     assert n0 == n1 == 10 and l0 == l1
     assert (p0 == p1).all() and (t0 == t1).all() and (v0 == v1).all()
     B._lib.check(L.bdr_comm_destroy(h))
+
+
+def test_overlapped_parameter_exchange_is_the_identity_at_one_rank(B, monkeypatch):
+    """bdr_agent_allreduce_params on the Nature-CNN agent runs per segment on the agent's communication queue, ordered against
+    the two compute queues with device flags: the l1 / l2 segment as soon as its Adam pass is done (beside the conv dX tail),
+    the conv segment behind k_reduce_adam; the next update's conv1 / l1 forward wait per segment.  With a 1-rank communicator
+    the exchange must not change a single bit - every third step, every step, across soft updates, with host reads in between
+    - and must equal the in-stream form (BDR_NO_XCHG_OVERLAP=1)."""
+    L = B._lib.lib()
+    uid = (C.c_uint8 * B._lib.BDR_UNIQUE_ID_BYTES)()
+    B._lib.check(L.bdr_comm_get_unique_id(uid))
+    h = C.c_void_p()
+    B._lib.check(L.bdr_comm_init_rank(uid, 1, 0, 0, C.byref(h)))
+
+    def run(every, overlap, reads=False):
+        if overlap:
+            monkeypatch.delenv("BDR_NO_XCHG_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("BDR_NO_XCHG_OVERLAP", "1")
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=800, seed=42), (4, 1, 84, 84), np.uint8)
+        rb.fill_synthetic(800, seed=3, kind=0, n_actions=6)
+        a = B.Dqn.build(B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=6), opt_config=B.OptimizerConfig.Adam(1e-4)),
+                                    device=0, batch_size=32, critic_loss="SmoothL1", tau=0.5, soft_update_interval=4, param_seed=9))
+        mid = None
+        for s in range(1, 26):
+            a.opt(rb)
+            if every and s % every == 0:
+                B._lib.check(L.bdr_agent_allreduce_params(a.handle, h, 0))
+            if reads and s == 13:
+                mid = a.get_params("qnet")          # a host read while an exchange may be pending
+        rec = a.opt_with_record(rb)
+        out = (a.get_params("qnet"), a.get_params("qnet_tgt"), a.get_params("exp_avg"), rec["loss"], mid)
+        a.close(); rb.close()
+        return out
+    base = run(0, True, reads=True)
+    for every, overlap, reads in ((3, True, False), (1, True, True), (4, True, False), (3, False, False)):
+        got = run(every, overlap, reads)
+        assert (got[0] == base[0]).all() and (got[1] == base[1]).all() and (got[2] == base[2]).all() and got[3] == base[3], (every, overlap)
+        if reads:
+            assert (got[4] == base[4]).all()
+    B._lib.check(L.bdr_comm_destroy(h))

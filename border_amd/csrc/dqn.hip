@@ -331,6 +331,7 @@ struct DqnCnn : bdr_agent {
     bool holds_gate_token = false;                   // see claim_gates()
     bool defer_adam = false;                         // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
     bool split_fwd = true;                           // schedule 3: target network forward on the other queue (BDR_NO_SPLIT_FWD=1: off)
+    bool three_queues = false;                       // BDR_TQ=1: gather + target forward on the third stream when it is free (measured SLOWER)
     bool tgt_enqueued = false;                       // opt_inner has put this update's target forward on the other queue
     unsigned track_epoch = 0;                        // epoch of the last update that was followed by a soft update (SIG_TRACK)
     bool track_wait_pending = false;                 // the other queue must see SIG_TRACK == track_epoch before it reads q_tgt again
@@ -924,23 +925,37 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
             // the dX queue waits for it with its own gate in front of conv1.
             const unsigned epoch = a->sig_epoch + 1;     // the epoch update_critic is about to take
             BDR_TRY(replay_flip_batch(r, a->cfg.batch_size));
-            BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->side));
+            // Third queue (opt-in, BDR_TQ=1): without prioritized replay the agent's third stream (its tree-update queue) is
+            // free, and the gather + target forward of update n can go there.  They depend on nothing but "head(n-1) is done",
+            // so they would run beside update n-1's backward instead of waiting behind this update's weight-gradient work.
+            // Measured on the same box: 4 420 vs 4 545 opt-steps/s - with two queues the chip is already throughput-bound
+            // (it clocks to its power budget), a third stream of GEMMs only slows the dX chain down.  Kept for experiments.
+            const bool tq3 = a->split_fwd && a->three_queues && !r->per && a->aux_gated;
+            hipStream_t tq = tq3 ? a->aux : a->side;
+            if (tq3) BDR_TRY(launch_gate(a, tq, SIG_HEAD, epoch - 1, -1));
+            BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, tq));
             if (a->split_fwd) {
                 // Split forward.  qnet_tgt(next_obs) depends on nothing the previous update computes (the target parameters
-                // only change at a soft update), and the host runs a step or two ahead of the device: put on this queue, the
-                // target network's forward overlaps the PREVIOUS update's backward on the dX queue, whose GEMMs leave a third
-                // of the CUs' issue slots idle (tile quantisation, prologues, epilogues).  The dX queue then runs the online
-                // instance only.  Order: gather -> signal(GATHER) -> [wait for the previous update's soft update, if it had
-                // one] -> target conv1..head -> gate(HEAD), whose start publishes TGT = "target rows complete".
-                hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, a->side, a->sig, SIG_GATHER, epoch);
+                // only change at a soft update), and the host runs a step or two ahead of the device: off the dX queue, the
+                // target network's forward overlaps the PREVIOUS update's backward, whose GEMMs leave a third of the CUs' issue
+                // slots idle (tile quantisation, prologues, epilogues).  The dX queue then runs the online instance only.
+                // Order: gather -> signal(GATHER) -> [wait for the previous update's soft update, if it had one] -> target
+                // conv1..head -> "target rows complete" (TGT), which the head kernel on the dX queue waits for in-kernel.
+                hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, tq, a->sig, SIG_GATHER, epoch);
                 BDR_HIP(hipGetLastError());
                 if (a->track_wait_pending) {
-                    BDR_TRY(launch_gate(a, a->side, SIG_TRACK, a->track_epoch, -1));
+                    BDR_TRY(launch_gate(a, tq, SIG_TRACK, a->track_epoch, -1));
                     a->track_wait_pending = false;
                 }
                 NetInst tg[1] = {{r->b_next, a->q_tgt, 1}};
-                BDR_TRY(forward(a, tg, 1, (int)a->cfg.batch_size, nullptr, a->side));
-                BDR_TRY(launch_gate(a, a->side, SIG_HEAD, epoch, SIG_TGT));
+                BDR_TRY(forward(a, tg, 1, (int)a->cfg.batch_size, nullptr, tq));
+                if (tq3) {
+                    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, tq, a->sig, SIG_TGT, epoch);
+                    BDR_HIP(hipGetLastError());
+                    BDR_TRY(launch_gate(a, a->side, SIG_HEAD, epoch, -1));
+                } else {
+                    BDR_TRY(launch_gate(a, a->side, SIG_HEAD, epoch, SIG_TGT));   // its start publishes TGT
+                }
                 a->tgt_enqueued = true;
             } else {
                 BDR_TRY(launch_gate(a, a->side, SIG_HEAD, epoch, SIG_GATHER));
@@ -1284,6 +1299,7 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->kev = getenv("BDR_NO_KEV") == nullptr;
     a->side_gather = getenv("BDR_NO_SIDE_GATHER") == nullptr;
     a->split_fwd = getenv("BDR_NO_SPLIT_FWD") == nullptr;
+    a->three_queues = getenv("BDR_TQ") != nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->ar.total));

@@ -317,6 +317,15 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     reinterpret_cast<f32x4*>(v)[i] = vv;
 }
 
+// util.rs:31-45 track: dest = tau * src + (1 - tau) * dest, every operation rounded on its own (see adam_element)
+__device__ __forceinline__ float track_element(float src, float dst, float tau, float omt)
+{
+#pragma clang fp contract(off)
+    const float x = tau * src;
+    const float y = omt * dst;
+    return x + y;
+}
+
 __global__ __launch_bounds__(256) void k_track(float* __restrict__ dst, const float* __restrict__ src, size_t n4, float tau,
                                                float omt)
 {
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) void k_track(float* __restrict__ dst, const fl
     if (i >= n4) return;
     f32x4 d = reinterpret_cast<f32x4*>(dst)[i], s = reinterpret_cast<const f32x4*>(src)[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d[j] = tau * s[j] + omt * d[j];
+    for (int j = 0; j < 4; ++j) d[j] = track_element(s[j], d[j], tau, omt);
     reinterpret_cast<f32x4*>(dst)[i] = d;
 }
 

@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "dense.hpp"
+#include "mlp_fused.hpp"
 
 using namespace bdr;
 
@@ -88,6 +89,8 @@ struct DqnMlp : bdr_agent {
     const float* last_reward = nullptr; int last_B = 0;
     uint64_t adam_step = 0, soft_update_counter = 0;
     bool defer_adam = false;   // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
+    bool fused = true;         // one-workgroup step for nets that fit a CU (mlp_fused.hpp; BDR_NO_MLP_FUSED=1: generic path)
+    bool track_with_next = false, track_done = false;   // opt(): the soft update rides on the fused kernel of the last update
 
     ~DqnMlp() override
     {
@@ -147,6 +150,46 @@ struct DqnMlp : bdr_agent {
         return BDR_OK;
     }
 
+    bool fused_ok(int Bn) const
+    {
+        if (!fused || prof || net.L.size() > MF_MAXL || Bn > 128 || net.out_dim > 64) return false;
+        for (const auto& l : net.L) if (l.Kp > 256 || l.Np > 256) return false;
+        return true;
+    }
+    // the whole update in one launch (mlp_fused.hpp)
+    int32_t update_critic_fused(int Bn, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
+                                const float* reward, const int8_t* term, const float* weight)
+    {
+        MlpFusedArgs f{};
+        const int L = (int)net.L.size();
+        f.L = L; f.nz = cfg.double_dqn ? 3 : 2; f.B = Bn; f.A = net.out_dim; f.in_dim = net.in_dim;
+        for (int i = 0; i < L; ++i) { f.Kp[i] = net.L[i].Kp; f.Np[i] = net.L[i].Np; f.relu[i] = net.L[i].relu; f.w[i] = net.L[i].w; f.b[i] = net.L[i].b; f.dy[i] = dys[i]; }
+        const float* par[3] = {q, q_tgt, q};
+        const uint8_t* rows[3] = {obs, next_obs, next_obs};
+        for (int z = 0; z < f.nz; ++z) {
+            f.params[z] = par[z]; f.in_rows[z] = reinterpret_cast<const float*>(rows[z]); f.x_in[z] = x_in[z];
+            for (int i = 0; i < L; ++i) f.act[z][i] = acts[z][i];
+        }
+        f.actions = act; f.act_bytes = act_bytes; f.reward = reward; f.term = term;
+        f.pred = pred; f.tgt = tgt; f.loss_row = loss_row; f.loss = loss;
+        f.gamma = (float)cfg.discount_factor; f.loss_kind = cfg.critic_loss; f.double_dqn = cfg.double_dqn;
+        f.weight = weight; f.td_abs = td_abs; f.has_clip = cfg.has_clip_td_err; f.clip_min = (float)cfg.clip_td_err_min; f.clip_max = (float)cfg.clip_td_err_max;
+        f.err = dev_err;
+        f.q = q; f.grad = grad; f.m = m; f.v = v; f.q_tgt = q_tgt; f.total = net.total;
+        f.do_adam = defer_adam ? 0 : 1;
+        if (f.do_adam) {
+            adam_step += 1;
+            f.adam = adam_scalars_for(cfg.opt_kind == BDR_OPT_ADAMW, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, adam_step);
+        }
+        f.do_track = (track_with_next && f.do_adam) ? 1 : 0;
+        f.tau = (float)cfg.tau; f.omt = (float)(1.0 - cfg.tau);
+        hipLaunchKernelGGL(k_dqn_mlp_step, dim3(1), dim3(512), 0, stream, f);
+        BDR_HIP(hipGetLastError());
+        if (f.do_track) track_done = true;
+        track_with_next = false;
+        return BDR_OK;
+    }
+
     // Dqn::update_critic (dqn/base.rs:60-160) on a device-resident batch
     int32_t update_critic(int Bn, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
                           const float* reward, const int8_t* term, const float* weight = nullptr, bdr_replay* per_buffer = nullptr)
@@ -155,6 +198,12 @@ struct DqnMlp : bdr_agent {
         BDR_TRY(ensure_batch(Bn));
         BDR_TRY(td_buffer(Bn));
         last_reward = reward; last_B = Bn;
+        if (fused_ok(Bn)) {
+            BDR_TRY(update_critic_fused(Bn, obs, next_obs, act, act_bytes, reward, term, weight));
+            if (per_buffer && weight) BDR_TRY(replay_update_priority_on_stream(per_buffer, Bn, td_abs, stream));
+            return BDR_OK;
+        }
+        track_with_next = false;
         const int L = (int)net.L.size();
         BDR_TRY(forward(0, q, obs, Bn));
         BDR_TRY(forward(1, q_tgt, next_obs, Bn));
@@ -201,9 +250,12 @@ struct DqnMlp : bdr_agent {
         soft_update_counter += 1;
         if (soft_update_counter == cfg.soft_update_interval) {
             soft_update_counter = 0;
-            Bracket br(this, "track");
-            BDR_TRY(launch_track(stream, q_tgt, q, net.total, cfg.tau));
+            if (!track_done) {   // (the fused step kernel of the last update may already have done it)
+                Bracket br(this, "track");
+                BDR_TRY(launch_track(stream, q_tgt, q, net.total, cfg.tau));
+            }
         }
+        track_done = false;
         n_opts += 1;
         return BDR_OK;
     }
@@ -218,6 +270,8 @@ struct DqnMlp : bdr_agent {
         for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
             { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, cfg.batch_size, stream)); }
             defer_adam = grad_comm != nullptr;
+            // the soft update that follows the last update of this opt (dqn/base.rs:190-196) rides on its fused kernel
+            track_with_next = u + 1 == cfg.n_updates_per_opt && soft_update_counter + 1 == cfg.soft_update_interval && !defer_adam;
             const int32_t st = update_critic((int)cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
                                              replay_batch_weights(r), r);
             defer_adam = false;
@@ -332,6 +386,7 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->net = make_mlp(cfg->net.in_dim, cfg->net.units, cfg->net.n_units, cfg->net.out_dim, false);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     BDR_TRY(a->err_init());
+    a->fused = getenv("BDR_NO_MLP_FUSED") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->net.total));

@@ -344,6 +344,10 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    if world > 1:
+        # the overlapped parameter exchange adds a communication queue to the agent's three streams (+ the buffer's): HIP's
+        # default pool of 4 hardware queues would alias them and the agent would fall back to the in-stream exchange
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch  # noqa: F401  (first: one HIP runtime per process, see border_amd/_lib.py)
     import border_amd as B
 

@@ -9,6 +9,7 @@
 #include "chacha.hpp"
 #include "common.hpp"
 #include "igemm.hpp"
+#include "step_graph.hpp"
 
 // DqnExplorer / IqnExplorer state (dqn/explorer.rs:8-120, iqn/explorer.rs:9-108).  The reference draws from
 // fastrand's global, unseeded generator; here the draws come from a seeded ChaCha12 stream (same generator
@@ -363,15 +364,13 @@ inline AdamScalars adam_scalars_for(bool adamw, double lr, double beta1, double 
 inline int32_t launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n_floats, const AdamScalars& s)
 {
     const size_t n4 = n_floats / 4;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p, g, m, v, n4, s, (const unsigned*)nullptr);
-    BDR_HIP(hipGetLastError());
+    BDR_HIP(step_launch(st, true, k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), p, g, m, v, n4, s, (const unsigned*)nullptr));
     return BDR_OK;
 }
 inline int32_t launch_track(hipStream_t st, float* dst, const float* src, size_t n_floats, double tau)
 {
     const size_t n4 = n_floats / 4;
-    hipLaunchKernelGGL(k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dst, src, n4, (float)tau, (float)(1.0 - tau));
-    BDR_HIP(hipGetLastError());
+    BDR_HIP(step_launch(st, false, k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), dst, src, n4, (float)tau, (float)(1.0 - tau)));
     return BDR_OK;
 }
 inline int32_t launch_scale(hipStream_t st, float* p, size_t n_floats, float sc)

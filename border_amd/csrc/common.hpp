@@ -84,6 +84,7 @@ struct bdr_replay {
     uint64_t stage_records = 0;
     // device batch buffers (lazily sized)
     uint64_t batch_cap = 0, batch_n = 0;
+    uint64_t uid = 0, batch_gen = 0;   // process-unique handle id; bumped whenever the batch buffers are re-allocated or flipped
     uint8_t *b_obs = nullptr, *b_next = nullptr, *b_act = nullptr;
     float* b_reward = nullptr;
     int8_t *b_term = nullptr, *b_trunc = nullptr;
@@ -111,6 +112,7 @@ namespace bdr {
 // Enqueue "draw n indices + gather" on `stream` (the consumer's stream).  Handles the
 // cross-stream ordering against pushes.  Advances the RNG like one batch(n).
 int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream);
+int32_t replay_prepare_sample(bdr_replay* r, uint64_t n, hipStream_t stream);
 int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n);
 // Consumer streams a replay buffer may have to record an event on later (lazy ordering): registered when they first sample,
 // retired by their owner after synchronising and before hipStreamDestroy, so that a buffer never touches a dead handle.

@@ -235,6 +235,13 @@ __global__ void k_pack_rows(const float* __restrict__ src, int src_ld, int cols,
 }
 
 // ---- host-side layer launches ------------------------------------------------------------------------
+// (two teams of four waves per tile taking alternate k-tiles - k_igemm's TEAMS = 2 - were measured on SAC's 1024 x 256 x 256
+// layers: no gain, these launches are bound by kernel start-up and first-touch latency, not by the length of the k loop)
+template <class P>
+inline hipError_t launch_dense(hipStream_t st, dim3 grid, const typename P::Args& d)
+{
+    return step_launch(st, false, k_igemm<P, 1>, grid, dim3(256), d);
+}
 inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, const float* params_base, DenseSrc x, float* out, int M,
                              const float* had = nullptr, int had_ld = 0, int had_group = 1, float* out2 = nullptr)
 {
@@ -242,8 +249,7 @@ inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, 
     d.had = had; d.had_ld = had_ld; d.had_group = had_group; d.out2 = out2;
     d.x = x; d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
     d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
-    hipLaunchKernelGGL(k_igemm<DenseFwd>, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), dim3(256), 0, st, d);
-    BDR_HIP(hipGetLastError());
+    BDR_HIP(launch_dense<DenseFwd>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), d));
     return BDR_OK;
 }
 
@@ -256,8 +262,7 @@ inline int32_t dense_forward_z(hipStream_t st, const DenseLayer& l, int nz, cons
         d.x = x[z]; d.w = params_base[z] + l.w; d.bias = params_base[z] + l.b; d.out = out[z]; d.ldo = l.Np;
         d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np; d.had_group = 1;
     }
-    hipLaunchKernelGGL(k_igemm<DenseFwdZ>, dim3(((M + 63) / 64) * (l.Np / 64), 1, nz), dim3(256), 0, st, dz);
-    BDR_HIP(hipGetLastError());
+    BDR_HIP(launch_dense<DenseFwdZ>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, nz), dz));
     return BDR_OK;
 }
 inline int32_t dense_dx_z(hipStream_t st, const DenseLayer& l, int nz, const float* const* params_base, const float* const* dy, float* const* dx,
@@ -269,8 +274,7 @@ inline int32_t dense_dx_z(hipStream_t st, const DenseLayer& l, int nz, const flo
         d.x = DenseSrc{dy[z], l.Np}; d.w = params_base[z] + l.w; d.out = dx[z]; d.ldo = l.Kp; d.mask = mask ? mask[z] : nullptr; d.ldm = l.Kp;
         d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np;
     }
-    hipLaunchKernelGGL(k_igemm<DenseDxZ>, dim3(((M + 63) / 64) * (l.Kp / 64), 1, nz), dim3(256), 0, st, dz);
-    BDR_HIP(hipGetLastError());
+    BDR_HIP(launch_dense<DenseDxZ>(st, dim3(((M + 63) / 64) * (l.Kp / 64), 1, nz), dz));
     return BDR_OK;
 }
 
@@ -282,8 +286,7 @@ inline int32_t dense_dx(hipStream_t st, const DenseLayer& l, const float* params
     d.accum = accum ? 1 : 0;
     d.x = DenseSrc{dy, l.Np}; d.w = params_base + l.w; d.out = dx; d.ldo = l.Kp; d.mask = mask; d.ldm = l.Kp;
     d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np;
-    hipLaunchKernelGGL(k_igemm<DenseDx>, dim3(((M + 63) / 64) * (l.Kp / 64), 1, 1), dim3(256), 0, st, d);
-    BDR_HIP(hipGetLastError());
+    BDR_HIP(launch_dense<DenseDx>(st, dim3(((M + 63) / 64) * (l.Kp / 64), 1, 1), d));
     return BDR_OK;
 }
 
@@ -294,11 +297,9 @@ inline int32_t dense_dw(hipStream_t st, const DenseLayer& l, float* grad_base, D
     const int tiles = (l.Kp / 64) * (l.Np / 64);
     const int n = l.Kp * l.Np + l.Np;
     DenseDwArgs d{x, dy, chunks > 1 ? part : grad_base + l.w, chunks > 1 ? (size_t)n : 0, M, l.Kp, l.Np};
-    hipLaunchKernelGGL(k_igemm_red<DenseDw>, dim3(tiles * chunks), dim3(256), 0, st, d);
-    BDR_HIP(hipGetLastError());
+    BDR_HIP(step_launch(st, false, k_igemm_red<DenseDw>, dim3(tiles * chunks), dim3(256), d));
     if (chunks > 1) {
-        hipLaunchKernelGGL(k_dense_reduce, dim3((n + 63) / 64), dim3(256), 0, st, part, (size_t)n, chunks, grad_base + l.w, n);
-        BDR_HIP(hipGetLastError());
+        BDR_HIP(step_launch(st, false, k_dense_reduce, dim3((n + 63) / 64), dim3(256), part, (size_t)n, chunks, grad_base + l.w, n));
     }
     return BDR_OK;
 }
@@ -313,11 +314,84 @@ inline int dense_dw_chunks(const DenseLayer& l, int M)
 }
 inline size_t dense_dw_part_floats(const DenseLayer& l) { return 16 * ((size_t)l.Kp * l.Np + l.Np); }
 
+// ---- grouped weight gradients + fused reduce / Adam / track (launch-bound agents) -----------------------
+// All dW GEMMs of a backward pass only meet again in the optimizer, so they run as ONE grouped launch (k_igemm_red_group) into
+// per-GEMM row-chunk partials, and ONE kernel sums the partials in k_dense_reduce's order, stores the gradient arena and applies
+// Adam (and the target tracking) - 2 launches where the layer-by-layer path takes 3 per layer + 2 per network.
+constexpr int DW_GROUP = 16;
+struct DenseDwJob { const DenseLayer* l; DenseSrc x; const float* dy; float* part; int chunks; };
+inline int32_t dense_dw_group(hipStream_t st, const DenseDwJob* jobs, int n, int M)
+{
+    for (int j0 = 0; j0 < n; j0 += DW_GROUP) {
+        IgemmRedGroup<DenseDwArgs, DW_GROUP> g{};
+        const int nj = std::min(DW_GROUP, n - j0);
+        int first = 0;
+        for (int j = 0; j < nj; ++j) {
+            const DenseDwJob& q = jobs[j0 + j];
+            const int tiles = (q.l->Kp / 64) * (q.l->Np / 64);
+            g.a[j] = DenseDwArgs{q.x, q.dy, q.part, (size_t)q.l->Kp * q.l->Np + q.l->Np, M, q.l->Kp, q.l->Np};
+            g.first[j] = first;
+            first += tiles * q.chunks;
+        }
+        for (int j = nj; j <= DW_GROUP; ++j) g.first[j] = first;
+        g.n = nj;
+        BDR_HIP(step_launch(st, false, k_igemm_red_group<DenseDw, DW_GROUP>, dim3(first), dim3(256), g));
+    }
+    return BDR_OK;
+}
+
+constexpr int RA_SEGS = 12, RA_INST = 4;
+struct DenseReduceSeg { const float* part; size_t stride; int chunks; unsigned off4, n4; };   // arena float4s [off4, off4 + n4)
+struct ReduceAdamArgs {
+    DenseReduceSeg seg[RA_SEGS]; int nseg; size_t inst_part_stride;   // instance z reads seg.part + z * inst_part_stride
+    float* p[RA_INST]; float* g[RA_INST]; float* m[RA_INST]; float* v[RA_INST]; float* tgt[RA_INST];
+    AdamScalars s[RA_INST]; unsigned n4; float tau, omt; int track;
+};
+__global__ __launch_bounds__(256) void k_dense_reduce_adam(ReduceAdamArgs a)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    const int z = blockIdx.y;
+    if (i >= a.n4) return;
+    int k = 0;
+    for (int q = 1; q < a.nseg; ++q) k += i >= a.seg[q].off4 ? 1 : 0;
+    const DenseReduceSeg sg = a.seg[k];
+    f32x4 gg = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < sg.off4 + sg.n4) {   // (arena slack past the last layer keeps a zero gradient)
+        const float* part = sg.part + (size_t)z * a.inst_part_stride + (size_t)(i - sg.off4) * 4;
+        f32x4 s4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < sg.chunks; c += 4) {   // k_dense_reduce's order: four interleaved partial sums
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c + q < sg.chunks) s4[q] += *reinterpret_cast<const f32x4*>(part + (size_t)(c + q) * sg.stride);
+        }
+        gg = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+    }
+    reinterpret_cast<f32x4*>(a.g[z])[i] = gg;
+    f32x4 pp = reinterpret_cast<f32x4*>(a.p[z])[i], mm = reinterpret_cast<f32x4*>(a.m[z])[i], vv = reinterpret_cast<f32x4*>(a.v[z])[i];
+    const AdamScalars s = a.s[z];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float pe = pp[j], me = mm[j], ve = vv[j];
+        adam_element(pe, gg[j], me, ve, s);
+        pp[j] = pe; mm[j] = me; vv[j] = ve;
+    }
+    reinterpret_cast<f32x4*>(a.p[z])[i] = pp;
+    reinterpret_cast<f32x4*>(a.m[z])[i] = mm;
+    reinterpret_cast<f32x4*>(a.v[z])[i] = vv;
+    if (a.track) {
+        f32x4 d = reinterpret_cast<f32x4*>(a.tgt[z])[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = track_element(pp[j], d[j], a.tau, a.omt);
+        reinterpret_cast<f32x4*>(a.tgt[z])[i] = d;
+    }
+}
+
 inline int32_t pack_rows(hipStream_t st, const float* src, int src_ld, int cols, float* dst, int ld, int col0, int B)
 {
     const int n = B * cols;
-    hipLaunchKernelGGL(k_pack_rows, dim3((n + 255) / 256), dim3(256), 0, st, src, src_ld, cols, dst, ld, col0, B);
-    BDR_HIP(hipGetLastError());
+    BDR_HIP(step_launch(st, false, k_pack_rows, dim3((n + 255) / 256), dim3(256), src, src_ld, cols, dst, ld, col0, B));
     return BDR_OK;
 }
 

@@ -644,10 +644,10 @@ inline hipError_t launch_igemm(hipStream_t st, dim3 grid, const typename P::Args
 // by the ko-tile-0 workgroups from the very Y tiles they stage.
 // LDS: As[32 rows][KO_T (+4)] (read with lane = output row: consecutive floats), Ys[32][N_T].
 // ------------------------------------------------------------------------------------------------
+// body: workgroup `bx` of `gx` (the launch's 1-D grid, or this GEMM's slice of a grouped launch)
 template <class P>
-__global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
+__device__ __forceinline__ void igemm_red_body(const typename P::Args& args, const int bx, const int gx)
 {
-    if constexpr (has_start_signal<typename P::Args>::value) start_signal(args.sig_flag, args.sig_epoch);
     using A = typename P::A;
     constexpr int KO_T = P::WM * P::TM * 32, N_T = P::WN * P::TN * 32;
     constexpr int LDAR = KO_T + 4, LDY = N_T;
@@ -671,15 +671,15 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
     // grid: 1-D, TILES * nchunks workgroups with nchunks % 8 == 0 (else the identity map).
     const int NT_N = P::N(args) / N_T;
     const int TILES = (P::K(args) / KO_T) * NT_N;
-    const int nchunks = gridDim.x / TILES;
+    const int nchunks = gx / TILES;
     int tile, chunk;
     if (nchunks % 8 == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int xcd = bx & 7, j = bx >> 3;
         chunk = (j / TILES) * 8 + xcd;
         tile = j % TILES;
     } else {
-        chunk = blockIdx.x / TILES;
-        tile = blockIdx.x % TILES;
+        chunk = bx / TILES;
+        tile = bx % TILES;
     }
     const int kot = tile / NT_N, nt = tile % NT_N;
     const int ko0 = kot * KO_T, n0 = nt * N_T;
@@ -814,6 +814,28 @@ __global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
             part[(size_t)P::K(args) * P::N(args) + n0 + tid] = s;
         }
     }
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void k_igemm_red(typename P::Args args)
+{
+    if constexpr (has_start_signal<typename P::Args>::value) start_signal(args.sig_flag, args.sig_epoch);
+    igemm_red_body<P>(args, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Up to NG independent weight-gradient GEMMs of one policy (different shapes, operands and chunk counts) in ONE launch: the
+// 1-D grid is the concatenation of their grids, first[g] = first workgroup of GEMM g, first[n] = the grid size.  For the
+// launch-bound dense agents, where a step is a chain of 2-5 us kernels and every kernel boundary costs as much as the kernel.
+template <class Args, int NG>
+struct IgemmRedGroup { Args a[NG]; int first[NG + 1]; int n; };
+template <class P, int NG>
+__global__ __launch_bounds__(256) void k_igemm_red_group(IgemmRedGroup<typename P::Args, NG> g)
+{
+    const int b = (int)blockIdx.x;
+    int z = 0;
+#pragma unroll
+    for (int k = 1; k < NG; ++k) z += (k < g.n && b >= g.first[k]) ? 1 : 0;
+    igemm_red_body<P>(g.a[z], b - g.first[z], g.first[z + 1] - g.first[z]);
 }
 
 }  // namespace bdr

@@ -4,10 +4,12 @@
 // :376-402 (batch); border-tch-agent/src/tensor_batch.rs:85-120 (row storage).
 #include "chacha.hpp"
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <unordered_set>
 
 #include "common.hpp"
+#include "step_graph.hpp"
 
 namespace bdr {
 thread_local char g_err[512] = "";
@@ -438,6 +440,7 @@ int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out)
     BDR_REQUIRE(cfg->act_row_bytes > 0 && cfg->act_row_bytes % 4 == 0, "act_row_bytes must be a positive multiple of 4");
     BDR_TRY(ensure_device(cfg->device));
     bdr_replay* r = new bdr_replay();
+    { static std::atomic<uint64_t> next_uid{1}; r->uid = next_uid.fetch_add(1); }
     r->device = cfg->device;
     r->capacity = cfg->capacity;
     r->obs_bytes = cfg->obs_row_bytes;
@@ -688,6 +691,7 @@ int32_t replay_flip_batch(bdr_replay* r, uint64_t n)
     std::swap(r->b_obs, r->alt.obs); std::swap(r->b_next, r->alt.next); std::swap(r->b_act, r->alt.act);
     std::swap(r->b_reward, r->alt.reward); std::swap(r->b_term, r->alt.term); std::swap(r->b_trunc, r->alt.trunc);
     std::swap(r->b_ixs, r->alt.ixs);
+    r->batch_gen += 1;
     return BDR_OK;
 }
 
@@ -706,6 +710,7 @@ int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n)
     BDR_HIP(hipMalloc((void**)&r->b_trunc, round_up(n, 16)));
     BDR_HIP(hipMalloc((void**)&r->b_ixs, n * 8));
     r->batch_cap = n;
+    r->batch_gen += 1;
     return BDR_OK;
 }
 
@@ -720,7 +725,10 @@ static int32_t launch_indices(bdr_replay* r, uint64_t n, hipStream_t stream)
     return BDR_OK;
 }
 
-int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
+// Everything a sample on `stream` needs BEFORE its kernels can be enqueued: the batch buffers, the order behind the writer and
+// the handover from the previous consumer.  Idempotent; agents that capture their step into a graph call it ahead of the
+// capture (allocation, event waits on work outside the graph and device syncs are not capturable).
+int32_t replay_prepare_sample(bdr_replay* r, uint64_t n, hipStream_t stream)
 {
     if (r->size == 0) return fail(BDR_ERR_EMPTY, "batch() on an empty replay buffer");
     BDR_REQUIRE(n > 0 && n < (1ull << 24), "batch size out of range");
@@ -734,6 +742,12 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
         BDR_HIP(hipDeviceSynchronize());
         r->read_pending = false;
     }
+    return BDR_OK;
+}
+
+int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
+{
+    BDR_TRY(replay_prepare_sample(r, n, stream));
     GatherArgs a{};
     a.ring = r->ring; a.stride = r->stride; a.obs_bytes = r->obs_bytes; a.act_bytes = r->act_bytes;
     a.next_off = r->next_off; a.act_off = r->act_off; a.tail_off = r->tail_off; a.ixs = r->b_ixs;
@@ -752,20 +766,19 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
         g.ixs = a.ixs; g.key = a.key; g.word_pos = a.word_pos; g.size = a.size;
         g.b_obs = a.b_obs; g.b_next = a.b_next; g.b_act = a.b_act; g.b_reward = a.b_reward; g.b_term = a.b_term; g.b_trunc = a.b_trunc;
         g.given = a.given;
-        hipLaunchKernelGGL(k_gather_frames, dim3((uint32_t)(n * 2)), dim3(256), 0, stream, g);
+        BDR_HIP(step_launch(stream, true, k_gather_frames, dim3((uint32_t)(n * 2)), dim3(256), g));
     } else if (r->obs_bytes % 16 == 0) {
         const uint64_t nvec = r->obs_bytes / 16;
         // up to 4 vectors per thread per section and pass: 2 workgroups per sample for Atari rows (1764 vectors)
         a.chunks = (uint32_t)std::max<uint64_t>(1, (nvec + 1023) / 1024);
         a.vec_per_chunk = (uint32_t)((nvec + a.chunks - 1) / a.chunks);
-        hipLaunchKernelGGL(k_gather<u32x4>, dim3((uint32_t)(n * a.chunks)), dim3(256), 0, stream, a);
+        BDR_HIP(step_launch(stream, true, k_gather<u32x4>, dim3((uint32_t)(n * a.chunks)), dim3(256), a));
     } else {
         const uint64_t nvec = r->obs_bytes / 4;
         a.chunks = (uint32_t)std::max<uint64_t>(1, (nvec + 1023) / 1024);
         a.vec_per_chunk = (uint32_t)((nvec + a.chunks - 1) / a.chunks);
-        hipLaunchKernelGGL(k_gather<uint32_t>, dim3((uint32_t)(n * a.chunks)), dim3(256), 0, stream, a);
+        BDR_HIP(step_launch(stream, true, k_gather<uint32_t>, dim3((uint32_t)(n * a.chunks)), dim3(256), a));
     }
-    BDR_HIP(hipGetLastError());
     r->read_pending = true; r->read_stream = stream;   // recorded only if somebody has to wait for it (wait_for_reader)
     r->batch_n = n;
     return BDR_OK;

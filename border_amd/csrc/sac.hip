@@ -16,6 +16,16 @@ using namespace bdr;
 
 namespace {
 
+// counter-based N(0,1): splitmix64 hash -> Box-Muller (the reference draws from torch's global CPU RNG)
+__device__ __forceinline__ float randn_at(uint64_t seed, uint64_t counter, size_t i)
+{
+    uint64_t x = (seed + 0x9E3779B97F4A7C15ull) ^ ((counter + i + 1) * 0xBF58476D1CE4E5B9ull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    const float u1 = ((float)(x >> 40) + 1.0f) * (1.0f / 16777217.0f);
+    const float u2 = (float)((x >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
 // a = tanh(sigma*z + mean), log_p = sum(-0.5 ln 2pi - 0.5 z^2) - sum ln(1 - a^2 + eps).   One wave per row.
 struct SacActionArgs {
     const float* mean; const float* e; int ld;     // head outputs [B][ld]
@@ -54,19 +64,49 @@ struct SacSelectArgs {
     const float* q[4]; int ldq;          // critic outputs [B][ldq], value in column 0
     float* dout[4];                      // [B][ldq]
     const float* logp; const float* log_alpha;
-    float* loss_row;
+    float* out; float scale; int accumulate;   // loss_actor += mean(alpha*log_p - qmin)
     int B, NC;
+    // EntCoef::update (ent_coef.rs:69-75) first: loss = -(log_alpha * (logp + H)).mean(); Adam on the scalar
+    int auto_alpha; float target; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
 };
-__global__ void k_sac_select(SacSelectArgs p)
+// one workgroup: the row terms are summed as k_sum_rows does (thread t takes rows t, t+256, ...; tree over the 256 partials), so
+// loss_actor is the same number whether the sum is fused here or not.  Only column 0 of the upstream gradients is written: the
+// other ldq-1 (padding) columns are zero from allocation and nothing else stores there.
+__global__ __launch_bounds__(256) void k_sac_select(SacSelectArgs p)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= p.B) return;
-    int im = 0;
-    float qm = p.q[0][(size_t)b * p.ldq];
-    for (int i = 1; i < p.NC; ++i) { const float v = p.q[i][(size_t)b * p.ldq]; if (v < qm) { qm = v; im = i; } }
-    for (int i = 0; i < p.NC; ++i)
-        for (int c = 0; c < p.ldq; ++c) p.dout[i][(size_t)b * p.ldq + c] = (c == 0 && i == im) ? 1.0f : 0.0f;
-    p.loss_row[b] = expf(p.log_alpha[0]) * p.logp[b] - qm;
+    __shared__ float red[256];
+    __shared__ float s_log_alpha;
+    if (threadIdx.x == 0) s_log_alpha = p.log_alpha[0];
+    if (p.auto_alpha) {   // update_actor calls ent_coef.update(log_p) before it uses alpha (sac/base.rs:155)
+        float acc = 0.f;
+        for (int b = threadIdx.x; b < p.B; b += 256) acc += p.logp[b] + p.target;
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+        if (threadIdx.x == 0) {
+            const float g = -(red[0] / (float)p.B);
+            const float mm = p.al_m[0] * p.s.b1 + g * p.s.omb1;
+            const float vv = p.al_v[0] * p.s.b2 + p.s.omb2 * g * g;
+            const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
+            s_log_alpha = s_log_alpha + p.s.neg_step * mm / denom;
+            p.log_alpha_rw[0] = s_log_alpha;
+            p.al_m[0] = mm; p.al_v[0] = vv;
+        }
+    }
+    __syncthreads();
+    const float alpha = expf(s_log_alpha);
+    float s = 0.f;
+    for (int b = threadIdx.x; b < p.B; b += 256) {
+        int im = 0;
+        float qm = p.q[0][(size_t)b * p.ldq];
+        for (int i = 1; i < p.NC; ++i) { const float v = p.q[i][(size_t)b * p.ldq]; if (v < qm) { qm = v; im = i; } }
+        for (int i = 0; i < p.NC; ++i) p.dout[i][(size_t)b * p.ldq] = i == im ? 1.0f : 0.0f;
+        s += alpha * p.logp[b] - qm;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) p.out[0] = (p.accumulate ? p.out[0] : 0.f) + red[0] * p.scale;
 }
 
 // dL/dmean, dL/d(head2) from dL/da = (alpha * 2a/(1-a^2+eps) - d qmin/da) / B
@@ -96,78 +136,74 @@ __global__ void k_sac_actor_grad(SacActorGradArgs p)
     p.ge[t] = gu * p.z[(size_t)b * p.A + j] * sd * inr * s;
 }
 
-// EntCoef::update (ent_coef.rs:69-75): loss = -(log_alpha * (logp + H)).mean(); Adam on the scalar.
-__global__ __launch_bounds__(256) void k_sac_alpha_update(const float* __restrict__ logp, int B, float target, float* log_alpha,
-                                                           float* m, float* v, AdamScalars s)
+// critic losses + upstream gradients (column 0; see k_sac_select) of every critic in one workgroup:
+// loss_critic += sum_i mean(loss(Q_i - tgt)) / NC, critic by critic in k_sum_rows' order
+struct SacTdArgs {
+    const float* q[4]; float* dout[4]; int ldq; int NC;
+    float* out; float scale; int accumulate; int B; int loss_kind;
+    // tgt = reward_scale*r + ((1 - term)*gamma) * (min_i Qtgt_i - alpha*logp')   (sac/base.rs:113-122; is_truncated ignored)
+    const float* qt[4]; const float* logp; const float* log_alpha; const float* reward; const int8_t* term; float gamma, reward_scale;
+    float* tgt;
+};
+__global__ __launch_bounds__(256) void k_sac_critic_td(SacTdArgs p)
 {
     __shared__ float red[256];
-    float acc = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) acc += logp[b] + target;
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
-    if (threadIdx.x == 0) {
-        const float g = -(red[0] / (float)B);
-        const float mm = m[0] * s.b1 + g * s.omb1;
-        const float vv = v[0] * s.b2 + s.omb2 * g * g;
-        const float denom = __fsqrt_rn(vv) / s.sqrt_bc2 + s.eps;
-        log_alpha[0] = log_alpha[0] + s.neg_step * mm / denom;
-        m[0] = mm; v[0] = vv;
+    float total = (threadIdx.x == 0 && p.accumulate) ? p.out[0] : 0.f;
+    const float alpha = expf(p.log_alpha[0]);
+    for (int b = threadIdx.x; b < p.B; b += 256) {   // (this thread reads back only the rows it writes)
+        float qm = p.qt[0][(size_t)b * p.ldq];
+        for (int i = 1; i < p.NC; ++i) qm = fminf(qm, p.qt[i][(size_t)b * p.ldq]);
+        const float nq = qm - alpha * p.logp[b];
+        p.tgt[b] = p.reward_scale * p.reward[b] + ((1.0f - (float)p.term[b]) * p.gamma) * nq;
+    }
+    for (int i = 0; i < p.NC; ++i) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < p.B; b += 256) {
+            const float d = p.q[i][(size_t)b * p.ldq] - p.tgt[b];
+            float l, dl;
+            if (p.loss_kind == 1) { const float z = fabsf(d); l = z < 1.f ? 0.5f * z * z : z - 0.5f; dl = z < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
+            else { l = d * d; dl = 2.f * d; }
+            p.dout[i][(size_t)b * p.ldq] = dl / (float)p.B;
+            s += l;
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+        if (threadIdx.x == 0) total = total + red[0] * p.scale;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.out[0] = total;
+}
+
+// every input matrix of the step from the batch rows in one launch: the actor's zero-padded obs / next_obs, and the critics'
+// three inputs (obs | a_pi), (next_obs | a_pi'), (obs | act) - the sampled actions are filled in by k_sac_action
+struct SacPackArgs {
+    const float* obs; const float* next; const float* act; int O, A, B;
+    float* x_o; float* x_no; int ldp;
+    float* xq_a; float* xq_n; float* xq_c; int ldq;
+    float* z; size_t nz; uint64_t seed, counter;   // nz > 0: also draw the step's N(0,1) numbers (randn_at)
+};
+__global__ void k_sac_pack(SacPackArgs p)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((size_t)t < p.nz) p.z[t] = randn_at(p.seed, p.counter, (size_t)t);
+    const int W = p.O + p.A;
+    if (t >= p.B * W) return;
+    const int b = t / W, c = t % W;
+    if (c < p.O) {
+        const float o = p.obs[(size_t)b * p.O + c], n = p.next[(size_t)b * p.O + c];
+        p.x_o[(size_t)b * p.ldp + c] = o; p.x_no[(size_t)b * p.ldp + c] = n;
+        p.xq_a[(size_t)b * p.ldq + c] = o; p.xq_c[(size_t)b * p.ldq + c] = o; p.xq_n[(size_t)b * p.ldq + c] = n;
+    } else {
+        p.xq_c[(size_t)b * p.ldq + c] = p.act[(size_t)b * p.A + (c - p.O)];
     }
 }
 
-// tgt = reward_scale*r + ((1 - term)*gamma) * (min_i Qtgt_i - alpha*logp')   (sac/base.rs:113-122)
-struct SacTargetArgs {
-    const float* q[4]; int ldq; int NC;
-    const float* logp; const float* log_alpha;
-    const float* reward; const int8_t* term;
-    float* tgt; int B; float gamma, reward_scale;
-};
-__global__ void k_sac_target(SacTargetArgs p)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= p.B) return;
-    float qm = p.q[0][(size_t)b * p.ldq];
-    for (int i = 1; i < p.NC; ++i) qm = fminf(qm, p.q[i][(size_t)b * p.ldq]);
-    const float nq = qm - expf(p.log_alpha[0]) * p.logp[b];
-    p.tgt[b] = p.reward_scale * p.reward[b] + ((1.0f - (float)p.term[b]) * p.gamma) * nq;
-}
-
-// critic loss rows + upstream gradient (column 0)
-__global__ void k_sac_critic_td(const float* __restrict__ q, int ldq, const float* __restrict__ tgt, float* __restrict__ dout,
-                                float* __restrict__ loss_row, int B, int loss_kind)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const float d = q[(size_t)b * ldq] - tgt[b];
-    float l, dl;
-    if (loss_kind == 1) { const float z = fabsf(d); l = z < 1.f ? 0.5f * z * z : z - 0.5f; dl = z < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
-    else { l = d * d; dl = 2.f * d; }
-    loss_row[b] = l;
-    for (int c = 0; c < ldq; ++c) dout[(size_t)b * ldq + c] = c == 0 ? dl / (float)B : 0.f;
-}
-
-__global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ x, int n, float* __restrict__ out, float scale, int accumulate)
-{
-    __shared__ float red[256];
-    float s = 0.f;
-    for (int b = threadIdx.x; b < n; b += 256) s += x[b];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
-    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + red[0] * scale;
-}
-
-// counter-based N(0,1): splitmix64 hash -> Box-Muller (the reference draws from torch's global CPU RNG)
 __global__ void k_randn(float* __restrict__ out, size_t n, uint64_t seed, uint64_t counter)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint64_t x = (seed + 0x9E3779B97F4A7C15ull) ^ ((counter + i + 1) * 0xBF58476D1CE4E5B9ull);
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
-    const float u1 = ((float)(x >> 40) + 1.0f) * (1.0f / 16777217.0f);
-    const float u2 = (float)((x >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
-    out[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    out[i] = randn_at(seed, counter, i);
 }
 
 }  // namespace
@@ -185,21 +221,25 @@ struct Sac : bdr_agent {
     float *log_alpha = nullptr, *al_m = nullptr, *al_v = nullptr;
     uint64_t step_pi = 0, step_q[4] = {0}, step_al = 0;
     // batch buffers
-    int B = 0;
+    int B = 0; uint64_t batch_gen = 0;   // bumped by every re-allocation (the captured graph holds the old pointers)
     float *x_o = nullptr, *x_no = nullptr;          // packed obs / next_obs [B][Kp_pi]
     std::vector<float*> t_act;                      // trunk activations
     float *mean = nullptr, *e = nullptr, *a_s = nullptr, *s_s = nullptr, *sd_s = nullptr, *gmean = nullptr, *ge = nullptr;
     std::vector<float*> t_dy;                       // trunk gradients
-    float* xq = nullptr;                            // critic input [B][Kp_q]
-    std::vector<float*> c_act[4];                   // critic activations
+    float *xq_a = nullptr, *xq_n = nullptr, *xq_c = nullptr;   // critic inputs [B][Kp_q]: (obs | a_pi), (next_obs | a_pi'), (obs | act)
+    std::vector<float*> c_act[4];                   // critic activations on xq_a / xq_n
+    std::vector<float*> c2_act[4];                  // critic activations on xq_c (the TD pass)
     std::vector<float*> c_dy[4];                    // critic gradients per layer
     float* dxq[4] = {nullptr};                      // critic input gradients [B][Kp_q]
-    float *logp = nullptr, *tgt = nullptr, *loss_row = nullptr, *z_a = nullptr, *z_n = nullptr;
-    float* dw_part = nullptr;   // row-chunk partials of the dW launches (dense_dw_chunks)
+    float *logp = nullptr, *tgt = nullptr, *z_a = nullptr;   // z_a: [2][B][A] N(0,1) draws (actor pass, then target pass)
+    // row-chunk partials of the grouped dW launches: pi layer l at pi_part + pi_off[l]; critic i, layer l at q_part + i * q_part_stride + q_off[l]
+    float *pi_part = nullptr, *q_part = nullptr; size_t q_part_stride = 0;
+    std::vector<size_t> pi_off, q_off; std::vector<int> pi_chunks, q_chunks;
     float* scal = nullptr;                          // [0] loss_critic (sum over critics / NC), [1] loss_actor
     // host staging for update_on_batch
     float *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr, *u_rew = nullptr; int8_t* u_term = nullptr; uint64_t u_cap = 0;
     uint64_t noise_counter = 0;
+    StepGraph graph; bool use_graph = true;   // BDR_NO_STEP_GRAPH=1: eager launches
 
     ~Sac() override
     {
@@ -213,15 +253,16 @@ struct Sac : bdr_agent {
     }
     void free_batch()
     {
-        float** singles[] = {&x_o, &x_no, &mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge, &xq, &logp, &tgt, &loss_row, &z_a, &z_n, &dw_part};
+        float** singles[] = {&x_o, &x_no, &mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge, &xq_a, &xq_n, &xq_c, &logp, &tgt, &z_a, &pi_part, &q_part};
         for (auto p : singles) { (void)hipFree(*p); *p = nullptr; }
         for (auto p : t_act) (void)hipFree(p);
         for (auto p : t_dy) (void)hipFree(p);
         t_act.clear(); t_dy.clear();
         for (int i = 0; i < 4; ++i) {
             for (auto p : c_act[i]) (void)hipFree(p);
+            for (auto p : c2_act[i]) (void)hipFree(p);
             for (auto p : c_dy[i]) (void)hipFree(p);
-            c_act[i].clear(); c_dy[i].clear();
+            c_act[i].clear(); c2_act[i].clear(); c_dy[i].clear();
             (void)hipFree(dxq[i]); dxq[i] = nullptr;
         }
     }
@@ -242,22 +283,34 @@ struct Sac : bdr_agent {
         for (int i = 0; i < n_trunk; ++i) { float* p = nullptr; BDR_TRY(zalloc(&p, (size_t)Bn * pi.L[i].Np)); t_dy.push_back(p); }
         float** heads[] = {&mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge};
         for (auto p : heads) BDR_TRY(zalloc(p, (size_t)Bn * Ap));
-        BDR_TRY(zalloc(&xq, (size_t)Bn * Kq));
+        BDR_TRY(zalloc(&xq_a, (size_t)Bn * Kq)); BDR_TRY(zalloc(&xq_n, (size_t)Bn * Kq)); BDR_TRY(zalloc(&xq_c, (size_t)Bn * Kq));
         for (int i = 0; i < NC; ++i) {
             for (const auto& l : qn.L) {
-                float *p = nullptr, *d = nullptr;
-                BDR_TRY(zalloc(&p, (size_t)Bn * l.Np)); BDR_TRY(zalloc(&d, (size_t)Bn * l.Np));
-                c_act[i].push_back(p); c_dy[i].push_back(d);
+                float *p = nullptr, *p2 = nullptr, *d = nullptr;
+                BDR_TRY(zalloc(&p, (size_t)Bn * l.Np)); BDR_TRY(zalloc(&p2, (size_t)Bn * l.Np)); BDR_TRY(zalloc(&d, (size_t)Bn * l.Np));
+                c_act[i].push_back(p); c2_act[i].push_back(p2); c_dy[i].push_back(d);
             }
             BDR_TRY(zalloc(&dxq[i], (size_t)Bn * Kq));
         }
-        BDR_TRY(zalloc(&logp, Bn)); BDR_TRY(zalloc(&tgt, Bn)); BDR_TRY(zalloc(&loss_row, Bn));
-        BDR_TRY(zalloc(&z_a, (size_t)Bn * A)); BDR_TRY(zalloc(&z_n, (size_t)Bn * A));
-        size_t pmax = 4;
-        for (const auto& l : pi.L) pmax = std::max(pmax, dense_dw_part_floats(l));
-        for (const auto& l : qn.L) pmax = std::max(pmax, dense_dw_part_floats(l));
-        BDR_TRY(zalloc(&dw_part, pmax));
-        B = Bn;
+        BDR_TRY(zalloc(&logp, Bn)); BDR_TRY(zalloc(&tgt, Bn));
+        BDR_TRY(zalloc(&z_a, (size_t)2 * Bn * A));
+        // row chunks of the grouped dW launches: about 512 workgroups per launch over all its GEMMs, >= 64 rows per chunk
+        auto plan = [&](const MlpLayout& net, int jobs, std::vector<size_t>& off, std::vector<int>& chunks) {
+            off.clear(); chunks.clear();
+            size_t o = 0;
+            const int target = std::max(32, 512 / jobs);
+            for (const auto& l : net.L) {
+                const int tiles = (l.Kp / 64) * (l.Np / 64);
+                const int c = std::max(1, std::min(std::min(16, Bn / 64), (target + tiles - 1) / tiles));
+                off.push_back(o); chunks.push_back(c);
+                o += (size_t)c * ((size_t)l.Kp * l.Np + l.Np);
+            }
+            return o;
+        };
+        BDR_TRY(zalloc(&pi_part, plan(pi, (int)pi.L.size(), pi_off, pi_chunks)));
+        q_part_stride = plan(qn, (int)qn.L.size() * NC, q_off, q_chunks);
+        BDR_TRY(zalloc(&q_part, q_part_stride * NC));
+        B = Bn; batch_gen += 1;
         return BDR_OK;
     }
 
@@ -271,12 +324,16 @@ struct Sac : bdr_agent {
             BDR_TRY(dense_forward(a, stream, pi.L[i], pi_p, in, t_act[i], Bn));
             in = DenseSrc{t_act[i], pi.L[i].Np};
         }
-        { Bracket br(a, "pi_head"); BDR_TRY(dense_forward(a, stream, pi.L[n_trunk], pi_p, in, mean, Bn)); }
-        { Bracket br(a, "pi_head"); BDR_TRY(dense_forward(a, stream, pi.L[n_trunk + 1], pi_p, in, e, Bn)); }
-        return BDR_OK;
+        // both heads (same shape, same input, consecutive in the arena) in one launch
+        const DenseLayer& h0 = pi.L[n_trunk];
+        const float* pb[2] = {pi_p, pi_p + (pi.L[n_trunk + 1].w - h0.w)};
+        const DenseSrc ins[2] = {in, in};
+        float* outs[2] = {mean, e};
+        Bracket br(a, "pi_head");
+        return dense_forward_z(stream, h0, 2, pb, ins, outs, Bn);
     }
-    // action_logp: writes the action into xq's action columns, log_p into logp
-    int32_t action_logp(const float* x, const float* z, int Bn, bool save)
+    // action_logp: writes the action into the action columns of the critic input `xq`, log_p into logp
+    int32_t action_logp(const float* x, const float* z, int Bn, bool save, float* xq)
     {
         BDR_TRY(pi_forward(x, Bn));
         SacActionArgs p{};
@@ -284,83 +341,101 @@ struct Sac : bdr_agent {
         p.a_out = save ? a_s : nullptr; p.s_out = s_s; p.sd_out = sd_s; p.logp = logp;
         p.B = Bn; p.A = A; p.lo = (float)cfg.min_lstd; p.hi = (float)cfg.max_lstd; p.eps = (float)cfg.epsilon;
         Bracket br(this, "sac_action");
-        hipLaunchKernelGGL(k_sac_action, dim3((Bn + 3) / 4), dim3(256), 0, stream, p);
-        BDR_HIP(hipGetLastError());
+        BDR_HIP(step_launch(stream, false, k_sac_action, dim3((Bn + 3) / 4), dim3(256), p));
         return BDR_OK;
     }
-    int32_t critic_forward(int i, const float* params, int Bn)
+    // Forward passes of the critic architecture, layer by layer, up to 4 (parameters, input) pairs per launch:
+    // pass j runs parameters params[j] on input x[j] into acts[j][layer].
+    int32_t critic_forward_n(int n, const float* const* params, const float* const* x, std::vector<float*>* const* acts, int Bn)
     {
         bdr_agent* a = this;
-        DenseSrc in{xq, qn.L[0].Kp};
-        for (size_t l = 0; l < qn.L.size(); ++l) {
-            Bracket br(a, "q_fwd");
-            BDR_TRY(dense_forward(a, stream, qn.L[l], params, in, c_act[i][l], Bn));
-            in = DenseSrc{c_act[i][l], qn.L[l].Np};
+        for (int j0 = 0; j0 < n; j0 += 4) {
+            const int nz = std::min(4, n - j0);
+            DenseSrc in[4]; float* out[4];
+            for (int j = 0; j < nz; ++j) in[j] = DenseSrc{x[j0 + j], qn.L[0].Kp};
+            for (size_t l = 0; l < qn.L.size(); ++l) {
+                for (int j = 0; j < nz; ++j) out[j] = (*acts[j0 + j])[l];
+                Bracket br(a, "q_fwd");
+                if (nz == 1) BDR_TRY(dense_forward(a, stream, qn.L[l], params[j0], in[0], out[0], Bn));
+                else BDR_TRY(dense_forward_z(stream, qn.L[l], nz, params + j0, in, out, Bn));
+                for (int j = 0; j < nz; ++j) in[j] = DenseSrc{out[j], qn.L[l].Np};
+            }
         }
         return BDR_OK;
     }
-    // all critics (same architecture, own parameters, shared input xq) layer by layer in one launch each
-    int32_t critic_forward_all(float* const* params, int Bn)
-    {
-        if (NC == 1) return critic_forward(0, params[0], Bn);
-        bdr_agent* a = this;
-        DenseSrc in[4];
-        const float* pb[4]; float* out[4];
-        for (int i = 0; i < NC; ++i) { in[i] = DenseSrc{xq, qn.L[0].Kp}; pb[i] = params[i]; }
-        for (size_t l = 0; l < qn.L.size(); ++l) {
-            for (int i = 0; i < NC; ++i) out[i] = c_act[i][l];
-            Bracket br(a, "q_fwd");
-            BDR_TRY(dense_forward_z(stream, qn.L[l], NC, pb, in, out, Bn));
-            for (int i = 0; i < NC; ++i) in[i] = DenseSrc{c_act[i][l], qn.L[l].Np};
-        }
-        return BDR_OK;
-    }
-    // dX of layer l for all critics in one launch: c_dy[i][l] -> (l == 0 ? dxq[i] : c_dy[i][l-1])
-    int32_t critic_dx_all(int l, int Bn)
+    // dX of layer l for all critics in one launch: c_dy[i][l] -> (l == 0 ? dxq[i] : c_dy[i][l-1]), ReLU mask from `acts`
+    int32_t critic_dx_all(int l, int Bn, std::vector<float*>* acts)
     {
         const float* pb[4]; const float* dy[4]; float* dx[4]; const float* mask[4];
         for (int i = 0; i < NC; ++i) {
-            pb[i] = q_p[i]; dy[i] = c_dy[i][l]; dx[i] = l == 0 ? dxq[i] : c_dy[i][l - 1]; mask[i] = l == 0 ? nullptr : c_act[i][l - 1];
+            pb[i] = q_p[i]; dy[i] = c_dy[i][l]; dx[i] = l == 0 ? dxq[i] : c_dy[i][l - 1]; mask[i] = l == 0 ? nullptr : acts[i][l - 1];
         }
         if (NC == 1) return dense_dx(stream, qn.L[l], pb[0], dy[0], dx[0], mask[0], Bn);
         return dense_dx_z(stream, qn.L[l], NC, pb, dy, dx, l == 0 ? nullptr : mask, Bn);
     }
-    int32_t pack_obs_into_xq(const float* obs_rows, int Bn) { return pack_rows(stream, obs_rows, O, O, xq, qn.L[0].Kp, 0, Bn); }
+    // partial sums of a grouped dW launch -> gradient arena, Adam, (tracking) for `ninst` networks of one layout
+    int32_t reduce_adam(const MlpLayout& net, const std::vector<size_t>& off, const std::vector<int>& chunks, int Bn, const float* part,
+                        size_t inst_stride, int ninst, float* const* p, float* const* g, float* const* m, float* const* v,
+                        float* const* tgt_p, const AdamScalars* sc)
+    {
+        ReduceAdamArgs ra{};
+        ra.nseg = (int)net.L.size(); ra.inst_part_stride = inst_stride;
+        for (size_t l = 0; l < net.L.size(); ++l) {
+            const DenseLayer& L = net.L[l];
+            const size_t nfl = (size_t)L.Kp * L.Np + L.Np;
+            ra.seg[l] = DenseReduceSeg{part + off[l], nfl, std::min(chunks[l], std::max(1, Bn / 64)), (unsigned)(L.w / 4), (unsigned)(nfl / 4)};
+        }
+        for (int i = 0; i < ninst; ++i) { ra.p[i] = p[i]; ra.g[i] = g[i]; ra.m[i] = m[i]; ra.v[i] = v[i]; ra.tgt[i] = tgt_p ? tgt_p[i] : nullptr; ra.s[i] = sc[i]; }
+        ra.n4 = (unsigned)(net.total / 4); ra.track = tgt_p ? 1 : 0; ra.tau = (float)cfg.tau; ra.omt = (float)(1.0 - cfg.tau);
+        BDR_HIP(step_launch(stream, true, k_dense_reduce_adam, dim3((ra.n4 + 255) / 256, ninst), dim3(256), ra));
+        return BDR_OK;
+    }
 
-    // one iteration of the Sac::opt_ loop on a device-resident batch (obs/next_obs/act rows are f32)
+    // One iteration of the Sac::opt_ loop on a device-resident batch (obs/next_obs/act rows are f32).  The order of the reference is
+    // kept where it matters (actor first, the critic target from the UPDATED actor, tracking after every critic step); launches that
+    // do not depend on each other are merged: 34 launches for twin critics instead of one per layer and tensor (70).
+    // draw_noise: z_actor / z_next ([Bn][A] each, contiguous) are drawn on the device inside the first launch
     int32_t update(int Bn, const float* obs, const float* act, const float* next_obs, const float* reward, const int8_t* term,
-                   const float* z_actor, const float* z_next, bool first)
+                   float* z_actor, float* z_next, bool first, bool draw_noise = false)
     {
         bdr_agent* a = this;
         BDR_TRY(ensure_batch(Bn));
         const int L = (int)qn.L.size(), ldq = qn.L[L - 1].Np, Ap = pi.L[n_trunk].Np, Kq = qn.L[0].Kp;
-        BDR_TRY(pack_rows(stream, obs, O, O, x_o, pi.L[0].Kp, 0, Bn));
-        BDR_TRY(pack_rows(stream, next_obs, O, O, x_no, pi.L[0].Kp, 0, Bn));
-
-        // ---------------- update_actor (sac/base.rs:151-167) ----------------
-        BDR_TRY(pack_obs_into_xq(obs, Bn));
-        BDR_TRY(action_logp(x_o, z_actor, Bn, true));
-        if (cfg.ent_coef_auto) {
-            step_al += 1;
-            const AdamScalars s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
-            Bracket br(a, "alpha_update");
-            hipLaunchKernelGGL(k_sac_alpha_update, dim3(1), dim3(256), 0, stream, logp, Bn, (float)cfg.target_entropy, log_alpha, al_m, al_v, s);
-            BDR_HIP(hipGetLastError());
+        {
+            SacPackArgs p{obs, next_obs, act, O, A, Bn, x_o, x_no, pi.L[0].Kp, xq_a, xq_n, xq_c, Kq, nullptr, 0, 0, 0};
+            if (draw_noise) {
+                BDR_REQUIRE(z_next == z_actor + (size_t)Bn * A, "noise buffers must be contiguous");
+                p.z = z_actor; p.nz = (size_t)2 * Bn * A; p.seed = cfg.seed; p.counter = noise_counter;
+                noise_counter += p.nz;
+            }
+            const size_t nthr = std::max<size_t>((size_t)Bn * (O + A), p.nz);
+            Bracket br(a, "pack");
+            BDR_HIP(step_launch(stream, draw_noise, k_sac_pack, dim3((unsigned)((nthr + 255) / 256)), dim3(256), p));
         }
-        BDR_TRY(critic_forward_all(q_p, Bn));
+        // ---------------- update_actor (sac/base.rs:151-167) ----------------
+        BDR_TRY(action_logp(x_o, z_actor, Bn, true, xq_a));
+        {   // Q_i(obs, a_pi) for the actor loss and Q_i(obs, act) for the TD loss: the same parameters (the critics only step at the end)
+            const float* params[8]; const float* x[8]; std::vector<float*>* acts[8];
+            for (int i = 0; i < NC; ++i) { params[i] = q_p[i]; x[i] = xq_a; acts[i] = &c_act[i]; params[NC + i] = q_p[i]; x[NC + i] = xq_c; acts[NC + i] = &c2_act[i]; }
+            BDR_TRY(critic_forward_n(2 * NC, params, x, acts, Bn));
+        }
         {
             SacSelectArgs p{};
             for (int i = 0; i < NC; ++i) { p.q[i] = c_act[i][L - 1]; p.dout[i] = c_dy[i][L - 1]; }
-            p.ldq = ldq; p.logp = logp; p.log_alpha = log_alpha; p.loss_row = loss_row; p.B = Bn; p.NC = NC;
+            p.ldq = ldq; p.logp = logp; p.log_alpha = log_alpha; p.B = Bn; p.NC = NC;
+            p.out = scal + 1; p.scale = 1.0f / (float)Bn; p.accumulate = first ? 0 : 1;
+            p.auto_alpha = cfg.ent_coef_auto ? 1 : 0;
+            if (cfg.ent_coef_auto) {
+                step_al += 1;
+                p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v;
+                p.s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
+            }
             Bracket br(a, "sac_select");
-            hipLaunchKernelGGL(k_sac_select, dim3((Bn + 255) / 256), dim3(256), 0, stream, p);
-            BDR_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, scal + 1, 1.0f / (float)Bn, first ? 0 : 1);
-            BDR_HIP(hipGetLastError());
+            BDR_HIP(step_launch(stream, cfg.ent_coef_auto != 0, k_sac_select, dim3(1), dim3(256), p));
         }
         for (int l = L - 1; l >= 0; --l) {   // d qmin / d input through the critics (weights untouched here)
             Bracket br(a, "q_dx");
-            BDR_TRY(critic_dx_all(l, Bn));
+            BDR_TRY(critic_dx_all(l, Bn, c_act));
         }
         {
             SacActorGradArgs p{};
@@ -369,95 +444,93 @@ struct Sac : bdr_agent {
             p.log_alpha = log_alpha; p.gmean = gmean; p.ge = ge; p.B = Bn; p.A = A;
             p.lo = (float)cfg.min_lstd; p.hi = (float)cfg.max_lstd; p.eps = (float)cfg.epsilon;
             Bracket br(a, "sac_actor_grad");
-            hipLaunchKernelGGL(k_sac_actor_grad, dim3((Bn * Ap + 255) / 256), dim3(256), 0, stream, p);
-            BDR_HIP(hipGetLastError());
+            BDR_HIP(step_launch(stream, false, k_sac_actor_grad, dim3((Bn * Ap + 255) / 256), dim3(256), p));
         }
-        {   // heads, then trunk
-            DenseSrc hin = n_trunk ? DenseSrc{t_act[n_trunk - 1], pi.L[n_trunk - 1].Np} : DenseSrc{x_o, pi.L[0].Kp};
-            { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[n_trunk], pi_g, hin, gmean, Bn, dw_part, dense_dw_chunks(pi.L[n_trunk], Bn))); }
-            { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[n_trunk + 1], pi_g, hin, ge, Bn, dw_part, dense_dw_chunks(pi.L[n_trunk + 1], Bn))); }
+        {   // input gradients down the trunk first, then every weight gradient of the actor in one grouped launch
+            DenseDwJob jobs[RA_SEGS];
+            auto chunks_rt = [&](int c) { return std::min(c, std::max(1, Bn / 64)); };
+            const DenseSrc hin = n_trunk ? DenseSrc{t_act[n_trunk - 1], pi.L[n_trunk - 1].Np} : DenseSrc{x_o, pi.L[0].Kp};
             if (n_trunk) {
                 float* dh = t_dy[n_trunk - 1];
                 { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk], pi_p, gmean, dh, t_act[n_trunk - 1], Bn, false)); }
                 { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk + 1], pi_p, ge, dh, t_act[n_trunk - 1], Bn, true)); }
-                for (int l = n_trunk - 1; l >= 0; --l) {
-                    DenseSrc in = l == 0 ? DenseSrc{x_o, pi.L[0].Kp} : DenseSrc{t_act[l - 1], pi.L[l - 1].Np};
-                    { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw(stream, pi.L[l], pi_g, in, t_dy[l], Bn, dw_part, dense_dw_chunks(pi.L[l], Bn))); }
-                    if (l > 0) { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[l], pi_p, t_dy[l], t_dy[l - 1], t_act[l - 1], Bn)); }
-                }
+                for (int l = n_trunk - 1; l > 0; --l) { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[l], pi_p, t_dy[l], t_dy[l - 1], t_act[l - 1], Bn)); }
             }
+            int nj = 0;
+            for (int l = 0; l < n_trunk; ++l)
+                jobs[nj++] = DenseDwJob{&pi.L[l], l == 0 ? DenseSrc{x_o, pi.L[0].Kp} : DenseSrc{t_act[l - 1], pi.L[l - 1].Np}, t_dy[l], pi_part + pi_off[l], chunks_rt(pi_chunks[l])};
+            jobs[nj++] = DenseDwJob{&pi.L[n_trunk], hin, gmean, pi_part + pi_off[n_trunk], chunks_rt(pi_chunks[n_trunk])};
+            jobs[nj++] = DenseDwJob{&pi.L[n_trunk + 1], hin, ge, pi_part + pi_off[n_trunk + 1], chunks_rt(pi_chunks[n_trunk + 1])};
+            { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw_group(stream, jobs, nj, Bn)); }
+            step_pi += 1;
+            const AdamScalars sc = adam_scalars_for(false, cfg.lr_actor, 0, 0, 0, 0, step_pi);
+            Bracket br(a, "adam_pi");
+            BDR_TRY(reduce_adam(pi, pi_off, pi_chunks, Bn, pi_part, 0, 1, &pi_p, &pi_g, &pi_m, &pi_v, nullptr, &sc));
         }
-        step_pi += 1;
-        { Bracket br(a, "adam_pi"); BDR_TRY(launch_adam(stream, pi_p, pi_g, pi_m, pi_v, pi.total, adam_scalars_for(false, cfg.lr_actor, 0, 0, 0, 0, step_pi))); }
 
         // ---------------- update_critic (sac/base.rs:107-149) ----------------
-        BDR_TRY(pack_obs_into_xq(next_obs, Bn));
-        BDR_TRY(action_logp(x_no, z_next, Bn, false));            // the UPDATED actor
-        BDR_TRY(critic_forward_all(q_t, Bn));
+        BDR_TRY(action_logp(x_no, z_next, Bn, false, xq_n));            // the UPDATED actor
         {
-            SacTargetArgs p{};
-            for (int i = 0; i < NC; ++i) p.q[i] = c_act[i][L - 1];
-            p.ldq = ldq; p.NC = NC; p.logp = logp; p.log_alpha = log_alpha; p.reward = reward; p.term = term; p.tgt = tgt;
-            p.B = Bn; p.gamma = (float)cfg.gamma; p.reward_scale = (float)cfg.reward_scale;
-            Bracket br(a, "sac_target");
-            hipLaunchKernelGGL(k_sac_target, dim3((Bn + 255) / 256), dim3(256), 0, stream, p);
-            BDR_HIP(hipGetLastError());
+            const float* params[4]; const float* x[4]; std::vector<float*>* acts[4];
+            for (int i = 0; i < NC; ++i) { params[i] = q_t[i]; x[i] = xq_n; acts[i] = &c_act[i]; }
+            BDR_TRY(critic_forward_n(NC, params, x, acts, Bn));
         }
-        BDR_TRY(pack_obs_into_xq(obs, Bn));
-        BDR_TRY(pack_rows(stream, act, A, A, xq, Kq, O, Bn));
-        BDR_TRY(critic_forward_all(q_p, Bn));   // every critic on (obs, act); their updates below do not depend on each other
-        for (int i = 0; i < NC; ++i) {
+        {
+            SacTdArgs p{};
+            for (int i = 0; i < NC; ++i) { p.q[i] = c2_act[i][L - 1]; p.dout[i] = c_dy[i][L - 1]; }
+            for (int i = 0; i < NC; ++i) p.qt[i] = c_act[i][L - 1];
+            p.logp = logp; p.log_alpha = log_alpha; p.reward = reward; p.term = term; p.gamma = (float)cfg.gamma; p.reward_scale = (float)cfg.reward_scale;
+            p.ldq = ldq; p.NC = NC; p.tgt = tgt; p.out = scal; p.scale = 1.0f / ((float)Bn * (float)NC); p.accumulate = first ? 0 : 1;
+            p.B = Bn; p.loss_kind = cfg.critic_loss;
             Bracket br(a, "critic_td");
-            hipLaunchKernelGGL(k_sac_critic_td, dim3((Bn + 255) / 256), dim3(256), 0, stream, c_act[i][L - 1], ldq, tgt, c_dy[i][L - 1], loss_row, Bn, cfg.critic_loss);
-            BDR_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, scal, 1.0f / ((float)Bn * (float)NC), (first && i == 0) ? 0 : 1);
-            BDR_HIP(hipGetLastError());
+            BDR_HIP(step_launch(stream, false, k_sac_critic_td, dim3(1), dim3(256), p));
         }
-        for (int l = L - 1; l >= 0; --l) {
-            for (int i = 0; i < NC; ++i) {
-                DenseSrc in = l == 0 ? DenseSrc{xq, Kq} : DenseSrc{c_act[i][l - 1], qn.L[l - 1].Np};
-                Bracket br(a, "q_dw");
-                BDR_TRY(dense_dw(stream, qn.L[l], q_g[i], in, c_dy[i][l], Bn, dw_part, dense_dw_chunks(qn.L[l], Bn)));
-            }
-            if (l > 0) { Bracket br(a, "q_dx"); BDR_TRY(critic_dx_all(l, Bn)); }
+        for (int l = L - 1; l > 0; --l) { Bracket br(a, "q_dx"); BDR_TRY(critic_dx_all(l, Bn, c2_act)); }
+        {   // every weight gradient of every critic in one grouped launch; partial sums -> gradients, Adam and soft_update (:169-173) in one more
+            std::vector<DenseDwJob> jobs;
+            for (int i = 0; i < NC; ++i)
+                for (int l = 0; l < L; ++l)
+                    jobs.push_back(DenseDwJob{&qn.L[l], l == 0 ? DenseSrc{xq_c, Kq} : DenseSrc{c2_act[i][l - 1], qn.L[l - 1].Np}, c_dy[i][l],
+                                              q_part + (size_t)i * q_part_stride + q_off[l], std::min(q_chunks[l], std::max(1, Bn / 64))});
+            { Bracket br(a, "q_dw"); BDR_TRY(dense_dw_group(stream, jobs.data(), (int)jobs.size(), Bn)); }
+            AdamScalars sc[4];
+            for (int i = 0; i < NC; ++i) { step_q[i] += 1; sc[i] = adam_scalars_for(false, cfg.lr_critic, 0, 0, 0, 0, step_q[i]); }
+            Bracket br(a, "adam_q_track");
+            BDR_TRY(reduce_adam(qn, q_off, q_chunks, Bn, q_part, q_part_stride, NC, q_p, q_g, q_m, q_v, q_t, sc));
         }
-        for (int i = 0; i < NC; ++i) {
-            step_q[i] += 1;
-            Bracket br(a, "adam_q");
-            BDR_TRY(launch_adam(stream, q_p[i], q_g[i], q_m[i], q_v[i], qn.total, adam_scalars_for(false, cfg.lr_critic, 0, 0, 0, 0, step_q[i])));
-        }
-        // ---------------- soft_update (:169-173) ----------------
-        for (int i = 0; i < NC; ++i) { Bracket br(a, "track"); BDR_TRY(launch_track(stream, q_t[i], q_p[i], qn.total, cfg.tau)); }
         n_opts += 1;
         return BDR_OK;
     }
 
     int32_t gen_noise(float* dst, size_t n)
     {
-        hipLaunchKernelGGL(k_randn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, n, cfg.seed, noise_counter);
-        BDR_HIP(hipGetLastError());
+        BDR_HIP(step_launch(stream, true, k_randn, dim3((unsigned)((n + 255) / 256)), dim3(256), dst, n, cfg.seed, noise_counter));
         noise_counter += n;
         return BDR_OK;
     }
 
     const char* kind() const override { return "sac"; }
+    // the launch sequence of one opt() (Sac::opt_, sac/base.rs:175-192)
+    int32_t opt_enqueue(bdr_replay* r, int Bn)
+    {
+        for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
+            { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, Bn, stream)); }
+            // the noise of the actor pass, then of the target pass: 2*Bn*A consecutive draws of the agent's stream
+            BDR_TRY(update(Bn, (const float*)r->b_obs, (const float*)r->b_act, (const float*)r->b_next, r->b_reward, r->b_term, z_a, z_a + (size_t)Bn * A, u == 0, true));
+        }
+        return BDR_OK;
+    }
     int32_t opt(bdr_replay* r) override
     {
         BDR_REQUIRE(r->obs_bytes == (uint64_t)O * 4 && r->act_bytes == (uint64_t)A * 4, "replay rows do not match SAC obs/act dims");
         BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
         const int Bn = (int)cfg.batch_size;
         BDR_TRY(ensure_batch(Bn));
-        for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
-            { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, Bn, stream)); }
-            BDR_TRY(gen_noise(z_a, (size_t)Bn * A));
-            BDR_TRY(gen_noise(z_n, (size_t)Bn * A));
-            BDR_TRY(update(Bn, (const float*)r->b_obs, (const float*)r->b_act, (const float*)r->b_next, r->b_reward, r->b_term, z_a, z_n, u == 0));
-        }
-        if (cfg.n_updates_per_opt > 1) {   // loss_critic /= n_updates_per_opt etc. (sac/base.rs:187-188)
-            hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, stream, scal, 0, scal, 0.f, 1);   // no-op placeholder keeps ordering simple
-            BDR_HIP(hipGetLastError());
-        }
-        return BDR_OK;
+        // ~70 kernels of 2-8 us: replayed from a captured graph (step_graph.hpp).  Profiling brackets and prioritized replay
+        // (tree kernels with their own host state) take the eager path - the same sequence, launched one by one.
+        if (!use_graph || prof || r->per) return opt_enqueue(r, Bn);
+        BDR_TRY(replay_prepare_sample(r, Bn, stream));
+        return step_graph_run(&graph, stream, r->uid, r->batch_gen, batch_gen, [&]() { return opt_enqueue(r, Bn); });
     }
     void record_keys(std::vector<std::string>& keys) override { keys = {"loss_critic", "loss_actor", "ent_coef"}; }
     int32_t noise(float* dev, size_t n) override { return gen_noise(dev, n); }   // the N(0,1) stream of action_logp
@@ -611,6 +684,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     a->qn = make_mlp(a->O + a->A, cfg->q_units, cfg->n_q_units, 1, false);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     BDR_TRY(a->err_init());
+    { const char* e = getenv("BDR_NO_STEP_GRAPH"); a->use_graph = !(e && e[0] == '1'); }
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};
     for (auto p : pis) BDR_TRY(a->zalloc(p, a->pi.total));
     for (int i = 0; i < a->NC; ++i) {
@@ -659,8 +733,8 @@ int32_t bdr_sac_update_on_batch(bdr_agent* base, uint64_t n, const float* obs, c
     BDR_HIP(hipMemcpyAsync(a->u_rew, reward, n * 4, hipMemcpyHostToDevice, s));
     BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, s));
     BDR_HIP(hipMemcpyAsync(a->z_a, z_actor, n * a->A * 4, hipMemcpyHostToDevice, s));
-    BDR_HIP(hipMemcpyAsync(a->z_n, z_next, n * a->A * 4, hipMemcpyHostToDevice, s));
-    BDR_TRY(a->update((int)n, a->u_obs, a->u_act, a->u_next, a->u_rew, a->u_term, a->z_a, a->z_n, true));
+    BDR_HIP(hipMemcpyAsync(a->z_a + n * a->A, z_next, n * a->A * 4, hipMemcpyHostToDevice, s));
+    BDR_TRY(a->update((int)n, a->u_obs, a->u_act, a->u_next, a->u_rew, a->u_term, a->z_a, a->z_a + n * a->A, true));
     prof_collect(a);
     if (rec3) {
         float h[2], la;
@@ -691,7 +765,7 @@ int32_t bdr_sac_sample(bdr_agent* base, uint64_t n, const float* obs, float* act
         if (a->train) st = a->gen_noise(a->z_a, n * a->A);
         else { hipError_t e = hipMemsetAsync(a->z_a, 0, n * a->A * 4, a->stream); if (e != hipSuccess) st = fail(BDR_ERR_HIP, "memset failed"); }
     }
-    if (st == BDR_OK) st = a->action_logp(a->x_o, a->z_a, (int)n, true);
+    if (st == BDR_OK) st = a->action_logp(a->x_o, a->z_a, (int)n, true, a->xq_a);
     const int Ap = a->pi.L[a->n_trunk].Np;
     std::vector<float> tmp(n * Ap);
     if (st == BDR_OK) {

@@ -1,0 +1,169 @@
+// Replaying a launch-bound opt step from a hipGraph.
+//
+// The SAC and Mlp-DQN steps are chains of 20-70 kernels of 2-8 us: the host needs 4-5 us per launch (hipLaunchKernel + argument
+// marshalling), which is what bounds those configurations.  The step's launch sequence is the same every time - only
+// a handful of by-value arguments change (Adam's bias corrections, the RNG counters, the replay stream position) - so it is
+// captured once into a hipGraph and replayed with ONE hipGraphLaunch; the varying arguments are patched into their kernel nodes
+// (hipGraphExecKernelNodeSetParams) right before the launch.
+//
+// Every launch of such a step goes through bdr::step_launch().  The agent runs its normal C++ enqueue sequence in one of
+// three modes:
+//   EAGER    plain launches (parity entry points, profiling, prioritized replay, anything the graph does not cover)
+//   CAPTURE  the same launches inside hipStreamBeginCapture / EndCapture; the function of every kernel node is remembered
+//   REPLAY   NO launches: the sequence only redoes its host bookkeeping (counters, stream positions) and, for launches marked
+//            `varying`, patches the freshly built arguments into node #cursor
+// so graph and eager execution are the same code path and produce the same bits; a sequence that launches a different number of
+// kernels than the captured one (batch size changed, buffers re-allocated...) is detected and re-captured.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <tuple>
+#include <vector>
+
+#include "common.hpp"
+
+namespace bdr {
+
+struct StepGraph {
+    enum Mode { EAGER = 0, CAPTURE = 1, REPLAY = 2 };
+    Mode mode = EAGER;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<hipGraphNode_t> nodes;   // kernel nodes in launch order
+    std::vector<void*> funcs;            // their functions, as launched during capture
+    size_t cursor = 0;
+    bool broken = false;                 // a graph API failed once: this agent stays eager (results are identical)
+    int32_t status = BDR_OK;             // first error inside a REPLAY / CAPTURE pass
+    // what the captured sequence depended on
+    uint64_t key_a = 0, key_b = 0, key_n = 0;
+
+    void reset()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr; graph = nullptr; nodes.clear(); funcs.clear(); cursor = 0;
+    }
+    ~StepGraph() { reset(); }
+};
+
+// the pass a thread is currently running (nullptr: eager)
+inline StepGraph*& step_graph_current()
+{
+    static thread_local StepGraph* g = nullptr;
+    return g;
+}
+
+template <class... KArgs, class... Args>
+inline hipError_t step_launch(hipStream_t st, bool varying, void (*kernel)(KArgs...), dim3 grid, dim3 block, Args... args)
+{
+    StepGraph* g = step_graph_current();
+    if (!g || g->mode == StepGraph::EAGER) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+        return hipGetLastError();
+    }
+    if (g->mode == StepGraph::CAPTURE) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+        g->funcs.push_back(reinterpret_cast<void*>(kernel));
+        g->cursor += 1;
+        return hipGetLastError();
+    }
+    // REPLAY
+    const size_t k = g->cursor++;
+    if (k >= g->nodes.size() || g->funcs[k] != reinterpret_cast<void*>(kernel)) { g->status = BDR_ERR_INVALID; return hipSuccess; }   // sequence changed: re-capture
+    if (!varying) return hipSuccess;
+    { static const bool nopatch = getenv("BDR_STEP_GRAPH_NOPATCH") != nullptr; if (nopatch) return hipSuccess; }   // timing experiments only
+    std::tuple<KArgs...> vals(static_cast<KArgs>(args)...);   // arguments with the kernel's own parameter types
+    void* params[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
+    size_t i = 0;
+    std::apply([&](auto&... v) { ((params[i++] = (void*)&v), ...); }, vals);
+    hipKernelNodeParams np{};
+    np.func = reinterpret_cast<void*>(kernel);
+    np.gridDim = grid; np.blockDim = block; np.sharedMemBytes = 0; np.kernelParams = params; np.extra = nullptr;
+    return hipGraphExecKernelNodeSetParams(g->exec, g->nodes[k], &np);
+}
+
+// kernel nodes of a captured linear chain, in execution order
+inline int32_t step_graph_collect(StepGraph* g)
+{
+    size_t n = 0;
+    BDR_HIP(hipGraphGetNodes(g->graph, nullptr, &n));
+    std::vector<hipGraphNode_t> all(n);
+    BDR_HIP(hipGraphGetNodes(g->graph, all.data(), &n));
+    // walk from the root along the single-successor chain a stream capture produces
+    size_t nr = 0;
+    BDR_HIP(hipGraphGetRootNodes(g->graph, nullptr, &nr));
+    if (nr != 1) return fail(BDR_ERR_HIP, "captured step graph has %zu roots", nr);
+    hipGraphNode_t cur = nullptr;
+    BDR_HIP(hipGraphGetRootNodes(g->graph, &cur, &nr));
+    g->nodes.clear();
+    for (size_t step = 0; step < n && cur; ++step) {
+        hipGraphNodeType ty;
+        BDR_HIP(hipGraphNodeGetType(cur, &ty));
+        if (ty == hipGraphNodeTypeKernel) g->nodes.push_back(cur);
+        size_t nd = 0;
+        BDR_HIP(hipGraphNodeGetDependentNodes(cur, nullptr, &nd));
+        if (nd == 0) break;
+        if (nd != 1) return fail(BDR_ERR_HIP, "captured step graph is not a chain");
+        hipGraphNode_t nxt = nullptr;
+        BDR_HIP(hipGraphNodeGetDependentNodes(cur, &nxt, &nd));
+        cur = nxt;
+    }
+    if (g->nodes.size() != g->funcs.size()) return fail(BDR_ERR_HIP, "captured step graph: %zu kernel nodes for %zu launches", g->nodes.size(), g->funcs.size());
+    for (size_t k = 0; k < g->nodes.size(); ++k) {
+        hipKernelNodeParams np{};
+        BDR_HIP(hipGraphKernelNodeGetParams(g->nodes[k], &np));
+        if (np.func != g->funcs[k]) return fail(BDR_ERR_HIP, "captured step graph: node %zu is not launch %zu", k, k);
+    }
+    return BDR_OK;
+}
+
+// Runs `enqueue` (the agent's launch sequence on `st`) through the graph: capture + instantiate when there is no graph for this
+// key yet, else a REPLAY pass + one hipGraphLaunch.  The key must change whenever a buffer the sequence touches is re-allocated:
+// generation counters, not pointers (an allocator hands the same address out again).  `enqueue` must route every launch through
+// step_launch and do all allocation / cross-stream waiting BEFORE it is called.
+template <class F>
+inline int32_t step_graph_run(StepGraph* g, hipStream_t st, uint64_t key_a, uint64_t key_b, uint64_t key_n, F&& enqueue)
+{
+    if (g->broken) return enqueue();
+    if (g->exec && (g->key_a != key_a || g->key_b != key_b || g->key_n != key_n)) g->reset();
+    StepGraph*& cur = step_graph_current();
+    if (g->exec) {
+        g->mode = StepGraph::REPLAY; g->cursor = 0; g->status = BDR_OK;
+        cur = g;
+        const int32_t s = enqueue();
+        cur = nullptr; g->mode = StepGraph::EAGER;
+        BDR_TRY(s);
+        if (g->status == BDR_OK && g->cursor == g->nodes.size()) {
+            BDR_HIP(hipGraphLaunch(g->exec, st));
+            return BDR_OK;
+        }
+        // The sequence no longer matches the captured one.  Its host bookkeeping has already run once, so this step cannot be
+        // re-enqueued: report it (callers keep their shapes fixed between steps; tests cover the supported changes).
+        g->reset();
+        return fail(BDR_ERR_INVALID, "the step's launch sequence changed under a captured graph");
+    }
+    // capture
+    g->reset();
+    g->key_a = key_a; g->key_b = key_b; g->key_n = key_n;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { (void)hipGetLastError(); g->broken = true; return enqueue(); }
+    g->mode = StepGraph::CAPTURE; g->cursor = 0;
+    cur = g;
+    const int32_t s = enqueue();
+    cur = nullptr; g->mode = StepGraph::EAGER;
+    e = hipStreamEndCapture(st, &g->graph);
+    if (s != BDR_OK) { g->reset(); return s; }
+    if (e != hipSuccess || !g->graph) { (void)hipGetLastError(); g->reset(); g->broken = true; return fail(BDR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { g->reset(); g->broken = true; return fail(BDR_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    const int32_t c = step_graph_collect(g);
+    if (getenv("BDR_STEP_GRAPH_DEBUG")) fprintf(stderr, "[border_amd] step graph: %zu kernel nodes captured, collect=%d\n", g->nodes.size(), (int)c);
+    if (c != BDR_OK) { g->broken = true; }   // the graph is still valid for THIS step (nothing varies yet); later steps run eagerly
+    BDR_HIP(hipGraphLaunch(g->exec, st));
+    if (c != BDR_OK) g->reset();
+    return BDR_OK;
+}
+
+}  // namespace bdr

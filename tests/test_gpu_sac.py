@@ -124,6 +124,43 @@ def test_sac_opt_over_replay_and_sample(B, tmp_path):
     a.close(); b.close(); rb.close()
 
 
+def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monkeypatch):
+    """opt() replays its ~70 launches from a hipGraph whose varying arguments (Adam bias corrections, noise counter, replay
+    stream position) are patched per step (csrc/step_graph.hpp).  Same seeds, same pushes: every parameter, the target nets,
+    log_alpha and the recorded losses equal the eager path bit for bit - across pushes between opts (the ring grows), a mid-run
+    update_on_batch with a LARGER batch (buffers re-allocated: the graph is re-captured) and n_updates_per_opt = 2."""
+    from oracle import torch_ref as T
+    od, ad = 17, 6
+    def run(eager):
+        if eager: monkeypatch.setenv("BDR_NO_STEP_GRAPH", "1")
+        else: monkeypatch.delenv("BDR_NO_STEP_GRAPH", raising=False)
+        rng = np.random.default_rng(11)
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=3000, seed=7), (od,), np.float32, (ad,), np.float32)
+        def push(n):
+            rb.push(rng.standard_normal((n, od)).astype(np.float32), rng.uniform(-1, 1, (n, ad)).astype(np.float32),
+                    rng.standard_normal((n, od)).astype(np.float32), rng.standard_normal(n).astype(np.float32),
+                    (rng.random(n) < .05).astype(np.int8), np.zeros(n, np.int8))
+        push(1000)
+        cfg = B.SacConfig(obs_dim=od, act_dim=ad, pi_units=(64, 64), q_units=(64, 64), n_critics=2, batch_size=128,
+                          ent_coef_mode=("Auto", -6.0, 3e-4), n_updates_per_opt=2, device=0, seed=5)
+        a = B.Sac.build(cfg)
+        recs = []
+        for k in range(12):
+            recs.append(a.opt_with_record(rb) if k % 3 == 0 else (a.opt(rb), None)[1])
+            if k % 2 == 1: push(100)
+            if k == 6: a.update_on_batch(*T.sac_batch(256, od, ad, 99))
+        out = {n: a.get_params(n) for n in ("pi", "qnet_0", "qnet_1", "qnet_tgt_0", "qnet_tgt_1", "log_alpha")}
+        n_opts = a.n_opts
+        a.close(); rb.close()
+        return out, recs, n_opts
+    g, grec, gn = run(False)
+    e, erec, en = run(True)
+    assert gn == en == 25
+    for k in g: assert (g[k] == e[k]).all(), k
+    assert grec == erec
+    assert np.isfinite(g["pi"]).all()
+
+
 def test_device_noise_stream_moments_reproducibility_and_disjointness(B):
     """The N(0,1) draws of action_logp come from a counter-based device generator (sac.hip k_randn; the reference uses
     torch's global CPU generator, sac/base.rs:76, so only the distribution can be pinned): moments of a large draw, the same

@@ -234,6 +234,84 @@ __global__ void k_pack_rows(const float* __restrict__ src, int src_ld, int cols,
     dst[(size_t)b * ld + col0 + c] = src[(size_t)b * src_ld + c];
 }
 
+// ---- small layers: one 32x32 output tile per workgroup, the reduction split over its four waves ---------
+// A 64x64 tile of k_igemm keeps one CU busy for kred/2 * 64 cycles however its waves are arranged (the CU's four matrix pipes
+// are the bound: 3.4 us for kred = 256, measured 5.5 us with staging; tools/probes/dense_trace.hip), and a 1024 x 256 layer has
+// only 64 such tiles for 256 CUs.  Launch-bound agents (SAC: ~20 such GEMMs per step, one after the other) want latency, not
+// reuse: here a workgroup owns a 32x32 tile, wave w multiplies the k-slice [w*kred/4, (w+1)*kred/4) straight from global memory
+// (every operand load of the slice is issued before the first MFMA: no LDS staging, no barrier in the loop) and the four
+// partial tiles are added through LDS in a fixed order.  4x the workgroups, 1/4 of the MFMA chain per wave.
+// DX = false: out[m][n] = act(sum_k x[m][k] W[k][n] + bias[n]);  DX = true: out[m][kc] (+)= mask * sum_n dy[m][n] W[kc][n].
+template <bool DX>
+__global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
+{
+    const DenseArgs& a = dz.a[blockIdx.z];
+    __shared__ float red[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = a.ncols / 32;
+    const int m0 = ((int)blockIdx.x / NT) * 32, n0 = ((int)blockIdx.x % NT) * 32;
+    const int i = lane & 31, h = lane >> 5;
+    const int Kw = a.kred / 4;                 // kred % 64 == 0: a multiple of 16
+    const int kbeg = wave * Kw;
+    const float* arow = a.x.p + (size_t)min(m0 + i, a.M - 1) * a.x.ld;   // rows >= M alias the last row (never stored)
+    const float* wcol = DX ? a.w + (size_t)(n0 + i) * a.w_ld : a.w + n0 + i;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kb = 0; kb < Kw; kb += 64) {      // up to four 16-wide chunks in flight (all of the slice for kred <= 256)
+        f32x4 av[8], bv[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (kb + 16 * c < Kw) {            // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = kbeg + kb + 16 * c + 8 * u + 4 * h;   // this lane half's quad of the MFMA group (igemm.hpp: k-slots are free)
+                    av[c * 2 + u] = *reinterpret_cast<const f32x4*>(arow + k);
+                    if constexpr (DX) bv[c * 2 + u] = *reinterpret_cast<const f32x4*>(wcol + k);
+                    else { const float* p = wcol + (size_t)k * a.w_ld; bv[c * 2 + u] = f32x4{p[0], p[a.w_ld], p[2 * (size_t)a.w_ld], p[3 * (size_t)a.w_ld]}; }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (kb + 16 * c < Kw) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * 2 + u][q], bv[c * 2 + u][q], acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
+    __syncthreads();
+    const int r = tid >> 3, c4 = (tid & 7) * 4, m = m0 + r, n = n0 + c4;
+    if (m >= a.M) return;
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = ((red[0][r][c4 + q] + red[1][r][c4 + q]) + red[2][r][c4 + q]) + red[3][r][c4 + q];
+    float* o = a.out + (size_t)m * a.ldo + n;
+    if constexpr (!DX) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] += b[q]; if (a.relu) v[q] = v[q] > 0.f ? v[q] : 0.f; }
+    } else {
+        if (a.mask) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + (size_t)m * a.ldm + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (!(mk[q] > 0.f)) v[q] = 0.f;
+        }
+        if (a.accum) { const f32x4 old = *reinterpret_cast<const f32x4*>(o); v += old; }
+    }
+    *reinterpret_cast<f32x4*>(o) = v;
+}
+template <bool DX>
+inline hipError_t launch_dense_small(hipStream_t st, const DenseArgsZ& dz, int nz)
+{
+    const DenseArgs& d = dz.a[0];
+    return step_launch(st, false, k_dense_small<DX>, dim3(((d.M + 31) / 32) * (d.ncols / 32), 1, nz), dim3(256), dz);
+}
+
 // ---- host-side layer launches ------------------------------------------------------------------------
 // (two teams of four waves per tile taking alternate k-tiles - k_igemm's TEAMS = 2 - were measured on SAC's 1024 x 256 x 256
 // layers: no gain, these launches are bound by kernel start-up and first-touch latency, not by the length of the k loop)
@@ -243,18 +321,20 @@ inline hipError_t launch_dense(hipStream_t st, dim3 grid, const typename P::Args
     return step_launch(st, false, k_igemm<P, 1>, grid, dim3(256), d);
 }
 inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, const float* params_base, DenseSrc x, float* out, int M,
-                             const float* had = nullptr, int had_ld = 0, int had_group = 1, float* out2 = nullptr)
+                             const float* had = nullptr, int had_ld = 0, int had_group = 1, float* out2 = nullptr, bool small = false)
 {
     DenseArgs d{};
     d.had = had; d.had_ld = had_ld; d.had_group = had_group; d.out2 = out2;
     d.x = x; d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
     d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
+    if (small && !had) { DenseArgsZ dz{}; dz.a[0] = d; BDR_HIP(launch_dense_small<false>(st, dz, 1)); return BDR_OK; }
     BDR_HIP(launch_dense<DenseFwd>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), d));
     return BDR_OK;
 }
 
 // the same layer of nz (<= 4) networks of one architecture in one launch: params_base[z], x[z], out[z]
-inline int32_t dense_forward_z(hipStream_t st, const DenseLayer& l, int nz, const float* const* params_base, const DenseSrc* x, float* const* out, int M)
+inline int32_t dense_forward_z(hipStream_t st, const DenseLayer& l, int nz, const float* const* params_base, const DenseSrc* x, float* const* out, int M,
+                               bool small = false)
 {
     DenseArgsZ dz{};
     for (int z = 0; z < nz; ++z) {
@@ -262,11 +342,12 @@ inline int32_t dense_forward_z(hipStream_t st, const DenseLayer& l, int nz, cons
         d.x = x[z]; d.w = params_base[z] + l.w; d.bias = params_base[z] + l.b; d.out = out[z]; d.ldo = l.Np;
         d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np; d.had_group = 1;
     }
+    if (small) { BDR_HIP(launch_dense_small<false>(st, dz, nz)); return BDR_OK; }
     BDR_HIP(launch_dense<DenseFwdZ>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, nz), dz));
     return BDR_OK;
 }
 inline int32_t dense_dx_z(hipStream_t st, const DenseLayer& l, int nz, const float* const* params_base, const float* const* dy, float* const* dx,
-                          const float* const* mask, int M)
+                          const float* const* mask, int M, bool small = false)
 {
     DenseArgsZ dz{};
     for (int z = 0; z < nz; ++z) {
@@ -274,18 +355,20 @@ inline int32_t dense_dx_z(hipStream_t st, const DenseLayer& l, int nz, const flo
         d.x = DenseSrc{dy[z], l.Np}; d.w = params_base[z] + l.w; d.out = dx[z]; d.ldo = l.Kp; d.mask = mask ? mask[z] : nullptr; d.ldm = l.Kp;
         d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np;
     }
+    if (small) { BDR_HIP(launch_dense_small<true>(st, dz, nz)); return BDR_OK; }
     BDR_HIP(launch_dense<DenseDxZ>(st, dim3(((M + 63) / 64) * (l.Kp / 64), 1, nz), dz));
     return BDR_OK;
 }
 
 // dX (masked by the ReLU of the producing layer's post-activation `mask`, may be null)
 inline int32_t dense_dx(hipStream_t st, const DenseLayer& l, const float* params_base, const float* dy, float* dx,
-                        const float* mask, int M, bool accum = false)
+                        const float* mask, int M, bool accum = false, bool small = false)
 {
     DenseArgs d{};
     d.accum = accum ? 1 : 0;
     d.x = DenseSrc{dy, l.Np}; d.w = params_base + l.w; d.out = dx; d.ldo = l.Kp; d.mask = mask; d.ldm = l.Kp;
     d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np;
+    if (small) { DenseArgsZ dz{}; dz.a[0] = d; BDR_HIP(launch_dense_small<true>(st, dz, 1)); return BDR_OK; }
     BDR_HIP(launch_dense<DenseDx>(st, dim3(((M + 63) / 64) * (l.Kp / 64), 1, 1), d));
     return BDR_OK;
 }

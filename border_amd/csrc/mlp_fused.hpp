@@ -50,7 +50,7 @@ struct MlpFusedArgs {
 // index is ONE 16-byte load per group instead of four strided 4-byte loads (a row-per-lane scalar load touches 64 cache lines
 // per wave instruction - the first version of this kernel spent 60 us on that).  Two chunks (16 k = 8 MFMAs each) are in
 // flight: the next chunk's loads are issued before this chunk's MFMAs.
-template <class FA, class FB>
+template <bool SHORT_K = false, class FA, class FB>
 __device__ __forceinline__ f32x16 mf_block(int K, int lane, FA&& a4, FB&& b4)
 {
     const int i = lane & 31, h = lane >> 5;
@@ -68,6 +68,14 @@ __device__ __forceinline__ f32x16 mf_block(int K, int lane, FA&& a4, FB&& b4)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q], bv[u][q], acc, 0, 0, 0);
     };
+    if (SHORT_K && K <= 64) {   // short reductions (the 64-wide layers of the CartPole net): every operand load before the first MFMA - one round trip
+        f32x4 a2[2], b2[2], a3[2], b3[2];
+        load(0, a0, b0); load(16, a1, b1);
+        if (K > 32) { load(32, a2, b2); load(48, a3, b3); }
+        mma(a0, b0); mma(a1, b1);
+        if (K > 32) { mma(a2, b2); mma(a3, b3); }
+        return acc;
+    }
     load(0, a0, b0);
     for (int k0 = 0; k0 < K; k0 += 32) {
         load(k0 + 16, a1, b1);                       // K % 32 == 0: always inside
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(512) void k_dqn_mlp_step(MlpFusedArgs a)
             const int ldx = l == 0 ? a.Kp[0] : a.Np[l - 1];
             const float* w = a.params[z] + a.w[l];
             const float* bias = a.params[z] + a.b[l];
-            const f32x16 acc = mf_block(Kp, lane,
+            const f32x16 acc = mf_block<true>(Kp, lane,
                                         [&](int i, int kq) {
                                             const int r = min(rb * 32 + i, B - 1);   // rows >= B alias the last row (never stored)
                                             return *reinterpret_cast<const f32x4*>(x + (size_t)r * ldx + kq);
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(512) void k_dqn_mlp_step(MlpFusedArgs a)
                 for (int r = 0; r < 16; ++r) gw[(size_t)(kb * 32 + mf_row(r, lane)) * Np + col] = acc[r];
             } else {            // dX[b][k] = relu'(x[b][k]) * sum_n dy[b][n] W[k][n]
                 const int q = blk - n_dw, rb = q / KB, kb = q % KB;
-                const f32x16 acc = mf_block(Np, lane,
+                const f32x16 acc = mf_block<true>(Np, lane,
                                             [&](int i, int nq) {
                                                 const int r = min(rb * 32 + i, B - 1);
                                                 return *reinterpret_cast<const f32x4*>(dy + (size_t)r * Np + nq);

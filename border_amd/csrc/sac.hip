@@ -69,44 +69,49 @@ struct SacSelectArgs {
     // EntCoef::update (ent_coef.rs:69-75) first: loss = -(log_alpha * (logp + H)).mean(); Adam on the scalar
     int auto_alpha; float target; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
 };
-// one workgroup: the row terms are summed as k_sum_rows does (thread t takes rows t, t+256, ...; tree over the 256 partials), so
-// loss_actor is the same number whether the sum is fused here or not.  Only column 0 of the upstream gradients is written: the
-// other ldq-1 (padding) columns are zero from allocation and nothing else stores there.
-__global__ __launch_bounds__(256) void k_sac_select(SacSelectArgs p)
+// sum over the 1024 threads of a workgroup in a fixed order: butterfly inside each wave, then the 16 wave totals one by one
+__device__ __forceinline__ float block_sum_1024(float v, float* red16)
 {
-    __shared__ float red[256];
-    __shared__ float s_log_alpha;
-    if (threadIdx.x == 0) s_log_alpha = p.log_alpha[0];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red16[w];
+    __syncthreads();
+    return t;
+}
+
+// One workgroup of 1024 threads (a row per thread at SAC's batch sizes: every load of the kernel is in flight at once).  Only
+// column 0 of the upstream gradients is written: the other ldq-1 (padding) columns are zero from allocation and nothing else
+// stores there.
+__global__ __launch_bounds__(1024) void k_sac_select(SacSelectArgs p)
+{
+    __shared__ float red[16];
+    float log_alpha = p.log_alpha[0];
     if (p.auto_alpha) {   // update_actor calls ent_coef.update(log_p) before it uses alpha (sac/base.rs:155)
         float acc = 0.f;
-        for (int b = threadIdx.x; b < p.B; b += 256) acc += p.logp[b] + p.target;
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
-        if (threadIdx.x == 0) {
-            const float g = -(red[0] / (float)p.B);
-            const float mm = p.al_m[0] * p.s.b1 + g * p.s.omb1;
-            const float vv = p.al_v[0] * p.s.b2 + p.s.omb2 * g * g;
-            const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
-            s_log_alpha = s_log_alpha + p.s.neg_step * mm / denom;
-            p.log_alpha_rw[0] = s_log_alpha;
-            p.al_m[0] = mm; p.al_v[0] = vv;
-        }
+        for (int b = threadIdx.x; b < p.B; b += 1024) acc += p.logp[b] + p.target;
+        const float g = -(block_sum_1024(acc, red) / (float)p.B);
+        const float mm = p.al_m[0] * p.s.b1 + g * p.s.omb1;       // every thread computes the same scalar step; thread 0 stores it
+        const float vv = p.al_v[0] * p.s.b2 + p.s.omb2 * g * g;
+        const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
+        log_alpha = log_alpha + p.s.neg_step * mm / denom;
+        __syncthreads();                                          // all reads of al_m / al_v / log_alpha are done
+        if (threadIdx.x == 0) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; }
     }
-    __syncthreads();
-    const float alpha = expf(s_log_alpha);
+    const float alpha = expf(log_alpha);
     float s = 0.f;
-    for (int b = threadIdx.x; b < p.B; b += 256) {
+    for (int b = threadIdx.x; b < p.B; b += 1024) {
         int im = 0;
         float qm = p.q[0][(size_t)b * p.ldq];
         for (int i = 1; i < p.NC; ++i) { const float v = p.q[i][(size_t)b * p.ldq]; if (v < qm) { qm = v; im = i; } }
         for (int i = 0; i < p.NC; ++i) p.dout[i][(size_t)b * p.ldq] = i == im ? 1.0f : 0.0f;
         s += alpha * p.logp[b] - qm;
     }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
-    if (threadIdx.x == 0) p.out[0] = (p.accumulate ? p.out[0] : 0.f) + red[0] * p.scale;
+    const float total = block_sum_1024(s, red);
+    if (threadIdx.x == 0) p.out[0] = (p.accumulate ? p.out[0] : 0.f) + total * p.scale;
 }
 
 // dL/dmean, dL/d(head2) from dL/da = (alpha * 2a/(1-a^2+eps) - d qmin/da) / B
@@ -145,33 +150,32 @@ struct SacTdArgs {
     const float* qt[4]; const float* logp; const float* log_alpha; const float* reward; const int8_t* term; float gamma, reward_scale;
     float* tgt;
 };
-__global__ __launch_bounds__(256) void k_sac_critic_td(SacTdArgs p)
+__global__ __launch_bounds__(1024) void k_sac_critic_td(SacTdArgs p)
 {
-    __shared__ float red[256];
-    float total = (threadIdx.x == 0 && p.accumulate) ? p.out[0] : 0.f;
+    __shared__ float red[16];
+    float total = p.accumulate ? p.out[0] : 0.f;
     const float alpha = expf(p.log_alpha[0]);
-    for (int b = threadIdx.x; b < p.B; b += 256) {   // (this thread reads back only the rows it writes)
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < p.B; b += 1024) {
         float qm = p.qt[0][(size_t)b * p.ldq];
         for (int i = 1; i < p.NC; ++i) qm = fminf(qm, p.qt[i][(size_t)b * p.ldq]);
         const float nq = qm - alpha * p.logp[b];
-        p.tgt[b] = p.reward_scale * p.reward[b] + ((1.0f - (float)p.term[b]) * p.gamma) * nq;
-    }
-    for (int i = 0; i < p.NC; ++i) {
-        float s = 0.f;
-        for (int b = threadIdx.x; b < p.B; b += 256) {
-            const float d = p.q[i][(size_t)b * p.ldq] - p.tgt[b];
+        const float tgt = p.reward_scale * p.reward[b] + ((1.0f - (float)p.term[b]) * p.gamma) * nq;
+        p.tgt[b] = tgt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= p.NC) break;
+            const float d = p.q[i][(size_t)b * p.ldq] - tgt;
             float l, dl;
             if (p.loss_kind == 1) { const float z = fabsf(d); l = z < 1.f ? 0.5f * z * z : z - 0.5f; dl = z < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
             else { l = d * d; dl = 2.f * d; }
             p.dout[i][(size_t)b * p.ldq] = dl / (float)p.B;
-            s += l;
+            part[i] += l;
         }
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
-        if (threadIdx.x == 0) total = total + red[0] * p.scale;
-        __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < p.NC) total = total + block_sum_1024(part[i], red) * p.scale;   // critic by critic (NC is uniform)
     if (threadIdx.x == 0) p.out[0] = total;
 }
 
@@ -240,6 +244,7 @@ struct Sac : bdr_agent {
     float *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr, *u_rew = nullptr; int8_t* u_term = nullptr; uint64_t u_cap = 0;
     uint64_t noise_counter = 0;
     StepGraph graph; bool use_graph = true;   // BDR_NO_STEP_GRAPH=1: eager launches
+    bool small_gemm = true;                   // BDR_NO_SMALL_GEMM=1: the 64x64-tile kernels of the large-batch agents
 
     ~Sac() override
     {
@@ -321,7 +326,7 @@ struct Sac : bdr_agent {
         DenseSrc in{x, pi.L[0].Kp};
         for (int i = 0; i < n_trunk; ++i) {
             Bracket br(a, "pi_fwd");
-            BDR_TRY(dense_forward(a, stream, pi.L[i], pi_p, in, t_act[i], Bn));
+            BDR_TRY(dense_forward(a, stream, pi.L[i], pi_p, in, t_act[i], Bn, nullptr, 0, 1, nullptr, small_gemm));
             in = DenseSrc{t_act[i], pi.L[i].Np};
         }
         // both heads (same shape, same input, consecutive in the arena) in one launch
@@ -330,7 +335,7 @@ struct Sac : bdr_agent {
         const DenseSrc ins[2] = {in, in};
         float* outs[2] = {mean, e};
         Bracket br(a, "pi_head");
-        return dense_forward_z(stream, h0, 2, pb, ins, outs, Bn);
+        return dense_forward_z(stream, h0, 2, pb, ins, outs, Bn, small_gemm);
     }
     // action_logp: writes the action into the action columns of the critic input `xq`, log_p into logp
     int32_t action_logp(const float* x, const float* z, int Bn, bool save, float* xq)
@@ -356,8 +361,8 @@ struct Sac : bdr_agent {
             for (size_t l = 0; l < qn.L.size(); ++l) {
                 for (int j = 0; j < nz; ++j) out[j] = (*acts[j0 + j])[l];
                 Bracket br(a, "q_fwd");
-                if (nz == 1) BDR_TRY(dense_forward(a, stream, qn.L[l], params[j0], in[0], out[0], Bn));
-                else BDR_TRY(dense_forward_z(stream, qn.L[l], nz, params + j0, in, out, Bn));
+                if (nz == 1) BDR_TRY(dense_forward(a, stream, qn.L[l], params[j0], in[0], out[0], Bn, nullptr, 0, 1, nullptr, small_gemm));
+                else BDR_TRY(dense_forward_z(stream, qn.L[l], nz, params + j0, in, out, Bn, small_gemm));
                 for (int j = 0; j < nz; ++j) in[j] = DenseSrc{out[j], qn.L[l].Np};
             }
         }
@@ -370,8 +375,8 @@ struct Sac : bdr_agent {
         for (int i = 0; i < NC; ++i) {
             pb[i] = q_p[i]; dy[i] = c_dy[i][l]; dx[i] = l == 0 ? dxq[i] : c_dy[i][l - 1]; mask[i] = l == 0 ? nullptr : acts[i][l - 1];
         }
-        if (NC == 1) return dense_dx(stream, qn.L[l], pb[0], dy[0], dx[0], mask[0], Bn);
-        return dense_dx_z(stream, qn.L[l], NC, pb, dy, dx, l == 0 ? nullptr : mask, Bn);
+        if (NC == 1) return dense_dx(stream, qn.L[l], pb[0], dy[0], dx[0], mask[0], Bn, false, small_gemm);
+        return dense_dx_z(stream, qn.L[l], NC, pb, dy, dx, l == 0 ? nullptr : mask, Bn, small_gemm);
     }
     // partial sums of a grouped dW launch -> gradient arena, Adam, (tracking) for `ninst` networks of one layout
     int32_t reduce_adam(const MlpLayout& net, const std::vector<size_t>& off, const std::vector<int>& chunks, int Bn, const float* part,
@@ -431,7 +436,7 @@ struct Sac : bdr_agent {
                 p.s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
             }
             Bracket br(a, "sac_select");
-            BDR_HIP(step_launch(stream, cfg.ent_coef_auto != 0, k_sac_select, dim3(1), dim3(256), p));
+            BDR_HIP(step_launch(stream, cfg.ent_coef_auto != 0, k_sac_select, dim3(1), dim3(1024), p));
         }
         for (int l = L - 1; l >= 0; --l) {   // d qmin / d input through the critics (weights untouched here)
             Bracket br(a, "q_dx");
@@ -452,9 +457,9 @@ struct Sac : bdr_agent {
             const DenseSrc hin = n_trunk ? DenseSrc{t_act[n_trunk - 1], pi.L[n_trunk - 1].Np} : DenseSrc{x_o, pi.L[0].Kp};
             if (n_trunk) {
                 float* dh = t_dy[n_trunk - 1];
-                { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk], pi_p, gmean, dh, t_act[n_trunk - 1], Bn, false)); }
-                { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk + 1], pi_p, ge, dh, t_act[n_trunk - 1], Bn, true)); }
-                for (int l = n_trunk - 1; l > 0; --l) { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[l], pi_p, t_dy[l], t_dy[l - 1], t_act[l - 1], Bn)); }
+                { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk], pi_p, gmean, dh, t_act[n_trunk - 1], Bn, false, small_gemm)); }
+                { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk + 1], pi_p, ge, dh, t_act[n_trunk - 1], Bn, true, small_gemm)); }
+                for (int l = n_trunk - 1; l > 0; --l) { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[l], pi_p, t_dy[l], t_dy[l - 1], t_act[l - 1], Bn, false, small_gemm)); }
             }
             int nj = 0;
             for (int l = 0; l < n_trunk; ++l)
@@ -483,7 +488,7 @@ struct Sac : bdr_agent {
             p.ldq = ldq; p.NC = NC; p.tgt = tgt; p.out = scal; p.scale = 1.0f / ((float)Bn * (float)NC); p.accumulate = first ? 0 : 1;
             p.B = Bn; p.loss_kind = cfg.critic_loss;
             Bracket br(a, "critic_td");
-            BDR_HIP(step_launch(stream, false, k_sac_critic_td, dim3(1), dim3(256), p));
+            BDR_HIP(step_launch(stream, false, k_sac_critic_td, dim3(1), dim3(1024), p));
         }
         for (int l = L - 1; l > 0; --l) { Bracket br(a, "q_dx"); BDR_TRY(critic_dx_all(l, Bn, c2_act)); }
         {   // every weight gradient of every critic in one grouped launch; partial sums -> gradients, Adam and soft_update (:169-173) in one more
@@ -685,6 +690,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     BDR_TRY(a->err_init());
     { const char* e = getenv("BDR_NO_STEP_GRAPH"); a->use_graph = !(e && e[0] == '1'); }
+    { const char* e = getenv("BDR_NO_SMALL_GEMM"); a->small_gemm = !(e && e[0] == '1'); }
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};
     for (auto p : pis) BDR_TRY(a->zalloc(p, a->pi.total));
     for (int i = 0; i < a->NC; ++i) {

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/border_amd.h"
+#include "chacha.hpp"
 
 namespace bdr {
 
@@ -113,6 +114,22 @@ namespace bdr {
 // cross-stream ordering against pushes.  Advances the RNG like one batch(n).
 int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream);
 int32_t replay_prepare_sample(bdr_replay* r, uint64_t n, hipStream_t stream);
+
+// arguments of the gather kernels (replay.hip k_gather) - also handed to agents whose own kernel does the gather (replay_sample_plan)
+struct GatherArgs {
+    const uint8_t* ring;
+    uint64_t stride, obs_bytes, act_bytes, next_off, act_off, tail_off;
+    uint64_t* ixs;           // [n] sampled indices (written by chunk 0 of every sample)
+    ChaChaKey key;           // K1 fused: every workgroup draws its own index (wave-uniform -> scalar unit)
+    uint64_t word_pos, size;
+    uint8_t *b_obs, *b_next, *b_act;
+    float* b_reward;
+    int8_t *b_term, *b_trunc;
+    uint32_t chunks;      // workgroups per sample
+    uint32_t vec_per_chunk;  // 16-byte vectors per chunk
+    uint32_t given;       // 1: ixs[] was produced by the PER sampler, gather those rows
+};
+int32_t replay_sample_plan(bdr_replay* r, uint64_t n, hipStream_t stream, GatherArgs* out);
 int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n);
 // Consumer streams a replay buffer may have to record an event on later (lazy ordering): registered when they first sample,
 // retired by their owner after synchronising and before hipStreamDestroy, so that a buffer never touches a dead handle.

@@ -89,6 +89,7 @@ struct DqnMlp : bdr_agent {
     const float* last_reward = nullptr; int last_B = 0;
     uint64_t adam_step = 0, soft_update_counter = 0;
     bool defer_adam = false;   // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
+    bool gather_in_step = true;   // the fused step kernel also draws and copies the batch (BDR_NO_STEP_GATHER=1: separate gather launch)
     bool fused = true;         // one-workgroup step for nets that fit a CU (mlp_fused.hpp; BDR_NO_MLP_FUSED=1: generic path)
     bool track_with_next = false, track_done = false;   // opt(): the soft update rides on the fused kernel of the last update
 
@@ -158,9 +159,10 @@ struct DqnMlp : bdr_agent {
     }
     // the whole update in one launch (mlp_fused.hpp)
     int32_t update_critic_fused(int Bn, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
-                                const float* reward, const int8_t* term, const float* weight)
+                                const float* reward, const int8_t* term, const float* weight, const GatherArgs* gather = nullptr)
     {
         MlpFusedArgs f{};
+        if (gather) { f.do_gather = 1; f.g = *gather; }
         const int L = (int)net.L.size();
         f.L = L; f.nz = cfg.double_dqn ? 3 : 2; f.B = Bn; f.A = net.out_dim; f.in_dim = net.in_dim;
         for (int i = 0; i < L; ++i) { f.Kp[i] = net.L[i].Kp; f.Np[i] = net.L[i].Np; f.relu[i] = net.L[i].relu; f.w[i] = net.L[i].w; f.b[i] = net.L[i].b; f.dy[i] = dys[i]; }
@@ -192,14 +194,15 @@ struct DqnMlp : bdr_agent {
 
     // Dqn::update_critic (dqn/base.rs:60-160) on a device-resident batch
     int32_t update_critic(int Bn, const uint8_t* obs, const uint8_t* next_obs, const uint8_t* act, int act_bytes,
-                          const float* reward, const int8_t* term, const float* weight = nullptr, bdr_replay* per_buffer = nullptr)
+                          const float* reward, const int8_t* term, const float* weight = nullptr, bdr_replay* per_buffer = nullptr,
+                          const GatherArgs* gather = nullptr)
     {
         bdr_agent* a = this;
         BDR_TRY(ensure_batch(Bn));
         BDR_TRY(td_buffer(Bn));
         last_reward = reward; last_B = Bn;
         if (fused_ok(Bn)) {
-            BDR_TRY(update_critic_fused(Bn, obs, next_obs, act, act_bytes, reward, term, weight));
+            BDR_TRY(update_critic_fused(Bn, obs, next_obs, act, act_bytes, reward, term, weight, gather));
             if (per_buffer && weight) BDR_TRY(replay_update_priority_on_stream(per_buffer, Bn, td_abs, stream));
             return BDR_OK;
         }
@@ -268,12 +271,17 @@ struct DqnMlp : bdr_agent {
         BDR_REQUIRE(r->act_bytes >= 8, "discrete actions are stored as i64");
         BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
         for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
-            { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, cfg.batch_size, stream)); }
+            // a uniform sample over the plain ring is drawn by the step kernel itself when the step is one kernel anyway
+            GatherArgs plan{};
+            const bool in_kernel = gather_in_step && fused_ok((int)cfg.batch_size) && !r->per && !r->frame_stack && cfg.batch_size <= 128 &&
+                                   r->obs_bytes % 4 == 0;
+            if (in_kernel) BDR_TRY(replay_sample_plan(r, cfg.batch_size, stream, &plan));
+            else { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, cfg.batch_size, stream)); }
             defer_adam = grad_comm != nullptr;
             // the soft update that follows the last update of this opt (dqn/base.rs:190-196) rides on its fused kernel
             track_with_next = u + 1 == cfg.n_updates_per_opt && soft_update_counter + 1 == cfg.soft_update_interval && !defer_adam;
             const int32_t st = update_critic((int)cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
-                                             replay_batch_weights(r), r);
+                                             replay_batch_weights(r), r, in_kernel ? &plan : nullptr);
             defer_adam = false;
             BDR_TRY(st);
             if (grad_comm) {   // synchronous data-parallel step (see bdr_agent::grad_comm)
@@ -387,6 +395,7 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     BDR_TRY(a->err_init());
     a->fused = getenv("BDR_NO_MLP_FUSED") == nullptr;
+    a->gather_in_step = getenv("BDR_NO_STEP_GATHER") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->net.total));

@@ -42,6 +42,9 @@ struct MlpFusedArgs {
     // optimizer
     float *q, *grad, *m, *v, *q_tgt; size_t total;
     AdamScalars adam; int do_adam, do_track; float tau, omt;
+    // do_gather: the kernel also IS the replay buffer's sample of this step (replay_sample_plan): it draws the B indices of the
+    // buffer's StdRng stream and copies the rows into the buffer's batch arrays - which in_rows / actions / reward / term point at
+    int do_gather; GatherArgs g;
 };
 
 // one 32x32 block of C = A * B, K % 32 == 0.  Operand fetchers work on QUADS of the reduction index: a4(i, kq) returns
@@ -94,6 +97,33 @@ __global__ __launch_bounds__(512) void k_dqn_mlp_step(MlpFusedArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, RB = (B + 31) / 32, L = a.L;
     MF_TP(0);
+    // ---- sample: what k_gather does for a batch (replay.hip), rows of a few words each
+    if (a.do_gather) {
+        __shared__ uint64_t s_row[128];
+        if (tid < B) {
+            const uint64_t row = (uint64_t)chacha12_word(a.g.key, a.g.word_pos + tid) % a.g.size;   // (StdRng::next_u32() as usize) % size
+            s_row[tid] = row; a.g.ixs[tid] = row;
+        }
+        __syncthreads();
+        const int ow = (int)(a.g.obs_bytes / 4), aw = (int)a.g.act_bytes;   // obs rows are f32 words here; actions are copied as bytes
+        for (int e = tid; e < B * ow; e += 512) {
+            const int sidx = e / ow, w = e % ow;
+            const uint8_t* rec = a.g.ring + s_row[sidx] * a.g.stride;
+            reinterpret_cast<uint32_t*>(a.g.b_obs)[e] = reinterpret_cast<const uint32_t*>(rec)[w];
+            reinterpret_cast<uint32_t*>(a.g.b_next)[e] = reinterpret_cast<const uint32_t*>(rec + a.g.next_off)[w];
+        }
+        for (int e = tid; e < B * aw; e += 512) {
+            const int sidx = e / aw, w = e % aw;
+            a.g.b_act[e] = a.g.ring[s_row[sidx] * a.g.stride + a.g.act_off + w];
+        }
+        if (tid < B) {
+            const uint8_t* rec = a.g.ring + s_row[tid] * a.g.stride;
+            a.g.b_reward[tid] = *reinterpret_cast<const float*>(rec + a.g.tail_off);
+            a.g.b_term[tid] = *reinterpret_cast<const int8_t*>(rec + a.g.tail_off + 4);
+            a.g.b_trunc[tid] = *reinterpret_cast<const int8_t*>(rec + a.g.tail_off + 5);
+        }
+        __syncthreads();
+    }
     // ---- phase 0: pack the input rows into the zero-padded [B][Kp0] matrices
     for (int z = 0; z < a.nz; ++z)
         for (int e = tid; e < B * a.Kp[0]; e += 512) {

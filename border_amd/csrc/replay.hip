@@ -50,20 +50,6 @@ __global__ void k_sample_indices(ChaChaKey key, uint64_t word_pos, uint64_t size
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-struct GatherArgs {
-    const uint8_t* ring;
-    uint64_t stride, obs_bytes, act_bytes, next_off, act_off, tail_off;
-    uint64_t* ixs;           // [n] sampled indices (written by chunk 0 of every sample)
-    ChaChaKey key;           // K1 fused: every workgroup draws its own index (wave-uniform -> scalar unit)
-    uint64_t word_pos, size;
-    uint8_t *b_obs, *b_next, *b_act;
-    float* b_reward;
-    int8_t *b_term, *b_trunc;
-    uint32_t chunks;      // workgroups per sample
-    uint32_t vec_per_chunk;  // 16-byte vectors per chunk
-    uint32_t given;       // 1: ixs[] was produced by the PER sampler, gather those rows
-};
-
 template <typename V>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a)
 {
@@ -781,6 +767,27 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     }
     r->read_pending = true; r->read_stream = stream;   // recorded only if somebody has to wait for it (wait_for_reader)
     r->batch_n = n;
+    return BDR_OK;
+}
+
+// The gather of a uniform sample over the plain ring as a descriptor instead of a launch: the caller's own kernel draws the
+// indices and copies the rows (the one-workgroup Mlp step, mlp_fused.hpp, where a separate gather launch is a fifth of the step).
+// All host bookkeeping of a sample (stream position, consumer hand-over) is done here; the caller MUST run a kernel on `stream`
+// that fills the batch buffers exactly as k_gather would.
+int32_t replay_sample_plan(bdr_replay* r, uint64_t n, hipStream_t stream, GatherArgs* out)
+{
+    BDR_REQUIRE(!r->per && !r->frame_stack, "sample plans cover the plain uniform ring only");
+    BDR_TRY(replay_prepare_sample(r, n, stream));
+    GatherArgs a{};
+    a.ring = r->ring; a.stride = r->stride; a.obs_bytes = r->obs_bytes; a.act_bytes = r->act_bytes;
+    a.next_off = r->next_off; a.act_off = r->act_off; a.tail_off = r->tail_off; a.ixs = r->b_ixs;
+    memcpy(a.key.k, r->key, sizeof a.key.k); a.word_pos = r->word_pos; a.size = r->size;
+    a.b_obs = r->b_obs; a.b_next = r->b_next; a.b_act = r->b_act; a.b_reward = r->b_reward; a.b_term = r->b_term; a.b_trunc = r->b_trunc;
+    a.chunks = 1; a.vec_per_chunk = 0; a.given = 0;
+    r->word_pos += n;  // one next_u32() per index
+    r->read_pending = true; r->read_stream = stream;
+    r->batch_n = n;
+    *out = a;
     return BDR_OK;
 }
 

@@ -275,6 +275,36 @@ def test_mlp_opt_over_replay(B):
     a.close(); rb.close()
 
 
+def test_mlp_step_kernel_draws_its_own_batch(B, monkeypatch):
+    """For nets that fit one workgroup the step kernel is also the replay buffer's sample (replay_sample_plan + the gather phase
+    of k_dqn_mlp_step): same StdRng stream position, same rows as the separate gather launch - parameters after 12 opts with
+    pushes in between are bit-identical, and both buffers continue their index stream from the same position."""
+    def run(separate):
+        if separate: monkeypatch.setenv("BDR_NO_STEP_GATHER", "1")
+        else: monkeypatch.delenv("BDR_NO_STEP_GATHER", raising=False)
+        rng = np.random.default_rng(9)
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=700, seed=3), (4,), np.float32)
+        def push(n):
+            rb.push(rng.standard_normal((n, 4)).astype(np.float32), rng.integers(0, 2, (n, 1)).astype(np.int64),
+                    rng.standard_normal((n, 4)).astype(np.float32), rng.standard_normal(n).astype(np.float32),
+                    (rng.random(n) < .1).astype(np.int8), np.zeros(n, np.int8))
+        push(300)
+        a = make_mlp_agent(B, batch_size=32, lr=1e-3, critic_loss="SmoothL1", tau=0.01, soft_update_interval=2, n_updates_per_opt=2,
+                           double_dqn=True)
+        losses = []
+        for k in range(12):
+            losses.append(a.opt_with_record(rb)["loss"] if k % 4 == 0 else (a.opt(rb), None)[1])
+            push(50)   # the ring wraps (capacity 700)
+        out = (a.get_params("qnet"), a.get_params("qnet_tgt"), rb.sample_indices(40), losses, a.n_opts)
+        a.close(); rb.close()
+        return out
+    f, s = run(False), run(True)
+    assert (f[0] == s[0]).all() and (f[1] == s[1]).all()
+    assert (f[2] == s[2]).all()
+    assert f[3] == s[3] and f[4] == s[4] == 12
+    assert np.isfinite(f[0]).all()
+
+
 def test_mlp_adamw_matches_aten(B):
     """OptimizerConfig::AdamW (opt.rs:20-27,38-55): decoupled weight decay, custom betas / eps, 5 steps vs ATen."""
     from oracle import torch_ref as T

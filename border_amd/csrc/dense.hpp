@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
 {
     const DenseArgs& a = dz.a[blockIdx.z];
     __shared__ float red[4][32][33];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = a.ncols / 32;
     const int m0 = ((int)blockIdx.x / NT) * 32, n0 = ((int)blockIdx.x % NT) * 32;
     const int i = lane & 31, h = lane >> 5;

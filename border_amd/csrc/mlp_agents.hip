@@ -89,6 +89,7 @@ struct DqnMlp : bdr_agent {
     const float* last_reward = nullptr; int last_B = 0;
     uint64_t adam_step = 0, soft_update_counter = 0;
     bool defer_adam = false;   // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
+    bool lds_step = true; size_t lds_attr = 0;   // BDR_NO_MLP_LDS=1: phases exchange their matrices through global memory
     bool gather_in_step = true;   // the fused step kernel also draws and copies the batch (BDR_NO_STEP_GATHER=1: separate gather launch)
     bool fused = true;         // one-workgroup step for nets that fit a CU (mlp_fused.hpp; BDR_NO_MLP_FUSED=1: generic path)
     bool track_with_next = false, track_done = false;   // opt(): the soft update rides on the fused kernel of the last update
@@ -185,7 +186,16 @@ struct DqnMlp : bdr_agent {
         }
         f.do_track = (track_with_next && f.do_adam) ? 1 : 0;
         f.tau = (float)cfg.tau; f.omt = (float)(1.0 - cfg.tau);
-        hipLaunchKernelGGL(k_dqn_mlp_step, dim3(1), dim3(512), 0, stream, f);
+        const size_t lds_bytes = lds_step ? mf_lds_plan(f) : 0;
+        if (lds_bytes) {   // activations and gradients resident in LDS (mlp_fused.hpp)
+            if (lds_bytes > lds_attr) {
+                BDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dqn_mlp_step_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                lds_attr = lds_bytes;
+            }
+            hipLaunchKernelGGL(k_dqn_mlp_step_lds, dim3(1), dim3(512), lds_bytes, stream, f);
+        } else {
+            hipLaunchKernelGGL(k_dqn_mlp_step, dim3(1), dim3(512), 0, stream, f);
+        }
         BDR_HIP(hipGetLastError());
         if (f.do_track) track_done = true;
         track_with_next = false;
@@ -396,6 +406,7 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_TRY(a->err_init());
     a->fused = getenv("BDR_NO_MLP_FUSED") == nullptr;
     a->gather_in_step = getenv("BDR_NO_STEP_GATHER") == nullptr;
+    a->lds_step = getenv("BDR_NO_MLP_LDS") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->net.total));

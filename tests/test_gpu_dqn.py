@@ -278,10 +278,11 @@ def test_mlp_opt_over_replay(B):
 def test_mlp_step_kernel_draws_its_own_batch(B, monkeypatch):
     """For nets that fit one workgroup the step kernel is also the replay buffer's sample (replay_sample_plan + the gather phase
     of k_dqn_mlp_step): same StdRng stream position, same rows as the separate gather launch - parameters after 12 opts with
-    pushes in between are bit-identical, and both buffers continue their index stream from the same position."""
-    def run(separate):
-        if separate: monkeypatch.setenv("BDR_NO_STEP_GATHER", "1")
-        else: monkeypatch.delenv("BDR_NO_STEP_GATHER", raising=False)
+    pushes in between are bit-identical, and both buffers continue their index stream from the same position.  The same holds
+    for the LDS-resident variant of the kernel (k_dqn_mlp_step_lds) against the one that exchanges matrices through global memory."""
+    def run(env):
+        for k in ("BDR_NO_STEP_GATHER", "BDR_NO_MLP_LDS", "BDR_NO_MLP_FUSED"): monkeypatch.delenv(k, raising=False)
+        for k in env: monkeypatch.setenv(k, "1")
         rng = np.random.default_rng(9)
         rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=700, seed=3), (4,), np.float32)
         def push(n):
@@ -298,11 +299,14 @@ def test_mlp_step_kernel_draws_its_own_batch(B, monkeypatch):
         out = (a.get_params("qnet"), a.get_params("qnet_tgt"), rb.sample_indices(40), losses, a.n_opts)
         a.close(); rb.close()
         return out
-    f, s = run(False), run(True)
-    assert (f[0] == s[0]).all() and (f[1] == s[1]).all()
-    assert (f[2] == s[2]).all()
-    assert f[3] == s[3] and f[4] == s[4] == 12
+    f = run(())
     assert np.isfinite(f[0]).all()
+    # separate gather launch; phases exchanging their matrices through global memory instead of LDS; both
+    for env in (("BDR_NO_STEP_GATHER",), ("BDR_NO_MLP_LDS",), ("BDR_NO_STEP_GATHER", "BDR_NO_MLP_LDS")):
+        s = run(env)
+        assert (f[0] == s[0]).all() and (f[1] == s[1]).all(), env
+        assert (f[2] == s[2]).all(), env
+        assert f[3] == s[3] and f[4] == s[4] == 12, env
 
 
 def test_mlp_adamw_matches_aten(B):

@@ -26,21 +26,28 @@ int main()
     f.gamma = 0.99f; f.loss_kind = 0; f.td_abs = dev(B, 0.f);
     unsigned* err; hipMalloc(&err, 16); hipMemset(err, 0, 16); f.err = err;
     f.adam = adam_scalars_for(false, 1e-3, 0, 0, 0, 0, 1); f.do_adam = 1; f.do_track = 1; f.tau = 0.01f; f.omt = 0.99f;
-    unsigned long long* tr; CK(hipMalloc(&tr, 16 * 8)); f.trace = tr;
+    unsigned long long* tr; CK(hipMalloc(&tr, 32 * 8)); f.trace = tr;
     hipStream_t st; CK(hipStreamCreate(&st));
+    const size_t lds_bytes = mf_lds_plan(f);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dqn_mlp_step_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  for (int variant = 0; variant < 2; ++variant) {
+    printf("---- %s\n", variant ? "k_dqn_mlp_step_lds (matrices resident in LDS)" : "k_dqn_mlp_step (phases exchange through global memory)");
     double sum[12] = {0};
     const int reps = 200;
     for (int r = 0; r < reps + 20; ++r) {
-        hipLaunchKernelGGL(k_dqn_mlp_step, dim3(1), dim3(512), 0, st, f);
+        if (variant) hipLaunchKernelGGL(k_dqn_mlp_step_lds, dim3(1), dim3(512), lds_bytes, st, f);
+        else hipLaunchKernelGGL(k_dqn_mlp_step, dim3(1), dim3(512), 0, st, f);
         CK(hipStreamSynchronize(st));
-        unsigned long long h[12];
+        unsigned long long h[18];
         CK(hipMemcpy(h, tr, sizeof h, hipMemcpyDeviceToHost));
         const int idx[10] = {0, 1, 2, 3, 4, 6, 7, 8, 9, 11};
+        if (r == reps + 19) printf("shader clock over the kernel: %.0f MHz\n", (double)(h[13] - h[12]) / ((double)(h[11] - h[0]) / 100.0));
         if (r >= 20) for (int k = 1; k < 10; ++k) sum[idx[k]] += (double)(h[idx[k]] - h[idx[k - 1]]) / 100.0;
     }
     const char* nm[12] = {"", "pack", "fwd0", "fwd1", "fwd2", "-", "td+loss", "bwd2", "bwd1", "bwd0", "-", "adam+track"};
     double tot = 0;
     for (int k = 1; k < 12; ++k) { if (k == 5 || k == 10) continue; printf("%-10s %.2f us\n", nm[k], sum[k] / reps); tot += sum[k] / reps; }
     printf("total in-kernel %.2f us\n", tot);
+  }
     return 0;
 }

@@ -86,6 +86,38 @@ def test_sac_baseline_shape_b1024_vs_oracle(B):
     a.close()
 
 
+@pytest.mark.parametrize("od,ad,pu,qu,nc,Bsz,ent", [
+    (11, 3, [96, 40], [72, 136], 3, 72, ("Auto", -3.0, 1e-3)),      # nothing a multiple of 32 / 64: every padding and row guard
+    (5, 2, [64], [300], 1, 200, ("Fix", 0.2)),                        # one trunk layer, one critic, a 320-wide (padded) layer
+    (23, 7, [128, 64, 32], [64, 64, 64], 4, 33, ("Auto", -7.0, 3e-4)),  # three trunk layers, four critics (12 dW GEMMs in one group), 33 rows
+])
+def test_sac_ragged_shapes_vs_oracle(B, od, ad, pu, qu, nc, Bsz, ent):
+    """The latency-shaped SAC kernels (32x32 split-reduction tiles, grouped dW launch, fused reduce+Adam+track over several
+    networks) on shapes that are not multiples of any tile: two updates against the C oracle - losses, every gradient, every
+    parameter, the targets and log_alpha."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    pi0 = T.init_params(T.sac_pi_shapes(od, pu, ad), 31) * np.float32(0.5)
+    q0 = [T.init_params(T.sac_q_shapes(od, ad, qu), 40 + i) for i in range(nc)]
+    kw = dict(lr_actor=1e-3, lr_critic=2e-3, ent_coef=ent, critic_loss="SmoothL1")
+    a = _agent(B, od, ad, pu, qu, nc, Bsz, kw, pi0, q0)
+    ref = O.SacOracle(od, ad, pu, qu, pi0, q0, **kw)
+    for s in range(2):
+        batch = T.sac_batch(Bsz, od, ad, 500 + s)
+        rec = a.update_on_batch(*batch)
+        r = ref.update(*batch)
+        for k in ("loss_critic", "loss_actor", "ent_coef"):
+            assert abs(rec[k] - r[k]) <= 5e-4 * abs(r[k]) + 1e-6, (s, k, rec[k], r[k])
+        assert rel(a.get_params("pi", "grad"), r["pi_grads"]) < 2e-3, s
+        for i in range(nc):
+            assert rel(a.get_params(f"qnet_{i}", "grad"), r["q_grads"][i]) < 2e-3, (s, i)
+    assert np.abs(a.get_params("pi") - ref.pi).max() < 0.3 * kw["lr_actor"]
+    for i in range(nc):
+        assert np.abs(a.get_params(f"qnet_{i}") - ref.qs[i]).max() < 0.3 * kw["lr_critic"]
+        assert rel(a.get_params(f"qnet_tgt_{i}"), ref.qs_tgt[i]) < 1e-4
+    a.close()
+
+
 def test_sac_opt_over_replay_and_sample(B, tmp_path):
     """Agent::opt over the HBM ring with device-generated noise: finite losses, counters, checkpoint round trip,
     Policy::sample in eval mode == tanh(mean) of the oracle actor."""

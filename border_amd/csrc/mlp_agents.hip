@@ -166,7 +166,7 @@ struct DqnMlp : bdr_agent {
         if (gather) { f.do_gather = 1; f.g = *gather; }
         const int L = (int)net.L.size();
         f.L = L; f.nz = cfg.double_dqn ? 3 : 2; f.B = Bn; f.A = net.out_dim; f.in_dim = net.in_dim;
-        for (int i = 0; i < L; ++i) { f.Kp[i] = net.L[i].Kp; f.Np[i] = net.L[i].Np; f.relu[i] = net.L[i].relu; f.w[i] = net.L[i].w; f.b[i] = net.L[i].b; f.dy[i] = dys[i]; }
+        for (int i = 0; i < L; ++i) { f.Kp[i] = net.L[i].Kp; f.Np[i] = net.L[i].Np; f.relu[i] = net.L[i].relu; f.w[i] = net.L[i].w; f.b[i] = net.L[i].b; f.dy[i] = dys[i]; f.in_rows_l[i] = net.L[i].in; }
         const float* par[3] = {q, q_tgt, q};
         const uint8_t* rows[3] = {obs, next_obs, next_obs};
         for (int z = 0; z < f.nz; ++z) {

@@ -47,6 +47,7 @@ struct MlpFusedArgs {
     int do_gather; GatherArgs g;
     // LDS-resident variant (k_dqn_mlp_step_lds): offsets in floats into the dynamic LDS block, rows padded by 4 floats
     int lds_x0, lds_act0[MF_MAXL], lds_pp[MF_MAXZ][2], lds_dy[MF_MAXL], lds_floats;
+    int in_rows_l[MF_MAXL];   // logical input width of every layer: rows >= it of W_l are structural zeros (padding)
 };
 
 // LDS plan of k_dqn_mlp_step_lds for this problem; returns the bytes needed (0: does not fit, use k_dqn_mlp_step)
@@ -681,39 +682,58 @@ __global__ __launch_bounds__(512) void k_dqn_mlp_step_lds(MlpFusedArgs a)
     // acquire barrier - placed AFTER the loads of the parameters and moments of the first pass are in flight (they do not depend
     // on the gradients), so that round trip overlaps the tail of the backward phases.
     if (a.do_adam || a.do_track) {
-        const size_t n4 = a.total / 4;
-        constexpr int V = 4;
-        for (size_t base = 0; base < n4; base += (size_t)512 * V) {   // uniform trip count (the barrier sits inside)
-            const size_t e0 = base + tid;
+        // Only the rows of W_l below the layer's logical input width (and the biases) can be non-zero: the zero-padding rows have
+        // zero gradients and moments, and Adam / track map (0, 0, 0, 0) to 0 exactly - they are skipped, not recomputed
+        // (CartPole: 4 of layer 0's 64 rows are real; 2 160 vectors instead of 3 120, one pass of the loop below).
+        unsigned r_off[2 * MF_MAXL], r_cnt[2 * MF_MAXL], T = 0;   // ranges of 16-byte vectors of the arena
+#pragma unroll
+        for (int l = 0; l < MF_MAXL; ++l) {
+            const bool on = l < L;
+            r_off[2 * l] = on ? (unsigned)(a.w[l] / 4) : 0u;     r_cnt[2 * l] = on ? (unsigned)(a.in_rows_l[l] * a.Np[l] / 4) : 0u;
+            r_off[2 * l + 1] = on ? (unsigned)(a.b[l] / 4) : 0u; r_cnt[2 * l + 1] = on ? (unsigned)(a.Np[l] / 4) : 0u;
+            T += r_cnt[2 * l] + r_cnt[2 * l + 1];
+        }
+        auto locate = [&](unsigned e) {   // e-th vector of the concatenated ranges -> vector index in the arena
+            unsigned at = 0;
+            bool done = false;
+#pragma unroll
+            for (int r = 0; r < 2 * MF_MAXL; ++r) {
+                if (!done && e < r_cnt[r]) { at = r_off[r] + e; done = true; }
+                if (!done) e -= r_cnt[r];
+            }
+            return at;
+        };
+        constexpr int V = 5;
+        for (unsigned base = 0; base < T; base += 512u * V) {   // uniform trip count (the barrier sits inside)
             f32x4 p[V], g[V], mm[V], vv[V], t[V];
+            unsigned at[V];
             bool ok[V];
 #pragma unroll
             for (int u = 0; u < V; ++u) {
-                const size_t e = e0 + (size_t)u * 512;
-                ok[u] = e < n4;
-                const size_t ec = ok[u] ? e : 0;
-                p[u] = reinterpret_cast<const f32x4*>(a.q)[ec];
-                if (a.do_adam) { mm[u] = reinterpret_cast<const f32x4*>(a.m)[ec]; vv[u] = reinterpret_cast<const f32x4*>(a.v)[ec]; }
-                if (a.do_track) t[u] = reinterpret_cast<const f32x4*>(a.q_tgt)[ec];
+                const unsigned e = base + tid + (unsigned)u * 512u;
+                ok[u] = e < T;
+                at[u] = locate(ok[u] ? e : 0u);
+                p[u] = reinterpret_cast<const f32x4*>(a.q)[at[u]];
+                if (a.do_adam) { mm[u] = reinterpret_cast<const f32x4*>(a.m)[at[u]]; vv[u] = reinterpret_cast<const f32x4*>(a.v)[at[u]]; }
+                if (a.do_track) t[u] = reinterpret_cast<const f32x4*>(a.q_tgt)[at[u]];
             }
             if (base == 0) __syncthreads();
             if (a.do_adam) {
 #pragma unroll
-                for (int u = 0; u < V; ++u) g[u] = reinterpret_cast<const f32x4*>(a.grad)[ok[u] ? e0 + (size_t)u * 512 : 0];
+                for (int u = 0; u < V; ++u) g[u] = reinterpret_cast<const f32x4*>(a.grad)[at[u]];
             }
 #pragma unroll
             for (int u = 0; u < V; ++u) {
                 if (!ok[u]) continue;
-                const size_t e = e0 + (size_t)u * 512;
                 if (a.do_adam) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { float pe = p[u][j], me = mm[u][j], ve = vv[u][j]; adam_element(pe, g[u][j], me, ve, a.adam); p[u][j] = pe; mm[u][j] = me; vv[u][j] = ve; }
-                    reinterpret_cast<f32x4*>(a.q)[e] = p[u]; reinterpret_cast<f32x4*>(a.m)[e] = mm[u]; reinterpret_cast<f32x4*>(a.v)[e] = vv[u];
+                    reinterpret_cast<f32x4*>(a.q)[at[u]] = p[u]; reinterpret_cast<f32x4*>(a.m)[at[u]] = mm[u]; reinterpret_cast<f32x4*>(a.v)[at[u]] = vv[u];
                 }
                 if (a.do_track) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) t[u][j] = track_element(p[u][j], t[u][j], a.tau, a.omt);
-                    reinterpret_cast<f32x4*>(a.q_tgt)[e] = t[u];
+                    reinterpret_cast<f32x4*>(a.q_tgt)[at[u]] = t[u];
                 }
             }
         }

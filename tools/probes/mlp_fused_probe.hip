@@ -12,7 +12,7 @@ int main()
     MlpFusedArgs f{};
     f.L = L; f.nz = 2; f.B = B; f.A = A; f.in_dim = in_dim;
     size_t o = 0;
-    for (int i = 0; i < L; ++i) { f.Kp[i] = Kp[i]; f.Np[i] = Np[i]; f.relu[i] = i < L - 1; f.w[i] = o; o += Kp[i] * Np[i]; f.b[i] = o; o += Np[i]; }
+    for (int i = 0; i < L; ++i) { f.Kp[i] = Kp[i]; f.Np[i] = Np[i]; f.relu[i] = i < L - 1; f.w[i] = o; o += Kp[i] * Np[i]; f.b[i] = o; o += Np[i]; f.in_rows_l[i] = i == 0 ? in_dim : 64; }
     f.total = o;
     auto dev = [&](size_t n, float fill) { float* p; hipMalloc(&p, n * 4); std::vector<float> h(n, fill); for (size_t i = 0; i < n; ++i) h[i] = fill * (float)((i * 37 % 101) - 50) / 50.f; hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice); return p; };
     f.q = dev(o, 0.1f); f.q_tgt = dev(o, 0.1f); f.grad = dev(o, 0.f); f.m = dev(o, 0.f); f.v = dev(o, 0.f);

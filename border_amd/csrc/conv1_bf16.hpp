@@ -107,6 +107,7 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
 
     const float bias = a.bias[z][i];
     float* out = a.out[z];
+    asm volatile("" ::"v"(bias));   // land the bias load here: otherwise the epilogue's first store waits vmcnt(0), i.e. for the NEXT item's pixel loads
 
     for (; item < items; item += stride) {
         uint2 cur[16];
@@ -141,15 +142,27 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
             __builtin_amdgcn_sched_barrier(0);
         }
         const int m0 = item * 32;
+        // Full items (all of them when M % 32 == 0) store without per-row predicates.  With 16 predicated stores the compiler
+        // puts s_waitcnt vmcnt(0) into every predicate - a wait for the next item's pixel loads AND for the previous store
+        // (vmcnt counts stores): 16 memory round trips in a row per item.
+        if (m0 + 32 <= a.M) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = acc[r] * (1.0f / 255.0f) + bias;
+            for (int r = 0; r < 16; ++r) {
+                const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[r] * (1.0f / 255.0f) + bias;
 #ifdef C1_NOSTORE
-            if (mo < a.M && v == 123.456f) out[(size_t)mo * 32 + i] = v;
+                if (v == 123.456f) out[(size_t)mo * 32 + i] = v;
 #else
-            if (mo < a.M) out[(size_t)mo * 32 + i] = v > 0.f ? v : 0.f;
+                out[(size_t)mo * 32 + i] = v > 0.f ? v : 0.f;
 #endif
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[r] * (1.0f / 255.0f) + bias;
+                if (mo < a.M) out[(size_t)mo * 32 + i] = v > 0.f ? v : 0.f;
+            }
         }
     }
 }

@@ -65,6 +65,18 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a)
     V* dst1 = reinterpret_cast<V*>(a.b_next + (uint64_t)sample * a.obs_bytes);
     const uint64_t v0 = (uint64_t)chunk * a.vec_per_chunk;
     const uint64_t v1 = min(v0 + a.vec_per_chunk, nvec);
+    // the record's small fields are requested now, next to the first row loads: as load -> store pairs after the copy loop they
+    // were three dependent HBM round trips at the tail of every sample's first workgroup
+    uint8_t t_act = 0; float t_rew = 0.f; int8_t t_term = 0, t_trunc = 0;
+    const bool tail = chunk == 0;
+    if (tail) {
+        if (threadIdx.x < a.act_bytes) t_act = rec[a.act_off + threadIdx.x];
+        if (threadIdx.x == 0) {
+            t_rew = *reinterpret_cast<const float*>(rec + a.tail_off);
+            t_term = *reinterpret_cast<const int8_t*>(rec + a.tail_off + 4);
+            t_trunc = *reinterpret_cast<const int8_t*>(rec + a.tail_off + 5);
+        }
+    }
     // 4 vectors of each section per thread and pass: all 8 loads are issued before the first store, so a
     // thread keeps 8 x 16 B in flight (the row addresses are random, every load is an HBM round trip)
     for (uint64_t v = v0 + threadIdx.x; v < v1; v += 1024) {
@@ -81,14 +93,11 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a)
             if (w < v1) { dst0[w] = x[u]; dst1[w] = y[u]; }
         }
     }
-    if (chunk == 0) {
-        for (uint32_t t = threadIdx.x; t < a.act_bytes; t += 256)
+    if (tail) {
+        if (threadIdx.x < a.act_bytes) a.b_act[(uint64_t)sample * a.act_bytes + threadIdx.x] = t_act;
+        for (uint32_t t = threadIdx.x + 256; t < a.act_bytes; t += 256)      // (actions longer than 256 bytes)
             a.b_act[(uint64_t)sample * a.act_bytes + t] = rec[a.act_off + t];
-        if (threadIdx.x == 0) {
-            a.b_reward[sample] = *reinterpret_cast<const float*>(rec + a.tail_off);
-            a.b_term[sample] = *reinterpret_cast<const int8_t*>(rec + a.tail_off + 4);
-            a.b_trunc[sample] = *reinterpret_cast<const int8_t*>(rec + a.tail_off + 5);
-        }
+        if (threadIdx.x == 0) { a.b_reward[sample] = t_rew; a.b_term[sample] = t_term; a.b_trunc[sample] = t_trunc; }
     }
 }
 

@@ -73,7 +73,6 @@ inline hipError_t step_launch(hipStream_t st, bool varying, void (*kernel)(KArgs
     const size_t k = g->cursor++;
     if (k >= g->nodes.size() || g->funcs[k] != reinterpret_cast<void*>(kernel)) { g->status = BDR_ERR_INVALID; return hipSuccess; }   // sequence changed: re-capture
     if (!varying) return hipSuccess;
-    { static const bool nopatch = getenv("BDR_STEP_GRAPH_NOPATCH") != nullptr; if (nopatch) return hipSuccess; }   // timing experiments only
     std::tuple<KArgs...> vals(static_cast<KArgs>(args)...);   // arguments with the kernel's own parameter types
     void* params[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
     size_t i = 0;

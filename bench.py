@@ -125,7 +125,8 @@ def build_config(B, name, args, rank, local_rank):
         step_flops = 2 * fwd + fwd + sum(2 * bs * i * o for i, o in dims[1:])     # two forwards, dW of every layer, dX of all but the first
         n_par = sum(i * o + o for i, o in dims)
         by = {"sample": bs * (2 * 16 + 8 + 6), "adam": 7 * 4 * n_par, "track": 3 * 4 * n_par}
-        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops={}, bytes=by, step_flops=step_flops,
+        # the whole step (sample, two forwards, TD, backward, Adam, track) is ONE launch of one workgroup: label "mlp_step"
+        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops={"mlp_step": step_flops}, bytes=by, step_flops=step_flops,
                     metric="agent opt-steps/sec (DQN CartPole-shaped Mlp[64,64], batch 32)",
                     workload=f"CartPole-shaped DQN Mlp[64,64] (obs 4 f32, 2 actions), replay {cap}, batch {bs}",
                     cfg_extra={"critic_loss": "Mse", "optimizer": "Adam lr=1e-3", "soft_update_interval": 1, "tau": 0.01},
@@ -172,8 +173,13 @@ def build_config(B, name, args, rank, local_rank):
         step_flops = (f_pi + 2 * f_q + 2 * dx_q_all + f_pi + dx_pi) + (f_pi + 2 * f_q + 2 * f_q + 2 * (f_q + dx_q_inner))
         n_pi = sum(i * o + o for i, o in pi + heads)
         n_q = sum(i * o + o for i, o in qd)
-        by = {"sample": bs * (2 * od * 4 + ad * 4 + 6), "adam_pi": 7 * 4 * n_pi, "adam_q": 7 * 4 * n_q, "track": 3 * 4 * n_q}
-        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops={}, bytes=by, step_flops=step_flops,
+        # per profile label (labels repeat within a step and are summed): algorithmic work of all launches carrying the label
+        f_trunk = sum(2 * bs * i * o for i, o in pi)
+        f_heads = sum(2 * bs * i * o for i, o in heads)
+        fl = {"pi_fwd": 2 * f_trunk, "pi_head": 2 * f_heads, "q_fwd": 6 * f_q, "q_dx": 2 * dx_q_all + 2 * dx_q_inner, "pi_dx": dx_pi,
+              "pi_dw": f_pi, "q_dw": 2 * f_q}
+        by = {"sample": bs * (2 * od * 4 + ad * 4 + 6), "adam_pi": 7 * 4 * n_pi, "adam_q_track": 2 * 10 * 4 * n_q}
+        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops=fl, bytes=by, step_flops=step_flops,
                     metric="agent opt-steps/sec (SAC obs 17 / act 6, twin-Q, batch 1024)",
                     workload=f"SAC on HalfCheetah-shaped synthetic rows (obs 17, act 6 f32), actor Mlp2[256,256], twin-Q Mlp[256,256], "
                              f"Auto entropy coefficient, replay {cap}, batch {bs}",

@@ -154,7 +154,7 @@ struct DqnMlp : bdr_agent {
 
     bool fused_ok(int Bn) const
     {
-        if (!fused || prof || net.L.size() > MF_MAXL || Bn > 128 || net.out_dim > 64) return false;
+        if (!fused || net.L.size() > MF_MAXL || Bn > 128 || net.out_dim > 64) return false;
         for (const auto& l : net.L) if (l.Kp > 256 || l.Np > 256) return false;
         return true;
     }
@@ -187,6 +187,7 @@ struct DqnMlp : bdr_agent {
         f.do_track = (track_with_next && f.do_adam) ? 1 : 0;
         f.tau = (float)cfg.tau; f.omt = (float)(1.0 - cfg.tau);
         const size_t lds_bytes = lds_step ? mf_lds_plan(f) : 0;
+        Bracket br(this, "mlp_step");
         if (lds_bytes) {   // activations and gradients resident in LDS (mlp_fused.hpp)
             if (lds_bytes > lds_attr) {
                 BDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dqn_mlp_step_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -142,7 +142,7 @@ def build_config(B, name, args, rank, local_rank):
         c1, c2, c3 = 2 * bs * 400 * 256 * 32, 2 * bs * 81 * 512 * 64, 2 * bs * 49 * 576 * 64
         fl = {"psi_conv1": 2 * c1, "psi_conv2": 2 * c2, "psi_conv3": 2 * c3, "psi_conv1_dw": c1, "psi_conv2_dw": c2, "psi_conv2_dx": c2,
               "psi_conv3_dw": c3, "psi_conv3_dx": c3,
-              "iqn_phi_merge": 2 * (2 * M * E * F), "iqn_f_fwd1": 2 * (2 * M * F * H), "iqn_f_fwd2": 2 * (2 * M * H * N_ACTIONS),
+              "iqn_phi": 2 * (2 * M * E * F), "iqn_f_fwd1": 2 * (2 * M * F * H), "iqn_f_fwd2": 2 * (2 * M * H * N_ACTIONS),
               "iqn_f_dw2": 2 * M * H * N_ACTIONS, "iqn_f_dx2": 2 * M * H * N_ACTIONS, "iqn_f_dw1": 2 * M * F * H, "iqn_f_dx1": 2 * M * F * H,
               "iqn_cos_dw": 2 * M * E * F}
         by = {"sample": 2 * bs * 28224 + bs * 14}

@@ -106,8 +106,8 @@ struct DenseArgs {
     int M, ncols, kred, relu;
     int w_ld;            // row stride of W (= Np of the layer)
     int accum;           // dx: out += result (sum of several branches' input gradients)
-    // fwd: optional Hadamard merge (IQN: m = relu(cos-embed) * psi[b]):  out2[m][n] = out[m][n] * had[(m / had_group)][n]
-    const float* had; int had_ld, had_group; float* out2;
+    // optional second factor of the A operand (DenseFwdHad): A(m,k) = x[m][k] * xhad[m / xhad_group][k]
+    const float* xhad; int xhad_ld, xhad_group;
 };
 
 struct DenseFwd {
@@ -132,8 +132,12 @@ struct DenseFwd {
         v += bias;
         if (a.relu) v = v > 0.f ? v : 0.f;
         a.out[(size_t)m * a.ldo + n] = v;
-        if (a.had) a.out2[(size_t)m * a.ldo + n] = v * a.had[(size_t)(m / a.had_group) * a.had_ld + n];
     }
+};
+// forward layer whose input rows are a Hadamard product that is never materialised (igemm.hpp ADenseHad)
+struct DenseFwdHad : DenseFwd {
+    using A = ADenseHad;
+    __device__ static DenseSrcHad a_src(const Args& a, int) { return DenseSrcHad{a.x.p, a.x.ld, a.xhad, a.xhad_ld, a.xhad_group}; }
 };
 
 // Several networks of the same architecture in one launch (SAC's critics): instance z = blockIdx.z
@@ -197,6 +201,7 @@ struct DenseDwArgs {
     const float* dy;     // [M][Np]
     float* part; size_t part_stride;
     int M, Kp, Np;
+    const float* xhad; int xhad_ld, xhad_group;   // DenseDwHad: x[m][k] * xhad[m / xhad_group][k]
 };
 struct DenseDw {
     using A = ADense;
@@ -208,6 +213,11 @@ struct DenseDw {
     __device__ static DenseSrc a_src(const Args& a) { return a.x; }
     __device__ static const float* y_src(const Args& a) { return a.dy; }
     __device__ static float* part(const Args& a, int chunk) { return a.part + (size_t)chunk * a.part_stride; }
+};
+
+struct DenseDwHad : DenseDw {
+    using A = ADenseHad;
+    __device__ static DenseSrcHad a_src(const Args& a) { return DenseSrcHad{a.x.p, a.x.ld, a.xhad, a.xhad_ld, a.xhad_group}; }
 };
 
 // g[i] = sum_c part[c][i]  (same deterministic scheme as the conv path)
@@ -321,14 +331,24 @@ inline hipError_t launch_dense(hipStream_t st, dim3 grid, const typename P::Args
     return step_launch(st, false, k_igemm<P, 1>, grid, dim3(256), d);
 }
 inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, const float* params_base, DenseSrc x, float* out, int M,
-                             const float* had = nullptr, int had_ld = 0, int had_group = 1, float* out2 = nullptr, bool small = false)
+                             bool small = false)
 {
     DenseArgs d{};
-    d.had = had; d.had_ld = had_ld; d.had_group = had_group; d.out2 = out2;
     d.x = x; d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
     d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
-    if (small && !had) { DenseArgsZ dz{}; dz.a[0] = d; BDR_HIP(launch_dense_small<false>(st, dz, 1)); return BDR_OK; }
+    if (small) { DenseArgsZ dz{}; dz.a[0] = d; BDR_HIP(launch_dense_small<false>(st, dz, 1)); return BDR_OK; }
     BDR_HIP(launch_dense<DenseFwd>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), d));
+    return BDR_OK;
+}
+// the same layer on input rows x[m][k] * had[m / had_group][k] (the product exists only inside the kernel)
+inline int32_t dense_forward_had(hipStream_t st, const DenseLayer& l, const float* params_base, DenseSrc x, const float* had, int had_ld,
+                                 int had_group, float* out, int M)
+{
+    DenseArgs d{};
+    d.x = x; d.xhad = had; d.xhad_ld = had_ld; d.xhad_group = had_group;
+    d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
+    d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
+    BDR_HIP(launch_dense<DenseFwdHad>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), d));
     return BDR_OK;
 }
 
@@ -340,7 +360,7 @@ inline int32_t dense_forward_z(hipStream_t st, const DenseLayer& l, int nz, cons
     for (int z = 0; z < nz; ++z) {
         DenseArgs& d = dz.a[z];
         d.x = x[z]; d.w = params_base[z] + l.w; d.bias = params_base[z] + l.b; d.out = out[z]; d.ldo = l.Np;
-        d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np; d.had_group = 1;
+        d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
     }
     if (small) { BDR_HIP(launch_dense_small<false>(st, dz, nz)); return BDR_OK; }
     BDR_HIP(launch_dense<DenseFwdZ>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, nz), dz));
@@ -375,12 +395,13 @@ inline int32_t dense_dx(hipStream_t st, const DenseLayer& l, const float* params
 
 // dW, db straight into the gradient arena (single row chunk), or through `part` (chunks > 1)
 inline int32_t dense_dw(hipStream_t st, const DenseLayer& l, float* grad_base, DenseSrc x, const float* dy, int M,
-                        float* part = nullptr, int chunks = 1)
+                        float* part = nullptr, int chunks = 1, const float* had = nullptr, int had_ld = 0, int had_group = 1)
 {
     const int tiles = (l.Kp / 64) * (l.Np / 64);
     const int n = l.Kp * l.Np + l.Np;
-    DenseDwArgs d{x, dy, chunks > 1 ? part : grad_base + l.w, chunks > 1 ? (size_t)n : 0, M, l.Kp, l.Np};
-    BDR_HIP(step_launch(st, false, k_igemm_red<DenseDw>, dim3(tiles * chunks), dim3(256), d));
+    DenseDwArgs d{x, dy, chunks > 1 ? part : grad_base + l.w, chunks > 1 ? (size_t)n : 0, M, l.Kp, l.Np, had, had_ld, had_group};
+    if (had) BDR_HIP(step_launch(st, false, k_igemm_red<DenseDwHad>, dim3(tiles * chunks), dim3(256), d));
+    else BDR_HIP(step_launch(st, false, k_igemm_red<DenseDw>, dim3(tiles * chunks), dim3(256), d));
     if (chunks > 1) {
         BDR_HIP(step_launch(st, false, k_dense_reduce, dim3((n + 63) / 64), dim3(256), part, (size_t)n, chunks, grad_base + l.w, n));
     }
@@ -412,7 +433,7 @@ inline int32_t dense_dw_group(hipStream_t st, const DenseDwJob* jobs, int n, int
         for (int j = 0; j < nj; ++j) {
             const DenseDwJob& q = jobs[j0 + j];
             const int tiles = (q.l->Kp / 64) * (q.l->Np / 64);
-            g.a[j] = DenseDwArgs{q.x, q.dy, q.part, (size_t)q.l->Kp * q.l->Np + q.l->Np, M, q.l->Kp, q.l->Np};
+            g.a[j] = DenseDwArgs{q.x, q.dy, q.part, (size_t)q.l->Kp * q.l->Np + q.l->Np, M, q.l->Kp, q.l->Np, nullptr, 0, 1};
             g.first[j] = first;
             first += tiles * q.chunks;
         }

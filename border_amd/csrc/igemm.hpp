@@ -229,6 +229,29 @@ struct ADense {
     __device__ static const float* chunk(const Row& r, int kt, int q) { return r.p + kt * BK + q * 4; }
 };
 
+// Dense rows multiplied element-wise by a row of a second matrix on their way into LDS: A(m,k) = x[m][k] * h[m / group][k]
+// (IQN's merge m = relu(phi) * psi(x)[b]: the product is an operand of two big GEMMs and is never written out).  The kernels
+// load both vectors in the prefetch and multiply when the tile is committed to LDS (policies with HAD, see a_has_had).
+struct DenseSrcHad { const float* p; int ld; const float* had; int had_ld, had_group; };
+struct ADenseHad {
+    static constexpr int VEC = 4;
+    static constexpr bool HAD = true;
+    struct Row { const float* p; const float* h; bool ok; };
+    __device__ static Row row(DenseSrcHad s, int m, int M)
+    {
+        Row r;
+        r.ok = m < M;
+        const int mm = r.ok ? m : 0;
+        r.p = s.p + (size_t)mm * s.ld;
+        r.h = s.had + (size_t)(mm / s.had_group) * s.had_ld;
+        return r;
+    }
+    __device__ static void load(const Row& r, int kt, int q, f32x4* v) { v[0] = *reinterpret_cast<const f32x4*>(r.p + kt * BK + q * 4); }
+    __device__ static f32x4 load_had(const Row& r, int kt, int q) { return *reinterpret_cast<const f32x4*>(r.h + kt * BK + q * 4); }
+};
+template <class A, class = void> struct a_has_had : std::false_type {};
+template <class A> struct a_has_had<A, std::void_t<decltype(A::HAD)>> : std::bool_constant<A::HAD> {};
+
 // Keeps a wave-uniform pointer in an SGPR pair from here on (otherwise the compiler re-loads kernel-argument
 // pointers inside every conditional store block of the epilogue: 16 scalar-load round trips per tile).
 // The pinned pointer is typed as global address space so that accesses stay global_load / global_store
@@ -446,11 +469,16 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
     // of MFMAs is ~0.5 us; an L2/MALL round trip under load is longer than that).
     f32x4 ra[2][A_PASSES][AV];
     f32x4 rb[2][B_VECS];
+    constexpr bool HAD = a_has_had<A>::value;
+    f32x4 rh[2][HAD ? A_PASSES : 1];   // second factor of a Hadamard A operand (ADenseHad)
     auto prefetch_a = [&](auto set, int kt) {
         constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p)
-            if (A_ELEMS % NT == 0 || tid + p * NT < A_ELEMS) A::load(rows[p], kt, a_q, ra[S][p]);
+            if (A_ELEMS % NT == 0 || tid + p * NT < A_ELEMS) {
+                A::load(rows[p], kt, a_q, ra[S][p]);
+                if constexpr (HAD) rh[S][p] = A::load_had(rows[p], kt, a_q);
+            }
     };
     auto prefetch_b = [&](auto set, int kt) {
         constexpr int S = decltype(set)::value;
@@ -477,8 +505,11 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
         for (int p = 0; p < A_PASSES; ++p) {
             if (A_ELEMS % NT != 0 && tid + p * NT >= A_ELEMS) continue;
 #pragma unroll
-            for (int j = 0; j < AV; ++j)
-                *reinterpret_cast<f32x4*>(&As[(p * (NT / APR) + a_r) * LDA + a_q * A::VEC + j * 4]) = ra[S][p][j];
+            for (int j = 0; j < AV; ++j) {
+                f32x4 v = ra[S][p][j];
+                if constexpr (HAD) v *= rh[S][p];
+                *reinterpret_cast<f32x4*>(&As[(p * (NT / APR) + a_r) * LDA + a_q * A::VEC + j * 4]) = v;
+            }
         }
     };
     auto commit_b = [&](auto set, int stage) {
@@ -692,6 +723,8 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
     const float* ysrc = P::y_src(args);
 
     f32x4 ra[A_PASSES][AV];
+    constexpr bool HAD = a_has_had<A>::value;
+    f32x4 rh[HAD ? A_PASSES : 1];
     f32x4 ry[Y_VECS];
     f32x4 bsum[Y_VECS];
 #pragma unroll
@@ -705,6 +738,7 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
             const int row = idx % 32, ksub = idx / 32;
             typename A::Row r = A::row(P::a_src(args), mt * 32 + row, M);
             A::load(r, ko0 / BK + ksub, a_q, ra[p]);
+            if constexpr (HAD) rh[p] = A::load_had(r, ko0 / BK + ksub, a_q);
         }
     };
     auto prefetch_y = [&](int mt) {   // rows >= M contribute zero (select, no branch)
@@ -724,8 +758,11 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
             const int idx = p * ROWS_PER_PASS + a_r;
             const int row = idx % 32, ksub = idx / 32;
 #pragma unroll
-            for (int j = 0; j < AV; ++j)
-                *reinterpret_cast<f32x4*>(&As[row * LDAR + ksub * BK + a_q * A::VEC + j * 4]) = ra[p][j];
+            for (int j = 0; j < AV; ++j) {
+                f32x4 v = ra[p][j];
+                if constexpr (HAD) v *= rh[p];
+                *reinterpret_cast<f32x4*>(&As[row * LDAR + ksub * BK + a_q * A::VEC + j * 4]) = v;
+            }
         }
     };
     auto commit_y = [&](int stage, bool count) {

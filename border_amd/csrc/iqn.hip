@@ -260,11 +260,14 @@ struct Iqn : bdr_agent {
         BDR_TRY(psi_forward(params, obs, Bn, &feat, &ldf));
         const int M = Bn * N, Ep = hd.L[0].Kp;
         { Bracket br(a, "iqn_cos"); hipLaunchKernelGGL(k_iqn_cos, dim3((M * Ep + 255) / 256), dim3(256), 0, stream, tau, cosv, M, E, Ep); BDR_HIP(hipGetLastError()); }
-        { Bracket br(a, "iqn_phi_merge"); BDR_TRY(dense_forward(a, stream, hd.L[0], params, DenseSrc{cosv, Ep}, phi, M, feat, ldf, N, mrg)); }
-        DenseSrc in{mrg, hd.L[0].Np};
+        // phi = relu(cos-embedding * W + b); the merge m = phi * psi(x)[b] (iqn/model/base.rs) is the input of the next layer and of
+        // its weight gradient and is formed inside those two GEMMs on the way into LDS: [B*N][F] floats that are never written
+        { Bracket br(a, "iqn_phi"); BDR_TRY(dense_forward(a, stream, hd.L[0], params, DenseSrc{cosv, Ep}, phi, M)); }
+        DenseSrc in{phi, hd.L[0].Np};
         for (size_t i = 1; i < hd.L.size(); ++i) {
             Bracket br(a, ("iqn_f_fwd" + std::to_string(i)).c_str());
-            BDR_TRY(dense_forward(a, stream, hd.L[i], params, in, f_act[i - 1], M));
+            if (i == 1) BDR_TRY(dense_forward_had(stream, hd.L[1], params, in, feat, ldf, N, f_act[0], M));
+            else BDR_TRY(dense_forward(a, stream, hd.L[i], params, in, f_act[i - 1], M));
             in = DenseSrc{f_act[i - 1], hd.L[i].Np};
         }
         return BDR_OK;
@@ -297,16 +300,19 @@ struct Iqn : bdr_agent {
         }
         const int ch = dw_chunks(M);
         // f backward
-        for (int i = L - 1; i >= 1; --i) {
-            DenseSrc in = i == 1 ? DenseSrc{mrg, Fp} : DenseSrc{f_act[i - 2], hd.L[i - 1].Np};
-            { Bracket br(a, ("iqn_f_dw" + std::to_string(i)).c_str()); BDR_TRY(dense_dw(stream, hd.L[i], grad, in, f_dy[i - 1], M, part, ch)); }
-            if (i > 1) { Bracket br(a, ("iqn_f_dx" + std::to_string(i)).c_str()); BDR_TRY(dense_dx(stream, hd.L[i], p, f_dy[i - 1], f_dy[i - 2], f_act[i - 2], M)); }
-        }
-        // dm = dL/dm (no ReLU mask: m is a product, not an activation) overwrites m itself: the dW launch of
-        // layer 1 that reads m is already enqueued ahead of this kernel on the same stream
-        { Bracket br(a, "iqn_f_dx1"); BDR_TRY(dense_dx(stream, hd.L[1], p, f_dy[0], mrg, nullptr, M)); }
         const float* feat = cnn ? a3 : psi_act.back();
         const int ldf = cnn ? 3136 : psi_mlp.L.back().Np;
+        for (int i = L - 1; i >= 1; --i) {
+            DenseSrc in = i == 1 ? DenseSrc{phi, Fp} : DenseSrc{f_act[i - 2], hd.L[i - 1].Np};
+            {
+                Bracket br(a, ("iqn_f_dw" + std::to_string(i)).c_str());
+                if (i == 1) BDR_TRY(dense_dw(stream, hd.L[i], grad, in, f_dy[i - 1], M, part, ch, feat, ldf, Np));   // x = phi * psi[b]
+                else BDR_TRY(dense_dw(stream, hd.L[i], grad, in, f_dy[i - 1], M, part, ch));
+            }
+            if (i > 1) { Bracket br(a, ("iqn_f_dx" + std::to_string(i)).c_str()); BDR_TRY(dense_dx(stream, hd.L[i], p, f_dy[i - 1], f_dy[i - 2], f_act[i - 2], M)); }
+        }
+        // dm = dL/dm (no ReLU mask: m is a product, not an activation)
+        { Bracket br(a, "iqn_f_dx1"); BDR_TRY(dense_dx(stream, hd.L[1], p, f_dy[0], mrg, nullptr, M)); }
         float* dpsi = cnn ? dy3 : psi_dy.back();
         const int mask_psi = cnn ? 1 : (cfg.psi.activation_out ? 1 : 0);
         {

@@ -326,7 +326,7 @@ struct Sac : bdr_agent {
         DenseSrc in{x, pi.L[0].Kp};
         for (int i = 0; i < n_trunk; ++i) {
             Bracket br(a, "pi_fwd");
-            BDR_TRY(dense_forward(a, stream, pi.L[i], pi_p, in, t_act[i], Bn, nullptr, 0, 1, nullptr, small_gemm));
+            BDR_TRY(dense_forward(a, stream, pi.L[i], pi_p, in, t_act[i], Bn, small_gemm));
             in = DenseSrc{t_act[i], pi.L[i].Np};
         }
         // both heads (same shape, same input, consecutive in the arena) in one launch
@@ -361,7 +361,7 @@ struct Sac : bdr_agent {
             for (size_t l = 0; l < qn.L.size(); ++l) {
                 for (int j = 0; j < nz; ++j) out[j] = (*acts[j0 + j])[l];
                 Bracket br(a, "q_fwd");
-                if (nz == 1) BDR_TRY(dense_forward(a, stream, qn.L[l], params[j0], in[0], out[0], Bn, nullptr, 0, 1, nullptr, small_gemm));
+                if (nz == 1) BDR_TRY(dense_forward(a, stream, qn.L[l], params[j0], in[0], out[0], Bn, small_gemm));
                 else BDR_TRY(dense_forward_z(stream, qn.L[l], nz, params + j0, in, out, Bn, small_gemm));
                 for (int j = 0; j < nz; ++j) in[j] = DenseSrc{out[j], qn.L[l].Np};
             }

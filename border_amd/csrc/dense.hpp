@@ -444,6 +444,111 @@ inline int32_t dense_dw_group(hipStream_t st, const DenseDwJob* jobs, int n, int
     return BDR_OK;
 }
 
+// The same grouped launch with the latency-oriented tile of k_dense_small: a workgroup owns a 32x32 tile of dW (k rows x n
+// columns) for one row chunk, its four waves reduce a quarter of the chunk's batch rows each, straight from global memory (x and
+// dY rows are read along their contiguous dimension, 128 B per row and operand), partial tiles are added through LDS in a fixed
+// order; the workgroups of k-tile 0 also produce the bias partials (column sums of the dY values they hold).  A 64x64 tile of
+// k_igemm_red_group walks 2-6 row blocks with a barrier each and there are few of them; here 450-770 workgroups run 16-32 MFMAs
+// per wave.  Partials have k_igemm_red's layout ([Kp*Np] weights then [Np] bias per chunk): k_dense_reduce_adam is unchanged.
+struct DenseDwSmallGroup { DenseDwArgs a[DW_GROUP]; int first[DW_GROUP + 1]; int chunks[DW_GROUP]; int n; };
+__global__ __launch_bounds__(256) void k_dense_dw_small_group(DenseDwSmallGroup g)
+{
+    __shared__ float red[4][32][33];
+    __shared__ float bred[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.x;
+    int z = 0;
+#pragma unroll
+    for (int k = 1; k < DW_GROUP; ++k) z += (k < g.n && b >= g.first[k]) ? 1 : 0;
+    const DenseDwArgs& a = g.a[z];
+    const int nch = g.chunks[z], local = b - g.first[z];
+    const int tile = local / nch, chunk = local % nch;
+    const int NT = a.Np / 32, kt = tile / NT, nt = tile % NT;
+    const int i = lane & 31, h = lane >> 5;
+    // rows of this chunk, then of this wave: multiples of 8 (an MFMA group takes 8 batch rows)
+    const int per_chunk = ((a.M + nch - 1) / nch + 31) / 32 * 32;
+    const int r0 = chunk * per_chunk, r1 = min(a.M, r0 + per_chunk);
+    const int per_wave = per_chunk / 4;                       // multiple of 8
+    const int w0 = r0 + wave * per_wave, w1 = min(r1, w0 + per_wave);
+    const float* xcol = a.x.p + kt * 32 + i;
+    const float* ycol = a.dy + nt * 32 + i;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    // 32 rows = 4 MFMA groups = 32 loads per lane; the next 32 rows are requested before this batch's MFMAs (two batches in flight)
+    auto load32 = [&](int rb, float (&av)[4][4], float (&bv)[4][4]) {
+        const float* px = xcol + (size_t)(rb + 4 * h) * a.x.ld;
+        const float* py = ycol + (size_t)(rb + 4 * h) * a.Np;
+        if (rb + 32 <= w1) {                                  // full batch (wave-uniform): straight-line loads
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { av[u][s] = px[(8 * u + s) * a.x.ld]; bv[u][s] = py[(8 * u + s) * a.Np]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bool ok = rb + 8 * u + 4 * h + s < w1;
+                    const float xa = ok ? px[(8 * u + s) * a.x.ld] : 0.f, ya = ok ? py[(8 * u + s) * a.Np] : 0.f;
+                    av[u][s] = xa; bv[u][s] = ya;
+                }
+        }
+    };
+    auto mma32 = [&](const float (&av)[4][4], const float (&bv)[4][4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][s], bv[u][s], acc, 0, 0, 0);
+                bsum += bv[u][s];
+            }
+    };
+    {
+        float a0[4][4], b0[4][4], a1[4][4], b1[4][4];
+        if (w0 < w1) load32(w0, a0, b0);
+        for (int rb = w0; rb < w1; rb += 64) {
+            if (rb + 32 < w1) load32(rb + 32, a1, b1);
+            mma32(a0, b0);
+            if (rb + 64 < w1) load32(rb + 64, a0, b0);
+            if (rb + 32 < w1) mma32(a1, b1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
+    if (kt == 0) {
+        bsum += __shfl_xor(bsum, 32);                         // the two row parities of the lane's column
+        if (h == 0) bred[wave][i] = bsum;
+    }
+    __syncthreads();
+    float* part = a.part + (size_t)chunk * a.part_stride;
+    const int r = tid >> 3, c4 = (tid & 7) * 4;
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = ((red[0][r][c4 + q] + red[1][r][c4 + q]) + red[2][r][c4 + q]) + red[3][r][c4 + q];
+    *reinterpret_cast<f32x4*>(part + (size_t)(kt * 32 + r) * a.Np + nt * 32 + c4) = v;
+    if (kt == 0 && tid < 32) part[(size_t)a.Kp * a.Np + nt * 32 + tid] = ((bred[0][tid] + bred[1][tid]) + bred[2][tid]) + bred[3][tid];
+}
+inline int32_t dense_dw_small_group(hipStream_t st, const DenseDwJob* jobs, int n, int M)
+{
+    for (int j0 = 0; j0 < n; j0 += DW_GROUP) {
+        DenseDwSmallGroup g{};
+        const int nj = std::min(DW_GROUP, n - j0);
+        int first = 0;
+        for (int j = 0; j < nj; ++j) {
+            const DenseDwJob& q = jobs[j0 + j];
+            g.a[j] = DenseDwArgs{q.x, q.dy, q.part, (size_t)q.l->Kp * q.l->Np + q.l->Np, M, q.l->Kp, q.l->Np, nullptr, 0, 1};
+            g.first[j] = first; g.chunks[j] = q.chunks;
+            first += (q.l->Kp / 32) * (q.l->Np / 32) * q.chunks;
+        }
+        for (int j = nj; j <= DW_GROUP; ++j) g.first[j] = first;
+        g.n = nj;
+        BDR_HIP(step_launch(st, false, k_dense_dw_small_group, dim3(first), dim3(256), g));
+    }
+    return BDR_OK;
+}
+
 constexpr int RA_SEGS = 12, RA_INST = 4;
 struct DenseReduceSeg { const float* part; size_t stride; int chunks; unsigned off4, n4; };   // arena float4s [off4, off4 + n4)
 struct ReduceAdamArgs {

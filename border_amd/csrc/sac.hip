@@ -299,14 +299,16 @@ struct Sac : bdr_agent {
         }
         BDR_TRY(zalloc(&logp, Bn)); BDR_TRY(zalloc(&tgt, Bn));
         BDR_TRY(zalloc(&z_a, (size_t)2 * Bn * A));
-        // row chunks of the grouped dW launches: about 512 workgroups per launch over all its GEMMs, >= 64 rows per chunk
+        // row chunks of the grouped dW launches.  64x64 tiles (k_igemm_red_group): about 512 workgroups per launch over all its
+        // GEMMs, >= 64 rows per chunk; 32x32 split-reduction tiles (k_dense_dw_small_group): 256 rows per workgroup
         auto plan = [&](const MlpLayout& net, int jobs, std::vector<size_t>& off, std::vector<int>& chunks) {
             off.clear(); chunks.clear();
             size_t o = 0;
             const int target = std::max(32, 512 / jobs);
             for (const auto& l : net.L) {
                 const int tiles = (l.Kp / 64) * (l.Np / 64);
-                const int c = std::max(1, std::min(std::min(16, Bn / 64), (target + tiles - 1) / tiles));
+                const int c = small_gemm ? std::max(1, std::min(16, Bn / 256))
+                                         : std::max(1, std::min(std::min(16, Bn / 64), (target + tiles - 1) / tiles));
                 off.push_back(o); chunks.push_back(c);
                 o += (size_t)c * ((size_t)l.Kp * l.Np + l.Np);
             }
@@ -388,7 +390,7 @@ struct Sac : bdr_agent {
         for (size_t l = 0; l < net.L.size(); ++l) {
             const DenseLayer& L = net.L[l];
             const size_t nfl = (size_t)L.Kp * L.Np + L.Np;
-            ra.seg[l] = DenseReduceSeg{part + off[l], nfl, std::min(chunks[l], std::max(1, Bn / 64)), (unsigned)(L.w / 4), (unsigned)(nfl / 4)};
+            ra.seg[l] = DenseReduceSeg{part + off[l], nfl, std::min(chunks[l], std::max(1, Bn / (small_gemm ? 256 : 64))), (unsigned)(L.w / 4), (unsigned)(nfl / 4)};
         }
         for (int i = 0; i < ninst; ++i) { ra.p[i] = p[i]; ra.g[i] = g[i]; ra.m[i] = m[i]; ra.v[i] = v[i]; ra.tgt[i] = tgt_p ? tgt_p[i] : nullptr; ra.s[i] = sc[i]; }
         ra.n4 = (unsigned)(net.total / 4); ra.track = tgt_p ? 1 : 0; ra.tau = (float)cfg.tau; ra.omt = (float)(1.0 - cfg.tau);
@@ -453,7 +455,7 @@ struct Sac : bdr_agent {
         }
         {   // input gradients down the trunk first, then every weight gradient of the actor in one grouped launch
             DenseDwJob jobs[RA_SEGS];
-            auto chunks_rt = [&](int c) { return std::min(c, std::max(1, Bn / 64)); };
+            auto chunks_rt = [&](int c) { return std::min(c, std::max(1, Bn / (small_gemm ? 256 : 64))); };
             const DenseSrc hin = n_trunk ? DenseSrc{t_act[n_trunk - 1], pi.L[n_trunk - 1].Np} : DenseSrc{x_o, pi.L[0].Kp};
             if (n_trunk) {
                 float* dh = t_dy[n_trunk - 1];
@@ -466,7 +468,7 @@ struct Sac : bdr_agent {
                 jobs[nj++] = DenseDwJob{&pi.L[l], l == 0 ? DenseSrc{x_o, pi.L[0].Kp} : DenseSrc{t_act[l - 1], pi.L[l - 1].Np}, t_dy[l], pi_part + pi_off[l], chunks_rt(pi_chunks[l])};
             jobs[nj++] = DenseDwJob{&pi.L[n_trunk], hin, gmean, pi_part + pi_off[n_trunk], chunks_rt(pi_chunks[n_trunk])};
             jobs[nj++] = DenseDwJob{&pi.L[n_trunk + 1], hin, ge, pi_part + pi_off[n_trunk + 1], chunks_rt(pi_chunks[n_trunk + 1])};
-            { Bracket br(a, "pi_dw"); BDR_TRY(dense_dw_group(stream, jobs, nj, Bn)); }
+            { Bracket br(a, "pi_dw"); BDR_TRY(small_gemm ? dense_dw_small_group(stream, jobs, nj, Bn) : dense_dw_group(stream, jobs, nj, Bn)); }
             step_pi += 1;
             const AdamScalars sc = adam_scalars_for(false, cfg.lr_actor, 0, 0, 0, 0, step_pi);
             Bracket br(a, "adam_pi");
@@ -496,8 +498,8 @@ struct Sac : bdr_agent {
             for (int i = 0; i < NC; ++i)
                 for (int l = 0; l < L; ++l)
                     jobs.push_back(DenseDwJob{&qn.L[l], l == 0 ? DenseSrc{xq_c, Kq} : DenseSrc{c2_act[i][l - 1], qn.L[l - 1].Np}, c_dy[i][l],
-                                              q_part + (size_t)i * q_part_stride + q_off[l], std::min(q_chunks[l], std::max(1, Bn / 64))});
-            { Bracket br(a, "q_dw"); BDR_TRY(dense_dw_group(stream, jobs.data(), (int)jobs.size(), Bn)); }
+                                              q_part + (size_t)i * q_part_stride + q_off[l], std::min(q_chunks[l], std::max(1, Bn / (small_gemm ? 256 : 64)))});
+            { Bracket br(a, "q_dw"); BDR_TRY(small_gemm ? dense_dw_small_group(stream, jobs.data(), (int)jobs.size(), Bn) : dense_dw_group(stream, jobs.data(), (int)jobs.size(), Bn)); }
             AdamScalars sc[4];
             for (int i = 0; i < NC; ++i) { step_q[i] += 1; sc[i] = adam_scalars_for(false, cfg.lr_critic, 0, 0, 0, 0, step_q[i]); }
             Bracket br(a, "adam_q_track");

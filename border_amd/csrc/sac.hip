@@ -186,20 +186,49 @@ struct SacPackArgs {
     float* x_o; float* x_no; int ldp;
     float* xq_a; float* xq_n; float* xq_c; int ldq;
     float* z; size_t nz; uint64_t seed, counter;   // nz > 0: also draw the step's N(0,1) numbers (randn_at)
+    // do_gather: the kernel is also the replay buffer's sample of this step (replay_sample_plan): eight rows per workgroup draw their
+    // indices of the buffer's StdRng stream, and the rows go to the buffer's batch arrays (obs / next / act above, reward, flags)
+    // as well as into the padded matrices
+    int do_gather; GatherArgs g;
 };
-__global__ void k_sac_pack(SacPackArgs p)
+constexpr int SAC_PACK_ROWS = 8;
+__global__ __launch_bounds__(256) void k_sac_pack(SacPackArgs p)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if ((size_t)t < p.nz) p.z[t] = randn_at(p.seed, p.counter, (size_t)t);
+    __shared__ uint64_t s_row[SAC_PACK_ROWS];
+    const int tid = threadIdx.x, r0 = (int)blockIdx.x * SAC_PACK_ROWS;
+    for (size_t t = (size_t)blockIdx.x * 256 + tid; t < p.nz; t += (size_t)gridDim.x * 256) p.z[t] = randn_at(p.seed, p.counter, t);
+    if (p.do_gather) {
+        if (tid < SAC_PACK_ROWS && r0 + tid < p.B) {
+            const uint64_t row = (uint64_t)chacha12_word(p.g.key, p.g.word_pos + (uint64_t)(r0 + tid)) % p.g.size;   // (StdRng::next_u32() as usize) % size
+            s_row[tid] = row; p.g.ixs[r0 + tid] = row;
+            const uint8_t* rec = p.g.ring + row * p.g.stride;
+            p.g.b_reward[r0 + tid] = *reinterpret_cast<const float*>(rec + p.g.tail_off);
+            p.g.b_term[r0 + tid] = *reinterpret_cast<const int8_t*>(rec + p.g.tail_off + 4);
+            p.g.b_trunc[r0 + tid] = *reinterpret_cast<const int8_t*>(rec + p.g.tail_off + 5);
+        }
+        __syncthreads();
+    }
     const int W = p.O + p.A;
-    if (t >= p.B * W) return;
-    const int b = t / W, c = t % W;
-    if (c < p.O) {
-        const float o = p.obs[(size_t)b * p.O + c], n = p.next[(size_t)b * p.O + c];
-        p.x_o[(size_t)b * p.ldp + c] = o; p.x_no[(size_t)b * p.ldp + c] = n;
-        p.xq_a[(size_t)b * p.ldq + c] = o; p.xq_c[(size_t)b * p.ldq + c] = o; p.xq_n[(size_t)b * p.ldq + c] = n;
-    } else {
-        p.xq_c[(size_t)b * p.ldq + c] = p.act[(size_t)b * p.A + (c - p.O)];
+    for (int e = tid; e < SAC_PACK_ROWS * W; e += 256) {
+        const int rr = e / W, c = e % W, b = r0 + rr;
+        if (b >= p.B) break;
+        if (c < p.O) {
+            float o, n;
+            if (p.do_gather) {
+                const uint8_t* rec = p.g.ring + s_row[rr] * p.g.stride;
+                o = reinterpret_cast<const float*>(rec)[c]; n = reinterpret_cast<const float*>(rec + p.g.next_off)[c];
+                reinterpret_cast<float*>(p.g.b_obs)[(size_t)b * p.O + c] = o; reinterpret_cast<float*>(p.g.b_next)[(size_t)b * p.O + c] = n;
+            } else { o = p.obs[(size_t)b * p.O + c]; n = p.next[(size_t)b * p.O + c]; }
+            p.x_o[(size_t)b * p.ldp + c] = o; p.x_no[(size_t)b * p.ldp + c] = n;
+            p.xq_a[(size_t)b * p.ldq + c] = o; p.xq_c[(size_t)b * p.ldq + c] = o; p.xq_n[(size_t)b * p.ldq + c] = n;
+        } else {
+            float av;
+            if (p.do_gather) {
+                av = reinterpret_cast<const float*>(p.g.ring + s_row[rr] * p.g.stride + p.g.act_off)[c - p.O];
+                reinterpret_cast<float*>(p.g.b_act)[(size_t)b * p.A + (c - p.O)] = av;
+            } else av = p.act[(size_t)b * p.A + (c - p.O)];
+            p.xq_c[(size_t)b * p.ldq + c] = av;
+        }
     }
 }
 
@@ -244,6 +273,7 @@ struct Sac : bdr_agent {
     float *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr, *u_rew = nullptr; int8_t* u_term = nullptr; uint64_t u_cap = 0;
     uint64_t noise_counter = 0;
     StepGraph graph; bool use_graph = true;   // BDR_NO_STEP_GRAPH=1: eager launches
+    bool gather_in_pack = true;               // BDR_NO_STEP_GATHER=1: separate gather launch
     bool small_gemm = true;                   // BDR_NO_SMALL_GEMM=1: the 64x64-tile kernels of the large-batch agents
 
     ~Sac() override
@@ -403,21 +433,23 @@ struct Sac : bdr_agent {
     // do not depend on each other are merged: 34 launches for twin critics instead of one per layer and tensor (70).
     // draw_noise: z_actor / z_next ([Bn][A] each, contiguous) are drawn on the device inside the first launch
     int32_t update(int Bn, const float* obs, const float* act, const float* next_obs, const float* reward, const int8_t* term,
-                   float* z_actor, float* z_next, bool first, bool draw_noise = false)
+                   float* z_actor, float* z_next, bool first, bool draw_noise = false, const GatherArgs* gather = nullptr)
     {
         bdr_agent* a = this;
         BDR_TRY(ensure_batch(Bn));
         const int L = (int)qn.L.size(), ldq = qn.L[L - 1].Np, Ap = pi.L[n_trunk].Np, Kq = qn.L[0].Kp;
         {
-            SacPackArgs p{obs, next_obs, act, O, A, Bn, x_o, x_no, pi.L[0].Kp, xq_a, xq_n, xq_c, Kq, nullptr, 0, 0, 0};
+            SacPackArgs p{};
+            p.obs = obs; p.next = next_obs; p.act = act; p.O = O; p.A = A; p.B = Bn; p.x_o = x_o; p.x_no = x_no; p.ldp = pi.L[0].Kp;
+            p.xq_a = xq_a; p.xq_n = xq_n; p.xq_c = xq_c; p.ldq = Kq;
             if (draw_noise) {
                 BDR_REQUIRE(z_next == z_actor + (size_t)Bn * A, "noise buffers must be contiguous");
                 p.z = z_actor; p.nz = (size_t)2 * Bn * A; p.seed = cfg.seed; p.counter = noise_counter;
                 noise_counter += p.nz;
             }
-            const size_t nthr = std::max<size_t>((size_t)Bn * (O + A), p.nz);
+            if (gather) { p.do_gather = 1; p.g = *gather; }
             Bracket br(a, "pack");
-            BDR_HIP(step_launch(stream, draw_noise, k_sac_pack, dim3((unsigned)((nthr + 255) / 256)), dim3(256), p));
+            BDR_HIP(step_launch(stream, draw_noise || gather != nullptr, k_sac_pack, dim3((unsigned)((Bn + SAC_PACK_ROWS - 1) / SAC_PACK_ROWS)), dim3(256), p));
         }
         // ---------------- update_actor (sac/base.rs:151-167) ----------------
         BDR_TRY(action_logp(x_o, z_actor, Bn, true, xq_a));
@@ -521,9 +553,15 @@ struct Sac : bdr_agent {
     int32_t opt_enqueue(bdr_replay* r, int Bn)
     {
         for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
-            { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, Bn, stream)); }
+            // a uniform sample over the plain ring is drawn by the pack kernel itself (replay_sample_plan); prioritized and
+            // single-frame buffers keep their own gather launch
+            GatherArgs plan{};
+            const bool in_pack = gather_in_pack && !r->per && !r->frame_stack;
+            if (in_pack) BDR_TRY(replay_sample_plan(r, Bn, stream, &plan));
+            else { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, Bn, stream)); }
             // the noise of the actor pass, then of the target pass: 2*Bn*A consecutive draws of the agent's stream
-            BDR_TRY(update(Bn, (const float*)r->b_obs, (const float*)r->b_act, (const float*)r->b_next, r->b_reward, r->b_term, z_a, z_a + (size_t)Bn * A, u == 0, true));
+            BDR_TRY(update(Bn, (const float*)r->b_obs, (const float*)r->b_act, (const float*)r->b_next, r->b_reward, r->b_term, z_a, z_a + (size_t)Bn * A, u == 0, true,
+                           in_pack ? &plan : nullptr));
         }
         return BDR_OK;
     }
@@ -693,6 +731,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     BDR_TRY(a->err_init());
     { const char* e = getenv("BDR_NO_STEP_GRAPH"); a->use_graph = !(e && e[0] == '1'); }
     { const char* e = getenv("BDR_NO_SMALL_GEMM"); a->small_gemm = !(e && e[0] == '1'); }
+    a->gather_in_pack = getenv("BDR_NO_STEP_GATHER") == nullptr;
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};
     for (auto p : pis) BDR_TRY(a->zalloc(p, a->pi.total));
     for (int i = 0; i < a->NC; ++i) {

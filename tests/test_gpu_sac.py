@@ -160,12 +160,14 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
     """opt() replays its ~70 launches from a hipGraph whose varying arguments (Adam bias corrections, noise counter, replay
     stream position) are patched per step (csrc/step_graph.hpp).  Same seeds, same pushes: every parameter, the target nets,
     log_alpha and the recorded losses equal the eager path bit for bit - across pushes between opts (the ring grows), a mid-run
-    update_on_batch with a LARGER batch (buffers re-allocated: the graph is re-captured) and n_updates_per_opt = 2."""
+    update_on_batch with a LARGER batch (buffers re-allocated: the graph is re-captured) and n_updates_per_opt = 2.  The same for
+    the sample drawn inside the pack kernel (replay_sample_plan) against the separate gather launch, incl. the buffer's stream
+    position afterwards."""
     from oracle import torch_ref as T
     od, ad = 17, 6
-    def run(eager):
-        if eager: monkeypatch.setenv("BDR_NO_STEP_GRAPH", "1")
-        else: monkeypatch.delenv("BDR_NO_STEP_GRAPH", raising=False)
+    def run(env):
+        for k in ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER", "BDR_NO_SMALL_GEMM"): monkeypatch.delenv(k, raising=False)
+        for k in env: monkeypatch.setenv(k, "1")
         rng = np.random.default_rng(11)
         rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=3000, seed=7), (od,), np.float32, (ad,), np.float32)
         def push(n):
@@ -182,15 +184,18 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
             if k % 2 == 1: push(100)
             if k == 6: a.update_on_batch(*T.sac_batch(256, od, ad, 99))
         out = {n: a.get_params(n) for n in ("pi", "qnet_0", "qnet_1", "qnet_tgt_0", "qnet_tgt_1", "log_alpha")}
+        out["next_indices"] = rb.sample_indices(50)
         n_opts = a.n_opts
         a.close(); rb.close()
         return out, recs, n_opts
-    g, grec, gn = run(False)
-    e, erec, en = run(True)
-    assert gn == en == 25
-    for k in g: assert (g[k] == e[k]).all(), k
-    assert grec == erec
-    assert np.isfinite(g["pi"]).all()
+    g, grec, gn = run(())
+    assert gn == 25 and np.isfinite(g["pi"]).all()
+    # eager launches; the separate gather launch instead of the sample drawn inside the pack kernel; both
+    for env in (("BDR_NO_STEP_GRAPH",), ("BDR_NO_STEP_GATHER",), ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER")):
+        e, erec, en = run(env)
+        assert en == gn, env
+        for k in g: assert (g[k] == e[k]).all(), (env, k)
+        assert grec == erec, env
 
 
 def test_device_noise_stream_moments_reproducibility_and_disjointness(B):

@@ -555,6 +555,7 @@ struct ReduceAdamArgs {
     DenseReduceSeg seg[RA_SEGS]; int nseg; size_t inst_part_stride;   // instance z reads seg.part + z * inst_part_stride
     float* p[RA_INST]; float* g[RA_INST]; float* m[RA_INST]; float* v[RA_INST]; float* tgt[RA_INST];
     AdamScalars s[RA_INST]; unsigned n4; float tau, omt; int track;
+    int grads_only;   // 1: sum the partials into the gradient arena and stop (synchronous-DP mode: the all-reduce comes before Adam)
 };
 __global__ __launch_bounds__(256) void k_dense_reduce_adam(ReduceAdamArgs a)
 {
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(256) void k_dense_reduce_adam(ReduceAdamArgs a)
         gg = ((s4[0] + s4[1]) + s4[2]) + s4[3];
     }
     reinterpret_cast<f32x4*>(a.g[z])[i] = gg;
+    if (a.grads_only) return;
     f32x4 pp = reinterpret_cast<f32x4*>(a.p[z])[i], mm = reinterpret_cast<f32x4*>(a.m[z])[i], vv = reinterpret_cast<f32x4*>(a.v[z])[i];
     const AdamScalars s = a.s[z];
 #pragma unroll

@@ -71,6 +71,16 @@ __global__ __launch_bounds__(256) void k_mean_rows(const float* __restrict__ x, 
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// [B][in_dim] f32 rows of up to MAXZ network instances into their zero-padded [B][Kp0] input matrices, one launch
+struct MlpPackArgs { const float* rows[MAXZ]; float* x[MAXZ]; int nz, B, in_dim, Kp0; };
+__global__ void k_mlp_pack_z(MlpPackArgs p)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, per = p.B * p.in_dim;
+    if (t >= p.nz * per) return;
+    const int z = t / per, e = t % per, b = e / p.in_dim, c = e % p.in_dim;
+    p.x[z][(size_t)b * p.Kp0 + c] = p.rows[z][e];
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -91,6 +101,8 @@ struct DqnMlp : bdr_agent {
     bool defer_adam = false;   // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
     bool lds_step = true; size_t lds_attr = 0;   // BDR_NO_MLP_LDS=1: phases exchange their matrices through global memory
     bool gather_in_step = true;   // the fused step kernel also draws and copies the batch (BDR_NO_STEP_GATHER=1: separate gather launch)
+    bool small_gemm = true;    // layer-by-layer path on the latency-shaped kernels of dense.hpp (BDR_NO_SMALL_GEMM=1: 64x64 tiles, one launch per tensor)
+    float* dw_part = nullptr; std::vector<size_t> dw_off; std::vector<int> dw_chunks_l;   // row-chunk partials of the grouped dW launch
     bool fused = true;         // one-workgroup step for nets that fit a CU (mlp_fused.hpp; BDR_NO_MLP_FUSED=1: generic path)
     bool track_with_next = false, track_done = false;   // opt(): the soft update rides on the fused kernel of the last update
 
@@ -111,8 +123,8 @@ struct DqnMlp : bdr_agent {
         }
         for (auto p : dys) (void)hipFree(p);
         dys.clear();
-        (void)hipFree(pred); (void)hipFree(tgt); (void)hipFree(loss_row);
-        pred = tgt = loss_row = nullptr;
+        (void)hipFree(pred); (void)hipFree(tgt); (void)hipFree(loss_row); (void)hipFree(dw_part);
+        pred = tgt = loss_row = dw_part = nullptr;
     }
     int32_t ensure_batch(int Bn)
     {
@@ -134,6 +146,16 @@ struct DqnMlp : bdr_agent {
             dys.push_back(p);
         }
         BDR_TRY(alloc_f(&pred, Bn)); BDR_TRY(alloc_f(&tgt, Bn)); BDR_TRY(alloc_f(&loss_row, Bn));
+        {   // grouped dW (dense.hpp k_dense_dw_small_group): 256 batch rows per workgroup
+            dw_off.clear(); dw_chunks_l.clear();
+            size_t o = 0;
+            for (const auto& l : net.L) {
+                const int c = std::max(1, std::min(16, Bn / 256));
+                dw_off.push_back(o); dw_chunks_l.push_back(c);
+                o += (size_t)c * ((size_t)l.Kp * l.Np + l.Np);
+            }
+            BDR_TRY(alloc_f(&dw_part, o));
+        }
         B = Bn;
         return BDR_OK;
     }
@@ -156,6 +178,11 @@ struct DqnMlp : bdr_agent {
     {
         if (!fused || net.L.size() > MF_MAXL || Bn > 128 || net.out_dim > 64) return false;
         for (const auto& l : net.L) if (l.Kp > 256 || l.Np > 256) return false;
+        // One workgroup wins while every phase is a single pass of its eight waves over the phase's 32x32 blocks; beyond that the
+        // layer-by-layer path, which spreads a layer over the chip, is faster (tools/probes/mlp_sizes.py: Mlp[256,256] at B = 64 -
+        // the reference's own CartPole example - 4.1 k opt-steps/s in one workgroup, 11.7 k layer by layer).
+        const int nz = cfg.double_dqn ? 3 : 2, RB = (Bn + 31) / 32;
+        for (const auto& l : net.L) if (nz * RB * (l.Np / 32) > 8 || RB * (l.Kp / 32) * (l.Np / 32) > 8) return false;
         return true;
     }
     // the whole update in one launch (mlp_fused.hpp)
@@ -217,11 +244,30 @@ struct DqnMlp : bdr_agent {
             if (per_buffer && weight) BDR_TRY(replay_update_priority_on_stream(per_buffer, Bn, td_abs, stream));
             return BDR_OK;
         }
-        track_with_next = false;
         const int L = (int)net.L.size();
-        BDR_TRY(forward(0, q, obs, Bn));
-        BDR_TRY(forward(1, q_tgt, next_obs, Bn));
-        if (cfg.double_dqn) BDR_TRY(forward(2, q, next_obs, Bn));
+        const bool lat = small_gemm && L <= RA_SEGS;   // latency-shaped kernels: ~11 launches instead of ~21
+        if (lat) {
+            const int nz = cfg.double_dqn ? 3 : 2;
+            const float* par[MAXZ] = {q, q_tgt, q};
+            MlpPackArgs pk{};
+            pk.rows[0] = reinterpret_cast<const float*>(obs); pk.rows[1] = pk.rows[2] = reinterpret_cast<const float*>(next_obs);
+            for (int z = 0; z < nz; ++z) pk.x[z] = x_in[z];
+            pk.nz = nz; pk.B = Bn; pk.in_dim = net.in_dim; pk.Kp0 = net.L[0].Kp;
+            { Bracket br(a, "mlp_pack"); LAUNCH(k_mlp_pack_z, dim3((nz * Bn * net.in_dim + 255) / 256), pk); }
+            DenseSrc in[MAXZ]; float* out[MAXZ];
+            for (int z = 0; z < nz; ++z) in[z] = DenseSrc{x_in[z], net.L[0].Kp};
+            for (int i = 0; i < L; ++i) {
+                for (int z = 0; z < nz; ++z) out[z] = acts[z][i];
+                Bracket br(a, "mlp_fwd");
+                BDR_TRY(dense_forward_z(stream, net.L[i], nz, par, in, out, Bn, true));
+                for (int z = 0; z < nz; ++z) in[z] = DenseSrc{out[z], net.L[i].Np};
+            }
+        } else {
+            track_with_next = false;
+            BDR_TRY(forward(0, q, obs, Bn));
+            BDR_TRY(forward(1, q_tgt, next_obs, Bn));
+            if (cfg.double_dqn) BDR_TRY(forward(2, q, next_obs, Bn));
+        }
         TdDenseArgs t{};
         t.q_on = acts[0][L - 1]; t.q_tg = acts[1][L - 1]; t.q_on_next = cfg.double_dqn ? acts[2][L - 1] : nullptr;
         t.ld = net.L[L - 1].Np; t.act = act; t.act_bytes = act_bytes; t.reward = reward; t.term = term;
@@ -236,6 +282,34 @@ struct DqnMlp : bdr_agent {
             Bracket br(a, "loss_mean");
             hipLaunchKernelGGL(k_mean_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, loss, 1.0f / (float)Bn);
             BDR_HIP(hipGetLastError());
+        }
+        if (lat) {
+            // input gradients down the net, then every weight gradient in one grouped launch; its row-chunk partials are summed
+            // into the gradient arena by the kernel that also applies Adam (and the soft update that follows this update)
+            for (int i = L - 1; i > 0; --i) { Bracket br(a, "mlp_dx"); BDR_TRY(dense_dx(stream, net.L[i], q, dys[i], dys[i - 1], acts[0][i - 1], Bn, false, true)); }
+            DenseDwJob jobs[RA_SEGS];
+            for (int i = 0; i < L; ++i)
+                jobs[i] = DenseDwJob{&net.L[i], i == 0 ? DenseSrc{x_in[0], net.L[0].Kp} : DenseSrc{acts[0][i - 1], net.L[i - 1].Np}, dys[i], dw_part + dw_off[i],
+                                     std::min(dw_chunks_l[i], std::max(1, Bn / 256))};
+            { Bracket br(a, "mlp_dw"); BDR_TRY(dense_dw_small_group(stream, jobs, L, Bn)); }
+            ReduceAdamArgs ra{};
+            ra.nseg = L;
+            for (int i = 0; i < L; ++i) {
+                const size_t nfl = (size_t)net.L[i].Kp * net.L[i].Np + net.L[i].Np;
+                ra.seg[i] = DenseReduceSeg{dw_part + dw_off[i], nfl, jobs[i].chunks, (unsigned)(net.L[i].w / 4), (unsigned)(nfl / 4)};
+            }
+            ra.p[0] = q; ra.g[0] = grad; ra.m[0] = m; ra.v[0] = v; ra.tgt[0] = q_tgt; ra.n4 = (unsigned)(net.total / 4);
+            ra.grads_only = defer_adam ? 1 : 0;
+            if (!defer_adam) {
+                adam_step += 1;
+                ra.s[0] = adam_scalars_for(cfg.opt_kind == BDR_OPT_ADAMW, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, adam_step);
+                ra.track = track_with_next ? 1 : 0; ra.tau = (float)cfg.tau; ra.omt = (float)(1.0 - cfg.tau);
+                if (ra.track) track_done = true;
+            }
+            track_with_next = false;
+            Bracket br(a, "adam");
+            BDR_HIP(step_launch(stream, true, k_dense_reduce_adam, dim3((ra.n4 + 255) / 256, 1), dim3(256), ra));
+            return BDR_OK;
         }
         for (int i = L - 1; i >= 0; --i) {
             DenseSrc x = i == 0 ? DenseSrc{x_in[0], net.L[0].Kp} : DenseSrc{acts[0][i - 1], net.L[i - 1].Np};
@@ -407,6 +481,7 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_TRY(a->err_init());
     a->fused = getenv("BDR_NO_MLP_FUSED") == nullptr;
     a->gather_in_step = getenv("BDR_NO_STEP_GATHER") == nullptr;
+    { const char* e = getenv("BDR_NO_SMALL_GEMM"); a->small_gemm = !(e && e[0] == '1'); }
     a->lds_step = getenv("BDR_NO_MLP_LDS") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {

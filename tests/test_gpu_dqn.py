@@ -309,6 +309,46 @@ def test_mlp_step_kernel_draws_its_own_batch(B, monkeypatch):
         assert f[3] == s[3] and f[4] == s[4] == 12, env
 
 
+@pytest.mark.parametrize("units,Bsz,double", [((256, 256), 64, False), ((128, 96, 64), 200, True), ((64, 64), 128, False)])
+def test_mlp_layer_by_layer_path_vs_oracle(B, units, Bsz, double, monkeypatch):
+    """Q-networks too large for the one-workgroup step (the reference's own CartPole example is Mlp[256,256] at batch 64,
+    examples/gym/dqn_cartpole_tch/src/main.rs:31-46) take the layer-by-layer path on the latency-shaped kernels: z-batched
+    32x32-tile forwards, grouped weight gradients, fused reduce + Adam + track.  Agent::opt over the ring against the oracle's
+    replay + update, and the same run on the 64x64-tile kernels (BDR_NO_SMALL_GEMM) agrees to rounding."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    def run(env):
+        for k in ("BDR_NO_SMALL_GEMM",): monkeypatch.delenv(k, raising=False)
+        for k in env: monkeypatch.setenv(k, "1")
+        rng = np.random.default_rng(5)
+        cap = 4000
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (4,), np.float32)
+        oref = O.Replay(cap, 42, 16, 8)
+        n = 1500
+        tr = (rng.standard_normal((n, 4)).astype(np.float32), rng.integers(0, 2, (n, 1)).astype(np.int64),
+              rng.standard_normal((n, 4)).astype(np.float32), np.ones(n, np.float32), (rng.random(n) < .1).astype(np.int8), np.zeros(n, np.int8))
+        rb.push(*tr); oref.push(*tr)
+        p0 = T.init_params(T.mlp_shapes(4, list(units), 2), 11)
+        a = make_mlp_agent(B, units=units, batch_size=Bsz, lr=1e-3, critic_loss="Mse", tau=0.01, soft_update_interval=1, double_dqn=double)
+        a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+        ref = O.DqnOracle(O.mlp_cfg(4, list(units), 2), p0, lr=1e-3, critic_loss="Mse", tau=0.01, soft_update_interval=1, double_dqn=double)
+        for step in range(3):
+            rec = a.opt_with_record(rb)
+            b = oref.batch(Bsz)
+            r = ref.update(b["obs"].view(np.float32).reshape(Bsz, 4), b["act"].view(np.int64).ravel(),
+                           b["next_obs"].view(np.float32).reshape(Bsz, 4), b["reward"], b["is_terminated"], probe=True)
+            assert rel(a.probe("q_pred_all", Bsz * 2), r["q_pred_all"].ravel()) < 3e-4, step
+            assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-7
+            assert_grads_close(a.get_params("grad"), r["grads"], T.mlp_shapes(4, list(units), 2), tol=5e-4)
+        out = (a.get_params("qnet"), a.get_params("qnet_tgt"))
+        assert np.abs(out[0] - ref.q).max() < 0.3 * 1e-3 and rel(out[1], ref.q_tgt) < 1e-3
+        a.close(); rb.close()
+        return out
+    lat = run(())
+    big = run(("BDR_NO_SMALL_GEMM",))
+    assert np.abs(lat[0] - big[0]).max() < 0.3 * 1e-3 and rel(lat[1], big[1]) < 1e-3
+
+
 def test_mlp_adamw_matches_aten(B):
     """OptimizerConfig::AdamW (opt.rs:20-27,38-55): decoupled weight decay, custom betas / eps, 5 steps vs ATen."""
     from oracle import torch_ref as T

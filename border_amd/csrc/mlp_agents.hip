@@ -101,6 +101,7 @@ struct DqnMlp : bdr_agent {
     bool defer_adam = false;   // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
     bool lds_step = true; size_t lds_attr = 0;   // BDR_NO_MLP_LDS=1: phases exchange their matrices through global memory
     bool gather_in_step = true;   // the fused step kernel also draws and copies the batch (BDR_NO_STEP_GATHER=1: separate gather launch)
+    StepGraph graph; StepGraphPolicy graph_policy; uint64_t batch_gen = 0;   // the layer-by-layer step replayed from a hipGraph (step_graph.hpp)
     bool small_gemm = true;    // layer-by-layer path on the latency-shaped kernels of dense.hpp (BDR_NO_SMALL_GEMM=1: 64x64 tiles, one launch per tensor)
     float* dw_part = nullptr; std::vector<size_t> dw_off; std::vector<int> dw_chunks_l;   // row-chunk partials of the grouped dW launch
     bool fused = true;         // one-workgroup step for nets that fit a CU (mlp_fused.hpp; BDR_NO_MLP_FUSED=1: generic path)
@@ -156,7 +157,7 @@ struct DqnMlp : bdr_agent {
             }
             BDR_TRY(alloc_f(&dw_part, o));
         }
-        B = Bn;
+        B = Bn; batch_gen += 1;
         return BDR_OK;
     }
 
@@ -253,7 +254,7 @@ struct DqnMlp : bdr_agent {
             pk.rows[0] = reinterpret_cast<const float*>(obs); pk.rows[1] = pk.rows[2] = reinterpret_cast<const float*>(next_obs);
             for (int z = 0; z < nz; ++z) pk.x[z] = x_in[z];
             pk.nz = nz; pk.B = Bn; pk.in_dim = net.in_dim; pk.Kp0 = net.L[0].Kp;
-            { Bracket br(a, "mlp_pack"); LAUNCH(k_mlp_pack_z, dim3((nz * Bn * net.in_dim + 255) / 256), pk); }
+            { Bracket br(a, "mlp_pack"); BDR_HIP(step_launch(stream, false, k_mlp_pack_z, dim3((nz * Bn * net.in_dim + 255) / 256), dim3(256), pk)); }
             DenseSrc in[MAXZ]; float* out[MAXZ];
             for (int z = 0; z < nz; ++z) in[z] = DenseSrc{x_in[z], net.L[0].Kp};
             for (int i = 0; i < L; ++i) {
@@ -276,12 +277,11 @@ struct DqnMlp : bdr_agent {
         t.weight = weight; t.td_abs = td_abs;
         t.has_clip = cfg.has_clip_td_err; t.clip_min = (float)cfg.clip_td_err_min; t.clip_max = (float)cfg.clip_td_err_max;
         t.err = dev_err;
-        { Bracket br(a, "td_dense"); LAUNCH(k_td_dense, dim3((Bn + 3) / 4), t); }
+        { Bracket br(a, "td_dense"); BDR_HIP(step_launch(stream, false, k_td_dense, dim3((Bn + 3) / 4), dim3(256), t)); }
         if (per_buffer && weight) { Bracket br(a, "per_update"); BDR_TRY(replay_update_priority_on_stream(per_buffer, Bn, td_abs, stream)); }
         {
             Bracket br(a, "loss_mean");
-            hipLaunchKernelGGL(k_mean_rows, dim3(1), dim3(256), 0, stream, loss_row, Bn, loss, 1.0f / (float)Bn);
-            BDR_HIP(hipGetLastError());
+            BDR_HIP(step_launch(stream, false, k_mean_rows, dim3(1), dim3(256), loss_row, Bn, loss, 1.0f / (float)Bn));
         }
         if (lat) {
             // input gradients down the net, then every weight gradient in one grouped launch; its row-chunk partials are summed
@@ -355,6 +355,25 @@ struct DqnMlp : bdr_agent {
                     (unsigned long long)r->obs_bytes, net.in_dim);
         BDR_REQUIRE(r->act_bytes >= 8, "discrete actions are stored as i64");
         BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
+        const int bs = (int)cfg.batch_size;
+        // The layer-by-layer step (nets beyond the one-workgroup kernel) is ~11 launches of a few us: replayed from a captured graph
+        // when the host is what the device waits for (step_graph.hpp).  Not with prioritized replay (tree kernels with host state),
+        // the synchronous-DP exchange, profiling, or a soft update that does not ride on the step's last kernel.
+        const bool graphable = !fused_ok(bs) && small_gemm && net.L.size() <= (size_t)RA_SEGS && !r->per && !grad_comm && !prof;
+        if (graphable) {
+            const int w = graph_policy.want(stream);
+            if (w < 0) return fail(BDR_ERR_HIP, "hipStreamQuery failed");
+            if (w == 1) {
+                BDR_TRY(ensure_batch(bs));
+                BDR_TRY(td_buffer(bs));
+                BDR_TRY(replay_prepare_sample(r, bs, stream));
+                return step_graph_run(&graph, stream, r->uid, r->batch_gen, batch_gen ^ ((uint64_t)(uintptr_t)td_abs << 8), [&]() { return opt_enqueue(r); });
+            }
+        }
+        return opt_enqueue(r);
+    }
+    int32_t opt_enqueue(bdr_replay* r)
+    {
         for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
             // a uniform sample over the plain ring is drawn by the step kernel itself when the step is one kernel anyway
             GatherArgs plan{};
@@ -482,6 +501,7 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->fused = getenv("BDR_NO_MLP_FUSED") == nullptr;
     a->gather_in_step = getenv("BDR_NO_STEP_GATHER") == nullptr;
     { const char* e = getenv("BDR_NO_SMALL_GEMM"); a->small_gemm = !(e && e[0] == '1'); }
+    a->graph_policy.from_env();
     a->lds_step = getenv("BDR_NO_MLP_LDS") == nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {

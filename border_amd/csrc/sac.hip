@@ -272,12 +272,7 @@ struct Sac : bdr_agent {
     // host staging for update_on_batch
     float *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr, *u_rew = nullptr; int8_t* u_term = nullptr; uint64_t u_cap = 0;
     uint64_t noise_counter = 0;
-    // graph_mode: 0 eager launches (BDR_NO_STEP_GRAPH=1 / BDR_STEP_GRAPH=0), 1 always from the graph (BDR_STEP_GRAPH=1), 2 adaptive
-    // (default): from the graph while the stream is found idle when opt() is entered, i.e. while the HOST is what the device waits
-    // for (a trainer loop that steps environments and pushes between opts: 27 us of host time per opt instead of 150), eager while
-    // the host runs ahead of the device (a graph replay costs ~5 us of device time that eager launches do not).  Both are the same
-    // enqueue code and the same bits, so switching between them is free.
-    StepGraph graph; int graph_mode = 2; float starve = 0.f;
+    StepGraph graph; StepGraphPolicy graph_policy;   // step_graph.hpp
     bool gather_in_pack = true;               // BDR_NO_STEP_GATHER=1: separate gather launch
     bool small_gemm = true;                   // BDR_NO_SMALL_GEMM=1: the 64x64-tile kernels of the large-batch agents
 
@@ -578,12 +573,11 @@ struct Sac : bdr_agent {
         BDR_TRY(ensure_batch(Bn));
         // ~70 kernels of 2-8 us: replayed from a captured graph (step_graph.hpp).  Profiling brackets and prioritized replay
         // (tree kernels with their own host state) take the eager path - the same sequence, launched one by one.
-        if (graph_mode == 0 || prof || r->per) return opt_enqueue(r, Bn);
-        if (graph_mode == 2) {
-            const hipError_t q = hipStreamQuery(stream);              // hipSuccess: nothing pending - the device is waiting for us
-            if (q != hipSuccess && q != hipErrorNotReady) return fail(BDR_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
-            starve = 0.9f * starve + (q == hipSuccess ? 0.1f : 0.f);   // ~10-call memory
-            if (starve < 0.3f) return opt_enqueue(r, Bn);
+        if (prof || r->per) return opt_enqueue(r, Bn);
+        {
+            const int w = graph_policy.want(stream);
+            if (w < 0) return fail(BDR_ERR_HIP, "hipStreamQuery failed");
+            if (w == 0) return opt_enqueue(r, Bn);
         }
         BDR_TRY(replay_prepare_sample(r, Bn, stream));
         return step_graph_run(&graph, stream, r->uid, r->batch_gen, batch_gen, [&]() { return opt_enqueue(r, Bn); });
@@ -740,8 +734,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     a->qn = make_mlp(a->O + a->A, cfg->q_units, cfg->n_q_units, 1, false);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     BDR_TRY(a->err_init());
-    { const char* e = getenv("BDR_NO_STEP_GRAPH"); if (e && e[0] == '1') a->graph_mode = 0; }
-    { const char* e = getenv("BDR_STEP_GRAPH"); if (e && (e[0] == '0' || e[0] == '1')) a->graph_mode = e[0] - '0'; }
+    a->graph_policy.from_env();
     { const char* e = getenv("BDR_NO_SMALL_GEMM"); a->small_gemm = !(e && e[0] == '1'); }
     a->gather_in_pack = getenv("BDR_NO_STEP_GATHER") == nullptr;
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};

@@ -48,6 +48,59 @@ struct StepGraph {
     ~StepGraph() { reset(); }
 };
 
+// When to replay from the graph.  mode 0: never (BDR_NO_STEP_GRAPH=1 / BDR_STEP_GRAPH=0), 1: always (BDR_STEP_GRAPH=1), 2 (default):
+// whichever is faster HERE, by measurement.  A graph replay costs the host a few us per opt instead of ~5 us per launch, but ~5 us
+// of device time that eager launches do not; which one wins depends on what else the host does between opts (a bare opt loop:
+// eager; a trainer loop that steps environments and pushes: the graph).  Both modes are the same enqueue code and the same bits, so
+// the policy times them: 64 opts each (device time between two events on the agent's stream, read back only when ready - no
+// synchronisation), then 4 096 opts in the faster one, then again.
+struct StepGraphPolicy {
+    int mode = 2;
+    // adaptive state
+    int cur = 0;                       // 0 eager, 1 graph
+    int phase = 0;                     // 0 settle, 1 window running, 2 waiting for the end event, 3 exploiting
+    int count = 0, measured = 0;       // measured: bit m set once mode m has a time
+    float t_ms[2] = {0.f, 0.f};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int SETTLE = 8, WINDOW = 64, EXPLOIT = 4096;
+
+    void from_env()
+    {
+        { const char* e = getenv("BDR_NO_STEP_GRAPH"); if (e && e[0] == '1') mode = 0; }
+        { const char* e = getenv("BDR_STEP_GRAPH"); if (e && (e[0] == '0' || e[0] == '1')) mode = e[0] - '0'; }
+    }
+    ~StepGraphPolicy() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
+    // called on entry of every graphable opt(); -> 1 replay from the graph, 0 launch eagerly, <0 error
+    int want(hipStream_t st)
+    {
+        if (mode != 2) return mode;
+        if (!ev0) { if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return -1; }
+        switch (phase) {
+        case 0:   // let the mode settle (first graph use captures and instantiates)
+            if (++count >= SETTLE) { if (hipEventRecord(ev0, st) != hipSuccess) return -1; phase = 1; count = 0; }
+            break;
+        case 1:
+            if (++count >= WINDOW) { if (hipEventRecord(ev1, st) != hipSuccess) return -1; phase = 2; count = 0; }
+            break;
+        case 2: {
+            const hipError_t q = hipEventQuery(ev1);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return -1;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1;
+            t_ms[cur] = ms; measured |= 1 << cur;
+            if (measured != 3) { cur ^= 1; phase = 0; count = 0; }                       // now time the other mode
+            else { cur = t_ms[1] < t_ms[0] ? 1 : 0; phase = 3; count = 0; }
+            break;
+        }
+        default:
+            if (++count >= EXPLOIT) { measured = 0; phase = 0; count = 0; }             // conditions change (the host's other work): measure again
+            break;
+        }
+        return cur;
+    }
+};
+
 // the pass a thread is currently running (nullptr: eager)
 inline StepGraph*& step_graph_current()
 {

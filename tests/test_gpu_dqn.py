@@ -314,12 +314,13 @@ def test_mlp_layer_by_layer_path_vs_oracle(B, units, Bsz, double, monkeypatch):
     """Q-networks too large for the one-workgroup step (the reference's own CartPole example is Mlp[256,256] at batch 64,
     examples/gym/dqn_cartpole_tch/src/main.rs:31-46) take the layer-by-layer path on the latency-shaped kernels: z-batched
     32x32-tile forwards, grouped weight gradients, fused reduce + Adam + track.  Agent::opt over the ring against the oracle's
-    replay + update, and the same run on the 64x64-tile kernels (BDR_NO_SMALL_GEMM) agrees to rounding."""
+    replay + update, and the same run on the 64x64-tile kernels (BDR_NO_SMALL_GEMM) agrees to rounding; replayed from a hipGraph
+    (step_graph.hpp) it is bit-identical to eager launches."""
     from oracle import oracle as O
     from oracle import torch_ref as T
     def run(env):
-        for k in ("BDR_NO_SMALL_GEMM",): monkeypatch.delenv(k, raising=False)
-        for k in env: monkeypatch.setenv(k, "1")
+        for k in ("BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH"): monkeypatch.delenv(k, raising=False)
+        for k, v in env.items(): monkeypatch.setenv(k, v)
         rng = np.random.default_rng(5)
         cap = 4000
         rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (4,), np.float32)
@@ -344,9 +345,13 @@ def test_mlp_layer_by_layer_path_vs_oracle(B, units, Bsz, double, monkeypatch):
         assert np.abs(out[0] - ref.q).max() < 0.3 * 1e-3 and rel(out[1], ref.q_tgt) < 1e-3
         a.close(); rb.close()
         return out
-    lat = run(())
-    big = run(("BDR_NO_SMALL_GEMM",))
+    lat = run({"BDR_STEP_GRAPH": "0"})
+    big = run({"BDR_NO_SMALL_GEMM": "1"})
     assert np.abs(lat[0] - big[0]).max() < 0.3 * 1e-3 and rel(lat[1], big[1]) < 1e-3
+    # the same launches replayed from a captured graph (every opt / by the default policy): bit-identical
+    for env in ({"BDR_STEP_GRAPH": "1"}, {}):
+        g = run(env)
+        assert (g[0] == lat[0]).all() and (g[1] == lat[1]).all(), env
 
 
 def test_mlp_adamw_matches_aten(B):

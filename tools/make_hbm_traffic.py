@@ -10,7 +10,7 @@ import re
 import sys
 
 KEY = {"bdr::k_conv1_bf16": "fwd_conv1", "k_adam": "adam_l1_l2", "k_gather": "sample", "k_igemm<DxC2P>": "bwd_conv2_dx",
-       "k_igemm<DxC3P>": "bwd_conv3_dx", "k_igemm<DxL1>": "bwd_l1_dx", "k_igemm<FwdL1>": "fwd_l1", "k_igemm<FwdL1Z2>": "fwd_l1", "k_igemm<FwdPC2>": "fwd_conv2",
+       "k_igemm<DxC3P": "bwd_conv3_dx", "k_igemm<DxL1>": "bwd_l1_dx", "k_igemm<FwdL1>": "fwd_l1", "k_igemm<FwdL1Z2>": "fwd_l1", "k_igemm<FwdPC2>": "fwd_conv2",
        "k_igemm<FwdPC3>": "fwd_conv3", "bdr::k_conv1_dw_bf16": "bwd_conv1_dw", "k_igemm_red<DwPC1>": "bwd_conv1_dw", "k_igemm_red<DwPC2>": "bwd_conv2_dw",
        "k_igemm_red<DwPC3>": "bwd_conv3_dw", "k_igemm_red<DwPL1>": "bwd_l1_dw", "k_reduce_partials3": "bwd_conv_reduce", "k_reduce_adam": "reduce_adam",
        "k_head<": "head_fwd_td", "k_head_fwd": "head_fwd", "k_head_bwd": "head_bwd", "k_td_rows": "td_rows"}
@@ -33,5 +33,5 @@ res = {k: int(round((2 * fetch[k] + write.get(k, 0.0)) * 1024)) for k in fetch}
 res["_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc (separate passes, B=256, "
                 "2 network instances per forward launch, BDR_NO_OVERLAP=1). gfx950 correction per MI355X_MICROARCH.md "
                 "(FETCH_SIZE counts half of wide coalesced reads), calibrated on k_gather (algorithmic 14.45 MB read / "
-                "14.45 MB written) and the full-arena Adam pass (27.0 MB / 20.2 MB). Source tables: profiles/rocprof_r01_pmc_v4.md")
+                "14.45 MB written) and the full-arena Adam pass (27.0 MB / 20.2 MB). Source tables: profiles/rocprof_r02_pmc.md")
 print(json.dumps(res, indent=1))

@@ -106,7 +106,10 @@ template <int S, int AMAX>
 __global__ __launch_bounds__(64 * HEAD_ROWS * MAXZ) void k_head(HeadArgs a, TdArgs t, int nz, int td)
 {
     __shared__ float sq[HEAD_ROWS][MAXZ][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (scalar wave index: the instance z selects kernel-argument pointers - a.p1[z], a.h1[z], a.qv[z] ... - which must be scalar loads;
+    //  with a per-lane z the compiler fetched them with vector loads, one memory round trip in front of the data loads and one
+    //  `vmcnt(0)` in front of each store block)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = wave / nz, z = wave % nz;
     const int row = blockIdx.x * HEAD_ROWS + r;
     const bool valid = row < a.B;

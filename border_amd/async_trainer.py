@@ -209,7 +209,7 @@ class AsyncTrainer:
         return c
 
     def train(self, agent, buffer, actor_agents, envs, obs_shape, obs_dtype, act_row_bytes=8, on_event=None, exchange=None,
-              learner_ops=None, actor_ops=None, mailbox=None):
+              learner_ops=None, actor_ops=None, mailbox=None, act_dtype=np.int64):
         """Runs until the learner has done max_opts opt steps.  `exchange(opt_steps)`: optional cross-rank hook called at every
         sync point (e.g. lambda s: param_exchange.average(agent)).  learner_ops / actor_ops: pre-built function tables (mock
         objects in the CPU tests); default = the library's handles with a device mailbox."""
@@ -236,7 +236,7 @@ class AsyncTrainer:
         if actor_ops is None:
             actor_ops = (ActorOps * n_act)()
             for i in range(n_act):
-                vt = env_vtable(envs[i], obs_shape, obs_dtype, act_row_bytes, keep=keep)
+                vt = env_vtable(envs[i], obs_shape, obs_dtype, act_row_bytes, act_dtype, keep=keep)
                 L.bdr_actor_ops_default(C.byref(actor_ops[i]), actor_agents[i].handle, mailbox.handle, C.byref(vt))
         else:
             arr = (ActorOps * n_act)()

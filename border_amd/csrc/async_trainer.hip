@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include "agent_base.hpp"
 #include "common.hpp"
 
 using namespace bdr;
@@ -373,7 +374,14 @@ int32_t bdr_async_train(const bdr_async_trainer_config* c, const bdr_learner_ops
 namespace {
 struct DefaultCtx { int32_t which; };
 int32_t d_set_train(void* a, int32_t on) { return bdr_agent_set_train((bdr_agent*)a, on); }
-int32_t d_sample(void* a, uint64_t n, const void* obs, void* act) { return bdr_agent_sample((bdr_agent*)a, n, obs, (int64_t*)act, nullptr); }
+// Policy::sample of the handle's kind: discrete agents return i64 actions (dqn/base.rs:211-242, iqn/base.rs:204-228), SAC f32 rows
+// (sac/base.rs:215-225)
+int32_t d_sample(void* a, uint64_t n, const void* obs, void* act)
+{
+    bdr_agent* ag = (bdr_agent*)a;
+    if (ag && !strcmp(ag->kind(), "sac")) return bdr_sac_sample(ag, n, (const float*)obs, (float*)act);
+    return bdr_agent_sample(ag, n, obs, (int64_t*)act, nullptr);
+}
 int32_t d_opt(void* a, void* b) { return bdr_agent_opt((bdr_agent*)a, (bdr_replay*)b); }
 int32_t d_opt_rec(void* a, void* b, float* out, int32_t cap, int32_t* n) { return bdr_agent_opt_with_scalars((bdr_agent*)a, (bdr_replay*)b, out, cap, n); }
 int32_t d_push(void* b, uint64_t n, const void* obs, const void* act, const void* next_obs, const float* rew, const int8_t* term, const int8_t* trunc)

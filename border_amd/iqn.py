@@ -71,6 +71,12 @@ def _p(a):
 class Iqn:
     WHICH = {"qnet": 0, "iqn": 0, "iqn_tgt": 1, "exp_avg": 2, "exp_avg_sq": 3, "grad": 4}
 
+    def arena_device_ptr(self, which="iqn"):
+        """(device pointer, float count) of a flat parameter arena in the kernels' internal layout."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _lib.check(_lib.lib().bdr_agent_arena_device_ptr(self._h, self.WHICH[which], C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
     def __init__(self, config: IqnConfig):
         self.config = config
         h = C.c_void_p()

@@ -105,7 +105,13 @@ class Sac:
             i = base[name]
         return i + {"param": 0, "grad": 100, "exp_avg": 200, "exp_avg_sq": 300}[role]
 
-    WHICH = {"qnet": 0}   # ParamExchange default: SyncModel ships `pi` (sac/base.rs:377-386) == model 0
+    WHICH = {"qnet": 0, "pi": 0}   # ParamExchange / ModelMailbox: SyncModel ships `pi` (sac/base.rs:377-386) == model 0
+
+    def arena_device_ptr(self, which="pi"):
+        """(device pointer, float count) of a flat parameter arena in the kernels' internal layout."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _lib.check(_lib.lib().bdr_agent_arena_device_ptr(self._h, self.WHICH[which], C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
 
     def train(self):
         _lib.check(_lib.lib().bdr_agent_set_train(self._h, 1))

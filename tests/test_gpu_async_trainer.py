@@ -144,3 +144,44 @@ def test_async_run_equals_its_sequential_replay_on_the_oracle(B, sync_interval, 
     for h in actors + [learner]:
         h.close()
     rb.close()
+
+
+def test_async_sac_learner_and_actors(B):
+    """a16 x a14: the compiled async loops with SAC handles - continuous f32 actions through the generic act rows
+    (bdr_actor_ops_default dispatches Policy::sample by agent kind), SyncModel ships only `pi` (sac/base.rs:377-386) through the
+    device mailbox.  Counters and interleaving rules as for DQN; the actors' pushed actions are valid tanh outputs, every actor
+    adopts the learner's actor network, critics stay the actors' own, and the learner's losses are finite."""
+    od, ad, n_act, max_opts, warm = 5, 2, 2, 30, 96
+    def sac(seed):
+        return B.Sac.build(B.SacConfig(obs_dim=od, act_dim=ad, pi_units=(64, 64), q_units=(64, 64), n_critics=2, batch_size=32,
+                                       ent_coef_mode=("Auto", -2.0, 3e-4), device=0, seed=seed))
+    learner = sac(1)
+    actors = [sac(10 + i) for i in range(n_act)]
+    q_before = [a.get_params("qnet_0").copy() for a in actors]
+    envs = [B.SyntheticEnv((od,), np.float32, seed=i, p_term=0.1) for i in range(n_act)]
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=500, seed=42), (od,), np.float32, (ad,), np.float32)
+    events = []
+    tr = B.AsyncTrainer(B.AsyncTrainerConfig(max_opts=max_opts, warmup_period=warm, sync_interval=5, record_agent_info_interval=10,
+                                             record_compute_cost_interval=0, warmup_sleep_ms=5), B.ActorManagerConfig(n_buffer=16))
+    st = tr.train(learner, rb, actors, envs, (od,), np.float32, act_row_bytes=ad * 4, act_dtype=np.float32, on_event=lambda *e: events.append(e))
+    assert st.opt_steps == max_opts and learner.n_opts == max_opts
+    assert st.samples_total >= warm and st.samples_total % 16 == 0 and len(rb) == min(st.samples_total, 500)
+    recs = [e for e in events if e[3] == "opt_record"]
+    assert len(recs) == max_opts // 10
+    for e in recs:
+        assert all(np.isfinite(v) for v in e[4]), e
+    # what the actors pushed: tanh-squashed actions; the ring rows came through the f32 act path
+    b = rb.batch(64)
+    assert b.act.dtype == np.float32 and b.act.shape == (64, ad) and (np.abs(b.act) <= 1.0).all() and np.abs(b.act).max() > 0
+    # SyncModel: pi only.  Every actor ends on a published actor network (the last publish is the learner's final pi unless
+    # the actor stopped before adopting it: it then holds an earlier version - compare with the sync events), critics untouched
+    pi_final = learner.get_params("pi")
+    synced = {e[0]: e[2] for e in events if e[3] == "actor_sync"}
+    for i, a in enumerate(actors):
+        assert (a.get_params("qnet_0") == q_before[i]).all()
+        if synced.get(i) == max_opts:
+            assert (a.get_params("pi") == pi_final).all()
+    assert any(v > 0 for v in synced.values())
+    for a in actors:
+        a.close()
+    learner.close(); rb.close()

@@ -178,3 +178,35 @@ def test_overlapped_parameter_exchange_is_the_identity_at_one_rank(B, monkeypatc
         if reads:
             assert (got[4] == base[4]).all()
     B._lib.check(L.bdr_comm_destroy(h))
+
+
+def test_parameter_exchange_entry_points_cover_every_agent_kind(B):
+    """bdr_agent_allreduce_params / bdr_agent_broadcast_params on the models bench.py exchanges for each configuration (DQN Mlp
+    `qnet`, IQN `iqn`, SAC `pi` - SyncModel ships only the actor, sac/base.rs:377-386): over a 1-rank communicator both are the
+    identity, bit for bit, and the agent keeps training afterwards."""
+    L = B._lib.lib()
+    uid = (C.c_uint8 * B._lib.BDR_UNIQUE_ID_BYTES)()
+    B._lib.check(L.bdr_comm_get_unique_id(uid))
+    h = C.c_void_p()
+    B._lib.check(L.bdr_comm_init_rank(uid, 1, 0, 0, C.byref(h)))
+    rng = np.random.default_rng(0)
+    agents = [
+        (mlp(B, 32, param_seed=3), "qnet", lambda a: a.update_on_batch(rng.standard_normal((32, 4)).astype(np.float32), rng.integers(0, 2, 32),
+                                                                        rng.standard_normal((32, 4)).astype(np.float32), np.ones(32, np.float32), np.zeros(32, np.int8))),
+        (B.Iqn.build(B.IqnConfig(f_config=B.MlpConfig(in_dim=4, units=(32,), out_dim=16), feature_dim=16, embed_dim=8, m_units=(32,), n_actions=3,
+                                 lr=1e-3, batch_size=8, device=0, seed=1)), "iqn", None),
+        (B.Sac.build(B.SacConfig(obs_dim=5, act_dim=2, pi_units=(64, 64), q_units=(64, 64), n_critics=2, batch_size=16, device=0, seed=2)), "pi", None),
+    ]
+    for a, which, step in agents:
+        if a is None:
+            continue
+        before = a.get_params(which).copy()
+        B._lib.check(L.bdr_agent_allreduce_params(a.handle, h, a.WHICH[which]))
+        B._lib.check(L.bdr_agent_broadcast_params(a.handle, h, a.WHICH[which], 0))
+        a.sync()
+        assert (a.get_params(which) == before).all(), which
+        if step is not None:
+            step(a)
+            assert not (a.get_params(which) == before).all()
+        a.close()
+    B._lib.check(L.bdr_comm_destroy(h))

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <vector>
 
+#include "agent_base.hpp"
 #include "common.hpp"
 
 using namespace bdr;
@@ -81,7 +82,13 @@ int32_t check(const bdr_trainer_config* c, const bdr_trainer_ops* ops)
 
 // defaults: the library's own handles
 int32_t d_set_train(void* a, int32_t on) { return bdr_agent_set_train((bdr_agent*)a, on); }
-int32_t d_sample(void* a, uint64_t n, const void* obs, void* act) { return bdr_agent_sample((bdr_agent*)a, n, obs, (int64_t*)act, nullptr); }
+// Policy::sample of the handle's kind: i64 actions for DQN / IQN, f32 action rows for SAC (sac/base.rs:215-225)
+int32_t d_sample(void* a, uint64_t n, const void* obs, void* act)
+{
+    bdr_agent* ag = (bdr_agent*)a;
+    if (ag && !strcmp(ag->kind(), "sac")) return bdr_sac_sample(ag, n, (const float*)obs, (float*)act);
+    return bdr_agent_sample(ag, n, obs, (int64_t*)act, nullptr);
+}
 int32_t d_opt(void* a, void* b) { return bdr_agent_opt((bdr_agent*)a, (bdr_replay*)b); }
 int32_t d_opt_rec(void* a, void* b, float* out, int32_t cap, int32_t* n) { return bdr_agent_opt_with_scalars((bdr_agent*)a, (bdr_replay*)b, out, cap, n); }
 int32_t d_push(void* b, uint64_t n, const void* obs, const void* act, const void* next_obs, const float* rew, const int8_t* term, const int8_t* trunc)

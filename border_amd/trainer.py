@@ -218,8 +218,9 @@ class NativeTrainer:
         _lib.check(_lib.lib().bdr_trainer_train_offline(C.byref(c), C.byref(ops), obs, None, C.byref(st)))
         return self._finish(st)
 
-    def train(self, env, agent, buffer, obs_shape, obs_dtype, act_row_bytes=8, on_event=None, ops=None):
-        """`env` has reset(None) -> obs[1, ...] and step_with_reset(act) -> Step (as SyntheticEnv)."""
+    def train(self, env, agent, buffer, obs_shape, obs_dtype, act_row_bytes=8, on_event=None, ops=None, act_dtype=np.int64):
+        """`env` has reset(None) -> obs[1, ...] and step_with_reset(act) -> Step (as SyntheticEnv).  Continuous-action agents
+        (SAC): act_row_bytes = 4 * act_dim, act_dtype = np.float32."""
         obs_dtype = np.dtype(obs_dtype)
         row = int(np.prod(obs_shape)) * obs_dtype.itemsize
 
@@ -231,7 +232,7 @@ class NativeTrainer:
             return 0
 
         def step(_ctx, act, obs_out, reward, term, trunc, init_out):
-            a = np.frombuffer((C.c_char * act_row_bytes).from_address(act), np.int64).copy()
+            a = np.frombuffer((C.c_char * act_row_bytes).from_address(act), act_dtype).copy()
             st = env.step_with_reset(a)
             write(obs_out, st.obs)
             reward[0], term[0], trunc[0] = float(st.reward[0]), int(st.is_terminated[0]), int(st.is_truncated[0])

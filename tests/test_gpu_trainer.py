@@ -116,6 +116,26 @@ def test_native_driver_equals_the_python_loop(B, kind):
         x.close()
 
 
+def test_native_driver_with_a_continuous_action_agent(B):
+    """bdr_trainer_train with SAC handles: the default function table samples f32 action rows (bdr_sac_sample) and pushes them
+    through the same generic act rows; the loop rules (warm-up, opt_interval, record interval, counters) are the DQN ones."""
+    od, ad = 5, 2
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=200, seed=9), (od,), np.float32, (ad,), np.float32)
+    a = B.Sac.build(B.SacConfig(obs_dim=od, act_dim=ad, pi_units=(64, 64), q_units=(64, 64), n_critics=2, batch_size=16,
+                                ent_coef_mode=("Auto", -2.0, 3e-4), device=0, seed=3))
+    env = B.SyntheticEnv((od,), np.float32, seed=11, p_term=0.1)
+    ev = []
+    st = B.NativeTrainer(B.TrainerConfig(max_opts=20, opt_interval=2, warmup_period=24, record_agent_info_interval=5)).train(
+        env, a, rb, (od,), np.float32, act_row_bytes=ad * 4, act_dtype=np.float32, on_event=lambda e, o, k, sc: ev.append((e, o, k, sc)))
+    a.sync()
+    assert st["opt_steps"] == a.n_opts == 20 and st["env_steps"] == rb.len() and 24 + 2 * 19 <= st["env_steps"] <= 24 + 2 * 20
+    recs = [sc for _, _, k, sc in ev if k == "opt_record"]
+    assert len(recs) == 4 and all(np.isfinite(v) for sc in recs for v in sc)
+    b = rb.batch(32)
+    assert b.act.dtype == np.float32 and (np.abs(b.act) <= 1.0).all() and np.abs(b.act).max() > 0
+    a.close(); rb.close()
+
+
 def test_compiled_example_program_trains(B):
     """examples/train_dqn_synthetic.cpp: a complete training program in compiled code on nothing but include/border_amd.h
     (environment callbacks, bdr_trainer_train, Nature-CNN DQN, HBM ring) - the integration a Rust shim would perform."""

@@ -420,6 +420,20 @@ def main():
     if rank == 0:
         ms = 1000.0 * dt / args.steps
         value = world * args.steps / dt
+        # A short timed window (the driver's 5 + 20 steps) sits inside the chip's clock ramp after idle (DESIGN.md section 6:
+        # a chip-filling MFMA kernel runs 12 % slower right after >= 10 ms of idle and recovers over ~10 ms of load).  `value` is
+        # the contract's window as it is; `steady_state` reports the same loop over a longer window right after it, so that one
+        # line carries both numbers.
+        steady = None
+        if world == 1 and args.steps < 500:
+            n_ss = max(200, int(0.5 / max(dt / args.steps, 1e-6)))   # about half a second
+            agent.sync()
+            t1 = time.perf_counter()
+            run(n_ss, args.warmup + args.steps)
+            agent.sync()
+            dt_ss = time.perf_counter() - t1
+            steady = {"value": round(n_ss / dt_ss, 2), "unit": "opt-steps/s", "steps": n_ss, "ms_per_step": round(1000.0 * dt_ss / n_ss, 5),
+                      "note": "same loop, longer window, right after the timed one"}
         # the timed steps trained a real network: one more step with its Record, which must be finite
         rec = agent.opt_with_record(rb)
         final_loss = float(rec[conf["loss_key"]])
@@ -446,6 +460,8 @@ def main():
                   "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                   "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks if world > 1 else 1,
                   "config": cfgd, "roofline": roof}
+        if steady is not None:
+            result["steady_state"] = steady
     agent.close()
     rb.close()
 

@@ -144,7 +144,7 @@ ABI_SYMBOLS = [
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
     "bdr_iqn_config_default", "bdr_iqn_create", "bdr_iqn_update_on_batch", "bdr_iqn_forward", "bdr_iqn_qvalues",
     "bdr_sac_config_default", "bdr_sac_create", "bdr_sac_update_on_batch", "bdr_sac_sample",
-    "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_agent_allreduce_params",
+    "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_comm_agree", "bdr_agent_allreduce_params",
     "bdr_agent_broadcast_params", "bdr_agent_set_grad_comm", "bdr_dqn_grads_on_batch", "bdr_agent_apply_grads",
     "bdr_atari_prep_create", "bdr_atari_prep_destroy", "bdr_atari_prep_reset", "bdr_atari_prep_step", "bdr_atari_prep_obs",
     "bdr_atari_prep_device_stacks", "bdr_atari_clip_reward",
@@ -239,6 +239,7 @@ def lib() -> C.CDLL:
     L.bdr_comm_get_unique_id.argtypes = [vp]
     L.bdr_comm_init_rank.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.bdr_comm_destroy.argtypes = [vp]
+    L.bdr_comm_agree.argtypes = [vp, i32, C.POINTER(i32)]
     L.bdr_agent_allreduce_params.argtypes = [vp, vp, i32]
     L.bdr_agent_broadcast_params.argtypes = [vp, vp, i32, i32]
     L.bdr_agent_set_grad_comm.argtypes = [vp, vp]

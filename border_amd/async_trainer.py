@@ -78,13 +78,14 @@ class AsyncTrainerConfigC(C.Structure):
 LEN_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64))
 PUBLISH_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
+AGREE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32))
 SYNC_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_int32))
 ASYNC_OBSERVER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_float), C.c_int32)
 
 
 class LearnerOps(C.Structure):
     _fields_ = [("t", _lib.TrainerOps), ("buffer_len", LEN_FN), ("publish_model", PUBLISH_FN), ("mailbox", C.c_void_p),
-                ("exchange", EXCHANGE_FN), ("exchange_ctx", C.c_void_p)]
+                ("exchange", EXCHANGE_FN), ("exchange_ctx", C.c_void_p), ("agree", AGREE_FN)]
 
 
 class ActorOps(C.Structure):
@@ -209,9 +210,11 @@ class AsyncTrainer:
         return c
 
     def train(self, agent, buffer, actor_agents, envs, obs_shape, obs_dtype, act_row_bytes=8, on_event=None, exchange=None,
-              learner_ops=None, actor_ops=None, mailbox=None, act_dtype=np.int64):
+              learner_ops=None, actor_ops=None, mailbox=None, act_dtype=np.int64, agree=None):
         """Runs until the learner has done max_opts opt steps.  `exchange(opt_steps)`: optional cross-rank hook called at every
-        sync point (e.g. lambda s: param_exchange.average(agent)).  learner_ops / actor_ops: pre-built function tables (mock
+        sync point (e.g. lambda s: param_exchange.average(agent)).  `agree(local_ok) -> bool`: optional agreement across ranks
+        before every exchange (ParamExchange.agree): a rank whose learner or actor fails says so once and every rank stops at
+        the same sync point instead of blocking in a collective its peer never joins.  learner_ops / actor_ops: pre-built function tables (mock
         objects in the CPU tests); default = the library's handles with a device mailbox."""
         L = _bind()
         keep = []
@@ -233,7 +236,20 @@ class AsyncTrainer:
             fn = EXCHANGE_FN(exch)
             keep.append(fn)
             learner_ops.exchange = fn
+        if agree is not None:
+            def agr(_ctx, local_ok, all_ok):
+                try:
+                    all_ok[0] = 1 if agree(bool(local_ok)) else 0
+                    return 0
+                except Exception:  # noqa: BLE001
+                    return 93
+            fn = AGREE_FN(agr)
+            keep.append(fn)
+            learner_ops.agree = fn
         if actor_ops is None:
+            if mailbox is None:
+                raise ValueError("AsyncTrainer.train: the default actor function tables need the learner's ModelMailbox "
+                                 "(pass mailbox=... together with learner_ops=...)")
             actor_ops = (ActorOps * n_act)()
             for i in range(n_act):
                 vt = env_vtable(envs[i], obs_shape, obs_dtype, act_row_bytes, act_dtype, keep=keep)
@@ -244,19 +260,36 @@ class AsyncTrainer:
                 arr[i] = actor_ops[i]
             actor_ops = arr
 
-        def obs_cb(_ctx, actor, a, b, event, scalars, n):
-            if on_event is not None:
+        # No observer, no callback: the compiled loop must not enter Python (and take the GIL, under its observer mutex, beside
+        # the actors' environment callbacks) on every iteration, message and sync when nobody listens.
+        cb = ASYNC_OBSERVER_FN()   # NULL function pointer
+        if on_event is not None:
+            def obs_cb(_ctx, actor, a, b, event, scalars, n):
                 vals = [scalars[i] for i in range(n)] if event in (2, 3) else n
                 on_event(None if actor == LEARNER else actor, a, b, EVENTS[event], vals)
-        cb = ASYNC_OBSERVER_FN(obs_cb)
+            cb = ASYNC_OBSERVER_FN(obs_cb)
         c, st, ast = self._config(row, act_row_bytes), AsyncStatsC(), (ActorStatC * n_act)()
         rc = L.bdr_async_train(C.byref(c), C.byref(learner_ops), actor_ops, n_act, cb, None, C.byref(st), ast)
-        if own_mailbox is not None:
-            agent.sync()
-            for a in actor_agents:
-                a.sync()
-            own_mailbox.close()
-        _lib.check(rc)
+        # the loop's own status is reported FIRST (a device error found by the clean-up below must not mask it), and the
+        # mailbox is closed whatever happens
+        run_err = None
+        try:
+            _lib.check(rc)
+        except Exception as e:  # noqa: BLE001
+            run_err = e
+        try:
+            if own_mailbox is not None:
+                agent.sync()
+                for a in actor_agents:
+                    a.sync()
+        except Exception:  # noqa: BLE001
+            if run_err is None:
+                raise
+        finally:
+            if own_mailbox is not None:
+                own_mailbox.close()
+            if run_err is not None:
+                raise run_err
         self.stat = AsyncTrainStat(st.samples_per_sec, st.duration_s, st.opt_per_sec, st.samples_total, st.opt_steps, st.n_syncs,
                                    st.n_messages, st.n_records)
         self.actor_stats = [ActorStat(ast[i].env_steps, ast[i].duration_s, ast[i].n_syncs) for i in range(n_act)]

@@ -241,7 +241,9 @@ int32_t bdr_agent::err_check()
     unsigned w[ERR_WORDS];
     BDR_HIP(hipMemcpy(w, dev_err, sizeof w, hipMemcpyDeviceToHost));
     BDR_TRY(err_report(w));
-    if (last_replay && last_replay->per) BDR_TRY(per_check(last_replay->per));
+    if (bdr_replay* lr = replay_lookup(last_replay_uid)) {
+        if (lr->per) BDR_TRY(per_check(lr->per));
+    } else last_replay_uid = 0;
     return BDR_OK;
 }
 
@@ -332,7 +334,7 @@ int32_t bdr_agent_opt(bdr_agent* a, bdr_replay* r)
     BDR_REQUIRE(a && r, "null argument");
     BDR_HIP(hipSetDevice(a->device));
     BDR_TRY(a->err_poll());   // asynchronous: a device-side failure of an earlier step surfaces here without a synchronisation
-    a->last_replay = r;
+    a->last_replay_uid = r->uid;
     BDR_TRY(a->opt(r));
     prof_collect(a);
     return BDR_OK;
@@ -343,7 +345,7 @@ int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* r, bdr_dqn_record* r
     BDR_REQUIRE(a && r && rec, "null argument");
     BDR_REQUIRE(is_dqn(a), "bdr_agent_opt_with_record(bdr_dqn_record) needs a DQN agent; use bdr_agent_opt_with_scalars");
     BDR_HIP(hipSetDevice(a->device));
-    a->last_replay = r;
+    a->last_replay_uid = r->uid;
     BDR_TRY(a->opt(r));
     prof_collect(a);
     float v[128]; int n = 0;
@@ -361,7 +363,7 @@ int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* r, float* out, int3
 {
     BDR_REQUIRE(a && r && out && n_out, "null argument");
     BDR_HIP(hipSetDevice(a->device));
-    a->last_replay = r;
+    a->last_replay_uid = r->uid;
     BDR_TRY(a->opt(r));
     prof_collect(a);
     int n = 0;

@@ -85,7 +85,8 @@ struct bdr_agent {
     unsigned* host_err = nullptr;       // [ERR_WORDS] pinned mirror (last asynchronous read-back)
     uint64_t err_poll_count = 0;
     bool rec_opt = false;               // record() is being called by Agent::opt_with_record (dqn/base.rs:316-342)
-    bdr_replay* last_replay = nullptr;  // buffer of the last opt (its PER error flag is checked with the agent's)
+    uint64_t last_replay_uid = 0;       // uid of the buffer of the last opt (its PER error flag is checked with the agent's); a uid, not a
+                                        // pointer: the buffer may be destroyed before the agent's next synchronising call (replay_lookup)
 
     virtual ~bdr_agent()
     {

@@ -279,8 +279,17 @@ int32_t bdr_async_train(const bdr_async_trainer_config* c, const bdr_learner_ops
     std::vector<std::thread> threads;
     for (uint32_t i = 0; i < n_actors; ++i) threads.emplace_back(actor_run, &sh, &actors[i], i, actor_stats ? &actor_stats[i] : nullptr);
     auto stop_and_join = [&]() { sh.stop.store(true); for (auto& t : threads) if (t.joinable()) t.join(); };
+    // Multi-rank runs: a rank that fails between two sync points tells its peers so at what would have been its next sync point
+    // (L->agree, one MIN all-reduce of an ok flag per sync point), unless the failure is the communication itself.
+    bool comm_failed = false, told_peers = false;
+    auto tell_peers = [&]() {
+        if (!L->agree || comm_failed || told_peers) return;
+        told_peers = true;
+        int32_t all = 0;
+        (void)L->agree(L->exchange_ctx, 0, &all);
+    };
 #define LEARNER_TRY(expr)                                                                  \
-    do { int32_t s__ = (expr); if (s__ != BDR_OK) { stop_and_join(); return s__; } } while (0)
+    do { int32_t s__ = (expr); if (s__ != BDR_OK) { std::string m__ = bdr_last_error(); tell_peers(); stop_and_join(); return fail(s__, "%s", m__.c_str()); } } while (0)
 
     uint64_t opt_steps = 0, samples_total = 0, samples_counter = 0, opt_steps_counter = 0, n_records = 0, n_syncs = 0, n_messages = 0;
     double timer_for_samples = 0, timer_for_opt_steps = 0;
@@ -288,7 +297,16 @@ int32_t bdr_async_train(const bdr_async_trainer_config* c, const bdr_learner_ops
     LEARNER_TRY(L->t.agent_set_train(L->t.agent, 1));                      // agent.train() (:317)
     const auto time_total = Clock::now();
     auto sync = [&]() -> int32_t {                                         // AsyncTrainer::sync (:268-272)
-        if (L->exchange) BDR_TRY(L->exchange(L->exchange_ctx, L->t.agent, opt_steps));   // cross-GPU averaging first (RCCL)
+        if (L->agree) {                                                     // every rank enters the collective, or none does
+            int32_t all = 1;
+            const int32_t s = L->agree(L->exchange_ctx, 1, &all);
+            if (s != BDR_OK) { comm_failed = true; return s; }
+            if (!all) { told_peers = true; return fail(BDR_ERR_COMM, "another rank's learner failed: stopping at the sync point of opt step %llu", (unsigned long long)opt_steps); }
+        }
+        if (L->exchange) {                                                  // cross-GPU averaging first (RCCL)
+            const int32_t s = L->exchange(L->exchange_ctx, L->t.agent, opt_steps);
+            if (s != BDR_OK) { comm_failed = true; return s; }
+        }
         BDR_TRY(L->publish_model(L->t.agent, L->mailbox, opt_steps));
         n_syncs += 1;
         sh.model_ready.store(true);
@@ -357,6 +375,7 @@ int32_t bdr_async_train(const bdr_async_trainer_config* c, const bdr_learner_ops
     }
     const double duration = std::chrono::duration<double>(Clock::now() - time_total).count();
     stop_and_join();
+    if (sh.err != BDR_OK) tell_peers();   // an actor failed (the loop above ended on its stop flag)
 #undef LEARNER_TRY
     if (out) {
         out->samples_total = samples_total; out->opt_steps = opt_steps; out->n_records = n_records; out->n_syncs = n_syncs; out->n_messages = n_messages;

@@ -25,7 +25,7 @@ namespace {
 typedef struct { char internal[128]; } rcclUniqueId;
 typedef void* rcclComm_t;
 // ncclDataType_t: ncclFloat32 = 7; ncclRedOp_t: ncclSum = 0
-constexpr int kNcclFloat = 7, kNcclSum = 0;
+constexpr int kNcclFloat = 7, kNcclInt32 = 2, kNcclSum = 0, kNcclMin = 3;
 
 struct Rccl {
     void* h = nullptr;
@@ -60,7 +60,10 @@ int32_t load_rccl()
     } while (0)
 }  // namespace
 
-struct bdr_comm { rcclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; };
+struct bdr_comm {
+    rcclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0;
+    int32_t* d_flag = nullptr; hipStream_t flag_stream = nullptr;   // bdr_comm_agree
+};
 
 extern "C" {
 
@@ -93,8 +96,31 @@ int32_t bdr_comm_init_rank(const uint8_t id[BDR_UNIQUE_ID_BYTES], int32_t nranks
 int32_t bdr_comm_destroy(bdr_comm* c)
 {
     if (!c) return BDR_OK;
+    if (c->flag_stream) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->flag_stream); (void)hipStreamDestroy(c->flag_stream); }
+    if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
+    return BDR_OK;
+}
+
+// Agreement before a collective (bdr_learner_ops::agree, ParamExchange.rccl_or_raise's counterpart on the data plane): MIN
+// all-reduce of one int32 on the communicator's own small stream, read back synchronously.  Every rank calls it the same number
+// of times; a rank that failed passes 0 and every rank learns it.
+int32_t bdr_comm_agree(bdr_comm* c, int32_t local_ok, int32_t* all_ok)
+{
+    BDR_REQUIRE(c && all_ok, "null argument");
+    BDR_HIP(hipSetDevice(c->device));
+    if (!c->d_flag) {
+        BDR_HIP(hipMalloc((void**)&c->d_flag, sizeof(int32_t)));
+        BDR_HIP(hipStreamCreateWithFlags(&c->flag_stream, hipStreamNonBlocking));
+    }
+    const int32_t v = local_ok ? 1 : 0;
+    BDR_HIP(hipMemcpyAsync(c->d_flag, &v, sizeof v, hipMemcpyHostToDevice, c->flag_stream));
+    BDR_NCCL(g_rccl.AllReduce(c->d_flag, c->d_flag, 1, kNcclInt32, kNcclMin, c->comm, c->flag_stream));
+    int32_t r = 0;
+    BDR_HIP(hipMemcpyAsync(&r, c->d_flag, sizeof r, hipMemcpyDeviceToHost, c->flag_stream));
+    BDR_HIP(hipStreamSynchronize(c->flag_stream));
+    *all_ok = r;
     return BDR_OK;
 }
 

@@ -136,6 +136,13 @@ int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n);
 void stream_register(hipStream_t s);
 void stream_retire(hipStream_t s);
 bool stream_alive(hipStream_t s);
+bdr_replay* replay_lookup(uint64_t uid);   // live handle with this uid, or nullptr once it was destroyed
+// the host state a sample advances (uniform ring): snapshot / restore around a step-graph pass that may have to be re-enqueued
+struct ReplaySnap {
+    uint64_t word_pos, batch_n; bool read_pending; hipStream_t read_stream;
+    explicit ReplaySnap(const bdr_replay* r) : word_pos(r->word_pos), batch_n(r->batch_n), read_pending(r->read_pending), read_stream(r->read_stream) {}
+    void restore(bdr_replay* r) const { r->word_pos = word_pos; r->batch_n = batch_n; r->read_pending = read_pending; r->read_stream = read_stream; }
+};
 int32_t replay_flip_batch(bdr_replay* r, uint64_t n);   // makes the other buffer set current (allocated on first use)
 
 // per.hip

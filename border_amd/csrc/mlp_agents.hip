@@ -367,7 +367,11 @@ struct DqnMlp : bdr_agent {
                 BDR_TRY(ensure_batch(bs));
                 BDR_TRY(td_buffer(bs));
                 BDR_TRY(replay_prepare_sample(r, bs, stream));
-                return step_graph_run(&graph, stream, r->uid, r->batch_gen, batch_gen ^ ((uint64_t)(uintptr_t)td_abs << 8), [&]() { return opt_enqueue(r); });
+                const ReplaySnap rs(r);   // host state the pass advances, put back if the step has to be enqueued a second time
+                const uint64_t s_adam = adam_step, s_soft = soft_update_counter, s_opts = n_opts;
+                const bool s_twn = track_with_next, s_td = track_done;
+                return step_graph_run(&graph, stream, r->uid, r->batch_gen, batch_gen ^ ((uint64_t)(uintptr_t)td_abs << 8), [&]() { return opt_enqueue(r); },
+                                      [&]() { rs.restore(r); adam_step = s_adam; soft_update_counter = s_soft; n_opts = s_opts; track_with_next = s_twn; track_done = s_td; });
             }
         }
         return opt_enqueue(r);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include <unordered_set>
 
 #include "common.hpp"
@@ -258,6 +259,19 @@ static std::unordered_set<hipStream_t> g_streams;
 void stream_register(hipStream_t s) { std::lock_guard<std::mutex> l(g_streams_mu); g_streams.insert(s); }
 void stream_retire(hipStream_t s) { std::lock_guard<std::mutex> l(g_streams_mu); g_streams.erase(s); }
 bool stream_alive(hipStream_t s) { std::lock_guard<std::mutex> l(g_streams_mu); return g_streams.count(s) != 0; }
+// Live replay handles by uid: an agent remembers the BUFFER OF ITS LAST OPT by uid, never by pointer (the buffer may be
+// destroyed before the agent's next synchronising call: train -> rb.close() -> agent.sample() for evaluation).
+static std::mutex g_replays_mu;
+static std::unordered_map<uint64_t, bdr_replay*> g_replays;
+static void replay_register(bdr_replay* r) { std::lock_guard<std::mutex> l(g_replays_mu); g_replays[r->uid] = r; }
+static void replay_retire(bdr_replay* r) { std::lock_guard<std::mutex> l(g_replays_mu); g_replays.erase(r->uid); }
+bdr_replay* replay_lookup(uint64_t uid)
+{
+    if (!uid) return nullptr;
+    std::lock_guard<std::mutex> l(g_replays_mu);
+    auto it = g_replays.find(uid);
+    return it == g_replays.end() ? nullptr : it->second;
+}
 }  // namespace bdr
 
 // `written` was just recorded on some stream: consumers have to wait for it again
@@ -485,6 +499,7 @@ int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out)
     BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
     r->stage_records = std::max<uint64_t>(1, std::min<uint64_t>(256, (8ull << 20) / r->stride));
     BDR_HIP(hipHostMalloc((void**)&r->stage, r->stage_records * r->stride, hipHostMallocDefault));
+    replay_register(r);
     *out = r;
     return BDR_OK;
 }
@@ -492,6 +507,7 @@ int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out)
 int32_t bdr_replay_destroy(bdr_replay* r)
 {
     if (!r) return BDR_OK;
+    replay_retire(r);   // agents that last sampled from this buffer find no handle for its uid from here on
     (void)hipSetDevice(r->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(r->ring);

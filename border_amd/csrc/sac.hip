@@ -580,7 +580,12 @@ struct Sac : bdr_agent {
             if (w == 0) return opt_enqueue(r, Bn);
         }
         BDR_TRY(replay_prepare_sample(r, Bn, stream));
-        return step_graph_run(&graph, stream, r->uid, r->batch_gen, batch_gen, [&]() { return opt_enqueue(r, Bn); });
+        // host state the pass advances, put back if the step has to be enqueued a second time (step_graph_run)
+        const ReplaySnap rs(r);
+        const uint64_t s_pi = step_pi, s_al = step_al, s_noise = noise_counter, s_opts = n_opts;
+        uint64_t s_q[4]; memcpy(s_q, step_q, sizeof s_q);
+        return step_graph_run(&graph, stream, r->uid, r->batch_gen, batch_gen, [&]() { return opt_enqueue(r, Bn); },
+                              [&]() { rs.restore(r); step_pi = s_pi; step_al = s_al; noise_counter = s_noise; n_opts = s_opts; memcpy(step_q, s_q, sizeof s_q); });
     }
     void record_keys(std::vector<std::string>& keys) override { keys = {"loss_critic", "loss_actor", "ent_coef"}; }
     int32_t noise(float* dev, size_t n) override { return gen_noise(dev, n); }   // the N(0,1) stream of action_logp

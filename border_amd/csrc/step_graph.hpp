@@ -36,6 +36,7 @@ struct StepGraph {
     size_t cursor = 0;
     bool broken = false;                 // a graph API failed once: this agent stays eager (results are identical)
     int32_t status = BDR_OK;             // first error inside a REPLAY / CAPTURE pass
+    long break_at = -2, replays = 0;     // test hook BDR_STEP_GRAPH_BREAK_AT=n: REPLAY pass number n is treated as diverged (-2: env not read yet)
     // what the captured sequence depended on
     uint64_t key_a = 0, key_b = 0, key_n = 0;
 
@@ -175,26 +176,38 @@ inline int32_t step_graph_collect(StepGraph* g)
 // key yet, else a REPLAY pass + one hipGraphLaunch.  The key must change whenever a buffer the sequence touches is re-allocated:
 // generation counters, not pointers (an allocator hands the same address out again).  `enqueue` must route every launch through
 // step_launch and do all allocation / cross-stream waiting BEFORE it is called.
-template <class F>
-inline int32_t step_graph_run(StepGraph* g, hipStream_t st, uint64_t key_a, uint64_t key_b, uint64_t key_n, F&& enqueue)
+//
+// A step is never dropped: `enqueue` advances host state (Adam step counters, RNG stream positions, the replay stream position)
+// while it builds its launches, so when a REPLAY pass finds that the sequence no longer matches the captured one - or the capture /
+// instantiation fails after the pass has run - `restore` puts that host state back to what it was on entry (the caller snapshots
+// it before the call) and the step is enqueued again with plain launches.  The graph is marked broken from then on (same code,
+// same bits, eager launches).
+template <class F, class R>
+inline int32_t step_graph_run(StepGraph* g, hipStream_t st, uint64_t key_a, uint64_t key_b, uint64_t key_n, F&& enqueue, R&& restore)
 {
     if (g->broken) return enqueue();
     if (g->exec && (g->key_a != key_a || g->key_b != key_b || g->key_n != key_n)) g->reset();
     StepGraph*& cur = step_graph_current();
+    auto eager_again = [&](const char* why) -> int32_t {
+        if (getenv("BDR_STEP_GRAPH_DEBUG")) fprintf(stderr, "[border_amd] step graph: %s; this step and all later ones run eagerly\n", why);
+        g->reset(); g->broken = true;
+        restore();
+        return enqueue();
+    };
     if (g->exec) {
+        if (g->break_at == -2) { const char* e = getenv("BDR_STEP_GRAPH_BREAK_AT"); g->break_at = e ? atol(e) : -1; }
+        const bool forced = g->break_at >= 0 && g->replays++ == g->break_at;
         g->mode = StepGraph::REPLAY; g->cursor = 0; g->status = BDR_OK;
         cur = g;
         const int32_t s = enqueue();
         cur = nullptr; g->mode = StepGraph::EAGER;
         BDR_TRY(s);
-        if (g->status == BDR_OK && g->cursor == g->nodes.size()) {
+        if (g->status == BDR_OK && g->cursor == g->nodes.size() && !forced) {
             BDR_HIP(hipGraphLaunch(g->exec, st));
             return BDR_OK;
         }
-        // The sequence no longer matches the captured one.  Its host bookkeeping has already run once, so this step cannot be
-        // re-enqueued: report it (callers keep their shapes fixed between steps; tests cover the supported changes).
-        g->reset();
-        return fail(BDR_ERR_INVALID, "the step's launch sequence changed under a captured graph");
+        // The sequence no longer matches the captured one; nothing of this step has been launched yet.
+        return eager_again("the launch sequence changed under a captured graph");
     }
     // capture
     g->reset();
@@ -206,10 +219,10 @@ inline int32_t step_graph_run(StepGraph* g, hipStream_t st, uint64_t key_a, uint
     const int32_t s = enqueue();
     cur = nullptr; g->mode = StepGraph::EAGER;
     e = hipStreamEndCapture(st, &g->graph);
-    if (s != BDR_OK) { g->reset(); return s; }
-    if (e != hipSuccess || !g->graph) { (void)hipGetLastError(); g->reset(); g->broken = true; return fail(BDR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
+    if (s != BDR_OK) { g->reset(); restore(); return s; }   // the step itself is in error: nothing was launched, nothing advanced
+    if (e != hipSuccess || !g->graph) { (void)hipGetLastError(); return eager_again("hipStreamEndCapture failed"); }
     e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { g->reset(); g->broken = true; return fail(BDR_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipGetLastError(); g->exec = nullptr; return eager_again("hipGraphInstantiate failed"); }
     const int32_t c = step_graph_collect(g);
     if (getenv("BDR_STEP_GRAPH_DEBUG")) fprintf(stderr, "[border_amd] step graph: %zu kernel nodes captured, collect=%d\n", g->nodes.size(), (int)c);
     if (c != BDR_OK) { g->broken = true; }   // the graph is still valid for THIS step (nothing varies yet); later steps run eagerly

@@ -346,6 +346,21 @@ class ParamExchange:
                 t /= self.world_size
                 agent.set_params(t.numpy(), w)
 
+    def agree(self, local_ok: bool = True) -> bool:
+        """MIN over ranks of local_ok: every rank calls it before a collective (bdr_learner_ops::agree); a rank that failed
+        passes False once and every rank learns it instead of blocking in the next all-reduce."""
+        if self.world_size == 1:
+            return bool(local_ok)
+        if self.backend == "rccl":
+            out = C.c_int32(0)
+            _lib.check(_lib.lib().bdr_comm_agree(self._comm, 1 if local_ok else 0, C.byref(out)))
+            return bool(out.value)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([1 if local_ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
     def broadcast(self, agent, root: int = 0) -> None:
         """The faithful learner->actors sync (SyncModel::sync_model on every actor)."""
         if self.world_size == 1:

@@ -443,6 +443,11 @@ typedef struct bdr_learner_ops {
     void* mailbox;
     int32_t (*exchange)(void* ctx, void* agent, uint64_t opt_steps);                     /* optional: cross-GPU averaging at a sync point */
     void* exchange_ctx;
+    /* optional, with `exchange`: agreement across ranks BEFORE every collective.  Called with local_ok = 1 at every sync point
+     * (a rank that gets *all_ok = 0 stops there with BDR_ERR_COMM instead of entering a collective a failed peer will never
+     * join) and once with local_ok = 0 by a rank whose learner or actor failed, so that its peers stop at their next sync point
+     * (bdr_comm_agree: an RCCL MIN all-reduce of the flag).  ctx = exchange_ctx. */
+    int32_t (*agree)(void* ctx, int32_t local_ok, int32_t* all_ok);
 } bdr_learner_ops;
 
 typedef struct bdr_actor_ops {              /* one Actor: its own agent (built from its own config) and environment */
@@ -604,6 +609,9 @@ BDR_API int32_t bdr_comm_get_unique_id(uint8_t id[BDR_UNIQUE_ID_BYTES]);
 BDR_API int32_t bdr_comm_init_rank(const uint8_t id[BDR_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank,
                                    int32_t device, bdr_comm** out);
 BDR_API int32_t bdr_comm_destroy(bdr_comm* c);
+/* *all_ok <- MIN over ranks of (local_ok != 0): the agreement every rank reaches before it enters a collective, so that a rank
+ * whose learner failed does not leave its peers blocked in the next all-reduce (bdr_learner_ops::agree).  Synchronous. */
+BDR_API int32_t bdr_comm_agree(bdr_comm* c, int32_t local_ok, int32_t* all_ok);
 /* params <- mean over ranks (ncclAllReduce sum on the flat arena, then 1/nranks), on the
  * agent's stream; which as in bdr_agent_get_params (0 qnet, 1 qnet_tgt, 2/3 Adam moments). */
 BDR_API int32_t bdr_agent_allreduce_params(bdr_agent* a, bdr_comm* c, int32_t which);

@@ -270,3 +270,73 @@ def test_world_size_2_gloo_learners_are_averaged_at_every_sync_point():
         assert [e for e in exchanged if e > 0] == [5, 10, 15, 20, 23] and all(e == 0 for e in exchanged[:len(exchanged) - 5])
         assert abs(params - p[rank]) < 1e-9, (rank, params, p)
     assert res[0][1] == res[1][1]
+
+
+# ---- a rank that fails between two sync points must not leave its peer in the next collective -------------------------------
+def _worker_fail(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from border_amd._lib import BdrError
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = Mock(2, opt_delay=0.0002)
+    base_ops = m.learner_ops()
+    n = [0]
+
+    def opt(_a, _b):
+        n[0] += 1
+        if rank == 1 and n[0] == 12:      # between the sync points of opt steps 10 and 15
+            return 1                       # BDR_ERR_INVALID from Agent::opt
+        m.params += 1.0
+        return 0
+    fn = _lib.OPT_FN(opt)
+    m.keep.append(fn)
+    base_ops.t.agent_opt = fn
+    exchanged, agreed = [], []
+
+    def exchange(opt_steps):
+        t = torch.tensor([m.params], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        m.params = float(t[0]) / world
+        exchanged.append(opt_steps)
+
+    def agree(local_ok):
+        t = torch.tensor([1 if local_ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        agreed.append((bool(local_ok), bool(int(t[0]))))
+        return bool(int(t[0]))
+    envs = [MockEnv(10 * rank + 1), MockEnv(10 * rank + 2)]
+    tr = AsyncTrainer(AsyncTrainerConfig(max_opts=40, warmup_period=16, sync_interval=5, record_agent_info_interval=0,
+                                         record_compute_cost_interval=0, warmup_sleep_ms=1), ActorManagerConfig(n_buffer=4))
+    err = None
+    try:
+        tr.train(None, None, [None, None], envs, (4,), np.float32, exchange=exchange, agree=agree, learner_ops=base_ops,
+                 actor_ops=[m.actor_ops(i, envs[i]) for i in range(2)])
+    except BdrError as e:
+        err = str(e)
+    out.put((rank, err, exchanged, agreed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_a_failed_rank_stops_its_peer_at_the_next_sync_point():
+    """`exchange` is a collective inside sync(); without an agreement a rank whose learner fails returns while its peer
+    blocks forever in the next all-reduce.  With bdr_learner_ops::agree (MIN of an ok flag before every collective) rank 1 fails
+    at its 12th opt and says so once; rank 0 reaches the sync point of opt step 15, learns it and stops with BDR_ERR_COMM - both
+    ranks return, neither enters the exchange of step 15."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fail, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, err0, ex0, ag0), (_, err1, ex1, ag1) = res
+    assert err1 is not None and err0 is not None and "another rank's learner failed" in err0, (err0, err1)
+    assert ex0 == ex1 == [0, 5, 10]                      # the first sync, steps 5 and 10; nobody entered the exchange of 15
+    assert ag0 == [(True, True)] * 3 + [(True, False)]
+    assert ag1 == [(True, True)] * 3 + [(False, False)]

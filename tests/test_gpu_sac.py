@@ -166,9 +166,10 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
     from oracle import torch_ref as T
     od, ad = 17, 6
     def run(env):
-        for k in ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER", "BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH"): monkeypatch.delenv(k, raising=False)
+        for k in ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER", "BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH", "BDR_STEP_GRAPH_BREAK_AT"): monkeypatch.delenv(k, raising=False)
         for k in env:
-            if k != "ADAPTIVE": monkeypatch.setenv(k, "1")
+            if k == "BREAK": monkeypatch.setenv("BDR_STEP_GRAPH_BREAK_AT", "2")   # the third replay pass "diverges"
+            elif k != "ADAPTIVE": monkeypatch.setenv(k, "1")
         if "BDR_NO_STEP_GRAPH" not in env and "ADAPTIVE" not in env: monkeypatch.setenv("BDR_STEP_GRAPH", "1")   # every opt from the graph
         rng = np.random.default_rng(11)
         rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=3000, seed=7), (od,), np.float32, (ad,), np.float32)
@@ -194,7 +195,9 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
     assert gn == 25 and np.isfinite(g["pi"]).all()
     # eager launches; the separate gather launch instead of the sample drawn inside the pack kernel; both
     # ... and the default policy, which switches between graph and eager launches by whether the stream is idle when opt() is entered
-    for env in (("BDR_NO_STEP_GRAPH",), ("BDR_NO_STEP_GATHER",), ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER"), ("ADAPTIVE",)):
+    # ... and a replay pass that finds the sequence changed (forced): host counters are restored, THAT step is enqueued eagerly -
+    # not dropped, Adam / RNG / replay positions not skewed - and the agent stays eager (step_graph_run)
+    for env in (("BDR_NO_STEP_GRAPH",), ("BDR_NO_STEP_GATHER",), ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER"), ("ADAPTIVE",), ("BREAK",)):
         e, erec, en = run(env)
         assert en == gn, env
         for k in g: assert (g[k] == e[k]).all(), (env, k)

@@ -318,6 +318,25 @@ def cpu_baseline(config, batch, loss, budget_s):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def self_launch(n_gpus: int, argv=None, python=None) -> int:
+    """Re-executes this script as n_gpus ranks of one node through torch.distributed.run (rendezvous on 127.0.0.1, a free port) and
+    returns the launcher's exit status.  Rank 0's JSON line goes to this process's stdout unchanged."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    return subprocess.call(cmd, env=env)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -335,6 +354,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--profile-steps", type=int, default=30)
+    ap.add_argument("--dry-run", action="store_true", help="launcher / control-plane check without a GPU (tests/test_bench_launcher.py): "
+                    "ranks rendezvous, barrier, agree on a MAX-reduced time; rank 0 prints one line with \"dry_run\": true and no value")
     args = ap.parse_args()
     defaults = {"c1": (5000, 200), "c2": (2000, 100), "c4": (60, 5), "c5": (2000, 100)}[args.config]
     if args.steps is None:
@@ -342,17 +363,23 @@ def main():
     if args.warmup is None:
         args.warmup = defaults[1]
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as a plain command: launch one rank per GPU ourselves (the driver's N>1 form,
+        # `python -m torch.distributed.run ... bench.py --gpus N`, arrives here with RANK / WORLD_SIZE set and skips this).
+        sys.exit(self_launch(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher decides, running {world} rank(s)\n")
         args.gpus = world
 
     if world > 1:
         # the overlapped parameter exchange adds a communication queue to the agent's three streams (+ the buffer's): HIP's
-        # default pool of 4 hardware queues would alias them and the agent would fall back to the in-stream exchange
+        # default pool of 4 hardware queues would alias them and the agent would fall back to the in-stream exchange.  The
+        # library asks for them itself when it is loaded in a multi-rank process (csrc/comm.hip); set here too because torch
+        # may touch HIP first.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch  # noqa: F401  (first: one HIP runtime per process, see border_amd/_lib.py)
     import border_amd as B
@@ -364,6 +391,24 @@ def main():
         # control plane (barrier, id hand-off, max-reduce of the timing) on gloo; the data plane
         # (parameter all-reduce) is the library's own RCCL communicator over xGMI
         dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    if args.dry_run:
+        t0 = time.perf_counter()
+        dt = time.perf_counter() - t0
+        if dist:
+            dist.barrier()
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ranks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64))
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "metric": None, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ranks_seen": [int(r[0]) for r in ranks] if dist else [0],
+                              "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}), flush=True)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     share = os.environ.get("BDR_BENCH_SHARE_GPU") == "1"   # flow test of the N>1 path on a 1-GPU box (ranks share device 0)
     if share:
@@ -411,7 +456,12 @@ def main():
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_gpu = None
     if dist:
+        # every rank's own window (its sync -> the common barrier is included: a rank that finishes early waits for the slowest)
+        own = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(own, torch.tensor([dt], dtype=torch.float64))
+        per_gpu = [round(args.steps / float(x[0]), 2) for x in own]
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
@@ -460,6 +510,9 @@ def main():
                   "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                   "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks if world > 1 else 1,
                   "config": cfgd, "roofline": roof}
+        if per_gpu is not None:
+            result["per_gpu"] = {"unit": "opt-steps/s", "values": per_gpu, "aggregate": round(value, 2),
+                                 "sync_interval": args.sync_interval, "data_plane": "rccl" if rccl_ranks else "host staging (BDR_BENCH_SHARE_GPU=1: ranks share one device, which RCCL refuses)"}
         if steady is not None:
             result["steady_state"] = steady
     agent.close()

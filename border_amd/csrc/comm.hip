@@ -60,6 +60,22 @@ int32_t load_rccl()
     } while (0)
 }  // namespace
 
+// Hardware queues for the N>1 path.  The overlapped parameter exchange adds a communication queue to the agent's three
+// streams and the replay buffer's: five streams that must not share an in-order HSA queue, and HIP multiplexes streams onto
+// GPU_MAX_HW_QUEUES (default 4) queues per process.  The variable is read when the HIP runtime initialises (its first API
+// call), so it is the LIBRARY that asks for the queues, when it is loaded - before any HIP call of a process that links it or
+// imports it first - whenever the process is one rank of several (torchrun / mpirun / BDR_NRANKS say so).  A host that
+// initialises HIP before loading the library sets it itself; the agent detects aliased queues and
+// falls back to the in-stream exchange, and bdr_comm_init_rank says so.
+namespace {
+int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; }
+bool multi_rank_env() { return env_int("WORLD_SIZE") > 1 || env_int("OMPI_COMM_WORLD_SIZE") > 1 || env_int("PMI_SIZE") > 1 || env_int("BDR_NRANKS") > 1; }
+__attribute__((constructor)) void bdr_request_hw_queues()
+{
+    if (multi_rank_env()) setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+}
+}  // namespace
+
 struct bdr_comm {
     rcclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0;
     int32_t* d_flag = nullptr; hipStream_t flag_stream = nullptr;   // bdr_comm_agree
@@ -89,6 +105,17 @@ int32_t bdr_comm_init_rank(const uint8_t id[BDR_UNIQUE_ID_BYTES], int32_t nranks
     c->nranks = nranks; c->rank = rank; c->device = device;
     int e = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
     if (e != 0) { delete c; return fail(BDR_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(e)); }
+    if (nranks > 1) {
+        static bool noted = false;
+        const int q = env_int("GPU_MAX_HW_QUEUES");
+        if (!noted && q < 5) {
+            noted = true;
+            fprintf(stderr, "border_amd: GPU_MAX_HW_QUEUES=%s with %d ranks: the overlapped parameter exchange needs 5 hardware queues; "
+                            "set GPU_MAX_HW_QUEUES=8 before the process's first HIP call (the library does so itself when it is loaded "
+                            "first and WORLD_SIZE / BDR_NRANKS > 1); agents fall back to the in-stream exchange\n",
+                    getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset (4)", nranks);
+        }
+    }
     *out = c;
     return BDR_OK;
 }

@@ -1,0 +1,223 @@
+"""Two REAL ranks over RCCL (csrc/comm.hip with nranks = 2): the N>1 data planes of SURVEY.md 8(e) on hardware.
+
+Needs >= 2 MI355X in one box: RCCL refuses two ranks on one device, so on the 1-GPU lease these tests SKIP (the single-rank
+forms live in tests/test_gpu_sync_dp.py, the control flow over gloo in tests/test_param_exchange_gloo.py and
+tests/test_async_trainer_host.py).  One process per GPU, spawned here; torch.distributed (gloo) is only the control plane
+(unique-id hand-off, barriers), exactly as in bench.py.
+
+Parity statements (8(e) "Parity at G>1"), each against something that IS parity-checked on one GPU:
+ (i)   synchronous data-parallel, 2 x 128 rows: grads_on_batch -> ncclAllReduce(grad)/2 -> apply_grads on both ranks == the C
+       oracle's ONE step on the 256-row batch (gradient and parameters), and the ranks stay bit-identical;
+       production form (bdr_agent_set_grad_comm + Agent::opt over identical rings) == the un-exchanged single-rank run, bit for bit
+       ((x + x) / 2 == x in f32);
+ (ii)  parameter averaging after K local steps == fl(fl(P0 + P1) * 0.5) of the two ranks' own parameters, which equal independent
+       single-GPU runs of the same seeds bit for bit;
+ (iii) broadcast == the root's parameters, bit for bit (the reference's learner -> actors sync, async_trainer/base.rs:268-272);
+ (iv)  the overlapped per-segment exchange (communication queue beside the backward) == the in-stream exchange, bit for bit;
+ (v)   bdr_comm_agree: MIN of the ranks' ok flags on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_gpus():
+    try:
+        import border_amd
+        return border_amd.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+needs_two = pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 MI355X in one box (RCCL refuses two ranks on one device)")
+
+
+def _cnn(B, bs, dev, **kw):
+    return B.Dqn.build(B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=6), opt_config=B.OptimizerConfig.Adam(1e-4)),
+                                   device=dev, batch_size=bs, critic_loss="SmoothL1", **kw))
+
+
+def _ring(B, dev, seed, fill_seed, n=800):
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=n, seed=seed), (4, 1, 84, 84), np.uint8, device=dev)
+    rb.fill_synthetic(n, seed=fill_seed, kind=0, n_actions=6)
+    return rb
+
+
+def _rank_main(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import border_amd as B
+    from oracle import torch_ref as T
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = B._lib.lib()
+    dev = rank
+
+    def bcast_bytes(b):
+        t = torch.zeros(B._lib.BDR_UNIQUE_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            t = torch.tensor(list(b), dtype=torch.uint8)
+        dist.broadcast(t, src=0)
+        return bytes(t.tolist())
+    ex = B.ParamExchange.rccl_or_raise(world, rank, 1, dev, bcast_bytes, ("qnet",))
+    comm = ex._comm
+    res = {"rank": rank}
+
+    # (v) agreement
+    res["agree_all_ok"] = ex.agree(True)
+    res["agree_one_failed"] = ex.agree(rank != 1)
+
+    # (i) synchronous DP on a fixed 256-row batch, halves per rank; three steps
+    p0 = T.init_params(T.cnn_shapes(6), 7)
+    a = _cnn(B, 128, dev, tau=1.0, soft_update_interval=10000)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    sync = []
+    for step in range(3):
+        obs, act, nobs, rew, term = T.synthetic_atari_batch(256, 6, 500 + step)
+        h = tuple(x[rank * 128:(rank + 1) * 128] for x in (obs, act, nobs, rew, term))
+        rec = a.grads_on_batch(*h)
+        B._lib.check(L.bdr_agent_allreduce_params(a.handle, comm, a.WHICH["grad"]))     # sum over ranks, then 1/2
+        g = a.get_params("grad")
+        a.apply_grads()
+        sync.append({"loss": rec["loss"], "grad": g, "qnet": a.get_params("qnet"), "n_opts": a.n_opts})
+    res["sync_dp"] = sync
+    a.close()
+
+    # (i') production form: set_grad_comm + opt over IDENTICAL rings and seeds on both ranks == the run without a communicator
+    outs = []
+    for use_comm in (False, True):
+        rb = _ring(B, dev, 42, 3, 600)
+        a = _cnn(B, 32, dev, tau=0.5, soft_update_interval=4, param_seed=9)
+        if use_comm:
+            B._lib.check(L.bdr_agent_set_grad_comm(a.handle, comm))
+        for _ in range(9):
+            a.opt(rb)
+        rec = a.opt_with_record(rb)
+        outs.append((a.get_params("qnet"), a.get_params("qnet_tgt"), rec["loss"]))
+        if use_comm:
+            B._lib.check(L.bdr_agent_set_grad_comm(a.handle, None))
+        a.close(); rb.close()
+    res["grad_comm_identity"] = bool((outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all() and outs[0][2] == outs[1][2])
+    res["grad_comm_qnet"] = outs[1][0]
+
+    # (ii) + (iv): K local steps on DIFFERENT shards (seed + rank), then averaging; overlapped and in-stream exchange
+    def local_run(exchange_every, overlap, steps=12):
+        if overlap:
+            os.environ.pop("BDR_NO_XCHG_OVERLAP", None)
+        else:
+            os.environ["BDR_NO_XCHG_OVERLAP"] = "1"
+        rb = _ring(B, dev, B.shard_seed(42, rank), 10 + rank)
+        a = _cnn(B, 32, dev, tau=0.5, soft_update_interval=5, param_seed=9)
+        before_avg = None
+        for s in range(1, steps + 1):
+            a.opt(rb)
+            if exchange_every and s % exchange_every == 0:
+                if s == steps:
+                    before_avg = a.get_params("qnet")
+                B._lib.check(L.bdr_agent_allreduce_params(a.handle, comm, 0))
+        a.sync()
+        out = (a.get_params("qnet"), a.get_params("qnet_tgt"), a.get_params("exp_avg"), before_avg)
+        a.close(); rb.close()
+        os.environ.pop("BDR_NO_XCHG_OVERLAP", None)
+        return out
+    solo = local_run(0, True)                  # an independent single-GPU run of this rank's shard
+    once = local_run(12, True)                 # the same 12 local steps, then ONE average
+    res["avg_own_before"] = once[3]
+    res["avg_own_equals_solo"] = bool((once[3] == solo[0]).all())
+    res["avg_after"] = once[0]
+    res["avg_moments_local"] = bool((once[2] == solo[2]).all())      # Adam moments stay local
+    ov = local_run(3, True)
+    ins = local_run(3, False)
+    res["overlap_equals_instream"] = bool((ov[0] == ins[0]).all() and (ov[1] == ins[1]).all() and (ov[2] == ins[2]).all())
+    res["exchanged_every_3"] = ov[0]
+
+    # (iii) broadcast from rank 1
+    a = _cnn(B, 32, dev, tau=1.0, soft_update_interval=10000, param_seed=100 + rank)
+    mine = a.get_params("qnet")
+    B._lib.check(L.bdr_agent_broadcast_params(a.handle, comm, 0, 1))
+    a.sync()
+    res["bcast_mine"], res["bcast_after"] = mine, a.get_params("qnet")
+    a.close()
+
+    ex.close()
+    out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def two_ranks():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(2)), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@needs_two
+def test_agreement_is_the_min_over_ranks(two_ranks):
+    assert all(r["agree_all_ok"] is True for r in two_ranks)
+    assert all(r["agree_one_failed"] is False for r in two_ranks)
+
+
+@needs_two
+def test_sync_dp_two_ranks_of_128_equal_the_oracles_step_on_256(two_ranks):
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    from tests.test_gpu_dqn import assert_grads_close
+    shapes = T.cnn_shapes(6)
+    p0 = T.init_params(shapes, 7)
+    ref = O.DqnOracle(O.cnn_cfg(6), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000)
+    r0, r1 = two_ranks[0]["sync_dp"], two_ranks[1]["sync_dp"]
+    for step in range(3):
+        assert (r0[step]["grad"] == r1[step]["grad"]).all() and (r0[step]["qnet"] == r1[step]["qnet"]).all()    # lock step, bit for bit
+        assert r0[step]["n_opts"] == r1[step]["n_opts"] == step + 1
+    obs, act, nobs, rew, term = T.synthetic_atari_batch(256, 6, 500)
+    r = ref.update(obs, act, nobs, rew, term, probe=True)
+    assert_grads_close(r0[0]["grad"], r["grads"], shapes)                                   # all-reduced mean gradient == full-batch gradient
+    assert abs(0.5 * (r0[0]["loss"] + r1[0]["loss"]) - r["loss"]) <= 1e-4 * abs(r["loss"])
+    dp = np.abs(r0[0]["qnet"].astype(np.float64) - ref.q)
+    assert (dp > 0.05 * 1e-4).sum() <= 2 * 257 and dp.max() <= 2.5e-4, ((dp > 0.05 * 1e-4).sum(), dp.max())
+
+
+@needs_two
+def test_grad_comm_over_identical_shards_is_the_identity(two_ranks):
+    assert all(r["grad_comm_identity"] for r in two_ranks)
+    assert (two_ranks[0]["grad_comm_qnet"] == two_ranks[1]["grad_comm_qnet"]).all()
+
+
+@needs_two
+def test_parameter_average_is_the_mean_of_two_independent_runs(two_ranks):
+    assert all(r["avg_own_equals_solo"] and r["avg_moments_local"] for r in two_ranks)
+    p0, p1 = two_ranks[0]["avg_own_before"], two_ranks[1]["avg_own_before"]
+    assert not (p0 == p1).all()                                   # different shards really diverged
+    mean = (p0 + p1) * np.float32(0.5)                            # f32 sum (commutative for two ranks), then the 1/N scale
+    assert (two_ranks[0]["avg_after"] == mean).all() and (two_ranks[1]["avg_after"] == mean).all()
+
+
+@needs_two
+def test_overlapped_exchange_equals_the_in_stream_exchange(two_ranks):
+    assert all(r["overlap_equals_instream"] for r in two_ranks)
+    assert (two_ranks[0]["exchanged_every_3"] == two_ranks[1]["exchanged_every_3"]).all()     # step 12 ended with an average
+
+
+@needs_two
+def test_broadcast_equals_the_root(two_ranks):
+    root = two_ranks[1]["bcast_mine"]
+    assert not (two_ranks[0]["bcast_mine"] == root).all()
+    assert (two_ranks[0]["bcast_after"] == root).all() and (two_ranks[1]["bcast_after"] == root).all()

@@ -35,7 +35,7 @@ class NetConfig(C.Structure):
 
 class DqnConfigC(C.Structure):
     _fields_ = [("net", NetConfig), ("opt_kind", C.c_int32), ("lr", C.c_double), ("beta1", C.c_double),
-                ("beta2", C.c_double), ("weight_decay", C.c_double), ("eps", C.c_double),
+                ("beta2", C.c_double), ("weight_decay", C.c_double), ("eps", C.c_double), ("amsgrad", C.c_int32),
                 ("soft_update_interval", C.c_uint64), ("n_updates_per_opt", C.c_uint64),
                 ("batch_size", C.c_uint64), ("discount_factor", C.c_double), ("tau", C.c_double),
                 ("train", C.c_int32), ("double_dqn", C.c_int32), ("critic_loss", C.c_int32),
@@ -144,7 +144,7 @@ ABI_SYMBOLS = [
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
     "bdr_iqn_config_default", "bdr_iqn_create", "bdr_iqn_update_on_batch", "bdr_iqn_forward", "bdr_iqn_qvalues",
     "bdr_sac_config_default", "bdr_sac_create", "bdr_sac_update_on_batch", "bdr_sac_sample",
-    "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_comm_agree", "bdr_agent_allreduce_params",
+    "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_comm_agree", "bdr_sac_probe", "bdr_agent_allreduce_params",
     "bdr_agent_broadcast_params", "bdr_agent_set_grad_comm", "bdr_dqn_grads_on_batch", "bdr_agent_apply_grads",
     "bdr_atari_prep_create", "bdr_atari_prep_destroy", "bdr_atari_prep_reset", "bdr_atari_prep_step", "bdr_atari_prep_obs",
     "bdr_atari_prep_device_stacks", "bdr_atari_clip_reward",
@@ -236,6 +236,7 @@ def lib() -> C.CDLL:
     L.bdr_sac_create.argtypes = [C.POINTER(SacConfigC), C.POINTER(vp)]
     L.bdr_sac_update_on_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.bdr_sac_sample.argtypes = [vp, u64, vp, vp]
+    L.bdr_sac_probe.argtypes = [vp, i32, vp, u64]
     L.bdr_comm_get_unique_id.argtypes = [vp]
     L.bdr_comm_init_rank.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.bdr_comm_destroy.argtypes = [vp]

@@ -319,6 +319,42 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     reinterpret_cast<f32x4*>(v)[i] = vv;
 }
 
+// AdamW{amsgrad: true} (opt.rs:20-27, 45-53 -> libtorch AdamW::step with amsgrad): max_exp_avg_sq = max(max_exp_avg_sq, exp_avg_sq) and
+// the denominator uses the running maximum; everything else as adam_element.
+__device__ __forceinline__ void adam_element_amsgrad(float& p, float g, float& m, float& v, float& vmax, const AdamScalars& s)
+{
+#pragma clang fp contract(off)
+    p = p * s.wd_mul;
+    const float mg = g * s.omb1;
+    m = m * s.b1 + mg;
+    const float gg = s.omb2 * g * g;
+    v = v * s.b2 + gg;
+    vmax = fmaxf(vmax, v);                        // torch::max_out(max_exp_avg_sq, exp_avg_sq, max_exp_avg_sq)
+    const float denom = __fsqrt_rn(vmax) / s.sqrt_bc2 + s.eps;
+    const float upd = s.neg_step * m / denom;
+    p = p + upd;
+}
+
+__global__ __launch_bounds__(256) void k_adam_amsgrad(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                      float* __restrict__ vmax, size_t n4, AdamScalars s, const unsigned* poison = nullptr)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    if (poison && *poison) return;
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], xx = reinterpret_cast<f32x4*>(vmax)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float pe = pp[j], me = mm[j], ve = vv[j], xe = xx[j];
+        adam_element_amsgrad(pe, gg[j], me, ve, xe, s);
+        pp[j] = pe; mm[j] = me; vv[j] = ve; xx[j] = xe;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    reinterpret_cast<f32x4*>(vmax)[i] = xx;
+}
+
 // util.rs:31-45 track: dest = tau * src + (1 - tau) * dest, every operation rounded on its own (see adam_element)
 __device__ __forceinline__ float track_element(float src, float dst, float tau, float omt)
 {
@@ -366,6 +402,13 @@ inline int32_t launch_adam(hipStream_t st, float* p, const float* g, float* m, f
 {
     const size_t n4 = n_floats / 4;
     BDR_HIP(step_launch(st, true, k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), p, g, m, v, n4, s, (const unsigned*)nullptr));
+    return BDR_OK;
+}
+inline int32_t launch_adam_amsgrad(hipStream_t st, float* p, const float* g, float* m, float* v, float* vmax, size_t n_floats, const AdamScalars& s,
+                                   const unsigned* poison = nullptr)
+{
+    const size_t n4 = n_floats / 4;
+    BDR_HIP(step_launch(st, true, k_adam_amsgrad, dim3((unsigned)((n4 + 255) / 256)), dim3(256), p, g, m, v, vmax, n4, s, poison));
     return BDR_OK;
 }
 inline int32_t launch_track(hipStream_t st, float* dst, const float* src, size_t n_floats, double tau)

@@ -347,6 +347,7 @@ struct DqnCnn : bdr_agent {
     int B = 0;          // activation buffers are sized for this batch
     // parameter arenas
     float *q = nullptr, *q_tgt = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
+    float* vmax = nullptr; bool amsgrad = false;   // AdamW{amsgrad: true}: max_exp_avg_sq arena (5); the step then always runs backward -> adam_all (the split path of synchronous DP)
     // activations [instance]
     float* a1[MAXZ] = {nullptr}; float* a2[MAXZ] = {nullptr}; float* a3[MAXZ] = {nullptr};
     float* p1[MAXZ] = {nullptr}; float* h1[MAXZ] = {nullptr}; float* qv[MAXZ] = {nullptr};
@@ -903,6 +904,8 @@ int32_t adam_all(DqnCnn* a)
     a->adam_step += 1;
     Bracket br(a, "adam_all");
     const size_t n4 = a->ar.total / 4;
+    if (a->amsgrad)
+        return launch_adam_amsgrad(a->stream, a->q, a->grad, a->m, a->v, a->vmax, a->ar.total, adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR));
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q, (const float*)a->grad, a->m, a->v, n4,
                        adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR));
     BDR_HIP(hipGetLastError());
@@ -969,15 +972,15 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
             Bracket br(a, "sample");
             BDR_TRY(replay_sample_on_stream(r, a->cfg.batch_size, a->stream));
         }
-        a->defer_adam = a->grad_comm != nullptr;
+        a->defer_adam = a->grad_comm != nullptr || a->amsgrad;
         const int32_t st = update_critic(a, (int)a->cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
                                          replay_batch_weights(r), r);
         a->defer_adam = false;
         BDR_TRY(st);
         if (a->grad_comm) {   // synchronous data-parallel step: mean gradient over the ranks, then everybody's optimizer step
-            { Bracket br(a, "grad_allreduce"); BDR_TRY(a->grad_reduce(a, a->grad_comm)); }
-            BDR_TRY(adam_all(a));
+            Bracket br(a, "grad_allreduce"); BDR_TRY(a->grad_reduce(a, a->grad_comm));
         }
+        if (a->grad_comm || a->amsgrad) BDR_TRY(adam_all(a));
     }
     return after_updates(a);
 }
@@ -1047,6 +1050,7 @@ float* arena_ptr(DqnCnn* a, int which)
 {
     switch (which) {
         case 0: return a->q; case 1: return a->q_tgt; case 2: return a->m; case 3: return a->v; case 4: return a->grad;
+        case 5: return a->vmax;   // AdamW amsgrad: max_exp_avg_sq (nullptr otherwise)
         default: return nullptr;
     }
 }
@@ -1152,7 +1156,7 @@ DqnCnn::~DqnCnn()
     (void)hipStreamSynchronize(stream);
     if (side) (void)hipStreamSynchronize(side);
     free_batch_buffers(this);
-    (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v);
+    (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v); (void)hipFree(vmax);
     (void)hipFree(loss);
     (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
     for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
@@ -1308,6 +1312,8 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
         BDR_TRY(alloc_f(p, a->ar.total));
         BDR_HIP(hipMemsetAsync(*p, 0, a->ar.total * 4, a->stream));
     }
+    a->amsgrad = cfg->opt_kind == BDR_OPT_ADAMW && cfg->amsgrad != 0;
+    if (a->amsgrad) { BDR_TRY(alloc_f(&a->vmax, a->ar.total)); BDR_HIP(hipMemsetAsync(a->vmax, 0, a->ar.total * 4, a->stream)); }
     BDR_TRY(alloc_f(&a->loss, 4));
     std::vector<float> ref, in(a->ar.total);
     init_reference_params(a->ar.A, cfg->param_seed, ref);
@@ -1352,8 +1358,14 @@ int32_t dqn_cnn_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, co
     BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, a->stream));
     const float* wd = nullptr;
     if (weight) { BDR_TRY(a->td_buffer(n)); BDR_HIP(hipMemcpyAsync(a->w_stage, weight, n * 4, hipMemcpyHostToDevice, a->stream)); wd = a->w_stage; }
+    const bool backward_only = a->defer_adam;      // grads_on_batch
+    if (a->amsgrad) a->defer_adam = true;          // the amsgrad step is backward -> adam_all
     const int32_t st = update_critic(a, (int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term, wd, nullptr);
-    if (st == BDR_OK && !a->defer_adam) BDR_TRY(after_updates(a));
+    a->defer_adam = backward_only;
+    if (st == BDR_OK && !backward_only) {
+        if (a->amsgrad) BDR_TRY(adam_all(a));
+        BDR_TRY(after_updates(a));
+    }
     BDR_TRY(st);
     BDR_HIP(hipStreamSynchronize(a->stream));   // host buffers may be reused by the caller
     return BDR_OK;

@@ -88,6 +88,7 @@ struct DqnMlp : bdr_agent {
     bdr_dqn_config cfg;
     MlpLayout net;
     float *q = nullptr, *q_tgt = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
+    float* vmax = nullptr; bool amsgrad = false;   // AdamW{amsgrad: true} (see DqnCnn)
     int B = 0;
     float* x_in[MAXZ] = {nullptr};                 // packed inputs [B][Kp0]
     std::vector<float*> acts[MAXZ];                // per layer [B][Np]
@@ -112,7 +113,7 @@ struct DqnMlp : bdr_agent {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
         free_batch();
-        (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v); (void)hipFree(loss);
+        (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v); (void)hipFree(vmax); (void)hipFree(loss);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
     }
     void free_batch()
@@ -324,6 +325,7 @@ struct DqnMlp : bdr_agent {
         adam_step += 1;
         const AdamScalars s = adam_scalars_for(cfg.opt_kind == BDR_OPT_ADAMW, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, adam_step);
         Bracket br(this, "adam");
+        if (amsgrad) return launch_adam_amsgrad(stream, q, grad, m, v, vmax, net.total, s);
         return launch_adam(stream, q, grad, m, v, net.total, s);
     }
     int32_t apply_grads() override
@@ -359,7 +361,7 @@ struct DqnMlp : bdr_agent {
         // The layer-by-layer step (nets beyond the one-workgroup kernel) is ~11 launches of a few us: replayed from a captured graph
         // when the host is what the device waits for (step_graph.hpp).  Not with prioritized replay (tree kernels with host state),
         // the synchronous-DP exchange, profiling, or a soft update that does not ride on the step's last kernel.
-        const bool graphable = !fused_ok(bs) && small_gemm && net.L.size() <= (size_t)RA_SEGS && !r->per && !grad_comm && !prof;
+        const bool graphable = !fused_ok(bs) && small_gemm && net.L.size() <= (size_t)RA_SEGS && !r->per && !grad_comm && !amsgrad && !prof;
         if (graphable) {
             const int w = graph_policy.want(stream);
             if (w < 0) return fail(BDR_ERR_HIP, "hipStreamQuery failed");
@@ -385,7 +387,7 @@ struct DqnMlp : bdr_agent {
                                    r->obs_bytes % 4 == 0;
             if (in_kernel) BDR_TRY(replay_sample_plan(r, cfg.batch_size, stream, &plan));
             else { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, cfg.batch_size, stream)); }
-            defer_adam = grad_comm != nullptr;
+            defer_adam = grad_comm != nullptr || amsgrad;
             // the soft update that follows the last update of this opt (dqn/base.rs:190-196) rides on its fused kernel
             track_with_next = u + 1 == cfg.n_updates_per_opt && soft_update_counter + 1 == cfg.soft_update_interval && !defer_adam;
             const int32_t st = update_critic((int)cfg.batch_size, r->b_obs, r->b_next, r->b_act, (int)r->act_bytes, r->b_reward, r->b_term,
@@ -393,9 +395,9 @@ struct DqnMlp : bdr_agent {
             defer_adam = false;
             BDR_TRY(st);
             if (grad_comm) {   // synchronous data-parallel step (see bdr_agent::grad_comm)
-                { Bracket br(this, "grad_allreduce"); BDR_TRY(grad_reduce(this, grad_comm)); }
-                BDR_TRY(adam_all());
+                Bracket br(this, "grad_allreduce"); BDR_TRY(grad_reduce(this, grad_comm));
             }
+            if (grad_comm || amsgrad) BDR_TRY(adam_all());
         }
         return after_updates();
     }
@@ -437,7 +439,7 @@ struct DqnMlp : bdr_agent {
     }
     float* arena_ptr(int which)
     {
-        switch (which) { case 0: return q; case 1: return q_tgt; case 2: return m; case 3: return v; case 4: return grad; default: return nullptr; }
+        switch (which) { case 0: return q; case 1: return q_tgt; case 2: return m; case 3: return v; case 4: return grad; case 5: return vmax; default: return nullptr; }
     }
     uint64_t param_count(int which) override { return which == -1 ? (uint64_t)net.out_dim : net.ref_total; }
     int32_t get_params(int which, float* out, uint64_t n) override
@@ -512,6 +514,8 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
         BDR_TRY(alloc_f(p, a->net.total));
         BDR_HIP(hipMemsetAsync(*p, 0, a->net.total * 4, a->stream));
     }
+    a->amsgrad = cfg->opt_kind == BDR_OPT_ADAMW && cfg->amsgrad != 0;
+    if (a->amsgrad) { BDR_TRY(alloc_f(&a->vmax, a->net.total)); BDR_HIP(hipMemsetAsync(a->vmax, 0, a->net.total * 4, a->stream)); }
     BDR_TRY(alloc_f(&a->loss, 4));
     std::vector<float> ref(a->net.ref_total);
     mlp_init_reference(a->net, cfg->param_seed, ref.data());
@@ -542,8 +546,15 @@ int32_t dqn_mlp_update_on_batch(bdr_agent* base, uint64_t n, const void* obs, co
     BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, a->stream));
     const float* wd = nullptr;
     if (weight) { BDR_TRY(a->td_buffer(n)); BDR_HIP(hipMemcpyAsync(a->w_stage, weight, n * 4, hipMemcpyHostToDevice, a->stream)); wd = a->w_stage; }
-    BDR_TRY(a->update_critic((int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term, wd, nullptr));
-    if (!a->defer_adam) BDR_TRY(a->after_updates());
+    const bool backward_only = a->defer_adam;      // grads_on_batch
+    if (a->amsgrad) a->defer_adam = true;          // the amsgrad step is backward -> adam_all
+    const int32_t st = a->update_critic((int)n, a->u_obs, a->u_next, a->u_act, 8, a->u_rew, a->u_term, wd, nullptr);
+    a->defer_adam = backward_only;
+    BDR_TRY(st);
+    if (!backward_only) {
+        if (a->amsgrad) BDR_TRY(a->adam_all());
+        BDR_TRY(a->after_updates());
+    }
     BDR_HIP(hipStreamSynchronize(a->stream));
     return BDR_OK;
 }

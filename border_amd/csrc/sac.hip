@@ -272,6 +272,10 @@ struct Sac : bdr_agent {
     // host staging for update_on_batch
     float *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr, *u_rew = nullptr; int8_t* u_term = nullptr; uint64_t u_cap = 0;
     uint64_t noise_counter = 0;
+    // bdr_sac_probe: the actor-phase values an update overwrites later (Q_i(obs, a_pi), log p(a_pi | obs)), copied aside by
+    // update_on_batch only (probe_copy; never inside a captured step)
+    bool probe_copy = false; int probe_B = 0; int last_B = 0;
+    float* pr_qpi[4] = {nullptr}; float* pr_logp = nullptr;
     StepGraph graph; StepGraphPolicy graph_policy;   // step_graph.hpp
     bool gather_in_pack = true;               // BDR_NO_STEP_GATHER=1: separate gather launch
     bool small_gemm = true;                   // BDR_NO_SMALL_GEMM=1: the 64x64-tile kernels of the large-batch agents
@@ -285,6 +289,8 @@ struct Sac : bdr_agent {
         for (int i = 0; i < 4; ++i) { (void)hipFree(q_p[i]); (void)hipFree(q_t[i]); (void)hipFree(q_g[i]); (void)hipFree(q_m[i]); (void)hipFree(q_v[i]); }
         (void)hipFree(log_alpha); (void)hipFree(al_m); (void)hipFree(al_v); (void)hipFree(scal);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
+        for (int i = 0; i < 4; ++i) (void)hipFree(pr_qpi[i]);
+        (void)hipFree(pr_logp);
     }
     void free_batch()
     {
@@ -472,6 +478,15 @@ struct Sac : bdr_agent {
             Bracket br(a, "sac_select");
             BDR_HIP(step_launch(stream, cfg.ent_coef_auto != 0, k_sac_select, dim3(1), dim3(1024), p));
         }
+        if (probe_copy) {   // parity probes (bdr_sac_probe 5 / 6): the critic phase reuses these buffers
+            if (probe_B < Bn) {
+                for (int i = 0; i < NC; ++i) { (void)hipFree(pr_qpi[i]); pr_qpi[i] = nullptr; BDR_HIP(hipMalloc((void**)&pr_qpi[i], (size_t)Bn * ldq * 4)); }
+                (void)hipFree(pr_logp); pr_logp = nullptr; BDR_HIP(hipMalloc((void**)&pr_logp, (size_t)Bn * 4));
+                probe_B = Bn;
+            }
+            for (int i = 0; i < NC; ++i) BDR_HIP(hipMemcpyAsync(pr_qpi[i], c_act[i][L - 1], (size_t)Bn * ldq * 4, hipMemcpyDeviceToDevice, stream));
+            BDR_HIP(hipMemcpyAsync(pr_logp, logp, (size_t)Bn * 4, hipMemcpyDeviceToDevice, stream));
+        }
         for (int l = L - 1; l >= 0; --l) {   // d qmin / d input through the critics (weights untouched here)
             Bracket br(a, "q_dx");
             BDR_TRY(critic_dx_all(l, Bn, c_act));
@@ -538,6 +553,7 @@ struct Sac : bdr_agent {
             BDR_TRY(reduce_adam(qn, q_off, q_chunks, Bn, q_part, q_part_stride, NC, q_p, q_g, q_m, q_v, q_t, sc));
         }
         n_opts += 1;
+        last_B = Bn;
         return BDR_OK;
     }
 
@@ -791,7 +807,10 @@ int32_t bdr_sac_update_on_batch(bdr_agent* base, uint64_t n, const float* obs, c
     BDR_HIP(hipMemcpyAsync(a->u_term, term, n, hipMemcpyHostToDevice, s));
     BDR_HIP(hipMemcpyAsync(a->z_a, z_actor, n * a->A * 4, hipMemcpyHostToDevice, s));
     BDR_HIP(hipMemcpyAsync(a->z_a + n * a->A, z_next, n * a->A * 4, hipMemcpyHostToDevice, s));
-    BDR_TRY(a->update((int)n, a->u_obs, a->u_act, a->u_next, a->u_rew, a->u_term, a->z_a, a->z_a + n * a->A, true));
+    a->probe_copy = true;
+    const int32_t ust = a->update((int)n, a->u_obs, a->u_act, a->u_next, a->u_rew, a->u_term, a->z_a, a->z_a + n * a->A, true);
+    a->probe_copy = false;
+    BDR_TRY(ust);
     prof_collect(a);
     if (rec3) {
         float h[2], la;
@@ -803,6 +822,70 @@ int32_t bdr_sac_update_on_batch(bdr_agent* base, uint64_t n, const float* obs, c
         BDR_HIP(hipStreamSynchronize(s));
     }
     return BDR_OK;
+}
+
+// Parity probes of the LAST update (see include/border_amd.h)
+int32_t bdr_sac_probe(bdr_agent* base, int32_t what, float* out, uint64_t n)
+{
+    BDR_REQUIRE(base && out, "null argument");
+    BDR_REQUIRE(!strcmp(base->kind(), "sac"), "not a SAC agent");
+    Sac* a = static_cast<Sac*>(base);
+    BDR_HIP(hipSetDevice(a->device));
+    const int Bn = a->last_B, NC = a->NC, L = (int)a->qn.L.size(), ldq = a->qn.L[L - 1].Np, Ap = a->pi.L[a->n_trunk].Np;
+    BDR_REQUIRE(Bn > 0, "no update has run yet");
+    BDR_HIP(hipStreamSynchronize(a->stream));
+    auto column0 = [&](float* const* mats, float* dst) -> int32_t {     // [NC] matrices [Bn][ldq] -> [NC][Bn]
+        std::vector<float> m((size_t)Bn * ldq);
+        for (int i = 0; i < NC; ++i) {
+            BDR_HIP(hipMemcpy(m.data(), mats[i], m.size() * 4, hipMemcpyDeviceToHost));
+            for (int b = 0; b < Bn; ++b) dst[(size_t)i * Bn + b] = m[(size_t)b * ldq];
+        }
+        return BDR_OK;
+    };
+    float* mats[4];
+    switch (what) {
+        case 0:   // Q_i(obs, act): the predictions of update_critic (sac/base.rs:128-131, qvals :89-98)
+            BDR_REQUIRE(n == (uint64_t)NC * Bn, "q_pred holds n_critics x batch values");
+            for (int i = 0; i < NC; ++i) mats[i] = a->c2_act[i][L - 1];
+            return column0(mats, out);
+        case 1:   // target critics on (next_obs, a' ~ pi(next_obs)) (:112-118)
+            BDR_REQUIRE(n == (uint64_t)NC * Bn, "q_next holds n_critics x batch values");
+            for (int i = 0; i < NC; ++i) mats[i] = a->c_act[i][L - 1];
+            return column0(mats, out);
+        case 2: { // qvals_min over the target critics (:100-105)
+            BDR_REQUIRE(n == (uint64_t)Bn, "qvals_min holds batch values");
+            std::vector<float> q((size_t)NC * Bn);
+            for (int i = 0; i < NC; ++i) mats[i] = a->c_act[i][L - 1];
+            BDR_TRY(column0(mats, q.data()));
+            for (int b = 0; b < Bn; ++b) { float m = q[b]; for (int i = 1; i < NC; ++i) m = std::min(m, q[(size_t)i * Bn + b]); out[b] = m; }
+            return BDR_OK;
+        }
+        case 3:   // log p(a' | next_obs) under the updated actor (:113)
+            BDR_REQUIRE(n == (uint64_t)Bn, "next_log_p holds batch values");
+            BDR_HIP(hipMemcpy(out, a->logp, (size_t)Bn * 4, hipMemcpyDeviceToHost));
+            return BDR_OK;
+        case 4:   // the TD target (:119-122)
+            BDR_REQUIRE(n == (uint64_t)Bn, "tgt holds batch values");
+            BDR_HIP(hipMemcpy(out, a->tgt, (size_t)Bn * 4, hipMemcpyDeviceToHost));
+            return BDR_OK;
+        case 5:   // Q_i(obs, a_pi) of update_actor (:157-158); bdr_sac_update_on_batch only
+            BDR_REQUIRE(a->probe_B >= Bn, "q_pi is kept by bdr_sac_update_on_batch only");
+            BDR_REQUIRE(n == (uint64_t)NC * Bn, "q_pi holds n_critics x batch values");
+            return column0(a->pr_qpi, out);
+        case 6:   // log p(a_pi | obs) of update_actor (:156); bdr_sac_update_on_batch only
+            BDR_REQUIRE(a->probe_B >= Bn, "log_p is kept by bdr_sac_update_on_batch only");
+            BDR_REQUIRE(n == (uint64_t)Bn, "log_p holds batch values");
+            BDR_HIP(hipMemcpy(out, a->pr_logp, (size_t)Bn * 4, hipMemcpyDeviceToHost));
+            return BDR_OK;
+        case 7: { // a' [B][A]
+            BDR_REQUIRE(n == (uint64_t)Bn * a->A, "next_act holds batch x act_dim values");
+            std::vector<float> m((size_t)Bn * Ap);
+            BDR_HIP(hipMemcpy(m.data(), a->a_s, m.size() * 4, hipMemcpyDeviceToHost));
+            for (int b = 0; b < Bn; ++b) for (int j = 0; j < a->A; ++j) out[(size_t)b * a->A + j] = m[(size_t)b * Ap + j];
+            return BDR_OK;
+        }
+        default: return fail(BDR_ERR_INVALID, "unknown SAC probe %d", what);
+    }
 }
 
 // Policy::sample (sac/base.rs:215-225): tanh(mean) in eval mode, tanh(sigma*z + mean) in train mode

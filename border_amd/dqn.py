@@ -46,6 +46,7 @@ class OptimizerConfig:
     beta2: float = 0.999
     wd: float = 0.0
     eps: float = 1e-8
+    amsgrad: bool = False
 
     @classmethod
     def Adam(cls, lr: float) -> "OptimizerConfig":
@@ -54,9 +55,7 @@ class OptimizerConfig:
     @classmethod
     def AdamW(cls, lr: float, beta1: float = 0.9, beta2: float = 0.999, wd: float = 0.01, eps: float = 1e-8,
               amsgrad: bool = False) -> "OptimizerConfig":
-        if amsgrad:
-            raise NotImplementedError("AdamW{amsgrad: true} is not built (no example of the reference sets it)")
-        return cls("AdamW", lr, beta1, beta2, wd, eps)
+        return cls("AdamW", lr, beta1, beta2, wd, eps, amsgrad)
 
 
 @dataclass
@@ -131,6 +130,7 @@ class DqnConfig:
         o = self.model_config.opt_config
         c.opt_kind = {"Adam": 0, "AdamW": 1}[o.kind]
         c.lr, c.beta1, c.beta2, c.weight_decay, c.eps = o.lr, o.beta1, o.beta2, o.wd, o.eps
+        c.amsgrad = 1 if (o.kind == "AdamW" and o.amsgrad) else 0
         c.soft_update_interval, c.n_updates_per_opt, c.batch_size = (self.soft_update_interval,
                                                                     self.n_updates_per_opt, self.batch_size)
         c.discount_factor, c.tau, c.train = self.discount_factor, self.tau, int(self.train)
@@ -328,7 +328,7 @@ class Dqn:
         return a
 
     # SyncModel / parameter access --------------------------------------------------------------
-    WHICH = {"qnet": 0, "qnet_tgt": 1, "exp_avg": 2, "exp_avg_sq": 3, "grad": 4}
+    WHICH = {"qnet": 0, "qnet_tgt": 1, "exp_avg": 2, "exp_avg_sq": 3, "grad": 4, "max_exp_avg_sq": 5}
 
     def arena_device_ptr(self, which="qnet"):
         """(device pointer, float count) of the flat parameter arena in the kernels' internal layout."""

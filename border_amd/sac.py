@@ -143,6 +143,17 @@ class Sac:
                                                       _p(z_actor), _p(z_next), _p(rec)))
         return dict(loss_critic=float(rec[0]), loss_actor=float(rec[1]), ent_coef=float(rec[2]))
 
+    PROBES = {"q_pred": 0, "q_next": 1, "qvals_min": 2, "next_log_p": 3, "tgt": 4, "q_pi": 5, "log_p": 6, "next_act": 7}
+
+    def probe(self, what: str, batch: int) -> np.ndarray:
+        """Intermediates of the last update (bdr_sac_probe): q_pred / q_next / q_pi [n_critics, B], qvals_min / next_log_p / tgt /
+        log_p [B], next_act [B, act_dim]."""
+        nc, ad = self.config.n_critics, self.config.act_dim
+        shape = {"q_pred": (nc, batch), "q_next": (nc, batch), "q_pi": (nc, batch), "next_act": (batch, ad)}.get(what, (batch,))
+        out = np.empty(shape, np.float32)
+        _lib.check(_lib.lib().bdr_sac_probe(self._h, self.PROBES[what], _p(out), out.size))
+        return out
+
     def sample(self, obs) -> np.ndarray:
         obs = np.ascontiguousarray(obs, dtype=np.float32)
         out = np.empty((obs.shape[0], self.config.act_dim), np.float32)

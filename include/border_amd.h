@@ -190,6 +190,7 @@ typedef struct {
     int32_t opt_kind; /* BDR_OPT_ADAM: lr only (tch nn::Adam::default(): .9,.999,1e-8,wd 0) */
     double lr;
     double beta1, beta2, weight_decay, eps; /* AdamW variant only */
+    int32_t amsgrad;  /* AdamW{amsgrad} (opt.rs:20-27): denominator from the running max of exp_avg_sq (arena 5) */
     uint64_t soft_update_interval;
     uint64_t n_updates_per_opt;
     uint64_t batch_size;
@@ -318,7 +319,7 @@ BDR_API int32_t bdr_agent_n_opts(const bdr_agent* a, uint64_t* n);
 /* SyncModel::model_info / sync_model (border-async-trainer/src/sync_model.rs:2-13,
  * dqn/base.rs:377-402) and checkpoint access.  Parameters cross the boundary in the
  * reference's variable order and layouts (c1.weight OIHW, c1.bias, ... l2.bias / mlp.ln{i}.*).
- * which: 0 = qnet, 1 = qnet_tgt, 2 = Adam exp_avg, 3 = Adam exp_avg_sq, 4 = last gradient. */
+ * which: 0 = qnet, 1 = qnet_tgt, 2 = Adam exp_avg, 3 = Adam exp_avg_sq, 4 = last gradient, 5 = AdamW amsgrad max_exp_avg_sq. */
 BDR_API int32_t bdr_agent_param_count(const bdr_agent* a, uint64_t* n);
 BDR_API int32_t bdr_agent_param_count_of(bdr_agent* a, int32_t which, uint64_t* n); /* per-model counts (SAC) */
 BDR_API int32_t bdr_agent_get_params(bdr_agent* a, int32_t which, float* out, uint64_t n);
@@ -597,6 +598,14 @@ BDR_API int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out);  /* 
 BDR_API int32_t bdr_sac_update_on_batch(bdr_agent* a, uint64_t n, const float* obs, const float* act,
                                         const float* next_obs, const float* reward, const int8_t* is_terminated,
                                         const float* z_actor, const float* z_next, float* rec3);
+/* Parity probes: intermediates of the LAST SAC update, to the host.  what:
+ *   0 q_pred [n_critics][B]   Q_i(obs, act), the predictions of update_critic (sac/base.rs:128-131; qvals :89-98)
+ *   1 q_next [n_critics][B]   target critics on (next_obs, a'), a' ~ pi(next_obs) of the UPDATED actor (:112-118)
+ *   2 qvals_min [B]           min over 1 (:100-105)          3 next_log_p [B]  log p(a' | next_obs) (:113)
+ *   4 tgt [B]                 the TD target (:119-122)       7 next_act [B][act_dim]
+ *   5 q_pi [n_critics][B]     Q_i(obs, a_pi) of update_actor (:157-158)      6 log_p [B]  log p(a_pi | obs) (:156)
+ * 5 and 6 are overwritten by the critic phase and therefore kept aside by bdr_sac_update_on_batch only. */
+BDR_API int32_t bdr_sac_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
 /* Policy::sample (sac/base.rs:215-225). */
 BDR_API int32_t bdr_sac_sample(bdr_agent* a, uint64_t n, const float* obs, float* act_out);
 

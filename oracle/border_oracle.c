@@ -850,6 +850,11 @@ typedef struct {
     float* a;            /* [B][A] actor action    or NULL */
     float* log_p;        /* [B]                    or NULL */
     float* tgt;          /* [B]                    or NULL */
+    float* q_pi;         /* [n_critics][B] Q_i(obs, a_pi), update_actor (sac/base.rs:157-158)          or NULL */
+    float* q_pred;       /* [n_critics][B] Q_i(obs, act), update_critic (:128-131)                     or NULL */
+    float* q_next;       /* [n_critics][B] target critics on (next_obs, a') (:112-118)                 or NULL */
+    float* next_log_p;   /* [B] log p(a' | next_obs) under the updated actor (:113)                    or NULL */
+    float* next_a;       /* [B][A] a'                                                                 or NULL */
 } orc_sac_probe;
 
 /* One Sac::opt_ update (sac/base.rs:175-198 body of the loop) on a given minibatch. */
@@ -886,6 +891,7 @@ ORC_API void orc_sac_update(const orc_sac_cfg* c, float* pi, float** qs, float**
     float* qv = (float*)malloc(sizeof(float) * (size_t)NC * B);
     float*** qacts = (float***)calloc(NC, sizeof(float**));
     for (int i = 0; i < NC; ++i) { qacts[i] = acts_alloc(&qm, B); sac_mlp_fwd(&qm, qs[i], xin, B, qacts[i]); memcpy(qv + (size_t)i * B, qacts[i][qm.n - 1], sizeof(float) * B); }
+    if (probe && probe->q_pi) memcpy(probe->q_pi, qv, sizeof(float) * (size_t)NC * B);
     double la = 0.0;
     int* imin = (int*)malloc(sizeof(int) * B);
     for (int b = 0; b < B; ++b) {
@@ -947,6 +953,8 @@ ORC_API void orc_sac_update(const orc_sac_cfg* c, float* pi, float** qs, float**
     float* na = (float*)malloc(sizeof(float) * (size_t)B * A);
     float* nlogp = (float*)malloc(sizeof(float) * B);
     sac_action_logp(c, pi, next_obs, z_next, B, na, nlogp, NULL);   /* updated actor */
+    if (probe && probe->next_log_p) memcpy(probe->next_log_p, nlogp, sizeof(float) * B);
+    if (probe && probe->next_a) memcpy(probe->next_a, na, sizeof(float) * (size_t)B * A);
     for (int b = 0; b < B; ++b) { memcpy(xin + (size_t)b * (O + A), next_obs + (size_t)b * O, sizeof(float) * O); memcpy(xin + (size_t)b * (O + A) + O, na + (size_t)b * A, sizeof(float) * A); }
     float* tgt = (float*)malloc(sizeof(float) * B);
     {
@@ -954,6 +962,7 @@ ORC_API void orc_sac_update(const orc_sac_cfg* c, float* pi, float** qs, float**
         float* nq = (float*)malloc(sizeof(float) * B);
         for (int i = 0; i < NC; ++i) {
             sac_mlp_fwd(&qm, qs_tgt[i], xin, B, ta);
+            if (probe && probe->q_next) memcpy(probe->q_next + (size_t)i * B, ta[qm.n - 1], sizeof(float) * B);
             for (int b = 0; b < B; ++b) nq[b] = (i == 0 || ta[qm.n - 1][b] < nq[b]) ? ta[qm.n - 1][b] : nq[b];
         }
         const float gm = (float)c->gamma, rs = (float)c->reward_scale;
@@ -969,6 +978,7 @@ ORC_API void orc_sac_update(const orc_sac_cfg* c, float* pi, float** qs, float**
     for (int i = 0; i < NC; ++i) {
         float** ca = acts_alloc(&qm, B);
         sac_mlp_fwd(&qm, qs[i], xin, B, ca);
+        if (probe && probe->q_pred) memcpy(probe->q_pred + (size_t)i * B, ca[qm.n - 1], sizeof(float) * B);
         float* dout = (float*)malloc(sizeof(float) * B);
         double ls = 0.0;
         for (int b = 0; b < B; ++b) {

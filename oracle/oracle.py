@@ -267,7 +267,7 @@ class SacRecord(C.Structure):
 
 
 class SacProbe(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("pi_grads", "q_grads", "a", "log_p", "tgt")]
+    _fields_ = [(n, C.c_void_p) for n in ("pi_grads", "q_grads", "a", "log_p", "tgt", "q_pi", "q_pred", "q_next", "next_log_p", "next_a")]
 
 
 class SacOracle:
@@ -312,7 +312,9 @@ class SacOracle:
         arr = lambda xs: (C.c_void_p * NC)(*[x.ctypes.data for x in xs])
         rec = SacRecord()
         bufs = dict(pi_grads=np.empty_like(self.pi), q_grads=np.empty((NC, self.qs[0].size), np.float32),
-                    a=np.empty((B, self.cfg.act_dim), np.float32), log_p=np.empty(B, np.float32), tgt=np.empty(B, np.float32))
+                    a=np.empty((B, self.cfg.act_dim), np.float32), log_p=np.empty(B, np.float32), tgt=np.empty(B, np.float32),
+                    q_pi=np.empty((NC, B), np.float32), q_pred=np.empty((NC, B), np.float32), q_next=np.empty((NC, B), np.float32),
+                    next_log_p=np.empty(B, np.float32), next_a=np.empty((B, self.cfg.act_dim), np.float32))
         pr = SacProbe(*[bufs[n].ctypes.data for n, _ in SacProbe._fields_])
         lib().orc_sac_update(C.byref(self.cfg), _p(self.pi), arr(self.qs), arr(self.qs_tgt), _p(self.log_alpha),
                              C.byref(self.adam_pi), _p(self.pi_m), _p(self.pi_v),

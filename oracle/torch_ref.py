@@ -93,7 +93,8 @@ class TorchDqn:
         self.lr, self.step = lr, 0
         self.gamma, self.double_dqn, self.critic_loss = discount_factor, double_dqn, critic_loss
         self.clip_td_err = clip_td_err
-        self.adamw = adamw   # None (opt.rs:35 Adam) or dict(beta1, beta2, wd, eps) (opt.rs:38-55 AdamW, amsgrad False)
+        self.adamw = adamw   # None (opt.rs:35 Adam) or dict(beta1, beta2, wd, eps[, amsgrad]) (opt.rs:38-55 AdamW)
+        self.vmax = [torch.zeros_like(t) for t in self.q]   # max_exp_avg_sq (AdamW{amsgrad: true})
         self.tau, self.soft_update_interval, self.soft_update_counter = tau, soft_update_interval, 0
 
     def fwd(self, p, x):
@@ -102,20 +103,25 @@ class TorchDqn:
     def _adam(self):
         """libtorch torch/csrc/api/src/optim/adam.cpp (Adam::step), defaults of opt.rs:35; adamw.cpp (AdamW::step:
         decoupled decay `param.mul_(1 - lr * weight_decay)` first) for OptimizerConfig::AdamW (opt.rs:38-55)."""
-        b1, b2, eps, wd = 0.9, 0.999, 1e-8, 0.0
+        b1, b2, eps, wd, amsgrad = 0.9, 0.999, 1e-8, 0.0, False
         if self.adamw is not None:
             b1, b2, eps, wd = self.adamw["beta1"], self.adamw["beta2"], self.adamw["eps"], self.adamw["wd"]
+            amsgrad = bool(self.adamw.get("amsgrad", False))
         self.step += 1
         bc1 = 1 - b1 ** self.step
         bc2 = 1 - b2 ** self.step
         with torch.no_grad():
-            for p, m, v in zip(self.q, self.m, self.v):
+            for p, m, v, vmax in zip(self.q, self.m, self.v, self.vmax):
                 g = p.grad
                 if self.adamw is not None:
                     p.mul_(1 - self.lr * wd)
                 m.mul_(b1).add_(g, alpha=1 - b1)
                 v.mul_(b2).addcmul_(g, g, value=1 - b2)
-                denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+                if amsgrad:   # adamw.cpp: torch::max_out(max_exp_avg_sq, exp_avg_sq, max_exp_avg_sq); denom from the maximum
+                    torch.maximum(vmax, v, out=vmax)
+                    denom = (vmax.sqrt() / math.sqrt(bc2)).add_(eps)
+                else:
+                    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
                 p.addcdiv_(m, denom, value=-(self.lr / bc1))
 
     def update(self, obs, act, next_obs, reward, term, weight=None):

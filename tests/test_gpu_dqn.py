@@ -160,8 +160,12 @@ def test_opt_over_replay_matches_oracle_pipeline(B):
         b = oref.batch(Bsz)
         r = ref.update(b["obs"].reshape(Bsz, 4, 1, 84, 84), b["act"].view(np.int64).ravel(),
                        b["next_obs"].reshape(Bsz, 4, 1, 84, 84), b["reward"], b["is_terminated"], probe=True)
-        assert rel(a.probe("q_pred_all", Bsz * 6), r["q_pred_all"].ravel()) < 3e-4, step
-        assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-7
+        # step 0 carries the parity bar (north_star: 1e-4 on Q-values for a fixed seed and minibatch): both sides start from the same
+        # parameters.  From step 1 on the two sides have taken one Adam step each, and Adam's first steps move a weight whose
+        # gradient is within round-off of 0 by +-lr on either side (sign of m / sqrt(v)): 3e-4 on the Q-values of later steps
+        tol = QTOL if step == 0 else 3e-4
+        assert rel(a.probe("q_pred_all", Bsz * 6), r["q_pred_all"].ravel()) < tol, (step, rel(a.probe("q_pred_all", Bsz * 6), r["q_pred_all"].ravel()))
+        assert abs(rec["loss"] - r["loss"]) <= tol * abs(r["loss"]) + 1e-7
         assert abs(rec["reward_mean"] - b["reward"].mean()) < 1e-6
     assert a.n_opts == 3
     assert rel(a.get_params("qnet_tgt"), ref.q_tgt) < 1e-3
@@ -373,6 +377,49 @@ def test_mlp_adamw_matches_aten(B):
         assert abs(rec["loss"] - r["loss"]) <= QTOL * abs(r["loss"]) + 1e-9
         d = np.abs(a.get_params("qnet").astype(np.float64) - t.params())
         assert d.max() < 0.05 * 2e-3, (s, d.max())          # a small fraction of one optimizer step
+    a.close()
+
+
+@pytest.mark.parametrize("kind", ["mlp", "cnn"])
+def test_adamw_amsgrad_matches_aten(B, kind):
+    """OptimizerConfig::AdamW{amsgrad: true} (opt.rs:20-27, 45-53): the denominator uses the running maximum of exp_avg_sq.  Batches
+    are scaled so the second moment really shrinks between steps (otherwise amsgrad == plain AdamW and the test proves nothing):
+    steps vs the ATen restatement (itself checked against torch.optim.AdamW(amsgrad=True) in tests/test_oracle_dqn.py), the
+    max_exp_avg_sq arena, and the same run over the replay ring (Agent::opt) stays finite and differs from plain AdamW."""
+    from oracle import torch_ref as T
+    kw = dict(beta1=0.8, beta2=0.9, wd=0.05, eps=1e-6, amsgrad=True)
+    if kind == "mlp":
+        shapes, lr = T.mlp_shapes(4, [64, 64], 2), 2e-3
+        qc = B.MlpConfig(in_dim=4, units=(64, 64), out_dim=2)
+        p0 = T.init_params(shapes, 23)
+        batches = [_cart(s) for s in range(6)]
+    else:
+        shapes, lr = T.cnn_shapes(6), 1e-4
+        qc = B.AtariCnnConfig(n_stack=4, out_dim=6)
+        p0 = T.init_params(shapes, 5)
+        batches = [T.synthetic_atari_batch(8, 6, 70 + s) for s in range(6)]
+    # rewards x10 on the first two steps: large gradients first, small ones after -> exp_avg_sq decays below its maximum
+    batches = [(o, a_, n, (r * (10.0 if s < 2 else 0.1)).astype(np.float32), t) for s, (o, a_, n, r, t) in enumerate(batches)]
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=qc, opt_config=B.OptimizerConfig.AdamW(lr, **kw)),
+                      device=0, batch_size=len(batches[0][3]), critic_loss="SmoothL1", tau=0.01, soft_update_interval=1)
+    a = B.Dqn.build(cfg)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    t = T.TorchDqn(kind, shapes, p0, lr=lr, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, adamw=kw)
+    plain = T.TorchDqn(kind, shapes, p0, lr=lr, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, adamw=dict(kw, amsgrad=False))
+    for s, batch in enumerate(batches):
+        r = t.update(*batch)
+        plain.update(*batch)
+        rec = a.update_on_batch(*batch)
+        assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-9, (s, rec["loss"], r["loss"])
+        d = np.abs(a.get_params("qnet").astype(np.float64) - t.params())
+        assert d.max() < 0.1 * lr, (s, d.max())
+    assert a.n_opts == len(batches)
+    vmax, v = a.get_params("max_exp_avg_sq"), a.get_params("exp_avg_sq")
+    assert (vmax >= v).all() and (vmax > v * 1.5).mean() > 0.2            # the maximum really is ahead of the decayed second moment
+    ref_vmax = np.concatenate([x.numpy().ravel() for x in t.vmax])
+    assert np.abs(vmax - ref_vmax).max() <= 2e-3 * np.abs(ref_vmax).max()
+    # ... and amsgrad is not a no-op here: the restatement with and without it has moved apart by more than the tolerance above
+    assert np.abs(t.params() - plain.params()).max() > 0.5 * lr
     a.close()
 
 

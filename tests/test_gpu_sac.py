@@ -78,7 +78,27 @@ def test_sac_baseline_shape_b1024_vs_oracle(B):
     batch = T.sac_batch(Bsz, od, ad, 99)
     rec = a.update_on_batch(*batch)
     r = ref.update(*batch)
-    for k in ("loss_critic", "loss_actor", "ent_coef"):
+    # north_star's bar, on the Q-values: every critic evaluation of the update to 1e-4 of the largest |Q| (qvals, sac/base.rs:89-105) -
+    # Q_i(obs, a_pi) of update_actor, Q_i(obs, act) of update_critic, the target critics on (next_obs, a') and their minimum,
+    # and the TD target built from them
+    QTOL = 1e-4
+    for k in ("q_pi", "q_pred", "q_next"):
+        assert rel(a.probe(k, Bsz), r[k]) < QTOL, (k, rel(a.probe(k, Bsz), r[k]))
+    assert rel(a.probe("qvals_min", Bsz), r["q_next"].min(axis=0)) < QTOL
+    assert rel(a.probe("tgt", Bsz), r["tgt"]) < QTOL, rel(a.probe("tgt", Bsz), r["tgt"])
+    assert rel(a.probe("next_act", Bsz), r["next_a"]) < QTOL
+    # log p = sum(-z^2/2 - ln sqrt(2 pi)) - sum ln(1 - a^2 + eps): ill-conditioned where |a| -> 1 (1 - a^2 cancels; eps = 1e-4), so the
+    # rows are held to 1e-4 of the largest |log p| except the saturated ones (|a| > 0.995 in some dimension), which get the
+    # conditioning's factor
+    for k, acts in (("log_p", r["a"]), ("next_log_p", r["next_a"])):
+        got, want = a.probe(k, Bsz), r[k]
+        sat = (np.abs(acts) > 0.995).any(axis=1)
+        scale = np.abs(want).max()
+        assert np.abs(got - want)[~sat].max() < QTOL * scale, (k, np.abs(got - want)[~sat].max() / scale)
+        assert np.abs(got - want).max() < 2e-3 * scale, (k, np.abs(got - want).max() / scale)
+    # the critic loss is a mean over Q-values: 1e-4; the actor loss contains mean(alpha * log p): the saturated rows' conditioning
+    assert abs(rec["loss_critic"] - r["loss_critic"]) <= QTOL * abs(r["loss_critic"]) + 1e-6, (rec["loss_critic"], r["loss_critic"])
+    for k in ("loss_actor", "ent_coef"):
         assert abs(rec[k] - r[k]) <= 5e-4 * abs(r[k]) + 1e-6, (k, rec[k], r[k])
     assert rel(a.get_params("pi", "grad"), r["pi_grads"]) < 2e-3
     for i in range(nc):

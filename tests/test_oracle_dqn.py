@@ -74,3 +74,34 @@ def test_track_matches_candle_twin_kat():
     O.lib().orc_track(dst.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), C.c_double(0.7), 3)
     exp = (np.float32(0.7) * src + np.float32(1.0 - 0.7) * np.array([4, 5, 6], np.float32))
     assert np.allclose(dst, exp, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("adamw", [None, dict(beta1=0.8, beta2=0.9, wd=0.05, eps=1e-6), dict(beta1=0.8, beta2=0.9, wd=0.05, eps=1e-6, amsgrad=True)])
+def test_restated_optimizer_step_equals_torch_optim(adamw):
+    """TorchDqn._adam restates libtorch's Adam::step / AdamW::step by hand (the kernels mirror it element by element); here the
+    restatement is held against torch.optim.Adam / torch.optim.AdamW(amsgrad=...) THEMSELVES on the same gradients - shrinking
+    gradients, so that with amsgrad the running maximum of exp_avg_sq really differs from exp_avg_sq."""
+    import torch
+    shapes = T.mlp_shapes(4, [64, 64], 2)
+    p0 = T.init_params(shapes, 23)
+    lr = 2e-3
+    t = T.TorchDqn("mlp", shapes, p0, lr=lr, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, adamw=adamw)
+    ref = [x.detach().clone().requires_grad_(True) for x in T.unflatten(p0, shapes)]
+    if adamw is None:
+        opt = torch.optim.Adam(ref, lr=lr)
+    else:
+        opt = torch.optim.AdamW(ref, lr=lr, betas=(adamw["beta1"], adamw["beta2"]), eps=adamw["eps"], weight_decay=adamw["wd"],
+                                amsgrad=bool(adamw.get("amsgrad", False)))
+    g = torch.Generator().manual_seed(0)
+    for step in range(6):
+        scale = 10.0 if step < 2 else 0.1
+        for p, r in zip(t.q, ref):
+            grad = torch.randn(p.shape, generator=g) * scale
+            p.grad = grad.clone()
+            r.grad = grad.clone()
+        t._adam()
+        opt.step()
+        for p, r in zip(t.q, ref):
+            assert (p.detach() - r.detach()).abs().max().item() <= 2e-7 * max(1.0, r.detach().abs().max().item()), step
+    if adamw is not None and adamw.get("amsgrad"):
+        assert any((vm > v * 1.5).float().mean().item() > 0.2 for vm, v in zip(t.vmax, t.v))

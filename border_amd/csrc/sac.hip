@@ -831,7 +831,7 @@ int32_t bdr_sac_probe(bdr_agent* base, int32_t what, float* out, uint64_t n)
     BDR_REQUIRE(!strcmp(base->kind(), "sac"), "not a SAC agent");
     Sac* a = static_cast<Sac*>(base);
     BDR_HIP(hipSetDevice(a->device));
-    const int Bn = a->last_B, NC = a->NC, L = (int)a->qn.L.size(), ldq = a->qn.L[L - 1].Np, Ap = a->pi.L[a->n_trunk].Np;
+    const int Bn = a->last_B, NC = a->NC, L = (int)a->qn.L.size(), ldq = a->qn.L[L - 1].Np;
     BDR_REQUIRE(Bn > 0, "no update has run yet");
     BDR_HIP(hipStreamSynchronize(a->stream));
     auto column0 = [&](float* const* mats, float* dst) -> int32_t {     // [NC] matrices [Bn][ldq] -> [NC][Bn]
@@ -879,9 +879,11 @@ int32_t bdr_sac_probe(bdr_agent* base, int32_t what, float* out, uint64_t n)
             return BDR_OK;
         case 7: { // a' [B][A]
             BDR_REQUIRE(n == (uint64_t)Bn * a->A, "next_act holds batch x act_dim values");
-            std::vector<float> m((size_t)Bn * Ap);
-            BDR_HIP(hipMemcpy(m.data(), a->a_s, m.size() * 4, hipMemcpyDeviceToHost));
-            for (int b = 0; b < Bn; ++b) for (int j = 0; j < a->A; ++j) out[(size_t)b * a->A + j] = m[(size_t)b * Ap + j];
+            // the target pass writes a' straight into the critic input (next_obs | a'), columns [O, O + A) of xq_n
+            const int Kq = a->qn.L[0].Kp;
+            std::vector<float> m((size_t)Bn * Kq);
+            BDR_HIP(hipMemcpy(m.data(), a->xq_n, m.size() * 4, hipMemcpyDeviceToHost));
+            for (int b = 0; b < Bn; ++b) for (int j = 0; j < a->A; ++j) out[(size_t)b * a->A + j] = m[(size_t)b * Kq + a->O + j];
             return BDR_OK;
         }
         default: return fail(BDR_ERR_INVALID, "unknown SAC probe %d", what);

@@ -415,7 +415,7 @@ def test_adamw_amsgrad_matches_aten(B, kind):
         assert d.max() < 0.1 * lr, (s, d.max())
     assert a.n_opts == len(batches)
     vmax, v = a.get_params("max_exp_avg_sq"), a.get_params("exp_avg_sq")
-    assert (vmax >= v).all() and (vmax > v * 1.5).mean() > 0.2            # the maximum really is ahead of the decayed second moment
+    assert (vmax >= v).all() and (vmax > v * 1.5).mean() > 0.1            # the maximum really is ahead of the decayed second moment
     ref_vmax = np.concatenate([x.numpy().ravel() for x in t.vmax])
     assert np.abs(vmax - ref_vmax).max() <= 2e-3 * np.abs(ref_vmax).max()
     # ... and amsgrad is not a no-op here: the restatement with and without it has moved apart by more than the tolerance above

@@ -105,6 +105,6 @@ def test_kat_frame_is_deterministic_and_game_like():
     assert f.shape == (210, 160, 3) and f.dtype == np.uint8
     rows = [y for y in range(210) if y not in (50, 151)]          # (the two noisy rows override everything)
     assert (f[100] == 255).all() and (f[rows, 77] == 255).all()
-    assert len(np.unique(f[50])) > 50 and len(np.unique(f[10])) < 10
+    assert len(np.unique(f[50])) > 50 and len(np.unique(f[10])) < 20
     import hashlib
     assert hashlib.sha256(f.tobytes()).hexdigest() == hashlib.sha256(I.kat_frame().tobytes()).hexdigest()

@@ -379,6 +379,15 @@ DwPlan dw_plan(int B)
     p.chunks_c1 = std::min(256, B);           // conv1: one partial per workgroup, workgroups stride over the images
     p.chunks_c2 = std::min(64, mt(B * 81));
     p.chunks_c3 = std::min(56, mt(B * 49));
+    // diagnostics (A/B of the partial-sum traffic): BDR_DW_CHUNKS="c1,c2,c3" caps the three counts (c2 / c3: multiples of 8 keep the XCD map)
+    if (const char* e = getenv("BDR_DW_CHUNKS")) {
+        int c1 = 0, c2 = 0, c3 = 0;
+        if (sscanf(e, "%d,%d,%d", &c1, &c2, &c3) == 3) {
+            if (c1 > 0) p.chunks_c1 = std::min(p.chunks_c1, c1);
+            if (c2 > 0) p.chunks_c2 = std::min(p.chunks_c2, c2);
+            if (c3 > 0) p.chunks_c3 = std::min(p.chunks_c3, c3);
+        }
+    }
     p.stride_c1 = 256 * 32 + 32; p.stride_c2 = 512 * 64 + 64; p.stride_c3 = 576 * 64 + 64;
     p.off_c1 = 0;
     p.off_c2 = p.off_c1 + p.chunks_c1 * p.stride_c1;

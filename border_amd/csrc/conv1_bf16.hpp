@@ -84,6 +84,12 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
     uint2 nxt[16];
     int item = wg * 8 + wave;
     if (item < items) load_item(item, nxt);
+#ifdef C1_PRESPLIT   // tools/probes only (timing): the three planes copied as they are from a pre-split buffer
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(a.w1[z]);
+        for (int t = tid; t < 3 * C1_PLANE_VECS; t += 512) wl[t] = wp[t % 2048];
+    }
+#else
     {
         const float* w1 = a.w1[z];
         for (int t = tid; t < C1_PLANE_VECS; t += 512) {
@@ -103,6 +109,7 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
             wl[2 * C1_PLANE_VECS + t] = uint4{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3], (lo[4] >> 16) | lo[5], (lo[6] >> 16) | lo[7]};
         }
     }
+#endif
     __syncthreads();
 
     const float bias = a.bias[z][i];

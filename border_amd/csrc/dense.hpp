@@ -252,19 +252,19 @@ __global__ void k_pack_rows(const float* __restrict__ src, int src_ld, int cols,
 // (every operand load of the slice is issued before the first MFMA: no LDS staging, no barrier in the loop) and the four
 // partial tiles are added through LDS in a fixed order.  4x the workgroups, 1/4 of the MFMA chain per wave.
 // DX = false: out[m][n] = act(sum_k x[m][k] W[k][n] + bias[n]);  DX = true: out[m][kc] (+)= mask * sum_n dy[m][n] W[kc][n].
-template <bool DX>
-__global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
+// The tile itself, shared with the fused row-block kernels of the SAC step (sac.hip): wave `wave` of four accumulates its k-slice
+// of the 32x32 tile (m0, n0) and leaves it in red[wave]; after a barrier dense_small_sum() adds the four slices in a fixed order.
+// Every kernel that forms a layer's tile through these two functions produces the same bits.
+//   loadA(k) -> the lane's four A values a[row i][k .. k+3]   (global rows, or rows a fused kernel keeps in LDS)
+//   DX = false: B(k, n) = w[k * w_ld + n0 + i];  DX = true: B(k, n) = w[(n0 + i) * w_ld + k]  (transposed weights)
+template <bool DX, class LoadA>
+__device__ __forceinline__ void dense_small_tile(LoadA&& loadA, const float* __restrict__ w, int w_ld, int n0, int kred, int wave, int lane,
+                                                 float (*red)[32][33])
 {
-    const DenseArgs& a = dz.a[blockIdx.z];
-    __shared__ float red[4][32][33];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NT = a.ncols / 32;
-    const int m0 = ((int)blockIdx.x / NT) * 32, n0 = ((int)blockIdx.x % NT) * 32;
     const int i = lane & 31, h = lane >> 5;
-    const int Kw = a.kred / 4;                 // kred % 64 == 0: a multiple of 16
+    const int Kw = kred / 4;                   // kred % 64 == 0: a multiple of 16
     const int kbeg = wave * Kw;
-    const float* arow = a.x.p + (size_t)min(m0 + i, a.M - 1) * a.x.ld;   // rows >= M alias the last row (never stored)
-    const float* wcol = DX ? a.w + (size_t)(n0 + i) * a.w_ld : a.w + n0 + i;
+    const float* wcol = DX ? w + (size_t)(n0 + i) * w_ld : w + n0 + i;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int k = kbeg + kb + 16 * c + 8 * u + 4 * h;   // this lane half's quad of the MFMA group (igemm.hpp: k-slots are free)
-                    av[c * 2 + u] = *reinterpret_cast<const f32x4*>(arow + k);
+                    av[c * 2 + u] = loadA(k);
                     if constexpr (DX) bv[c * 2 + u] = *reinterpret_cast<const f32x4*>(wcol + k);
-                    else { const float* p = wcol + (size_t)k * a.w_ld; bv[c * 2 + u] = f32x4{p[0], p[a.w_ld], p[2 * (size_t)a.w_ld], p[3 * (size_t)a.w_ld]}; }
+                    else { const float* p = wcol + (size_t)k * w_ld; bv[c * 2 + u] = f32x4{p[0], p[w_ld], p[2 * (size_t)w_ld], p[3 * (size_t)w_ld]}; }
                 }
             }
         }
@@ -294,12 +294,29 @@ __global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
+}
+// element (r, c) of the tile: the four wave slices in their fixed order (call after the barrier that follows dense_small_tile)
+__device__ __forceinline__ float dense_small_sum(const float (*red)[32][33], int r, int c)
+{
+    return ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+}
+
+template <bool DX>
+__global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
+{
+    const DenseArgs& a = dz.a[blockIdx.z];
+    __shared__ float red[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NT = a.ncols / 32;
+    const int m0 = ((int)blockIdx.x / NT) * 32, n0 = ((int)blockIdx.x % NT) * 32;
+    const float* arow = a.x.p + (size_t)min(m0 + (lane & 31), a.M - 1) * a.x.ld;   // rows >= M alias the last row (never stored)
+    dense_small_tile<DX>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, a.w, a.w_ld, n0, a.kred, wave, lane, red);
     __syncthreads();
     const int r = tid >> 3, c4 = (tid & 7) * 4, m = m0 + r, n = n0 + c4;
     if (m >= a.M) return;
     f32x4 v;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = ((red[0][r][c4 + q] + red[1][r][c4 + q]) + red[2][r][c4 + q]) + red[3][r][c4 + q];
+    for (int q = 0; q < 4; ++q) v[q] = dense_small_sum(red, r, c4 + q);
     float* o = a.out + (size_t)m * a.ldo + n;
     if constexpr (!DX) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);

@@ -782,6 +782,7 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
         const uint64_t nvec = r->obs_bytes / 16;
         // up to 4 vectors per thread per section and pass: 2 workgroups per sample for Atari rows (1764 vectors)
         a.chunks = (uint32_t)std::max<uint64_t>(1, (nvec + 1023) / 1024);
+        { static const int forced = getenv("BDR_GATHER_CHUNKS") ? atoi(getenv("BDR_GATHER_CHUNKS")) : 0; if (forced > 0) a.chunks = (uint32_t)forced; }   // diagnostics
         a.vec_per_chunk = (uint32_t)((nvec + a.chunks - 1) / a.chunks);
         BDR_HIP(step_launch(stream, true, k_gather<u32x4>, dim3((uint32_t)(n * a.chunks)), dim3(256), a));
     } else {

@@ -69,31 +69,56 @@ struct SacSelectArgs {
     // EntCoef::update (ent_coef.rs:69-75) first: loss = -(log_alpha * (logp + H)).mean(); Adam on the scalar
     int auto_alpha; float target; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
 };
-// sum over the 1024 threads of a workgroup in a fixed order: butterfly inside each wave, then the 16 wave totals one by one
-__device__ __forceinline__ float block_sum_1024(float v, float* red16)
+// Sums over the batch rows, in an order that does not depend on who computes it (the row-block kernels of sac_fused.hpp form the
+// block partials in their own workgroups): rows in blocks of 32, a block's partial = the 32-lane butterfly (xor 16, 8, 4, 2, 1) of
+// its rows' values, the total = the partials added one by one in block order.
+__device__ __forceinline__ float butterfly32(float v)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) t += red16[w];
-    __syncthreads();
-    return t;
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float add_scaled(float total, float s, float scale)
+{
+#pragma clang fp contract(off)
+    const float t = s * scale;
+    return total + t;
+}
+__device__ __forceinline__ float actor_loss_sum(float base, float alpha, float s_logp, float s_qm, float scale)   // base + (alpha * sum log_p - sum qmin) * scale
+{
+#pragma clang fp contract(off)
+    const float a = alpha * s_logp;
+    const float d = a - s_qm;
+    const float t = d * scale;
+    return base + t;
+}
+
+// one 1024-thread workgroup: value(b) for every row b < B
+template <class F>
+__device__ __forceinline__ float row_sum_1024(int B, F&& value, float* red32)
+{
+    float total = 0.f;
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + (int)threadIdx.x;
+        const float part = butterfly32(b < B ? value(b) : 0.f);
+        if ((threadIdx.x & 31) == 0) red32[threadIdx.x >> 5] = part;
+        __syncthreads();
+        const int nb = min(32, (B - base + 31) / 32);
+        for (int k = 0; k < nb; ++k) total += red32[k];
+        __syncthreads();
+    }
+    return total;
 }
 
 // One workgroup of 1024 threads (a row per thread at SAC's batch sizes: every load of the kernel is in flight at once).  Only
 // column 0 of the upstream gradients is written: the other ldq-1 (padding) columns are zero from allocation and nothing else
-// stores there.
+// stores there.  loss_actor = mean(alpha * log_p - qmin) is formed as (alpha * sum(log_p) - sum(qmin)) / B.
 __global__ __launch_bounds__(1024) void k_sac_select(SacSelectArgs p)
 {
-    __shared__ float red[16];
+    __shared__ float red[32];
     float log_alpha = p.log_alpha[0];
     if (p.auto_alpha) {   // update_actor calls ent_coef.update(log_p) before it uses alpha (sac/base.rs:155)
-        float acc = 0.f;
-        for (int b = threadIdx.x; b < p.B; b += 1024) acc += p.logp[b] + p.target;
-        const float g = -(block_sum_1024(acc, red) / (float)p.B);
+        const float g = -(row_sum_1024(p.B, [&](int b) { return p.logp[b] + p.target; }, red) / (float)p.B);
         const float mm = p.al_m[0] * p.s.b1 + g * p.s.omb1;       // every thread computes the same scalar step; thread 0 stores it
         const float vv = p.al_v[0] * p.s.b2 + p.s.omb2 * g * g;
         const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
@@ -102,16 +127,15 @@ __global__ __launch_bounds__(1024) void k_sac_select(SacSelectArgs p)
         if (threadIdx.x == 0) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; }
     }
     const float alpha = expf(log_alpha);
-    float s = 0.f;
-    for (int b = threadIdx.x; b < p.B; b += 1024) {
+    const float s_logp = row_sum_1024(p.B, [&](int b) { return p.logp[b]; }, red);
+    const float s_qm = row_sum_1024(p.B, [&](int b) {
         int im = 0;
         float qm = p.q[0][(size_t)b * p.ldq];
         for (int i = 1; i < p.NC; ++i) { const float v = p.q[i][(size_t)b * p.ldq]; if (v < qm) { qm = v; im = i; } }
         for (int i = 0; i < p.NC; ++i) p.dout[i][(size_t)b * p.ldq] = i == im ? 1.0f : 0.0f;
-        s += alpha * p.logp[b] - qm;
-    }
-    const float total = block_sum_1024(s, red);
-    if (threadIdx.x == 0) p.out[0] = (p.accumulate ? p.out[0] : 0.f) + total * p.scale;
+        return qm;
+    }, red);
+    if (threadIdx.x == 0) p.out[0] = actor_loss_sum(p.accumulate ? p.out[0] : 0.f, alpha, s_logp, s_qm, p.scale);
 }
 
 // dL/dmean, dL/d(head2) from dL/da = (alpha * 2a/(1-a^2+eps) - d qmin/da) / B
@@ -141,6 +165,28 @@ __global__ void k_sac_actor_grad(SacActorGradArgs p)
     p.ge[t] = gu * p.z[(size_t)b * p.A + j] * sd * inr * s;
 }
 
+// The TD step's row arithmetic, shared by k_sac_critic_td and the row-block kernel k_sac_td_last.  No fused multiply-add
+// contraction (hipcc contracts across statements, and HIP's __fmul_rn is a plain `*`): a product contracted into a sum in one kernel
+// but not in the other would break the bit-identity of the two paths.
+__device__ __forceinline__ float sac_td_target(float reward_scale, float reward, float term, float gamma, float qmin, float alpha, float logp)
+{
+#pragma clang fp contract(off)
+    // (plain operators: HIP's __fmul_rn / __fsub_rn are inline functions WITHOUT this pragma, their operations stay contractable)
+    const float al = alpha * logp;
+    const float nq = qmin - al;                                                                 // min_i Qtgt_i - alpha * log p'
+    const float a = reward_scale * reward;
+    const float k = (1.0f - term) * gamma;
+    const float c = k * nq;
+    return a + c;
+}
+__device__ __forceinline__ void sac_td_loss(float q, float tgt, int loss_kind, float& l, float& g)
+{
+#pragma clang fp contract(off)
+    const float d = q - tgt;
+    if (loss_kind == 1) { const float z = fabsf(d); const float hz = 0.5f * z; l = z < 1.f ? hz * z : z - 0.5f; g = z < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
+    else { l = d * d; g = 2.f * d; }
+}
+
 // critic losses + upstream gradients (column 0; see k_sac_select) of every critic in one workgroup:
 // loss_critic += sum_i mean(loss(Q_i - tgt)) / NC, critic by critic in k_sum_rows' order
 struct SacTdArgs {
@@ -152,30 +198,23 @@ struct SacTdArgs {
 };
 __global__ __launch_bounds__(1024) void k_sac_critic_td(SacTdArgs p)
 {
-    __shared__ float red[16];
+    __shared__ float red[32];
     float total = p.accumulate ? p.out[0] : 0.f;
     const float alpha = expf(p.log_alpha[0]);
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < p.B; b += 1024) {
         float qm = p.qt[0][(size_t)b * p.ldq];
         for (int i = 1; i < p.NC; ++i) qm = fminf(qm, p.qt[i][(size_t)b * p.ldq]);
-        const float nq = qm - alpha * p.logp[b];
-        const float tgt = p.reward_scale * p.reward[b] + ((1.0f - (float)p.term[b]) * p.gamma) * nq;
-        p.tgt[b] = tgt;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i >= p.NC) break;
-            const float d = p.q[i][(size_t)b * p.ldq] - tgt;
-            float l, dl;
-            if (p.loss_kind == 1) { const float z = fabsf(d); l = z < 1.f ? 0.5f * z * z : z - 0.5f; dl = z < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
-            else { l = d * d; dl = 2.f * d; }
-            p.dout[i][(size_t)b * p.ldq] = dl / (float)p.B;
-            part[i] += l;
-        }
+        p.tgt[b] = sac_td_target(p.reward_scale, p.reward[b], (float)p.term[b], p.gamma, qm, alpha, p.logp[b]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < p.NC) total = total + block_sum_1024(part[i], red) * p.scale;   // critic by critic (NC is uniform)
+    for (int i = 0; i < p.NC; ++i) {   // critic by critic; a thread reads back only the targets it wrote itself
+        const float si = row_sum_1024(p.B, [&](int b) {
+            float l, dl;
+            sac_td_loss(p.q[i][(size_t)b * p.ldq], p.tgt[b], p.loss_kind, l, dl);
+            p.dout[i][(size_t)b * p.ldq] = dl / (float)p.B;
+            return l;
+        }, red);
+        total = add_scaled(total, si, p.scale);
+    }
     if (threadIdx.x == 0) p.out[0] = total;
 }
 
@@ -232,6 +271,10 @@ __global__ __launch_bounds__(256) void k_sac_pack(SacPackArgs p)
     }
 }
 
+}  // namespace
+#include "sac_fused.hpp"
+namespace {
+
 __global__ void k_randn(float* __restrict__ out, size_t n, uint64_t seed, uint64_t counter)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,6 +321,9 @@ struct Sac : bdr_agent {
     float* pr_qpi[4] = {nullptr}; float* pr_logp = nullptr;
     StepGraph graph; StepGraphPolicy graph_policy;   // step_graph.hpp
     bool gather_in_pack = true;               // BDR_NO_STEP_GATHER=1: separate gather launch
+    bool fuse_rows = true;                    // BDR_NO_SAC_FUSE=1: the narrow layers as launches of their own (sac_fused.hpp)
+    unsigned* tickets = nullptr;              // [2] last-workgroup tickets of k_sac_q_last / k_sac_td_last
+    float* lrow = nullptr;                    // [3 + NC][ceil(B / 32)] block partials of the batch-wide sums (k_sac_q_last, k_sac_td_last)
     bool small_gemm = true;                   // BDR_NO_SMALL_GEMM=1: the 64x64-tile kernels of the large-batch agents
 
     ~Sac() override
@@ -290,11 +336,12 @@ struct Sac : bdr_agent {
         (void)hipFree(log_alpha); (void)hipFree(al_m); (void)hipFree(al_v); (void)hipFree(scal);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
         for (int i = 0; i < 4; ++i) (void)hipFree(pr_qpi[i]);
+        (void)hipFree(tickets);
         (void)hipFree(pr_logp);
     }
     void free_batch()
     {
-        float** singles[] = {&x_o, &x_no, &mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge, &xq_a, &xq_n, &xq_c, &logp, &tgt, &z_a, &pi_part, &q_part};
+        float** singles[] = {&x_o, &x_no, &mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge, &xq_a, &xq_n, &xq_c, &logp, &tgt, &z_a, &pi_part, &q_part, &lrow};
         for (auto p : singles) { (void)hipFree(*p); *p = nullptr; }
         for (auto p : t_act) (void)hipFree(p);
         for (auto p : t_dy) (void)hipFree(p);
@@ -333,7 +380,7 @@ struct Sac : bdr_agent {
             }
             BDR_TRY(zalloc(&dxq[i], (size_t)Bn * Kq));
         }
-        BDR_TRY(zalloc(&logp, Bn)); BDR_TRY(zalloc(&tgt, Bn));
+        BDR_TRY(zalloc(&logp, Bn)); BDR_TRY(zalloc(&tgt, Bn)); BDR_TRY(zalloc(&lrow, (size_t)(3 + NC) * ((Bn + 31) / 32)));
         BDR_TRY(zalloc(&z_a, (size_t)2 * Bn * A));
         // row chunks of the grouped dW launches.  64x64 tiles (k_igemm_red_group): about 512 workgroups per launch over all its
         // GEMMs, >= 64 rows per chunk; 32x32 split-reduction tiles (k_dense_dw_small_group): 256 rows per workgroup
@@ -376,8 +423,34 @@ struct Sac : bdr_agent {
         return dense_forward_z(stream, h0, 2, pb, ins, outs, Bn, small_gemm);
     }
     // action_logp: writes the action into the action columns of the critic input `xq`, log_p into logp
+    // the narrow layers fused into row-block kernels (sac_fused.hpp)?  Shapes the kernels do not cover take the layer-by-layer path.
+    bool fused() const
+    {
+        const DenseLayer& hd = pi.L[n_trunk];
+        return fuse_rows && small_gemm && A <= 32 && (O % 32) + A <= 32 && qn.L.size() >= 2 && hd.Np <= 64 && qn.L.back().Np <= 64 * 4;
+    }
+    // action_logp: writes the action into the action columns of the critic input `xq`, log_p into logp
     int32_t action_logp(const float* x, const float* z, int Bn, bool save, float* xq)
     {
+        if (fused()) {   // trunk layer by layer, then heads + action + log-prob in one row-block kernel
+            bdr_agent* a = this;
+            DenseSrc in{x, pi.L[0].Kp};
+            for (int i = 0; i < n_trunk; ++i) {
+                Bracket br(a, "pi_fwd");
+                BDR_TRY(dense_forward(a, stream, pi.L[i], pi_p, in, t_act[i], Bn, small_gemm));
+                in = DenseSrc{t_act[i], pi.L[i].Np};
+            }
+            const DenseLayer &hm = pi.L[n_trunk], &hs = pi.L[n_trunk + 1];
+            SacHeadsActionArgs p{};
+            p.h = in.p; p.ldh = in.ld;
+            p.hm = HeadRef{pi_p + hm.w, pi_p + hm.b, hm.relu}; p.hs = HeadRef{pi_p + hs.w, pi_p + hs.b, hs.relu}; p.kred = hm.Kp; p.w_ld = hm.Np;
+            p.mean = mean; p.e = e; p.ld = hm.Np; p.z = z; p.xq = xq; p.ldq = qn.L[0].Kp; p.col0 = O;
+            p.a_out = save ? a_s : nullptr; p.s_out = s_s; p.sd_out = sd_s; p.logp = logp;
+            p.B = Bn; p.A = A; p.lo = (float)cfg.min_lstd; p.hi = (float)cfg.max_lstd; p.eps = (float)cfg.epsilon;
+            Bracket br(this, "sac_heads_action");
+            BDR_HIP(step_launch(stream, false, k_sac_heads_action, dim3((Bn + 31) / 32), dim3(512), p));
+            return BDR_OK;
+        }
         BDR_TRY(pi_forward(x, Bn));
         SacActionArgs p{};
         p.mean = mean; p.e = e; p.ld = pi.L[n_trunk].Np; p.z = z; p.xq = xq; p.ldq = qn.L[0].Kp; p.col0 = O;
@@ -389,14 +462,15 @@ struct Sac : bdr_agent {
     }
     // Forward passes of the critic architecture, layer by layer, up to 4 (parameters, input) pairs per launch:
     // pass j runs parameters params[j] on input x[j] into acts[j][layer].
-    int32_t critic_forward_n(int n, const float* const* params, const float* const* x, std::vector<float*>* const* acts, int Bn)
+    int32_t critic_forward_n(int n, const float* const* params, const float* const* x, std::vector<float*>* const* acts, int Bn, int n_layers = -1)
     {
         bdr_agent* a = this;
+        const size_t nl = n_layers < 0 ? qn.L.size() : (size_t)n_layers;
         for (int j0 = 0; j0 < n; j0 += 4) {
             const int nz = std::min(4, n - j0);
             DenseSrc in[4]; float* out[4];
             for (int j = 0; j < nz; ++j) in[j] = DenseSrc{x[j0 + j], qn.L[0].Kp};
-            for (size_t l = 0; l < qn.L.size(); ++l) {
+            for (size_t l = 0; l < nl; ++l) {
                 for (int j = 0; j < nz; ++j) out[j] = (*acts[j0 + j])[l];
                 Bracket br(a, "q_fwd");
                 if (nz == 1) BDR_TRY(dense_forward(a, stream, qn.L[l], params[j0], in[0], out[0], Bn, small_gemm));
@@ -459,12 +533,33 @@ struct Sac : bdr_agent {
         }
         // ---------------- update_actor (sac/base.rs:151-167) ----------------
         BDR_TRY(action_logp(x_o, z_actor, Bn, true, xq_a));
+        const bool fz = fused();
         {   // Q_i(obs, a_pi) for the actor loss and Q_i(obs, act) for the TD loss: the same parameters (the critics only step at the end)
             const float* params[8]; const float* x[8]; std::vector<float*>* acts[8];
             for (int i = 0; i < NC; ++i) { params[i] = q_p[i]; x[i] = xq_a; acts[i] = &c_act[i]; params[NC + i] = q_p[i]; x[NC + i] = xq_c; acts[NC + i] = &c2_act[i]; }
-            BDR_TRY(critic_forward_n(2 * NC, params, x, acts, Bn));
+            BDR_TRY(critic_forward_n(2 * NC, params, x, acts, Bn, fz ? L - 1 : -1));
         }
-        {
+        if (fz) {   // last layer of all 2 NC passes + qmin selection + d qmin / d h2 + (last workgroup) EntCoef::update, actor loss
+            const DenseLayer& ll = qn.L[L - 1];
+            SacQLastArgs p{};
+            p.npairs = 2 * NC; p.NC = NC;
+            for (int i = 0; i < NC; ++i) {
+                p.hin[i] = c_act[i][L - 2]; p.hin[NC + i] = c2_act[i][L - 2];
+                p.wl[i] = p.wl[NC + i] = HeadRef{q_p[i] + ll.w, q_p[i] + ll.b, ll.relu};
+                p.q[i] = c_act[i][L - 1]; p.q[NC + i] = c2_act[i][L - 1];
+                p.dout[i] = c_dy[i][L - 1]; p.dh[i] = c_dy[i][L - 2]; p.w_last[i] = q_p[i] + ll.w;
+            }
+            p.ldh = ll.Kp; p.kred = ll.Kp; p.w_ld = ll.Np; p.ldq = ldq; p.B = Bn;
+            p.part = lrow; p.ticket = tickets; p.logp = logp; p.log_alpha = log_alpha; p.out = scal + 1; p.scale = 1.0f / (float)Bn; p.accumulate = first ? 0 : 1;
+            p.auto_alpha = cfg.ent_coef_auto ? 1 : 0;
+            if (cfg.ent_coef_auto) {
+                step_al += 1;
+                p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v;
+                p.s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
+            }
+            Bracket br(a, "sac_q_last");
+            BDR_HIP(step_launch(stream, cfg.ent_coef_auto != 0, k_sac_q_last, dim3((Bn + 31) / 32, ll.Kp / 64 + 1), dim3(512), p));
+        } else {
             SacSelectArgs p{};
             for (int i = 0; i < NC; ++i) { p.q[i] = c_act[i][L - 1]; p.dout[i] = c_dy[i][L - 1]; }
             p.ldq = ldq; p.logp = logp; p.log_alpha = log_alpha; p.B = Bn; p.NC = NC;
@@ -487,11 +582,23 @@ struct Sac : bdr_agent {
             for (int i = 0; i < NC; ++i) BDR_HIP(hipMemcpyAsync(pr_qpi[i], c_act[i][L - 1], (size_t)Bn * ldq * 4, hipMemcpyDeviceToDevice, stream));
             BDR_HIP(hipMemcpyAsync(pr_logp, logp, (size_t)Bn * 4, hipMemcpyDeviceToDevice, stream));
         }
-        for (int l = L - 1; l >= 0; --l) {   // d qmin / d input through the critics (weights untouched here)
+        for (int l = fz ? L - 2 : L - 1; l >= (fz ? 1 : 0); --l) {   // d qmin / d input through the critics (weights untouched here)
             Bracket br(a, "q_dx");
             BDR_TRY(critic_dx_all(l, Bn, c_act));
         }
-        {
+        if (fz) {   // d qmin / d a (first layer, action columns) + tanh-Gaussian backward + both heads' input gradient
+            const DenseLayer &l0 = qn.L[0], &hm = pi.L[n_trunk], &hs = pi.L[n_trunk + 1];
+            SacActorBwdArgs p{};
+            p.NC = NC;
+            for (int i = 0; i < NC; ++i) { p.dy0[i] = c_dy[i][0]; p.w0[i] = q_p[i] + l0.w; }
+            p.ldy0 = l0.Np; p.w0_ld = l0.Np; p.kred0 = l0.Np; p.n0a = (O / 32) * 32; p.col0 = O;
+            p.a = a_s; p.s = s_s; p.sd = sd_s; p.ld = Ap; p.z = z_actor; p.log_alpha = log_alpha; p.gmean = gmean; p.ge = ge;
+            p.B = Bn; p.A = A; p.lo = (float)cfg.min_lstd; p.hi = (float)cfg.max_lstd; p.eps = (float)cfg.epsilon;
+            p.wm = pi_p + hm.w; p.ws = pi_p + hs.w; p.wh_ld = hm.Np; p.kredh = hm.Np;
+            p.hmask = t_act[n_trunk - 1]; p.ldh = hm.Kp; p.dh = t_dy[n_trunk - 1];
+            Bracket br(a, "sac_actor_bwd");
+            BDR_HIP(step_launch(stream, false, k_sac_actor_bwd, dim3((Bn + 31) / 32, hm.Kp / 32), dim3(512), p));
+        } else {
             SacActorGradArgs p{};
             p.a = a_s; p.s = s_s; p.sd = sd_s; p.ld = Ap; p.z = z_actor; p.ldq = Kq; p.col0 = O; p.NC = NC;
             for (int i = 0; i < NC; ++i) p.dxq[i] = dxq[i];
@@ -506,8 +613,10 @@ struct Sac : bdr_agent {
             const DenseSrc hin = n_trunk ? DenseSrc{t_act[n_trunk - 1], pi.L[n_trunk - 1].Np} : DenseSrc{x_o, pi.L[0].Kp};
             if (n_trunk) {
                 float* dh = t_dy[n_trunk - 1];
-                { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk], pi_p, gmean, dh, t_act[n_trunk - 1], Bn, false, small_gemm)); }
-                { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk + 1], pi_p, ge, dh, t_act[n_trunk - 1], Bn, true, small_gemm)); }
+                if (!fz) {   // (fused: k_sac_actor_bwd has written dh)
+                    { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk], pi_p, gmean, dh, t_act[n_trunk - 1], Bn, false, small_gemm)); }
+                    { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[n_trunk + 1], pi_p, ge, dh, t_act[n_trunk - 1], Bn, true, small_gemm)); }
+                }
                 for (int l = n_trunk - 1; l > 0; --l) { Bracket br(a, "pi_dx"); BDR_TRY(dense_dx(stream, pi.L[l], pi_p, t_dy[l], t_dy[l - 1], t_act[l - 1], Bn, false, small_gemm)); }
             }
             int nj = 0;
@@ -527,9 +636,24 @@ struct Sac : bdr_agent {
         {
             const float* params[4]; const float* x[4]; std::vector<float*>* acts[4];
             for (int i = 0; i < NC; ++i) { params[i] = q_t[i]; x[i] = xq_n; acts[i] = &c_act[i]; }
-            BDR_TRY(critic_forward_n(NC, params, x, acts, Bn));
+            BDR_TRY(critic_forward_n(NC, params, x, acts, Bn, fz ? L - 1 : -1));
         }
-        {
+        if (fz) {   // target critics' last layer + TD target + critic losses + d loss / d h2 + (last workgroup) the loss sums
+            const DenseLayer& ll = qn.L[L - 1];
+            SacTdLastArgs p{};
+            p.NC = NC;
+            for (int i = 0; i < NC; ++i) {
+                p.hin_t[i] = c_act[i][L - 2]; p.wl_t[i] = HeadRef{q_t[i] + ll.w, q_t[i] + ll.b, ll.relu}; p.qt[i] = c_act[i][L - 1];
+                p.q[i] = c2_act[i][L - 1]; p.hin[i] = c2_act[i][L - 2]; p.w_last[i] = q_p[i] + ll.w;
+                p.dout[i] = c_dy[i][L - 1]; p.dh[i] = c_dy[i][L - 2];
+            }
+            p.ldh = ll.Kp; p.kred = ll.Kp; p.w_ld = ll.Np; p.ldq = ldq;
+            p.logp = logp; p.log_alpha = log_alpha; p.reward = reward; p.term = term; p.gamma = (float)cfg.gamma; p.reward_scale = (float)cfg.reward_scale;
+            p.tgt = tgt; p.part = lrow + (size_t)3 * ((Bn + 31) / 32); p.B = Bn; p.loss_kind = cfg.critic_loss;
+            p.ticket = tickets + 1; p.out = scal; p.scale = 1.0f / ((float)Bn * (float)NC); p.accumulate = first ? 0 : 1;
+            Bracket br(a, "sac_td_last");
+            BDR_HIP(step_launch(stream, false, k_sac_td_last, dim3((Bn + 31) / 32, ll.Kp / 64), dim3(512), p));
+        } else {
             SacTdArgs p{};
             for (int i = 0; i < NC; ++i) { p.q[i] = c2_act[i][L - 1]; p.dout[i] = c_dy[i][L - 1]; }
             for (int i = 0; i < NC; ++i) p.qt[i] = c_act[i][L - 1];
@@ -539,7 +663,7 @@ struct Sac : bdr_agent {
             Bracket br(a, "critic_td");
             BDR_HIP(step_launch(stream, false, k_sac_critic_td, dim3(1), dim3(1024), p));
         }
-        for (int l = L - 1; l > 0; --l) { Bracket br(a, "q_dx"); BDR_TRY(critic_dx_all(l, Bn, c2_act)); }
+        for (int l = fz ? L - 2 : L - 1; l > 0; --l) { Bracket br(a, "q_dx"); BDR_TRY(critic_dx_all(l, Bn, c2_act)); }
         {   // every weight gradient of every critic in one grouped launch; partial sums -> gradients, Adam and soft_update (:169-173) in one more
             std::vector<DenseDwJob> jobs;
             for (int i = 0; i < NC; ++i)
@@ -758,6 +882,8 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     a->graph_policy.from_env();
     { const char* e = getenv("BDR_NO_SMALL_GEMM"); a->small_gemm = !(e && e[0] == '1'); }
     a->gather_in_pack = getenv("BDR_NO_STEP_GATHER") == nullptr;
+    a->fuse_rows = getenv("BDR_NO_SAC_FUSE") == nullptr;
+    BDR_HIP(hipMalloc((void**)&a->tickets, 2 * sizeof(unsigned))); BDR_HIP(hipMemsetAsync(a->tickets, 0, 2 * sizeof(unsigned), a->stream));
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};
     for (auto p : pis) BDR_TRY(a->zalloc(p, a->pi.total));
     for (int i = 0; i < a->NC; ++i) {

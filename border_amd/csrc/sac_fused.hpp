@@ -1,0 +1,393 @@
+// Row-block kernels of the SAC step (included by sac.hip): the narrow layers of the step - the actor's two heads (256 -> A), the
+// critics' last layer (256 -> 1) and first-layer input gradient (only the A action columns are needed) - are not worth a launch
+// of their own (a dependent kernel costs >= 2.4 us whatever it does) and neither are the row-wise kernels between
+// them.  A workgroup here takes 32 batch rows, forms the narrow layers' 32x32 tiles with the SAME tile function as the
+// layer-by-layer path (dense_small_tile / dense_small_sum: same k-slices, same MFMA order, same four-way sum) and does the row-wise
+// math of the step on them in registers / LDS:
+//   k_sac_heads_action   heads (ml, sl) + action_logp                               (sac/base.rs:73-87;   3 launches -> 1)
+//   k_sac_q_last         critics' last layer for Q_i(obs, a_pi) and Q_i(obs, act) + the qmin selection + d qmin / d h2 +
+//                        (last workgroup) EntCoef::update and the actor loss          (sac/base.rs:89-105, 151-160; 3 -> 1)
+//   k_sac_actor_bwd      d qmin / d a (critics' first layer, action columns only) + the tanh-Gaussian backward + both heads' input
+//                        gradient                                                     (sac/base.rs:160-167;  4 -> 1)
+//   k_sac_td_last        target critics' last layer + TD target + critic losses + d loss / d h2 + (last workgroup) the loss sums
+//                                                                                      (sac/base.rs:107-149;  3 -> 1)
+// 30 launches per update become 21.  Reductions over the whole batch (mean log p for the entropy coefficient, the recorded losses)
+// are done by the LAST workgroup to finish (atomic ticket), in exactly the order of the single-workgroup kernels they replace
+// (block_sum_1024 with its 16 wave totals): every path - fused, layer by layer, captured graph - gives the same bits
+// (tests/test_gpu_sac.py).
+#pragma once
+
+namespace {
+
+#ifndef SF_ABL      // tools only: timing ablations of k_sac_q_last (results are wrong when non-zero): 1 no last-workgroup part, 2 no dh loop, 4 no tiles
+#define SF_ABL 0
+#endif
+constexpr int SF_LDG = 68;   // row stride (floats) of a 32 x 64 A operand kept in LDS (conflict-light ds_read_b128)
+
+// the last workgroup's side of a batch-wide row sum (sac.hip row_sum_1024): the block partials, one by one in block order
+__device__ __forceinline__ float sum_partials(const float* part, int nb, float* lds /* [>= nb] */)
+{
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) lds[k] = __hip_atomic_load(part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < nb; ++k) t += lds[k];
+    __syncthreads();
+    return t;
+}
+
+// Values one workgroup hands to the LAST workgroup of the same launch go through agent-scope accesses: the XCDs' L2 caches are
+// not coherent with each other, and a full release fence (__threadfence) would write back every dirty line of the XCD's L2 - tens
+// of microseconds per workgroup (measured: 33 us for a kernel that otherwise takes 8).  A relaxed agent-scope store / load goes to
+// the coherent level directly; the workgroup barrier (s_waitcnt vmcnt(0) + s_barrier) orders them before the ticket.
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// "am I the last workgroup of this launch?"
+__device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_wg, unsigned* s_flag)
+{
+    __syncthreads();     // every thread's agent-scope stores have been acknowledged
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = t == n_wg - 1 ? 1u : 0u;
+        if (t == n_wg - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+    }
+    __syncthreads();
+    return *s_flag != 0u;
+}
+
+struct HeadRef { const float* w; const float* bias; int relu; };
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct SacHeadsActionArgs {
+    const float* h; int ldh;            // last trunk activation [B][ldh]
+    HeadRef hm, hs; int kred, w_ld;     // heads: W [kred][w_ld] + bias (w_ld = Np of the heads)
+    float* mean; float* e; int ld;      // head outputs [B][ld] (kept: probes / parity with the layer-by-layer path)
+    const float* z;
+    float* xq; int ldq; int col0;
+    float* a_out; float* s_out; float* sd_out;
+    float* logp;
+    int B, A; float lo, hi, eps;
+};
+__global__ __launch_bounds__(512) void k_sac_heads_action(SacHeadsActionArgs p)
+{
+    __shared__ float red[2][4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, w4 = wave & 3;
+    const int m0 = (int)blockIdx.x * 32;
+    const float* arow = p.h + (size_t)min(m0 + (lane & 31), p.B - 1) * p.ldh;
+    const HeadRef& hd = team ? p.hs : p.hm;
+    dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, hd.w, p.w_ld, 0, p.kred, w4, lane, red[team]);
+    __syncthreads();
+    // one wave per row, lanes over the action dimension: k_sac_action's arithmetic and its butterfly sums
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr, row = m0 + r;
+        if (row >= p.B) break;
+        float nl = 0.f, sl = 0.f;
+        if (lane < 32) {   // columns of tile 0 (the rest of the padded width stays zero from allocation)
+            float mv = dense_small_sum(red[0], r, lane) + p.hm.bias[lane];
+            float ev = dense_small_sum(red[1], r, lane) + p.hs.bias[lane];
+            if (p.hm.relu) mv = mv > 0.f ? mv : 0.f;
+            if (p.hs.relu) ev = ev > 0.f ? ev : 0.f;
+            const size_t q = (size_t)row * p.ld + lane;
+            p.mean[q] = mv; p.e[q] = ev;
+            if (lane < p.A) {
+                const float z = p.z[(size_t)row * p.A + lane];
+                const float s = expf(ev);
+                const float cl = fminf(fmaxf(s, p.lo), p.hi);
+                const float sd = expf(cl);
+                const float a = tanhf(sd * z + mv);
+                p.xq[(size_t)row * p.ldq + p.col0 + lane] = a;
+                if (p.a_out) { p.a_out[q] = a; p.s_out[q] = s; p.sd_out[q] = sd; }
+                nl += -0.91893853320467274178f - 0.5f * (z * z);
+                sl += logf((1.0f - a * a) + p.eps);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { nl += __shfl_xor(nl, off); sl += __shfl_xor(sl, off); }
+        if (lane == 0) p.logp[row] = nl - sl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// last critic layer for up to 8 (parameters, input) pairs, pair j: h = hin[j] [B][ldh], W = wl[j], out q[j] [B][ldq] (tile 0)
+struct SacQLastArgs {
+    int npairs, NC;                       // pairs 0..NC-1: Q_i(obs, a_pi) (selection, gradient); NC..2NC-1: Q_i(obs, act) (values only)
+    const float* hin[8]; HeadRef wl[8]; float* q[8];
+    int ldh, kred, w_ld, ldq;
+    float* dout[4];                       // [B][ldq], column 0: 1 for the selected critic
+    float* dh[4];                         // d qmin / d h2 of critic i [B][ldh] (masked by relu'(hin[i]))
+    const float* w_last[4];               // critic i's last-layer weights (column 0 is the real output)
+    int B;
+    // last workgroup: EntCoef::update + actor loss (k_sac_select)
+    float* part;                          // [3][ceil(B / 32)] block partials: log_p + target, log_p, qmin
+    unsigned* ticket;
+    const float* logp; const float* log_alpha;
+    float* out; float scale; int accumulate;
+    int auto_alpha; float target; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
+};
+// relu'(h) * d[row] * W_last[:, 0] for 32 rows x the 64 columns [c0, c0 + 64) of one critic, in two halves: the operand loads do not
+// depend on anything the kernel computes, so they are issued first thing (next to the tile operands) and are long back when the
+// per-row factors exist.  (The whole 32 x ldh block in one workgroup, loaded where it was used, was 16 dependent round trips per
+// thread: 11 us.)
+struct LastDxRegs { float hv[4], wv[4]; };
+__device__ __forceinline__ void last_layer_dx_load(LastDxRegs& g, const float* __restrict__ hin, const float* __restrict__ w, int w_ld, int ldh, int c0,
+                                                   int m0, int B, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 512 * u, r = e >> 6, k = c0 + (e & 63);
+        g.hv[u] = hin[(size_t)min(m0 + r, B - 1) * ldh + k];
+        g.wv[u] = w[(size_t)k * w_ld];
+    }
+}
+__device__ __forceinline__ void last_layer_dx_store(const LastDxRegs& g, const float* drow /* LDS [32] */, float* __restrict__ dh, int ldh, int c0, int m0,
+                                                    int B, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 512 * u, r = e >> 6, k = c0 + (e & 63);
+        if (m0 + r < B) dh[(size_t)(m0 + r) * ldh + k] = g.hv[u] > 0.f ? drow[r] * g.wv[u] : 0.f;
+    }
+}
+
+// grid (row blocks, ldh / 64 + 1): y < ldh / 64: the Q_i(obs, a_pi) passes (every y forms the tiles and the selection - cheap - and
+// takes 64 columns of d qmin / d h2; y == 0 also stores the values); y == ldh / 64: the Q_i(obs, act) passes (values for the TD step)
+__global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
+{
+    __shared__ float red[2][4][32][33];
+    __shared__ float qv[4][32];
+    __shared__ float sel[4][32];
+    __shared__ float lsum[2048];
+    __shared__ unsigned s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, w4 = wave & 3;
+    const int CB = p.ldh / 64, y = (int)blockIdx.y;
+    const bool act_pass = y == CB, writer = y == 0 || act_pass;
+    const int m0 = (int)blockIdx.x * 32, jb = act_pass ? p.NC : 0;
+    LastDxRegs dxr[4];
+    if (!act_pass && !(SF_ABL & 2))
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < p.NC) last_layer_dx_load(dxr[i], p.hin[i], p.w_last[i], p.w_ld, p.ldh, y * 64, m0, p.B, tid);
+    for (int j0 = 0; j0 < p.NC; j0 += 2) {
+        const int j = j0 + team;
+        if (j < p.NC && !(SF_ABL & 4)) {   // team-uniform
+            const float* arow = p.hin[jb + j] + (size_t)min(m0 + (lane & 31), p.B - 1) * p.ldh;
+            dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, p.wl[jb + j].w, p.w_ld, 0, p.kred, w4, lane, red[team]);
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * 32 * 32; e += 512) {
+            const int t = e >> 10, r = (e >> 5) & 31, c = e & 31, jj = j0 + t;
+            if (jj >= p.NC || m0 + r >= p.B) continue;
+            float v = dense_small_sum(red[t], r, c) + p.wl[jb + jj].bias[c];
+            if (p.wl[jb + jj].relu) v = v > 0.f ? v : 0.f;
+            if (c == 0) qv[jj][r] = v;
+            if (!writer) continue;
+            p.q[jb + jj][(size_t)(m0 + r) * p.ldq + c] = v;
+        }
+        __syncthreads();
+    }
+    if (!act_pass) {
+        // selection (k_sac_select's row arithmetic) for this block's rows; y == 0 also leaves the block partials of the three sums
+        if (tid < 64) {   // wave 0; lanes 32..63 idle through the butterflies
+            const bool ok = tid < 32 && m0 + tid < p.B;
+            float qm = 0.f, lp = 0.f;
+            if (ok) {
+                int im = 0;
+                qm = qv[0][tid];
+                for (int i = 1; i < p.NC; ++i) { const float v = qv[i][tid]; if (v < qm) { qm = v; im = i; } }
+                for (int i = 0; i < p.NC; ++i) { const float d = i == im ? 1.0f : 0.0f; sel[i][tid] = d; if (writer) p.dout[i][(size_t)(m0 + tid) * p.ldq] = d; }
+                lp = p.logp[m0 + tid];
+            }
+            if (writer) {
+                const int nb = (p.B + 31) / 32;
+                const float p1 = butterfly32(ok ? lp + p.target : 0.f), p2 = butterfly32(ok ? lp : 0.f), p3 = butterfly32(ok ? qm : 0.f);
+                if (tid == 0) { st_agent(p.part + blockIdx.x, p1); st_agent(p.part + nb + blockIdx.x, p2); st_agent(p.part + 2 * nb + blockIdx.x, p3); }
+            }
+        }
+        __syncthreads();
+        // d qmin / d h2 = relu'(h2) * dout * W_last[:, 0]   (what the last layer's dX launch computes: its only non-zero term)
+        if (!(SF_ABL & 2))
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < p.NC) last_layer_dx_store(dxr[i], sel[i], p.dh[i], p.ldh, y * 64, m0, p.B, tid);
+    }
+    if (SF_ABL & 1) return;
+    if (!last_workgroup(p.ticket, gridDim.x * gridDim.y, &s_last)) return;
+    // ---- k_sac_select's batch-wide part, by the last workgroup to finish: the block partials in block order
+    const int nb = (p.B + 31) / 32;
+    float log_alpha = p.log_alpha[0];
+    if (p.auto_alpha) {
+        const float g = -(sum_partials(p.part, nb, lsum) / (float)p.B);
+        const float mm = p.al_m[0] * p.s.b1 + g * p.s.omb1;
+        const float vv = p.al_v[0] * p.s.b2 + p.s.omb2 * g * g;
+        const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
+        log_alpha = log_alpha + p.s.neg_step * mm / denom;
+        __syncthreads();
+        if (tid == 0) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; }
+    }
+    const float alpha = expf(log_alpha);
+    const float s_logp = sum_partials(p.part + nb, nb, lsum);
+    const float s_qm = sum_partials(p.part + 2 * nb, nb, lsum);
+    if (tid == 0) p.out[0] = actor_loss_sum(p.accumulate ? p.out[0] : 0.f, alpha, s_logp, s_qm, p.scale);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct SacActorBwdArgs {
+    // d qmin / d a: critic i's first layer, transposed, restricted to the action columns (all inside one 32-column tile)
+    int NC; const float* dy0[4]; int ldy0;             // gradient w.r.t. critic i's first hidden layer [B][ldy0]
+    const float* w0[4]; int w0_ld; int kred0; int n0a; // first-layer weights W0 [Kq][w0_ld]; kred0 = Np of that layer; n0a = tile start
+    int col0;                                          // first action column of the critic input
+    // tanh-Gaussian backward (k_sac_actor_grad)
+    const float* a; const float* s; const float* sd; int ld; const float* z; const float* log_alpha;
+    float* gmean; float* ge;
+    int B, A; float lo, hi, eps;
+    // heads' input gradient: dh = relu'(h) * (gmean Wml^T) + relu'(h) * (ge Wsl^T)
+    const float* wm; const float* ws; int wh_ld; int kredh;   // heads' weights [Hp][wh_ld], kredh = wh_ld (padded A)
+    const float* hmask; int ldh; float* dh;                   // last trunk activation / its gradient [B][ldh]
+};
+__global__ __launch_bounds__(512) void k_sac_actor_bwd(SacActorBwdArgs p)
+{
+    __shared__ float red[2][4][32][33];
+    __shared__ __attribute__((aligned(16))) float gm[32][SF_LDG];
+    __shared__ __attribute__((aligned(16))) float gs[32][SF_LDG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, w4 = wave & 3;
+    const int m0 = (int)blockIdx.x * 32, n0 = (int)blockIdx.y * 32;
+    const int r = (tid & 255) >> 3, c4 = (tid & 7) * 4;          // epilogue element of threads 0..255
+    // ---- sum over the critics of d qmin / d a, critic by critic (k_sac_actor_grad's order, starting from 0); two critics per round
+    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < p.NC; i0 += 2) {
+        const int i = i0 + team;
+        if (i < p.NC) {
+            const float* arow = p.dy0[i] + (size_t)min(m0 + (lane & 31), p.B - 1) * p.ldy0;
+            dense_small_tile<true>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, p.w0[i], p.w0_ld, p.n0a, p.kred0, w4, lane, red[team]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dq[q] += dense_small_sum(red[0], r, c4 + q);
+            if (i0 + 1 < p.NC) dq[q] += dense_small_sum(red[1], r, c4 + q);
+        }
+        __syncthreads();
+    }
+    // ---- gmean / ge of this block's rows into LDS (A operands of the heads' dX) and, from the first column block, to memory
+    for (int e = tid; e < 32 * p.ld; e += 512) { gm[e / p.ld][e % p.ld] = 0.f; gs[e / p.ld][e % p.ld] = 0.f; }
+    __syncthreads();
+    if (tid < 256) {
+        const float alpha = expf(p.log_alpha[0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = p.n0a + c4 + q - p.col0, b = m0 + r;
+            if (j < 0 || j >= p.A || b >= p.B) continue;
+            const size_t t = (size_t)b * p.ld + j;
+            const float a = p.a[t], s = p.s[t], sd = p.sd[t];
+            const float dlogp = (2.0f * a) / ((1.0f - a * a) + p.eps);
+            const float ga = (alpha * dlogp - dq[q]) / (float)p.B;
+            const float gu = ga * (1.0f - a * a);
+            const float inr = (s >= p.lo && s <= p.hi) ? 1.0f : 0.0f;
+            gm[r][j] = gu;
+            gs[r][j] = gu * p.z[(size_t)b * p.A + j] * sd * inr * s;
+        }
+    }
+    __syncthreads();
+    if (blockIdx.y == 0)
+        for (int e = tid; e < 32 * p.ld; e += 512) {
+            const int rr = e / p.ld, j = e % p.ld;
+            if (m0 + rr < p.B) { p.gmean[(size_t)(m0 + rr) * p.ld + j] = gm[rr][j]; p.ge[(size_t)(m0 + rr) * p.ld + j] = gs[rr][j]; }
+        }
+    // ---- both heads' input gradient for the 32 trunk features of this column block: team 0 gmean Wml^T, team 1 ge Wsl^T
+    const int i32 = lane & 31;
+    const float (*ga)[SF_LDG] = team ? gs : gm;
+    dense_small_tile<true>([&](int k) { return *reinterpret_cast<const f32x4*>(&ga[i32][k]); }, team ? p.ws : p.wm, p.wh_ld, n0, p.kredh, w4, lane, red[team]);
+    __syncthreads();
+    if (tid >= 256 || m0 + r >= p.B) return;
+    const size_t o = (size_t)(m0 + r) * p.ldh + n0 + c4;
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(p.hmask + o);
+    f32x4 out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a1 = dense_small_sum(red[0], r, c4 + q), v2 = dense_small_sum(red[1], r, c4 + q);
+        if (!(mk[q] > 0.f)) { a1 = 0.f; v2 = 0.f; }
+        out[q] = v2 + a1;            // second launch of the layer-by-layer path: masked v2 += the stored, masked v1
+    }
+    *reinterpret_cast<f32x4*>(p.dh + o) = out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct SacTdLastArgs {
+    int NC;
+    const float* hin_t[4]; HeadRef wl_t[4]; float* qt[4];   // target critics: last hidden activation on (next_obs, a'), last layer, output
+    int ldh, kred, w_ld, ldq;
+    const float* q[4];                                      // Q_i(obs, act) [B][ldq] (k_sac_q_last)
+    const float* hin[4]; const float* w_last[4];            // online critics on (obs, act): last hidden activation, last-layer weights
+    float* dout[4]; float* dh[4];
+    const float* logp; const float* log_alpha; const float* reward; const int8_t* term; float gamma, reward_scale;
+    float* tgt; float* part;                                // part: [NC][ceil(B / 32)] block partials of the critics' loss sums
+    int B; int loss_kind;
+    unsigned* ticket; float* out; float scale; int accumulate;
+};
+__global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
+{
+    __shared__ float red[2][4][32][33];
+    __shared__ float qtv[4][32];
+    __shared__ float dl[4][32];
+    __shared__ float lsum[2048];
+    __shared__ unsigned s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, w4 = wave & 3;
+    const int m0 = (int)blockIdx.x * 32;
+    const bool writer = blockIdx.y == 0;      // grid (row blocks, ldh / 64): every y forms the tiles and the row arithmetic, y takes 64 columns of dh
+    LastDxRegs dxr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < p.NC) last_layer_dx_load(dxr[i], p.hin[i], p.w_last[i], p.w_ld, p.ldh, (int)blockIdx.y * 64, m0, p.B, tid);
+    for (int j0 = 0; j0 < p.NC; j0 += 2) {
+        const int j = j0 + team;
+        if (j < p.NC) {
+            const float* arow = p.hin_t[j] + (size_t)min(m0 + (lane & 31), p.B - 1) * p.ldh;
+            dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, p.wl_t[j].w, p.w_ld, 0, p.kred, w4, lane, red[team]);
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * 32 * 32; e += 512) {
+            const int t = e >> 10, r = (e >> 5) & 31, c = e & 31, jj = j0 + t;
+            if (jj >= p.NC || m0 + r >= p.B) continue;
+            float v = dense_small_sum(red[t], r, c) + p.wl_t[jj].bias[c];
+            if (p.wl_t[jj].relu) v = v > 0.f ? v : 0.f;
+            if (writer) p.qt[jj][(size_t)(m0 + r) * p.ldq + c] = v;
+            if (c == 0) qtv[jj][r] = v;
+        }
+        __syncthreads();
+    }
+    // k_sac_critic_td's row arithmetic; y == 0 also leaves the block partials of the loss sums
+    if (tid < 64) {
+        const bool ok = tid < 32 && m0 + tid < p.B;
+        const int b = min(m0 + tid, p.B - 1);
+        const float alpha = expf(p.log_alpha[0]);
+        float qm = qtv[0][tid & 31];
+        for (int i = 1; i < p.NC; ++i) qm = fminf(qm, qtv[i][tid & 31]);
+        const float tgt = sac_td_target(p.reward_scale, p.reward[b], (float)p.term[b], p.gamma, qm, alpha, p.logp[b]);
+        if (ok && writer) p.tgt[b] = tgt;
+        for (int i = 0; i < p.NC; ++i) {
+            float l, g;
+            sac_td_loss(p.q[i][(size_t)b * p.ldq], tgt, p.loss_kind, l, g);
+            const float dv = g / (float)p.B;
+            if (ok) { dl[i][tid] = dv; if (writer) p.dout[i][(size_t)b * p.ldq] = dv; }
+            if (writer) {
+                const float pi_ = butterfly32(ok ? l : 0.f);
+                if (tid == 0) st_agent(p.part + (size_t)i * ((p.B + 31) / 32) + blockIdx.x, pi_);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < p.NC) last_layer_dx_store(dxr[i], dl[i], p.dh[i], p.ldh, (int)blockIdx.y * 64, m0, p.B, tid);
+    if (!last_workgroup(p.ticket, gridDim.x * gridDim.y, &s_last)) return;
+    const int nb = (p.B + 31) / 32;
+    float total = p.accumulate ? p.out[0] : 0.f;
+    for (int i = 0; i < p.NC; ++i) total = add_scaled(total, sum_partials(p.part + (size_t)i * nb, nb, lsum), p.scale);
+    if (tid == 0) p.out[0] = total;
+}
+
+}  // namespace

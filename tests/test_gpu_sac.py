@@ -138,6 +138,41 @@ def test_sac_ragged_shapes_vs_oracle(B, od, ad, pu, qu, nc, Bsz, ent):
     a.close()
 
 
+@pytest.mark.parametrize("od,ad,pu,qu,nc,Bsz,ent,loss", [
+    (17, 6, [256, 256], [256, 256], 2, 1024, ("Auto", -6.0, 3e-4), "Mse"),          # BASELINE config 5
+    (11, 3, [96, 40], [72, 136], 3, 72, ("Auto", -3.0, 1e-3), "SmoothL1"),           # three critics (an odd pair count), ragged rows
+    (5, 2, [64], [300], 1, 200, ("Fix", 0.2), "Mse"),                                # two-layer critic: the last layer's dX feeds the first layer directly
+    (23, 7, [128, 64, 32], [64, 64, 64], 4, 33, ("Auto", -7.0, 3e-4), "SmoothL1"),   # four critics (8 pairs), 33 rows, action columns 23..29 of the tile
+    (30, 8, [64, 64], [64, 64], 2, 64, ("Fix", 1.0), "Mse"),                         # obs % 32 + act > 32: not covered by the row-block kernels (same path twice)
+])
+def test_sac_row_block_kernels_equal_the_layer_by_layer_path(B, monkeypatch, od, ad, pu, qu, nc, Bsz, ent, loss):
+    """sac_fused.hpp: heads + action, critics' last layer + selection + EntCoef::update, d qmin / d a + tanh-Gaussian backward + heads'
+    dX, target critics' last layer + TD target + losses are row-block kernels built on the layer-by-layer path's tile function;
+    batch-wide sums are done by the last workgroup in the single-workgroup kernels' order.  Three updates on fixed minibatches:
+    every loss, every parameter, gradient, Adam moment, target network, log_alpha and every probe identical bit for bit."""
+    from oracle import torch_ref as T
+    pi0 = T.init_params(T.sac_pi_shapes(od, pu, ad), 31) * np.float32(0.5)
+    q0 = [T.init_params(T.sac_q_shapes(od, ad, qu), 40 + i) for i in range(nc)]
+    kw = dict(lr_actor=1e-3, lr_critic=2e-3, ent_coef=ent, critic_loss=loss)
+    outs = []
+    for fuse in (True, False):
+        if fuse: monkeypatch.delenv("BDR_NO_SAC_FUSE", raising=False)
+        else: monkeypatch.setenv("BDR_NO_SAC_FUSE", "1")
+        a = _agent(B, od, ad, pu, qu, nc, Bsz, kw, pi0, q0)
+        recs = [a.update_on_batch(*T.sac_batch(Bsz, od, ad, 700 + s)) for s in range(3)]
+        names = ["pi", "log_alpha"] + [f"qnet_{i}" for i in range(nc)] + [f"qnet_tgt_{i}" for i in range(nc)]
+        out = {n: a.get_params(n) for n in names}
+        out.update({n + "/grad": a.get_params(n, "grad") for n in names if n != "log_alpha" and not n.startswith("qnet_tgt")})
+        out.update({n + "/exp_avg_sq": a.get_params(n, "exp_avg_sq") for n in ("pi", "qnet_0")})
+        out.update({k: a.probe(k, Bsz) for k in ("q_pred", "q_next", "qvals_min", "next_log_p", "tgt", "q_pi", "log_p", "next_act")})
+        outs.append((out, recs))
+        a.close()
+    (f, frec), (u, urec) = outs
+    assert frec == urec, (frec, urec)
+    for k in f:
+        assert (f[k] == u[k]).all(), (k, np.abs(f[k].astype(np.float64) - u[k]).max())
+
+
 def test_sac_opt_over_replay_and_sample(B, tmp_path):
     """Agent::opt over the HBM ring with device-generated noise: finite losses, counters, checkpoint round trip,
     Policy::sample in eval mode == tanh(mean) of the oracle actor."""
@@ -186,7 +221,7 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
     from oracle import torch_ref as T
     od, ad = 17, 6
     def run(env):
-        for k in ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER", "BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH", "BDR_STEP_GRAPH_BREAK_AT"): monkeypatch.delenv(k, raising=False)
+        for k in ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER", "BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH", "BDR_STEP_GRAPH_BREAK_AT", "BDR_NO_SAC_FUSE"): monkeypatch.delenv(k, raising=False)
         for k in env:
             if k == "BREAK": monkeypatch.setenv("BDR_STEP_GRAPH_BREAK_AT", "2")   # the third replay pass "diverges"
             elif k != "ADAPTIVE": monkeypatch.setenv(k, "1")
@@ -217,7 +252,10 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
     # ... and the default policy, which switches between graph and eager launches by whether the stream is idle when opt() is entered
     # ... and a replay pass that finds the sequence changed (forced): host counters are restored, THAT step is enqueued eagerly -
     # not dropped, Adam / RNG / replay positions not skewed - and the agent stays eager (step_graph_run)
-    for env in (("BDR_NO_STEP_GRAPH",), ("BDR_NO_STEP_GATHER",), ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER"), ("ADAPTIVE",), ("BREAK",)):
+    # ... and the row-block kernels that fuse the narrow layers into their neighbours (sac_fused.hpp: 21 launches) against the
+    # layer-by-layer sequence (30 launches), from the graph and eagerly
+    for env in (("BDR_NO_STEP_GRAPH",), ("BDR_NO_STEP_GATHER",), ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER"), ("ADAPTIVE",), ("BREAK",),
+                ("BDR_NO_SAC_FUSE",), ("BDR_NO_SAC_FUSE", "BDR_NO_STEP_GRAPH")):
         e, erec, en = run(env)
         assert en == gn, env
         for k in g: assert (g[k] == e[k]).all(), (env, k)

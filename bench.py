@@ -104,7 +104,7 @@ def build_config(B, name, args, rank, local_rank):
         fl = dqn_kernel_flops(bs, nz)
         by = {"sample": 2 * bs * 28224 + bs * 14, "adam_l1_l2": 7 * 4 * (3136 * 512 + 512 + 512 * N_ACTIONS + N_ACTIONS)}
         step_flops = sum(fl.values()) + 2 * nz * bs * 512 * N_ACTIONS
-        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops=fl, bytes=by, step_flops=step_flops,
+        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops=fl, bytes=by, step_flops=step_flops, flops_per_instance=dqn_kernel_flops(bs, 1),
                     metric="agent opt-steps/sec (DQN Atari 84x84x4, batch 256)",
                     workload=f"synthetic Atari DQN Nature-CNN, replay {cap} u8 transitions/GPU, batch {bs}/GPU",
                     cfg_extra={"n_actions": N_ACTIONS, "critic_loss": args.loss, "double_dqn": args.double_dqn,
@@ -189,6 +189,19 @@ def build_config(B, name, args, rank, local_rank):
 
 
 # ------------------------------------------------------------------------------------------------ profile -> roofline
+def kernel_source_hash():
+    """sha256 (16 hex) over the kernel sources the library is built from (border_amd/csrc/*.hip, *.hpp + include/border_amd.h): what ties a
+    committed measurement (profiles/hbm_traffic.json, profiles/kernel_trace_*.json) to the binary that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "border_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "border_amd.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def read_profile(agent):
     """[(label, mean ms per launch)] in launch order (labels repeat: the same layer runs for several networks)."""
     import ctypes as C
@@ -250,12 +263,48 @@ def roofline(conf, prof, cnt, null_ms, ms_step):
             gbs = by[dom] / (prof[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "kernel_ms": round(prof[dom], 5)}
+    # PMC-derived HBM bytes per launch (rocprofv3 --pmc, separate passes, tools/make_hbm_traffic.py).  The file names the kernel
+    # sources it was measured on; when they are not the sources of the running library the number is withheld, not reused.
+    src = kernel_source_hash()
+    roof["kernel_source_sha16"] = src
+    if roof:
+        dom = roof["kernel"]
+        if dom in fl:   # what `achieved` is computed from, in one place: algorithmic work of ONE launch label and its launch count
+            roof["kernel_gflop"] = round(fl[dom] / 1e9, 4)
+            roof["units_per_launch"] = {"launches_per_step": cnt.get(dom, 1), "batch_rows": conf["batch"],
+                                        "network_instances": round(fl[dom] / max(conf["flops_per_instance"].get(dom, fl[dom]), 1)) if "flops_per_instance" in conf else None}
+        elif dom in by:
+            roof["kernel_bytes"] = by[dom]
+        roof["timing"] = ("HIP events on the agent's stream around every launch (serial schedule), minus half an empty bracket; rocprofv3 "
+                          "--kernel-trace of the same command: profiles/kernel_trace_" + conf["name"] + "_serial.json")
     tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if roof and os.path.exists(tr):   # PMC-derived HBM bytes per launch, measured with rocprofv3 --pmc (profiles/)
+    if roof and os.path.exists(tr):
         try:
-            roof["traffic"] = json.load(open(tr)).get(roof["kernel"])
-        except Exception:
-            pass
+            doc = json.load(open(tr))
+            meta = doc.get("_source", {})
+            if meta.get("kernel_source_sha16") == src:
+                roof["traffic"] = doc.get(roof["kernel"])
+                roof["traffic_source"] = {"file": "profiles/hbm_traffic.json", "pmc_tables": meta.get("pmc_tables"), "commit": meta.get("commit"),
+                                          "kernel_source_sha16": src, "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 B per launch (gfx950 correction)"}
+            else:
+                roof["traffic"] = None
+                roof["traffic_source"] = {"file": "profiles/hbm_traffic.json", "stale": True,
+                                          "note": f"measured on kernel sources {meta.get('kernel_source_sha16')}, the library is built from {src}: withheld"}
+        except Exception as e:  # noqa: BLE001
+            roof["traffic_source"] = {"error": repr(e)}
+    kt = os.path.join(ROOT, "profiles", f"kernel_trace_{conf['name']}_serial.json")
+    if roof and os.path.exists(kt):   # the box-independent tie between the HIP-event bracket and rocprofv3: same kernel, same sources
+        try:
+            doc = json.load(open(kt))
+            same = doc.get("kernel_source_sha16") == src
+            us = doc.get("kernels_us", {}).get(roof["kernel"])
+            if us is not None:
+                roof["rocprof_check"] = {"file": f"profiles/kernel_trace_{conf['name']}_serial.json", "rocprofv3_avg_us": us,
+                                         "hip_event_us": round(1000 * prof[roof["kernel"]] / max(cnt.get(roof["kernel"], 1), 1), 2) if roof["kernel"] in prof else None,
+                                         "same_kernel_sources": same,
+                                         "note": "different boxes (clock / HBM bins differ by a few %); both are per launch of the dominant kernel, serial schedule"}
+        except Exception as e:  # noqa: BLE001
+            roof["rocprof_check"] = {"error": repr(e)}
     sf = conf["step_flops"]
     step = {"gflop": round(sf / 1e9, 3), "achieved": round(sf / (ms_step * 1e-3) / 1e12, 2),
             "frac_of_fp32_peak": round(sf / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -390,7 +439,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (barrier, id hand-off, max-reduce of the timing) on gloo; the data plane
         # (parameter all-reduce) is the library's own RCCL communicator over xGMI
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."): the contract is ONE JSON line there
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     if args.dry_run:
         t0 = time.perf_counter()
@@ -424,6 +483,7 @@ def main():
         return bytes(t.tolist())
 
     conf = build_config(B, args.config, args, rank, local_rank)
+    conf["name"] = args.config
     agent, rb = conf["agent"], conf["rb"]
     agent.train()
     exch, rccl_ranks = None, 0

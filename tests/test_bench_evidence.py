@@ -1,0 +1,63 @@
+"""bench.py's `roofline` object says where its numbers come from: `traffic` (PMC-derived HBM bytes per launch) is reported only when
+profiles/hbm_traffic.json was measured on the kernel sources the running library is built from, otherwise null with a note; the
+inputs of `achieved` (kernel_gflop, launches, instances) and the rocprofv3 twin of the HIP-event time sit in the same object."""
+import json
+import os
+
+import bench
+
+
+def _tree(tmp_path, traffic_hash_matches, monkeypatch):
+    root = tmp_path / "repo"
+    (root / "border_amd" / "csrc").mkdir(parents=True)
+    (root / "include").mkdir()
+    (root / "profiles").mkdir()
+    (root / "border_amd" / "csrc" / "a.hip").write_text("__global__ void k() {}\n")
+    (root / "border_amd" / "csrc" / "b.hpp").write_text("// header\n")
+    (root / "include" / "border_amd.h").write_text("/* abi */\n")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    h = bench.kernel_source_hash()
+    meta = {"kernel_source_sha16": h if traffic_hash_matches else "0" * 16, "commit": "abc1234", "pmc_tables": "profiles/rocprof_r03_pmc.md"}
+    (root / "profiles" / "hbm_traffic.json").write_text(json.dumps({"fwd_conv2": 42938982, "_source": meta}))
+    (root / "profiles" / "kernel_trace_c2_serial.json").write_text(json.dumps({"kernel_source_sha16": h, "kernels_us": {"fwd_conv2": 32.1}}))
+    return root, h
+
+
+def _roof():
+    fl = bench.dqn_kernel_flops(256, 2)
+    conf = {"flops": fl, "bytes": {"sample": 14454272}, "step_flops": sum(fl.values()), "batch": 256, "name": "c2",
+            "flops_per_instance": bench.dqn_kernel_flops(256, 1)}
+    prof = {k: 0.02 for k in fl}
+    prof["fwd_conv2"] = 0.0307
+    prof["sample"] = 0.009
+    cnt = {k: 1 for k in prof}
+    return bench.roofline(conf, prof, cnt, 0.0026, 0.221)
+
+
+def test_traffic_is_reported_with_its_source_when_the_sources_match(tmp_path, monkeypatch):
+    _, h = _tree(tmp_path, True, monkeypatch)
+    r = _roof()
+    assert r["kernel"] == "fwd_conv2" and r["traffic"] == 42938982
+    assert r["traffic_source"]["kernel_source_sha16"] == h == r["kernel_source_sha16"] and r["traffic_source"]["pmc_tables"].endswith("pmc.md")
+    # everything `achieved` is computed from, in the object itself
+    assert abs(r["kernel_gflop"] - 2.7181) < 1e-3 and r["units_per_launch"] == {"launches_per_step": 1, "batch_rows": 256, "network_instances": 2}
+    assert abs(r["achieved"] - r["kernel_gflop"] / r["kernel_ms"]) < 0.05            # GFLOP / ms == TFLOP/s
+    assert abs(r["frac"] - r["achieved"] / 157.3) < 1e-3
+    assert r["rocprof_check"]["rocprofv3_avg_us"] == 32.1 and r["rocprof_check"]["same_kernel_sources"] is True
+    assert abs(r["rocprof_check"]["hip_event_us"] - 30.7) < 0.01
+
+
+def test_stale_traffic_is_withheld(tmp_path, monkeypatch):
+    root, h = _tree(tmp_path, False, monkeypatch)
+    r = _roof()
+    assert r["traffic"] is None and r["traffic_source"]["stale"] is True and h in r["traffic_source"]["note"]
+    # ... and any edit of a kernel source changes the hash
+    (root / "border_amd" / "csrc" / "a.hip").write_text("__global__ void k() { }\n")
+    assert bench.kernel_source_hash() != h
+
+
+def test_committed_evidence_files_are_stamped():
+    """What is committed under profiles/ names the sources it was measured on (it may be stale - then bench says so - but never unlabelled)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
+    assert "_source" in doc and len(doc["_source"]["kernel_source_sha16"]) == 16

@@ -1,5 +1,5 @@
-// Pre-split bf16 planes implicit GEMM (csrc/igemm_bp.hpp) vs the FP32-MFMA kernel: accuracy and time (B=256 Atari shapes).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iborder_amd/csrc tools/probes/bp_probe.hip -o tools/probes/bp_probe.bin
+// Pre-split bf16 planes implicit GEMM (tools/probes/igemm_bp.hpp) vs the FP32-MFMA kernel: accuracy and time (B=256 Atari shapes).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iborder_amd/csrc -Itools/probes tools/probes/bp_probe.hip -o tools/probes/bp_probe.bin
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

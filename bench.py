@@ -398,6 +398,10 @@ def main():
     ap.add_argument("--loss", default="SmoothL1", choices=["SmoothL1", "Mse"])
     ap.add_argument("--double-dqn", action="store_true")
     ap.add_argument("--sync-interval", type=int, default=10, help="opt steps between RCCL parameter averaging (N>1)")
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="N>1: the per-segment parameter exchange on the agent's communication queue, overlapped with the step (DESIGN.md 7). Default: "
+                         "the collective in the agent's own stream - the form with nothing but stream order between it and the step; the overlapped "
+                         "form has only ever run on ONE rank (tests/test_gpu_multi.py needs 2 GPUs), and a measurement must not hang")
     ap.add_argument("--per", action="store_true", help="prioritized replay (PerConfig defaults) instead of uniform sampling (c2)")
     ap.add_argument("--frame-ring", action="store_true", help="c2 / c4: single-frame store (8.8 GB instead of 56.6 GB for 1M transitions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -430,6 +434,8 @@ def main():
         # library asks for them itself when it is loaded in a multi-rank process (csrc/comm.hip); set here too because torch
         # may touch HIP first.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        if not args.overlap_exchange:
+            os.environ["BDR_NO_XCHG_OVERLAP"] = "1"
     import torch  # noqa: F401  (first: one HIP runtime per process, see border_amd/_lib.py)
     import border_amd as B
 
@@ -561,6 +567,7 @@ def main():
         par = f"dp{world} (replica + replay shard per GPU"
         if world > 1:
             par += f", parameter all-reduce every {args.sync_interval} opts over " + ("RCCL" if rccl_ranks else "host staging (BDR_BENCH_SHARE_GPU test mode)")
+            par += ", overlapped per-segment exchange" if args.overlap_exchange else ", exchange in the agent's stream"
         par += ")"
         cfgd = {"workload": conf["workload"], "name": args.config, "batch_size": conf["batch"], "replay_capacity": conf["capacity"]}
         cfgd.update(conf["cfg_extra"])

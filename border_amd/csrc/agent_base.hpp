@@ -162,8 +162,19 @@ namespace bdr {
 // loss = smooth_l1(x, 0) / mse(x, 0); the gradient follows autograd through abs / clip (clip passes the
 // gradient inside its closed range).  Returns dLoss_row/dpred (before the 1/B of Reduction::Mean).
 struct TdLossIn { int loss_kind; int weighted; float w; int has_clip; float cmin, cmax; };
+// r + (1 - is_terminated) * gamma * q'   (dqn/base.rs:104).  One definition for every kernel that forms it, without fused
+// multiply-add contraction: hipcc contracts across statements, and the same expression compiled into two kernels may round
+// differently - the paths that must agree bit for bit (one-workgroup step, layer-by-layer, row-block head) all call this.
+__device__ __forceinline__ float td_target(float reward, float not_done, float gamma, float qn)
+{
+#pragma clang fp contract(off)
+    const float k = not_done * gamma;
+    const float c = k * qn;
+    return reward + c;
+}
 __device__ __forceinline__ float td_loss_row(float pred, float tgt, const TdLossIn& c, float& lossb, float& td_abs)
 {
+#pragma clang fp contract(off)
     const float d = pred - tgt;
     if (!c.weighted) {
         td_abs = fabsf(d);

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * HEAD_ROWS * MAXZ) void k_head(HeadArgs a, TdAr
     const float qn = q_tg[idx];
     const float pred = sq[r][0][act];
     // reward + (1 - is_terminated) * discount_factor * q   (dqn/base.rs:104)
-    const float tgt = reward + ((float)(1 - term) * t.gamma) * qn;
+    const float tgt = td_target(reward, (float)(1 - term), t.gamma, qn);
     const TdLossIn li{t.loss_kind, t.weight != nullptr, wgt, t.has_clip, t.clip_min, t.clip_max};
     float lossb, tdv;
     const float dl = td_loss_row(pred, tgt, li, lossb, tdv);

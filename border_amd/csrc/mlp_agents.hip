@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_td_dense(TdDenseArgs a)
     }
     const float qn = a.q_tg[(size_t)row * a.ld + idx];
     const float pred = a.q_on[(size_t)row * a.ld + act];
-    const float tgt = a.reward[row] + ((float)(1 - (int)a.term[row]) * a.gamma) * qn;   // dqn/base.rs:104
+    const float tgt = td_target(a.reward[row], (float)(1 - (int)a.term[row]), a.gamma, qn);   // dqn/base.rs:104
     const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
     float lossb, td;
     const float dl = td_loss_row(pred, tgt, li, lossb, td);
@@ -71,6 +71,110 @@ __global__ __launch_bounds__(256) void k_mean_rows(const float* __restrict__ x, 
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// Row-block head of the layer-by-layer step (the SAC step's sac_fused.hpp pattern): the last layer (hidden -> A actions, narrower than
+// one 32-column tile) of every network instance, the TD step of the rows (k_td_dense), the loss mean (k_mean_rows, by the last
+// workgroup to finish) and the last layer's input gradient - four launches of ~4 us each at these sizes - in one.  A workgroup takes
+// 32 rows; the tiles come from the layer-by-layer path's own tile function, the row arithmetic is k_td_dense's, so both paths give
+// the same bits.  grid (row blocks, ldh / 64): every y forms the tiles and the TD rows (cheap) and takes 64 columns of the gradient.
+struct MlpHeadTdArgs {
+    int nz; const float* hin[MAXZ]; HeadRef wl[MAXZ]; float* q[MAXZ];   // instance z: last hidden activation [B][ldh], last layer, Q rows [B][ldq]
+    int ldh, kred, w_ld, ldq;
+    int sel_z;                                                           // double DQN: the instance whose rows choose the action (else -1)
+    TdDenseArgs t;                                                       // act, reward, term, dq_rows, pred, tgt, loss_row, ...
+    const float* w_last; float* dh;                                      // online last-layer weights, gradient w.r.t. hin[0] [B][ldh]
+    unsigned* ticket; float* loss; float scale;
+};
+__global__ __launch_bounds__(512) void k_mlp_head_td(MlpHeadTdArgs p)
+{
+    __shared__ float red[2][4][32][33];
+    __shared__ float qv[MAXZ][32][33];
+    __shared__ float s_dq[32];
+    __shared__ int s_act[32];
+    __shared__ float mred[256];
+    __shared__ unsigned s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, w4 = wave & 3;
+    const int m0 = (int)blockIdx.x * 32, c0 = (int)blockIdx.y * 64;
+    const bool writer = blockIdx.y == 0;
+    const TdDenseArgs& a = p.t;
+    for (int z0 = 0; z0 < p.nz; z0 += 2) {
+        const int z = z0 + team;
+        if (z < p.nz) {   // team-uniform
+            const float* arow = p.hin[z] + (size_t)min(m0 + (lane & 31), a.B - 1) * p.ldh;
+            dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, p.wl[z].w, p.w_ld, 0, p.kred, w4, lane, red[team]);
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * 32 * 32; e += 512) {
+            const int t = e >> 10, r = (e >> 5) & 31, c = e & 31, zz = z0 + t;
+            if (zz >= p.nz) continue;
+            float v = dense_small_sum(red[t], r, c) + p.wl[zz].bias[c];
+            if (p.wl[zz].relu) v = v > 0.f ? v : 0.f;
+            qv[zz][r][c] = v;
+            if (writer && m0 + r < a.B) p.q[zz][(size_t)(m0 + r) * p.ldq + c] = v;
+        }
+        __syncthreads();
+    }
+    // ---- k_td_dense, one wave per row (lanes over the A <= 32 actions; the butterflies are the original's)
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr, row = m0 + r;
+        if (row >= a.B) break;
+        long long act = *reinterpret_cast<const long long*>(a.act + (size_t)row * a.act_bytes);
+        if (act < 0 || act >= a.A) {
+            if (lane == 0 && a.err && writer) atomicOr(a.err + bdr_agent::ERR_ACTION, 1u);
+            act = act < 0 ? 0 : a.A - 1;
+        }
+        const float (*sel)[33] = p.sel_z >= 0 ? qv[p.sel_z] : qv[1];
+        float v = lane < a.A ? sel[r][lane] : -INFINITY;
+        int idx = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off);
+            const int oi = __shfl_xor(idx, off);
+            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+        const float qn = qv[1][r][idx];
+        const float pred = qv[0][r][(int)act];
+        const float tgt = td_target(a.reward[row], (float)(1 - (int)a.term[row]), a.gamma, qn);
+        const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
+        float lossb, td;
+        const float dl = td_loss_row(pred, tgt, li, lossb, td);
+        const float dq = dl / (float)a.B;
+        if (lane == 0) {
+            s_dq[r] = dq; s_act[r] = (int)act;
+            if (writer) { a.pred[row] = pred; a.tgt[row] = tgt; st_agent(a.loss_row + row, lossb); if (a.td_abs) a.td_abs[row] = td; }
+        }
+        if (writer) for (int c = lane; c < p.ldq; c += 64) a.dq_rows[(size_t)row * p.ldq + c] = c == act ? dq : 0.f;
+    }
+    __syncthreads();
+    // ---- last layer's input gradient: relu'(h) * dq * W_last[:, act]   (the dX launch's only non-zero term), columns [c0, c0 + 64)
+    {
+        float hv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 512 * u, r = e >> 6, k = c0 + (e & 63);
+            const int rc = min(m0 + r, a.B - 1);
+            hv[u] = p.hin[0][(size_t)rc * p.ldh + k];
+            wv[u] = m0 + r < a.B ? p.w_last[(size_t)k * p.w_ld + s_act[r]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 512 * u, r = e >> 6, k = c0 + (e & 63);
+            if (m0 + r < a.B) p.dh[(size_t)(m0 + r) * p.ldh + k] = hv[u] > 0.f ? s_dq[r] * wv[u] : 0.f;
+        }
+    }
+    if (!last_workgroup(p.ticket, gridDim.x * gridDim.y, &s_last)) return;
+    // ---- k_mean_rows, by the last workgroup to finish (threads 0..255 in its order)
+    float s = 0.f;
+    if (tid < 256) for (int b = tid; b < a.B; b += 256) s += ld_agent(a.loss_row + b);
+    if (tid < 256) mred[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) mred[tid] += mred[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) p.loss[0] = mred[0] * p.scale;
+}
+
 // [B][in_dim] f32 rows of up to MAXZ network instances into their zero-padded [B][Kp0] input matrices, one launch
 struct MlpPackArgs { const float* rows[MAXZ]; float* x[MAXZ]; int nz, B, in_dim, Kp0; };
 __global__ void k_mlp_pack_z(MlpPackArgs p)
@@ -89,6 +193,8 @@ struct DqnMlp : bdr_agent {
     MlpLayout net;
     float *q = nullptr, *q_tgt = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
     float* vmax = nullptr; bool amsgrad = false;   // AdamW{amsgrad: true} (see DqnCnn)
+    bool head_fuse = true, head_fuse_wide = false, head_fused = false;     // k_mlp_head_td (BDR_NO_MLP_HEAD_FUSE=1: last layer, TD, loss mean, last dX as four launches)
+    unsigned* ticket = nullptr;                    // its last-workgroup ticket
     int B = 0;
     float* x_in[MAXZ] = {nullptr};                 // packed inputs [B][Kp0]
     std::vector<float*> acts[MAXZ];                // per layer [B][Np]
@@ -113,7 +219,7 @@ struct DqnMlp : bdr_agent {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
         free_batch();
-        (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v); (void)hipFree(vmax); (void)hipFree(loss);
+        (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v); (void)hipFree(vmax); (void)hipFree(loss); (void)hipFree(ticket);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
     }
     void free_batch()
@@ -248,6 +354,7 @@ struct DqnMlp : bdr_agent {
         }
         const int L = (int)net.L.size();
         const bool lat = small_gemm && L <= RA_SEGS;   // latency-shaped kernels: ~11 launches instead of ~21
+        head_fused = false;
         if (lat) {
             const int nz = cfg.double_dqn ? 3 : 2;
             const float* par[MAXZ] = {q, q_tgt, q};
@@ -258,7 +365,11 @@ struct DqnMlp : bdr_agent {
             { Bracket br(a, "mlp_pack"); BDR_HIP(step_launch(stream, false, k_mlp_pack_z, dim3((nz * Bn * net.in_dim + 255) / 256), dim3(256), pk)); }
             DenseSrc in[MAXZ]; float* out[MAXZ];
             for (int z = 0; z < nz; ++z) in[z] = DenseSrc{x_in[z], net.L[0].Kp};
-            for (int i = 0; i < L; ++i) {
+            // the last layer, the TD rows, the loss mean and the last layer's input gradient in one row-block launch (k_mlp_head_td)
+            // measured (tools/probes/mlp_sizes.py, opt-steps/s fused / four launches): [64,64] B=128 27.6k / 24.5k, [128,128] B=64 25.9k / 25.3k,
+            // [256,256] B=64 23.1k / 24.8k - a 256-wide last hidden layer makes the row block's tile + gradient pass longer than the launches it saves
+            head_fused = head_fuse && L >= 2 && net.out_dim <= 32 && net.L[L - 1].Kp <= (head_fuse_wide ? 4096 : 128) && !(per_buffer && weight);
+            for (int i = 0; i < (head_fused ? L - 1 : L); ++i) {
                 for (int z = 0; z < nz; ++z) out[z] = acts[z][i];
                 Bracket br(a, "mlp_fwd");
                 BDR_TRY(dense_forward_z(stream, net.L[i], nz, par, in, out, Bn, true));
@@ -278,16 +389,29 @@ struct DqnMlp : bdr_agent {
         t.weight = weight; t.td_abs = td_abs;
         t.has_clip = cfg.has_clip_td_err; t.clip_min = (float)cfg.clip_td_err_min; t.clip_max = (float)cfg.clip_td_err_max;
         t.err = dev_err;
-        { Bracket br(a, "td_dense"); BDR_HIP(step_launch(stream, false, k_td_dense, dim3((Bn + 3) / 4), dim3(256), t)); }
-        if (per_buffer && weight) { Bracket br(a, "per_update"); BDR_TRY(replay_update_priority_on_stream(per_buffer, Bn, td_abs, stream)); }
-        {
-            Bracket br(a, "loss_mean");
-            BDR_HIP(step_launch(stream, false, k_mean_rows, dim3(1), dim3(256), loss_row, Bn, loss, 1.0f / (float)Bn));
+        if (lat && head_fused) {
+            const DenseLayer& ll = net.L[L - 1];
+            const int nz = cfg.double_dqn ? 3 : 2;
+            const float* par[MAXZ] = {q, q_tgt, q};
+            MlpHeadTdArgs h{};
+            h.nz = nz;
+            for (int z = 0; z < nz; ++z) { h.hin[z] = acts[z][L - 2]; h.wl[z] = HeadRef{par[z] + ll.w, par[z] + ll.b, ll.relu}; h.q[z] = acts[z][L - 1]; }
+            h.ldh = ll.Kp; h.kred = ll.Kp; h.w_ld = ll.Np; h.ldq = ll.Np; h.sel_z = cfg.double_dqn ? 2 : -1;
+            h.t = t; h.w_last = q + ll.w; h.dh = dys[L - 2]; h.ticket = ticket; h.loss = loss; h.scale = 1.0f / (float)Bn;
+            Bracket br(a, "mlp_head_td");
+            BDR_HIP(step_launch(stream, false, k_mlp_head_td, dim3((Bn + 31) / 32, ll.Kp / 64), dim3(512), h));
+        } else {
+            { Bracket br(a, "td_dense"); BDR_HIP(step_launch(stream, false, k_td_dense, dim3((Bn + 3) / 4), dim3(256), t)); }
+            if (per_buffer && weight) { Bracket br(a, "per_update"); BDR_TRY(replay_update_priority_on_stream(per_buffer, Bn, td_abs, stream)); }
+            {
+                Bracket br(a, "loss_mean");
+                BDR_HIP(step_launch(stream, false, k_mean_rows, dim3(1), dim3(256), loss_row, Bn, loss, 1.0f / (float)Bn));
+            }
         }
         if (lat) {
             // input gradients down the net, then every weight gradient in one grouped launch; its row-chunk partials are summed
             // into the gradient arena by the kernel that also applies Adam (and the soft update that follows this update)
-            for (int i = L - 1; i > 0; --i) { Bracket br(a, "mlp_dx"); BDR_TRY(dense_dx(stream, net.L[i], q, dys[i], dys[i - 1], acts[0][i - 1], Bn, false, true)); }
+            for (int i = head_fused ? L - 2 : L - 1; i > 0; --i) { Bracket br(a, "mlp_dx"); BDR_TRY(dense_dx(stream, net.L[i], q, dys[i], dys[i - 1], acts[0][i - 1], Bn, false, true)); }
             DenseDwJob jobs[RA_SEGS];
             for (int i = 0; i < L; ++i)
                 jobs[i] = DenseDwJob{&net.L[i], i == 0 ? DenseSrc{x_in[0], net.L[0].Kp} : DenseSrc{acts[0][i - 1], net.L[i - 1].Np}, dys[i], dw_part + dw_off[i],
@@ -509,6 +633,9 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
     { const char* e = getenv("BDR_NO_SMALL_GEMM"); a->small_gemm = !(e && e[0] == '1'); }
     a->graph_policy.from_env();
     a->lds_step = getenv("BDR_NO_MLP_LDS") == nullptr;
+    a->head_fuse = getenv("BDR_NO_MLP_HEAD_FUSE") == nullptr;
+    a->head_fuse_wide = getenv("BDR_MLP_HEAD_FUSE_WIDE") != nullptr;   // (tests: the row-block head for any width)
+    BDR_HIP(hipMalloc((void**)&a->ticket, sizeof(unsigned))); BDR_HIP(hipMemsetAsync(a->ticket, 0, sizeof(unsigned), a->stream));
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->net.total));

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512) void k_dqn_mlp_step(MlpFusedArgs a)
             }
             const float qn = q_tg[(size_t)row * ld + idx];
             const float pred = q_on[(size_t)row * ld + act];
-            const float tgt = a.reward[row] + ((float)(1 - (int)a.term[row]) * a.gamma) * qn;
+            const float tgt = td_target(a.reward[row], (float)(1 - (int)a.term[row]), a.gamma, qn);
             const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
             float lossb, td;
             const float dl = td_loss_row(pred, tgt, li, lossb, td);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512) void k_dqn_mlp_step_lds(MlpFusedArgs a)
             }
             const float qn = lds[q_tg + row * lds_ld + idx];
             const float pred = lds[q_on + row * lds_ld + act];
-            const float tgt = s_rew[row] + (s_nd[row] * a.gamma) * qn;
+            const float tgt = td_target(s_rew[row], s_nd[row], a.gamma, qn);
             const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
             float lossb, td;
             const float dl = td_loss_row(pred, tgt, li, lossb, td);

@@ -323,7 +323,8 @@ def test_mlp_layer_by_layer_path_vs_oracle(B, units, Bsz, double, monkeypatch):
     from oracle import oracle as O
     from oracle import torch_ref as T
     def run(env):
-        for k in ("BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH"): monkeypatch.delenv(k, raising=False)
+        for k in ("BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH", "BDR_NO_MLP_HEAD_FUSE"): monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("BDR_MLP_HEAD_FUSE_WIDE", "1")   # the row-block head also where the heuristic would not pick it (256-wide layers)
         for k, v in env.items(): monkeypatch.setenv(k, v)
         rng = np.random.default_rng(5)
         cap = 4000
@@ -345,11 +346,17 @@ def test_mlp_layer_by_layer_path_vs_oracle(B, units, Bsz, double, monkeypatch):
             assert rel(a.probe("q_pred_all", Bsz * 2), r["q_pred_all"].ravel()) < 3e-4, step
             assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-7
             assert_grads_close(a.get_params("grad"), r["grads"], T.mlp_shapes(4, list(units), 2), tol=5e-4)
-        out = (a.get_params("qnet"), a.get_params("qnet_tgt"))
+        out = (a.get_params("qnet"), a.get_params("qnet_tgt"), a.get_params("grad"), a.get_params("exp_avg_sq"), np.float32(rec["loss"]),
+               a.probe("pred", Bsz), a.probe("tgt", Bsz))
         assert np.abs(out[0] - ref.q).max() < 0.3 * 1e-3 and rel(out[1], ref.q_tgt) < 1e-3
         a.close(); rb.close()
         return out
     lat = run({"BDR_STEP_GRAPH": "0"})
+    # the row-block head (last layer + TD rows + loss mean + last dX in one launch, k_mlp_head_td) against the four launches it
+    # replaces: parameters, target net, gradients, second moments, the recorded loss and the TD probes bit for bit
+    unfused = run({"BDR_STEP_GRAPH": "0", "BDR_NO_MLP_HEAD_FUSE": "1"})
+    for x, y in zip(lat, unfused):
+        assert (np.asarray(x) == np.asarray(y)).all()
     big = run({"BDR_NO_SMALL_GEMM": "1"})
     assert np.abs(lat[0] - big[0]).max() < 0.3 * 1e-3 and rel(lat[1], big[1]) < 1e-3
     # the same launches replayed from a captured graph (every opt / by the default policy): bit-identical

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import border_amd as B
 
 def run(units, bs, env):
-    for k in ("BDR_NO_MLP_FUSED", "BDR_NO_MLP_LDS", "BDR_STEP_GRAPH", "BDR_NO_SMALL_GEMM"): os.environ.pop(k, None)
+    for k in ("BDR_NO_MLP_FUSED", "BDR_NO_MLP_LDS", "BDR_STEP_GRAPH", "BDR_NO_SMALL_GEMM", "BDR_NO_MLP_HEAD_FUSE"): os.environ.pop(k, None)
     for k in env: os.environ[k.split("=")[0]] = k.split("=")[1] if "=" in k else "1"
     rng = np.random.default_rng(0)
     rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=10000, seed=42), (4,), np.float32)
@@ -26,5 +26,5 @@ def run(units, bs, env):
     return N / dt
 
 for units, bs in (((64, 64), 32), ((256, 256), 64), ((256, 256), 128), ((128, 128), 64), ((64, 64), 128)):
-    r = {name: run(units, bs, env) for name, env in (("default", ()), ("eager", ("BDR_STEP_GRAPH=0",)), ("graph", ("BDR_STEP_GRAPH=1",)), ("layers_64x64", ("BDR_NO_MLP_FUSED", "BDR_NO_SMALL_GEMM")))}
+    r = {name: run(units, bs, env) for name, env in (("default", ()), ("eager", ("BDR_STEP_GRAPH=0",)), ("graph", ("BDR_STEP_GRAPH=1",)), ("no_head_fuse", ("BDR_NO_MLP_HEAD_FUSE",)), ("no_head_fuse_graph", ("BDR_NO_MLP_HEAD_FUSE", "BDR_STEP_GRAPH=1")), ("layers_64x64", ("BDR_NO_MLP_FUSED", "BDR_NO_SMALL_GEMM")))}
     print(units, bs, {k: round(v) for k, v in r.items()})

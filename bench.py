@@ -505,6 +505,12 @@ def main():
                 sys.stderr.write(f"bench.py: {e}; an N>1 run has no other data plane\n")
                 sys.exit(3)
         rccl_ranks = 0 if share else world
+        # Setup, before the warm-up: every replica starts from the learner's parameters (the reference's first sync,
+        # async_trainer/base.rs:268-272) and the communicator runs the measured collective once - RCCL builds its channels and
+        # loads its kernels on the first call of each kind, which would otherwise land inside a 20-step timed window.
+        exch.broadcast(agent, 0)
+        exch.average(agent)
+        agent.sync()
 
     def run(n, first_step):
         for s in range(n):

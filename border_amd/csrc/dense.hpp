@@ -304,14 +304,17 @@ __device__ __forceinline__ float dense_small_sum(const float (*red)[32][33], int
 // Values one workgroup hands to the LAST workgroup of the same launch go through agent-scope accesses: the XCDs' L2 caches are
 // not coherent with each other, and a full release fence (__threadfence) would write back every dirty line of the XCD's L2 - tens
 // of microseconds per workgroup (measured: 33 us for a kernel that otherwise takes 8).  A relaxed agent-scope store / load goes to
-// the coherent level directly; the workgroup barrier (s_waitcnt vmcnt(0) + s_barrier) orders them before the ticket.
+// the coherent level directly; an explicit s_waitcnt vmcnt(0) + the workgroup barrier order them before the ticket (last_workgroup).
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // "am I the last workgroup of this launch?"
 __device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_wg, unsigned* s_flag)
 {
-    __syncthreads();     // every thread's agent-scope stores have been acknowledged
+    // every thread's agent-scope stores acknowledged by the coherent level before the ticket is taken: the workgroup barrier alone
+    // does not wait for them (a workgroup-scope release is lgkmcnt only outside threadgroup-split mode)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_flag = t == n_wg - 1 ? 1u : 0u;

@@ -183,7 +183,9 @@ def build_config(B, name, args, rank, local_rank):
                     metric="agent opt-steps/sec (SAC obs 17 / act 6, twin-Q, batch 1024)",
                     workload=f"SAC on HalfCheetah-shaped synthetic rows (obs 17, act 6 f32), actor Mlp2[256,256], twin-Q Mlp[256,256], "
                              f"Auto entropy coefficient, replay {cap}, batch {bs}",
-                    cfg_extra={"optimizer": "Adam lr=3e-4 (actor, critics, alpha)", "n_critics": 2, "tau": 0.005},
+                    cfg_extra={"optimizer": "Adam lr=3e-4 (actor, critics, alpha)", "n_critics": 2, "tau": 0.005,
+                               "schedule": "one queue (BDR_SAC_SIDE_QUEUE=0)" if os.environ.get("BDR_SAC_SIDE_QUEUE") == "0" else
+                                           "two queues: the next update's sample + actor forward beside this update's critic phase (csrc/sac.hip)"},
                     which=("pi",), loss_key="loss_critic")
     raise SystemExit(f"unknown --config {name}")
 

@@ -141,7 +141,10 @@ struct DenseFwdHad : DenseFwd {
 };
 
 // Several networks of the same architecture in one launch (SAC's critics): instance z = blockIdx.z
-struct DenseArgsZ { DenseArgs a[4]; };
+struct DenseArgsZ {
+    DenseArgs a[4];
+    unsigned* sig_flag; unsigned sig_epoch;   // optional: the launch's first workgroup publishes "everything queued before me on my stream is complete" (igemm.hpp start_signal)
+};
 struct DenseFwdZ : DenseFwd {
     using Args = DenseArgsZ;
     __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.a[0].M, mv, mr); }
@@ -329,6 +332,7 @@ struct HeadRef { const float* w; const float* bias; int relu; };   // a narrow l
 template <bool DX>
 __global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
 {
+    start_signal(dz.sig_flag, dz.sig_epoch);
     const DenseArgs& a = dz.a[blockIdx.z];
     __shared__ float red[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,13 +376,14 @@ inline hipError_t launch_dense(hipStream_t st, dim3 grid, const typename P::Args
 {
     return step_launch(st, false, k_igemm<P, 1>, grid, dim3(256), d);
 }
+// sig_flag (small only): the kernel's start publishes sig_epoch (DenseArgsZ)
 inline int32_t dense_forward(bdr_agent* a, hipStream_t st, const DenseLayer& l, const float* params_base, DenseSrc x, float* out, int M,
-                             bool small = false)
+                             bool small = false, unsigned* sig_flag = nullptr, unsigned sig_epoch = 0)
 {
     DenseArgs d{};
     d.x = x; d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
     d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
-    if (small) { DenseArgsZ dz{}; dz.a[0] = d; BDR_HIP(launch_dense_small<false>(st, dz, 1)); return BDR_OK; }
+    if (small) { DenseArgsZ dz{}; dz.a[0] = d; dz.sig_flag = sig_flag; dz.sig_epoch = sig_epoch; BDR_HIP(launch_dense_small<false>(st, dz, 1)); return BDR_OK; }
     BDR_HIP(launch_dense<DenseFwd>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), d));
     return BDR_OK;
 }

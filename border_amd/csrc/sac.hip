@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "dense.hpp"
+#include "queue_flags.hpp"
 
 using namespace bdr;
 
@@ -285,7 +286,22 @@ __global__ void k_randn(float* __restrict__ out, size_t n, uint64_t seed, uint64
 }  // namespace
 
 // ================================================================================================
-struct Sac : bdr_agent {
+// The per-batch matrices of one update.  The agent owns TWO sets: with the side queue (Sac::two_queues) the first launches of
+// update n+1 - sample/pack, the actor's forward on obs - run while update n's critic phase is still using its own set.
+struct SacBatch {
+    float *x_o = nullptr, *x_no = nullptr;          // packed obs / next_obs [B][Kp_pi]
+    std::vector<float*> t_act;                      // trunk activations
+    float *mean = nullptr, *e = nullptr, *a_s = nullptr, *s_s = nullptr, *sd_s = nullptr, *gmean = nullptr, *ge = nullptr;
+    std::vector<float*> t_dy;                       // trunk gradients
+    float *xq_a = nullptr, *xq_n = nullptr, *xq_c = nullptr;   // critic inputs [B][Kp_q]: (obs | a_pi), (next_obs | a_pi'), (obs | act)
+    std::vector<float*> c_act[4];                   // critic activations on xq_a / xq_n
+    std::vector<float*> c2_act[4];                  // critic activations on xq_c (the TD pass)
+    std::vector<float*> c_dy[4];                    // critic gradients per layer
+    float* dxq[4] = {nullptr, nullptr, nullptr, nullptr};   // critic input gradients [B][Kp_q]
+    float *logp = nullptr, *tgt = nullptr, *z_a = nullptr;   // z_a: [2][B][A] N(0,1) draws (actor pass, then target pass)
+};
+
+struct Sac : bdr_agent, SacBatch {
     bdr_sac_config cfg;
     int O = 0, A = 0, NC = 1;
     MlpLayout pi;               // trunk layers + [ml, sl]
@@ -296,18 +312,9 @@ struct Sac : bdr_agent {
     float* q_p[4] = {nullptr}; float* q_t[4] = {nullptr}; float* q_g[4] = {nullptr}; float* q_m[4] = {nullptr}; float* q_v[4] = {nullptr};
     float *log_alpha = nullptr, *al_m = nullptr, *al_v = nullptr;
     uint64_t step_pi = 0, step_q[4] = {0}, step_al = 0;
-    // batch buffers
+    // batch buffers: the current set is the SacBatch base (flip() swaps it with `other`)
     int B = 0; uint64_t batch_gen = 0;   // bumped by every re-allocation (the captured graph holds the old pointers)
-    float *x_o = nullptr, *x_no = nullptr;          // packed obs / next_obs [B][Kp_pi]
-    std::vector<float*> t_act;                      // trunk activations
-    float *mean = nullptr, *e = nullptr, *a_s = nullptr, *s_s = nullptr, *sd_s = nullptr, *gmean = nullptr, *ge = nullptr;
-    std::vector<float*> t_dy;                       // trunk gradients
-    float *xq_a = nullptr, *xq_n = nullptr, *xq_c = nullptr;   // critic inputs [B][Kp_q]: (obs | a_pi), (next_obs | a_pi'), (obs | act)
-    std::vector<float*> c_act[4];                   // critic activations on xq_a / xq_n
-    std::vector<float*> c2_act[4];                  // critic activations on xq_c (the TD pass)
-    std::vector<float*> c_dy[4];                    // critic gradients per layer
-    float* dxq[4] = {nullptr};                      // critic input gradients [B][Kp_q]
-    float *logp = nullptr, *tgt = nullptr, *z_a = nullptr;   // z_a: [2][B][A] N(0,1) draws (actor pass, then target pass)
+    SacBatch other;
     // row-chunk partials of the grouped dW launches: pi layer l at pi_part + pi_off[l]; critic i, layer l at q_part + i * q_part_stride + q_off[l]
     float *pi_part = nullptr, *q_part = nullptr; size_t q_part_stride = 0;
     std::vector<size_t> pi_off, q_off; std::vector<int> pi_chunks, q_chunks;
@@ -325,11 +332,28 @@ struct Sac : bdr_agent {
     unsigned* tickets = nullptr;              // [2] last-workgroup tickets of k_sac_q_last / k_sac_td_last
     float* lrow = nullptr;                    // [3 + NC][ceil(B / 32)] block partials of the batch-wide sums (k_sac_q_last, k_sac_td_last)
     bool small_gemm = true;                   // BDR_NO_SMALL_GEMM=1: the 64x64-tile kernels of the large-batch agents
+    // Side queue (queue_flags.hpp).  The actor's forward on obs needs nothing of the previous update but its actor step, which
+    // is over before that update's critic phase starts: the prologue of update n+1 (sample + pack, trunk, heads + action) runs on
+    // `side`, in the other buffer set, beside the critic phase of update n on `stream`.
+    //   side:    wait PI(n) -> pack, trunk layers, heads+action (set n+1) -> set PRO(n+1)
+    //   stream:  wait PRO(n+1) -> critics on (obs, a_pi) ... actor step -> set PI(n+1) -> critic phase
+    // BDR_SAC_SIDE_QUEUE=0: everything on `stream` (also taken by profiling, prioritized / single-frame buffers, a captured step
+    // and bdr_sac_update_on_batch).  Same kernels, same arguments, same bits either way.
+    enum { SIG_PI = 0, SIG_PRO = 1, SIG_SCRATCH = 2 };
+    hipStream_t side = nullptr; hipEvent_t ev_main = nullptr;
+    unsigned* sig = nullptr;                  // [4] flag words
+    unsigned epoch = 0;                       // update counter of the two-queue sequence
+    bool two_queues = false;                  // the streams exist and sit on different hardware queues
+    bool main_ahead = true;                   // `stream` carries work the flags do not cover (a one-queue update, a parameter exchange,
+                                              // set_params, the buffers' first memset): the side queue waits for it once, with an event
 
     ~Sac() override
     {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
+        if (side) { (void)hipStreamSynchronize(side); stream_retire(side); (void)hipStreamDestroy(side); }   // (a replay buffer may name it as its last reader)
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        (void)hipFree(sig);
         free_batch();
         (void)hipFree(pi_p); (void)hipFree(pi_g); (void)hipFree(pi_m); (void)hipFree(pi_v);
         for (int i = 0; i < 4; ++i) { (void)hipFree(q_p[i]); (void)hipFree(q_t[i]); (void)hipFree(q_g[i]); (void)hipFree(q_m[i]); (void)hipFree(q_v[i]); }
@@ -339,49 +363,64 @@ struct Sac : bdr_agent {
         (void)hipFree(tickets);
         (void)hipFree(pr_logp);
     }
-    void free_batch()
+    static void free_set(SacBatch& b)
     {
-        float** singles[] = {&x_o, &x_no, &mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge, &xq_a, &xq_n, &xq_c, &logp, &tgt, &z_a, &pi_part, &q_part, &lrow};
+        float** singles[] = {&b.x_o, &b.x_no, &b.mean, &b.e, &b.a_s, &b.s_s, &b.sd_s, &b.gmean, &b.ge, &b.xq_a, &b.xq_n, &b.xq_c, &b.logp, &b.tgt, &b.z_a};
         for (auto p : singles) { (void)hipFree(*p); *p = nullptr; }
-        for (auto p : t_act) (void)hipFree(p);
-        for (auto p : t_dy) (void)hipFree(p);
-        t_act.clear(); t_dy.clear();
+        for (auto p : b.t_act) (void)hipFree(p);
+        for (auto p : b.t_dy) (void)hipFree(p);
+        b.t_act.clear(); b.t_dy.clear();
         for (int i = 0; i < 4; ++i) {
-            for (auto p : c_act[i]) (void)hipFree(p);
-            for (auto p : c2_act[i]) (void)hipFree(p);
-            for (auto p : c_dy[i]) (void)hipFree(p);
-            c_act[i].clear(); c2_act[i].clear(); c_dy[i].clear();
-            (void)hipFree(dxq[i]); dxq[i] = nullptr;
+            for (auto p : b.c_act[i]) (void)hipFree(p);
+            for (auto p : b.c2_act[i]) (void)hipFree(p);
+            for (auto p : b.c_dy[i]) (void)hipFree(p);
+            b.c_act[i].clear(); b.c2_act[i].clear(); b.c_dy[i].clear();
+            (void)hipFree(b.dxq[i]); b.dxq[i] = nullptr;
         }
     }
+    void free_batch()
+    {
+        free_set(*this); free_set(other);
+        float** singles[] = {&pi_part, &q_part, &lrow};
+        for (auto p : singles) { (void)hipFree(*p); *p = nullptr; }
+    }
+    void flip() { std::swap(static_cast<SacBatch&>(*this), other); }
     int32_t zalloc(float** p, size_t n)
     {
         BDR_TRY(alloc_f(p, n));
         BDR_HIP(hipMemsetAsync(*p, 0, std::max<size_t>(n, 4) * 4, stream));
         return BDR_OK;
     }
-    int32_t ensure_batch(int Bn)
+    int32_t alloc_set(SacBatch& b, int Bn)
     {
-        if (Bn <= B) return BDR_OK;
-        BDR_HIP(hipStreamSynchronize(stream));
-        free_batch();
         const int Kp = pi.L[0].Kp, Ap = pi.L[n_trunk].Np, Kq = qn.L[0].Kp;
-        BDR_TRY(zalloc(&x_o, (size_t)Bn * Kp)); BDR_TRY(zalloc(&x_no, (size_t)Bn * Kp));
-        for (int i = 0; i < n_trunk; ++i) { float* p = nullptr; BDR_TRY(zalloc(&p, (size_t)Bn * pi.L[i].Np)); t_act.push_back(p); }
-        for (int i = 0; i < n_trunk; ++i) { float* p = nullptr; BDR_TRY(zalloc(&p, (size_t)Bn * pi.L[i].Np)); t_dy.push_back(p); }
-        float** heads[] = {&mean, &e, &a_s, &s_s, &sd_s, &gmean, &ge};
+        BDR_TRY(zalloc(&b.x_o, (size_t)Bn * Kp)); BDR_TRY(zalloc(&b.x_no, (size_t)Bn * Kp));
+        for (int i = 0; i < n_trunk; ++i) { float* p = nullptr; BDR_TRY(zalloc(&p, (size_t)Bn * pi.L[i].Np)); b.t_act.push_back(p); }
+        for (int i = 0; i < n_trunk; ++i) { float* p = nullptr; BDR_TRY(zalloc(&p, (size_t)Bn * pi.L[i].Np)); b.t_dy.push_back(p); }
+        float** heads[] = {&b.mean, &b.e, &b.a_s, &b.s_s, &b.sd_s, &b.gmean, &b.ge};
         for (auto p : heads) BDR_TRY(zalloc(p, (size_t)Bn * Ap));
-        BDR_TRY(zalloc(&xq_a, (size_t)Bn * Kq)); BDR_TRY(zalloc(&xq_n, (size_t)Bn * Kq)); BDR_TRY(zalloc(&xq_c, (size_t)Bn * Kq));
+        BDR_TRY(zalloc(&b.xq_a, (size_t)Bn * Kq)); BDR_TRY(zalloc(&b.xq_n, (size_t)Bn * Kq)); BDR_TRY(zalloc(&b.xq_c, (size_t)Bn * Kq));
         for (int i = 0; i < NC; ++i) {
             for (const auto& l : qn.L) {
                 float *p = nullptr, *p2 = nullptr, *d = nullptr;
                 BDR_TRY(zalloc(&p, (size_t)Bn * l.Np)); BDR_TRY(zalloc(&p2, (size_t)Bn * l.Np)); BDR_TRY(zalloc(&d, (size_t)Bn * l.Np));
-                c_act[i].push_back(p); c2_act[i].push_back(p2); c_dy[i].push_back(d);
+                b.c_act[i].push_back(p); b.c2_act[i].push_back(p2); b.c_dy[i].push_back(d);
             }
-            BDR_TRY(zalloc(&dxq[i], (size_t)Bn * Kq));
+            BDR_TRY(zalloc(&b.dxq[i], (size_t)Bn * Kq));
         }
-        BDR_TRY(zalloc(&logp, Bn)); BDR_TRY(zalloc(&tgt, Bn)); BDR_TRY(zalloc(&lrow, (size_t)(3 + NC) * ((Bn + 31) / 32)));
-        BDR_TRY(zalloc(&z_a, (size_t)2 * Bn * A));
+        BDR_TRY(zalloc(&b.logp, Bn)); BDR_TRY(zalloc(&b.tgt, Bn));
+        BDR_TRY(zalloc(&b.z_a, (size_t)2 * Bn * A));
+        return BDR_OK;
+    }
+    int32_t ensure_batch(int Bn)
+    {
+        if (Bn <= B) return BDR_OK;
+        BDR_HIP(hipStreamSynchronize(stream));
+        if (side) BDR_HIP(hipStreamSynchronize(side));
+        free_batch();
+        BDR_TRY(alloc_set(*this, Bn)); BDR_TRY(alloc_set(other, Bn));
+        BDR_TRY(zalloc(&lrow, (size_t)(3 + NC) * ((Bn + 31) / 32)));
+        main_ahead = true;   // the memsets above are on `stream`
         // row chunks of the grouped dW launches.  64x64 tiles (k_igemm_red_group): about 512 workgroups per launch over all its
         // GEMMs, >= 64 rows per chunk; 32x32 split-reduction tiles (k_dense_dw_small_group): 256 rows per workgroup
         auto plan = [&](const MlpLayout& net, int jobs, std::vector<size_t>& off, std::vector<int>& chunks) {
@@ -405,13 +444,13 @@ struct Sac : bdr_agent {
     }
 
     // pi trunk + heads on packed input x -> mean, e
-    int32_t pi_forward(const float* x, int Bn)
+    int32_t pi_forward(const float* x, int Bn, hipStream_t st)
     {
         bdr_agent* a = this;
         DenseSrc in{x, pi.L[0].Kp};
         for (int i = 0; i < n_trunk; ++i) {
             Bracket br(a, "pi_fwd");
-            BDR_TRY(dense_forward(a, stream, pi.L[i], pi_p, in, t_act[i], Bn, small_gemm));
+            BDR_TRY(dense_forward(a, st, pi.L[i], pi_p, in, t_act[i], Bn, small_gemm));
             in = DenseSrc{t_act[i], pi.L[i].Np};
         }
         // both heads (same shape, same input, consecutive in the arena) in one launch
@@ -420,7 +459,7 @@ struct Sac : bdr_agent {
         const DenseSrc ins[2] = {in, in};
         float* outs[2] = {mean, e};
         Bracket br(a, "pi_head");
-        return dense_forward_z(stream, h0, 2, pb, ins, outs, Bn, small_gemm);
+        return dense_forward_z(st, h0, 2, pb, ins, outs, Bn, small_gemm);
     }
     // action_logp: writes the action into the action columns of the critic input `xq`, log_p into logp
     // the narrow layers fused into row-block kernels (sac_fused.hpp)?  Shapes the kernels do not cover take the layer-by-layer path.
@@ -430,14 +469,16 @@ struct Sac : bdr_agent {
         return fuse_rows && small_gemm && A <= 32 && (O % 32) + A <= 32 && qn.L.size() >= 2 && hd.Np <= 64 && qn.L.back().Np <= 64 * 4;
     }
     // action_logp: writes the action into the action columns of the critic input `xq`, log_p into logp
-    int32_t action_logp(const float* x, const float* z, int Bn, bool save, float* xq)
+    int32_t action_logp(const float* x, const float* z, int Bn, bool save, float* xq, hipStream_t st, unsigned* sig_flag = nullptr, unsigned sig_epoch = 0)
     {
+        // sig_flag: "everything queued before this pass is complete" - carried by the first trunk launch where that kernel can
+        if (sig_flag && !small_gemm) { BDR_TRY(flag_set(st, sig_flag, sig_epoch)); sig_flag = nullptr; }
         if (fused()) {   // trunk layer by layer, then heads + action + log-prob in one row-block kernel
             bdr_agent* a = this;
             DenseSrc in{x, pi.L[0].Kp};
             for (int i = 0; i < n_trunk; ++i) {
                 Bracket br(a, "pi_fwd");
-                BDR_TRY(dense_forward(a, stream, pi.L[i], pi_p, in, t_act[i], Bn, small_gemm));
+                BDR_TRY(dense_forward(a, st, pi.L[i], pi_p, in, t_act[i], Bn, small_gemm, i == 0 ? sig_flag : nullptr, sig_epoch));
                 in = DenseSrc{t_act[i], pi.L[i].Np};
             }
             const DenseLayer &hm = pi.L[n_trunk], &hs = pi.L[n_trunk + 1];
@@ -448,16 +489,17 @@ struct Sac : bdr_agent {
             p.a_out = save ? a_s : nullptr; p.s_out = s_s; p.sd_out = sd_s; p.logp = logp;
             p.B = Bn; p.A = A; p.lo = (float)cfg.min_lstd; p.hi = (float)cfg.max_lstd; p.eps = (float)cfg.epsilon;
             Bracket br(this, "sac_heads_action");
-            BDR_HIP(step_launch(stream, false, k_sac_heads_action, dim3((Bn + 31) / 32), dim3(512), p));
+            BDR_HIP(step_launch(st, false, k_sac_heads_action, dim3((Bn + 31) / 32), dim3(512), p));
             return BDR_OK;
         }
-        BDR_TRY(pi_forward(x, Bn));
+        if (sig_flag) BDR_TRY(flag_set(st, sig_flag, sig_epoch));
+        BDR_TRY(pi_forward(x, Bn, st));
         SacActionArgs p{};
         p.mean = mean; p.e = e; p.ld = pi.L[n_trunk].Np; p.z = z; p.xq = xq; p.ldq = qn.L[0].Kp; p.col0 = O;
         p.a_out = save ? a_s : nullptr; p.s_out = s_s; p.sd_out = sd_s; p.logp = logp;
         p.B = Bn; p.A = A; p.lo = (float)cfg.min_lstd; p.hi = (float)cfg.max_lstd; p.eps = (float)cfg.epsilon;
         Bracket br(this, "sac_action");
-        BDR_HIP(step_launch(stream, false, k_sac_action, dim3((Bn + 3) / 4), dim3(256), p));
+        BDR_HIP(step_launch(st, false, k_sac_action, dim3((Bn + 3) / 4), dim3(256), p));
         return BDR_OK;
     }
     // Forward passes of the critic architecture, layer by layer, up to 4 (parameters, input) pairs per launch:
@@ -515,9 +557,18 @@ struct Sac : bdr_agent {
     int32_t update(int Bn, const float* obs, const float* act, const float* next_obs, const float* reward, const int8_t* term,
                    float* z_actor, float* z_next, bool first, bool draw_noise = false, const GatherArgs* gather = nullptr)
     {
-        bdr_agent* a = this;
         BDR_TRY(ensure_batch(Bn));
-        const int L = (int)qn.L.size(), ldq = qn.L[L - 1].Np, Ap = pi.L[n_trunk].Np, Kq = qn.L[0].Kp;
+        main_ahead = true;
+        BDR_TRY(prologue(stream, Bn, obs, act, next_obs, z_actor, z_next, draw_noise, gather));
+        return update_rest(Bn, reward, term, z_actor, z_next, first, false);
+    }
+    // The part of an update that needs nothing of the previous one but its actor step: pack (+ sample, + noise) and the actor's
+    // forward on obs, up to the action in the critic input and its log-probability.
+    int32_t prologue(hipStream_t st, int Bn, const float* obs, const float* act, const float* next_obs, float* z_actor, float* z_next,
+                     bool draw_noise, const GatherArgs* gather)
+    {
+        bdr_agent* a = this;
+        const int Kq = qn.L[0].Kp;
         {
             SacPackArgs p{};
             p.obs = obs; p.next = next_obs; p.act = act; p.O = O; p.A = A; p.B = Bn; p.x_o = x_o; p.x_no = x_no; p.ldp = pi.L[0].Kp;
@@ -529,10 +580,17 @@ struct Sac : bdr_agent {
             }
             if (gather) { p.do_gather = 1; p.g = *gather; }
             Bracket br(a, "pack");
-            BDR_HIP(step_launch(stream, draw_noise || gather != nullptr, k_sac_pack, dim3((unsigned)((Bn + SAC_PACK_ROWS - 1) / SAC_PACK_ROWS)), dim3(256), p));
+            BDR_HIP(step_launch(st, draw_noise || gather != nullptr, k_sac_pack, dim3((unsigned)((Bn + SAC_PACK_ROWS - 1) / SAC_PACK_ROWS)), dim3(256), p));
         }
         // ---------------- update_actor (sac/base.rs:151-167) ----------------
-        BDR_TRY(action_logp(x_o, z_actor, Bn, true, xq_a));
+        (void)z_next;
+        return action_logp(x_o, z_actor, Bn, true, xq_a, st);
+    }
+    // signal_pi: publish "the actor step of this update is complete" (flag PI, two-queue sequence) once the actor's Adam launch has ended
+    int32_t update_rest(int Bn, const float* reward, const int8_t* term, float* z_actor, float* z_next, bool first, bool signal_pi)
+    {
+        bdr_agent* a = this;
+        const int L = (int)qn.L.size(), ldq = qn.L[L - 1].Np, Ap = pi.L[n_trunk].Np, Kq = qn.L[0].Kp;
         const bool fz = fused();
         {   // Q_i(obs, a_pi) for the actor loss and Q_i(obs, act) for the TD loss: the same parameters (the critics only step at the end)
             const float* params[8]; const float* x[8]; std::vector<float*>* acts[8];
@@ -632,7 +690,8 @@ struct Sac : bdr_agent {
         }
 
         // ---------------- update_critic (sac/base.rs:107-149) ----------------
-        BDR_TRY(action_logp(x_no, z_next, Bn, false, xq_n));            // the UPDATED actor
+        // the UPDATED actor; its first launch starts when the actor's Adam step is complete and says so (flag PI)
+        BDR_TRY(action_logp(x_no, z_next, Bn, false, xq_n, stream, signal_pi ? sig + SIG_PI : nullptr, epoch));
         {
             const float* params[4]; const float* x[4]; std::vector<float*>* acts[4];
             for (int i = 0; i < NC; ++i) { params[i] = q_t[i]; x[i] = xq_n; acts[i] = &c_act[i]; }
@@ -689,10 +748,33 @@ struct Sac : bdr_agent {
     }
 
     const char* kind() const override { return "sac"; }
+    void on_gate_timeout() override { two_queues = false; }   // a flag wait timed out: back to one queue
     // the launch sequence of one opt() (Sac::opt_, sac/base.rs:175-192)
+    // does this opt() take the two-queue sequence?
+    bool side_queue_for(const bdr_replay* r) const { return two_queues && !prof && graph_policy.mode != 1 && gather_in_pack && !r->per && !r->frame_stack; }   // (BDR_STEP_GRAPH=1: the captured step, one queue)
     int32_t opt_enqueue(bdr_replay* r, int Bn)
     {
+        const bool tq = side_queue_for(r) && step_graph_current() == nullptr;
         for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
+            if (tq) {
+                if (main_ahead) {   // once after anything the flags do not cover
+                    BDR_HIP(hipEventRecord(ev_main, stream));
+                    BDR_HIP(hipStreamWaitEvent(side, ev_main, 0));
+                    main_ahead = false;
+                }
+                // the other buffer set: the previous update's critic phase is still reading this one (and the buffer's batch arrays)
+                flip();
+                BDR_TRY(replay_flip_batch(r, Bn));
+                epoch += 1;
+                GatherArgs plan{};
+                BDR_TRY(flag_wait(side, sig + SIG_PI, epoch - 1, dev_err + ERR_GATE, 1u + SIG_PI));   // the actor parameters of update n-1 are final
+                BDR_TRY(replay_sample_plan(r, Bn, side, &plan));
+                BDR_TRY(prologue(side, Bn, (const float*)r->b_obs, (const float*)r->b_act, (const float*)r->b_next, z_a, z_a + (size_t)Bn * A, true, &plan));
+                BDR_TRY(flag_set(side, sig + SIG_PRO, epoch));
+                BDR_TRY(flag_wait(stream, sig + SIG_PRO, epoch, dev_err + ERR_GATE, 1u + SIG_PRO));
+                BDR_TRY(update_rest(Bn, r->b_reward, r->b_term, z_a, z_a + (size_t)Bn * A, u == 0, true));
+                continue;
+            }
             // a uniform sample over the plain ring is drawn by the pack kernel itself (replay_sample_plan); prioritized and
             // single-frame buffers keep their own gather launch
             GatherArgs plan{};
@@ -713,7 +795,7 @@ struct Sac : bdr_agent {
         BDR_TRY(ensure_batch(Bn));
         // ~70 kernels of 2-8 us: replayed from a captured graph (step_graph.hpp).  Profiling brackets and prioritized replay
         // (tree kernels with their own host state) take the eager path - the same sequence, launched one by one.
-        if (prof || r->per) return opt_enqueue(r, Bn);
+        if (prof || r->per || side_queue_for(r)) return opt_enqueue(r, Bn);
         {
             const int w = graph_policy.want(stream);
             if (w < 0) return fail(BDR_ERR_HIP, "hipStreamQuery failed");
@@ -782,7 +864,11 @@ struct Sac : bdr_agent {
         return BDR_OK;
     }
     // SyncModel ships only `pi` (sac/base.rs:377-386)
-    float* arena(int which, size_t* n) override { Slot s = slot(which); if (n) *n = s.n; return s.p; }
+    float* arena(int which, size_t* n) override
+    {
+        main_ahead = true;   // the caller (a parameter exchange) enqueues work on `stream` the flags know nothing about
+        Slot s = slot(which); if (n) *n = s.n; return s.p;
+    }
 
     std::vector<NamedTensor> pi_meta() const
     {
@@ -884,6 +970,16 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     a->gather_in_pack = getenv("BDR_NO_STEP_GATHER") == nullptr;
     a->fuse_rows = getenv("BDR_NO_SAC_FUSE") == nullptr;
     BDR_HIP(hipMalloc((void**)&a->tickets, 2 * sizeof(unsigned))); BDR_HIP(hipMemsetAsync(a->tickets, 0, 2 * sizeof(unsigned), a->stream));
+    {
+        const char* e = getenv("BDR_SAC_SIDE_QUEUE");
+        if (!(e && e[0] == '0')) {
+            BDR_HIP(hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking));
+            BDR_HIP(hipEventCreateWithFlags(&a->ev_main, hipEventDisableTiming));
+            BDR_HIP(hipMalloc((void**)&a->sig, 4 * sizeof(unsigned)));
+            BDR_HIP(hipMemset(a->sig, 0, 4 * sizeof(unsigned)));
+            BDR_TRY(flag_queues_independent(a->stream, a->side, a->sig + Sac::SIG_SCRATCH, &a->two_queues));
+        }
+    }
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};
     for (auto p : pis) BDR_TRY(a->zalloc(p, a->pi.total));
     for (int i = 0; i < a->NC; ++i) {
@@ -1033,7 +1129,7 @@ int32_t bdr_sac_sample(bdr_agent* base, uint64_t n, const float* obs, float* act
         if (a->train) st = a->gen_noise(a->z_a, n * a->A);
         else { hipError_t e = hipMemsetAsync(a->z_a, 0, n * a->A * 4, a->stream); if (e != hipSuccess) st = fail(BDR_ERR_HIP, "memset failed"); }
     }
-    if (st == BDR_OK) st = a->action_logp(a->x_o, a->z_a, (int)n, true, a->xq_a);
+    if (st == BDR_OK) st = a->action_logp(a->x_o, a->z_a, (int)n, true, a->xq_a, a->stream);
     const int Ap = a->pi.L[a->n_trunk].Np;
     std::vector<float> tmp(n * Ap);
     if (st == BDR_OK) {

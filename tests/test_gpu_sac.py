@@ -221,9 +221,11 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
     from oracle import torch_ref as T
     od, ad = 17, 6
     def run(env):
-        for k in ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER", "BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH", "BDR_STEP_GRAPH_BREAK_AT", "BDR_NO_SAC_FUSE"): monkeypatch.delenv(k, raising=False)
+        for k in ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER", "BDR_NO_SMALL_GEMM", "BDR_STEP_GRAPH", "BDR_STEP_GRAPH_BREAK_AT", "BDR_NO_SAC_FUSE", "BDR_SAC_SIDE_QUEUE"):
+            monkeypatch.delenv(k, raising=False)
         for k in env:
             if k == "BREAK": monkeypatch.setenv("BDR_STEP_GRAPH_BREAK_AT", "2")   # the third replay pass "diverges"
+            elif k == "ONE_QUEUE": monkeypatch.setenv("BDR_SAC_SIDE_QUEUE", "0")
             elif k != "ADAPTIVE": monkeypatch.setenv(k, "1")
         if "BDR_NO_STEP_GRAPH" not in env and "ADAPTIVE" not in env: monkeypatch.setenv("BDR_STEP_GRAPH", "1")   # every opt from the graph
         rng = np.random.default_rng(11)
@@ -236,13 +238,26 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
         cfg = B.SacConfig(obs_dim=od, act_dim=ad, pi_units=(64, 64), q_units=(64, 64), n_critics=2, batch_size=128,
                           ent_coef_mode=("Auto", -6.0, 3e-4), n_updates_per_opt=2, device=0, seed=5)
         a = B.Sac.build(cfg)
-        recs = []
+        a.train()
+        import ctypes as C
+        L = B._lib.lib()
+        uid = (C.c_uint8 * B._lib.BDR_UNIQUE_ID_BYTES)()
+        B._lib.check(L.bdr_comm_get_unique_id(uid))
+        comm = C.c_void_p()
+        B._lib.check(L.bdr_comm_init_rank(uid, 1, 0, 0, C.byref(comm)))
+        recs, acts = [], []
         for k in range(12):
             recs.append(a.opt_with_record(rb) if k % 3 == 0 else (a.opt(rb), None)[1])
             if k % 2 == 1: push(100)
             if k == 6: a.update_on_batch(*T.sac_batch(256, od, ad, 99))
+            # work on the agent's stream between opts that the two-queue sequence has to order itself behind: the in-stream parameter
+            # exchange (identity at one rank) and Policy::sample (its own rows through the current buffer set, noise from the agent's stream)
+            if k in (4, 9): B._lib.check(L.bdr_agent_allreduce_params(a.handle, comm, 0))
+            if k in (2, 5, 10): acts.append(a.sample(rng.standard_normal((3, od)).astype(np.float32)))
+        B._lib.check(L.bdr_comm_destroy(comm))
         out = {n: a.get_params(n) for n in ("pi", "qnet_0", "qnet_1", "qnet_tgt_0", "qnet_tgt_1", "log_alpha")}
         out["next_indices"] = rb.sample_indices(50)
+        out["sampled_actions"] = np.concatenate(acts)
         n_opts = a.n_opts
         a.close(); rb.close()
         return out, recs, n_opts
@@ -254,8 +269,11 @@ def test_sac_opt_from_captured_graph_is_bit_identical_to_eager_launches(B, monke
     # not dropped, Adam / RNG / replay positions not skewed - and the agent stays eager (step_graph_run)
     # ... and the row-block kernels that fuse the narrow layers into their neighbours (sac_fused.hpp: 21 launches) against the
     # layer-by-layer sequence (30 launches), from the graph and eagerly
-    for env in (("BDR_NO_STEP_GRAPH",), ("BDR_NO_STEP_GATHER",), ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER"), ("ADAPTIVE",), ("BREAK",),
-                ("BDR_NO_SAC_FUSE",), ("BDR_NO_SAC_FUSE", "BDR_NO_STEP_GRAPH")):
+    # ... and the two-queue sequence (csrc/sac.hip `side`: the next update's sample + actor forward beside this update's critic phase, in
+    # the other buffer set, ordered by device flags; what an eager opt() takes unless BDR_SAC_SIDE_QUEUE=0) against one queue
+    for env in (("BDR_NO_STEP_GRAPH",), ("BDR_NO_STEP_GRAPH", "ONE_QUEUE"), ("BDR_NO_STEP_GATHER",), ("BDR_NO_STEP_GRAPH", "BDR_NO_STEP_GATHER"),
+                ("ADAPTIVE",), ("ADAPTIVE", "ONE_QUEUE"), ("BREAK",), ("BDR_NO_SAC_FUSE",), ("BDR_NO_SAC_FUSE", "BDR_NO_STEP_GRAPH"),
+                ("BDR_NO_SAC_FUSE", "BDR_NO_STEP_GRAPH", "ONE_QUEUE")):
         e, erec, en = run(env)
         assert en == gn, env
         for k in g: assert (g[k] == e[k]).all(), (env, k)

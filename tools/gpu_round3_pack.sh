@@ -11,6 +11,7 @@ done
 timeout 600 python bench.py --config c2 --frame-ring --no-cpu-baseline > $O/bench_${tag}_c2_frame_ring.json 2>/dev/null
 timeout 600 python bench.py --config c2 --per --no-cpu-baseline > $O/bench_${tag}_c2_per.json 2>/dev/null
 BDR_NO_SAC_FUSE=1 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_layer_by_layer.json 2>/dev/null
+BDR_SAC_SIDE_QUEUE=0 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_one_queue.json 2>/dev/null
 trace() {  # name, env, bench args, json name (or -)
   ( cd /tmp && env $2 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_${tag}_$1 -o t -- python $GRAFT_REPO_ROOT/bench.py $3 --no-cpu-baseline --profile-steps 0 > $GRAFT_REPO_ROOT/$O/prof_${tag}_$1.log 2>&1 )
   db=$(find $O/prof_${tag}_$1 -name "*.db" | head -1)

@@ -254,10 +254,18 @@ def roofline(conf, prof, cnt, null_ms, ms_step):
     bf16 = [k for k in prof if k in fl and k in BF16_KERNELS and prof[k] > 0]
     roof = {}
     if fp32:
-        dom = max(fp32, key=lambda k: prof[k])
+        # the longest launch of the step; two launches within 5 % of each other (C2: conv2 forward of both networks and conv2's
+        # input gradient, 29-30 us each) trade places from run to run, so among those the one with the most algorithmic work
+        # is named - the same kernel in every line - and the other one is listed beside it
+        t_max = max(prof[k] for k in fp32)
+        near = sorted((k for k in fp32 if prof[k] >= 0.95 * t_max), key=lambda k: (-fl[k], k))
+        dom = near[0]
         ach = fl[dom] / (prof[dom] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel_ms": round(prof[dom], 5)}
+        if len(near) > 1:
+            roof["within_5pct"] = {k: {"kernel_ms": round(prof[k], 5), "frac": round(fl[k] / (prof[k] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                                   for k in near[1:]}
     else:   # launch / HBM-bound configurations: the dominant kernel with a byte model
         known = [k for k in prof if k in by and prof[k] > 0]
         dom = max(known, key=lambda k: prof[k]) if known else None
@@ -356,7 +364,9 @@ def cpu_baseline(config, batch, loss, budget_s):
     left = max(3.0, budget_s - (time.perf_counter() - t_budget0))
     v, thr = timer(steps=2000, warmup=1, threads=best_t, seconds=left, **kw)
     n = min(2000, max(1, int(round(v * left))))
-    out = {"value": round(v, 3), "unit": "opt-steps/s", "cores": thr, "kind": "port",
+    # the CPU's better number is the baseline: the long sample at the best thread count, or that count's short sample of the sweep when the
+    # host slowed down over the long one (shared boxes; the f32 ring's pages are touched as the run goes on)
+    out = {"value": round(max(v, sweep[best_t]), 3), "long_sample": round(v, 3), "unit": "opt-steps/s", "cores": thr, "kind": "port",
            "sample": f"~{n} opt steps in <= {left:.0f} s (batch {batch}" + (", f32 ring of 65536 transitions as the reference stores it" if config == "c2" else "")
                      + ") of oracle/torch_ref.py: the libtorch-CPU (ATen) op sequence border-tch-agent binds through tch; best of the thread sweep",
            "threads_1": sweep[1], "thread_sweep": sweep, "cpu_model": info["model"], "physical_cores": info["physical_cores"],

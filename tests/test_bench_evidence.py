@@ -61,3 +61,18 @@ def test_committed_evidence_files_are_stamped():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     doc = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
     assert "_source" in doc and len(doc["_source"]["kernel_source_sha16"]) == 16
+
+
+def test_the_dominant_kernel_of_the_line_does_not_flip_between_near_ties():
+    """C2's two longest launches (conv2 forward of both networks, conv2's input gradient) are within a few % of each other and trade
+    places from run to run; the line names the one with the most algorithmic work among launches within 5 % of the longest, and lists
+    the other beside it - a different kernel only when it really is longer."""
+    import bench
+    conf = {"name": "c2", "flops": {"fwd_conv2": 2.718e9, "bwd_conv2_dx": 1.359e9, "fwd_conv3": 1.85e9}, "bytes": {"sample": 14454272},
+            "step_flops": 17.46e9, "batch": 256}
+    cnt = {"fwd_conv2": 1, "bwd_conv2_dx": 1, "fwd_conv3": 1, "sample": 1}
+    r = bench.roofline(conf, {"fwd_conv2": 0.0299, "bwd_conv2_dx": 0.0301, "fwd_conv3": 0.022, "sample": 0.011}, cnt, 0.003, 0.22)
+    assert r["kernel"] == "fwd_conv2" and list(r["within_5pct"]) == ["bwd_conv2_dx"]
+    assert abs(r["frac"] - 2.718e9 / 0.0299e-3 / 1e12 / bench.PEAK_FP32_MFMA_TFLOPS) < 1e-3
+    r = bench.roofline(conf, {"fwd_conv2": 0.0299, "bwd_conv2_dx": 0.0330, "fwd_conv3": 0.022, "sample": 0.011}, cnt, 0.003, 0.22)
+    assert r["kernel"] == "bwd_conv2_dx" and "within_5pct" not in r

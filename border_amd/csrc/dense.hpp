@@ -298,6 +298,53 @@ __device__ __forceinline__ void dense_small_tile(LoadA&& loadA, const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
 }
+// The same tile with the B operand fetched ahead of time (kred <= 256: one pass of the loop above): a row-block kernel whose second
+// tile takes its A operand from LDS loads the weights at kernel start instead of as a dependent round trip in the middle.
+// Same k-slots, same MFMA order as dense_small_tile: same bits.
+template <bool DX>
+__device__ __forceinline__ void dense_small_load_b(const float* __restrict__ w, int w_ld, int n0, int kred, int wave, int lane, f32x4 (&bv)[8])
+{
+    const int i = lane & 31, h = lane >> 5;
+    const int Kw = kred / 4, kbeg = wave * Kw;
+    const float* wcol = DX ? w + (size_t)(n0 + i) * w_ld : w + n0 + i;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (16 * c < Kw) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = kbeg + 16 * c + 8 * u + 4 * h;
+                if constexpr (DX) bv[c * 2 + u] = *reinterpret_cast<const f32x4*>(wcol + k);
+                else { const float* p = wcol + (size_t)k * w_ld; bv[c * 2 + u] = f32x4{p[0], p[w_ld], p[2 * (size_t)w_ld], p[3 * (size_t)w_ld]}; }
+            }
+        }
+    }
+}
+template <class LoadA>
+__device__ __forceinline__ void dense_small_tile_pre(LoadA&& loadA, const f32x4 (&bv)[8], int kred, int wave, int lane, float (*red)[32][33])
+{
+    const int i = lane & 31, h = lane >> 5;
+    const int Kw = kred / 4, kbeg = wave * Kw;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 av[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (16 * c < Kw) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) av[c * 2 + u] = loadA(kbeg + 16 * c + 8 * u + 4 * h);
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (16 * c < Kw) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c * 2 + u][q], bv[c * 2 + u][q], acc, 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
+}
 // element (r, c) of the tile: the four wave slices in their fixed order (call after the barrier that follows dense_small_tile)
 __device__ __forceinline__ float dense_small_sum(const float (*red)[32][33], int r, int c)
 {
@@ -311,8 +358,11 @@ __device__ __forceinline__ float dense_small_sum(const float (*red)[32][33], int
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// "am I the last workgroup of this launch?"
-__device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_wg, unsigned* s_flag)
+// "am I the last workgroup of this launch?" in two halves, so that work the answer does not depend on (stores of results nobody in
+// this launch reads) can sit between them and hide the ticket's round trip:
+//   ticket_take   after the workgroup's LAST agent-scope store to data the last workgroup will read; contains a workgroup barrier
+//   ticket_last   the answer (contains a workgroup barrier)
+__device__ __forceinline__ void ticket_take(unsigned* ticket, unsigned n_wg, unsigned* s_flag)
 {
     // every thread's agent-scope stores acknowledged by the coherent level before the ticket is taken: the workgroup barrier alone
     // does not wait for them (a workgroup-scope release is lgkmcnt only outside threadgroup-split mode)
@@ -323,8 +373,16 @@ __device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_wg, 
         *s_flag = t == n_wg - 1 ? 1u : 0u;
         if (t == n_wg - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
     }
+}
+__device__ __forceinline__ bool ticket_last(const unsigned* s_flag)
+{
     __syncthreads();
     return *s_flag != 0u;
+}
+__device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_wg, unsigned* s_flag)
+{
+    ticket_take(ticket, n_wg, s_flag);
+    return ticket_last(s_flag);
 }
 
 struct HeadRef { const float* w; const float* bias; int relu; };   // a narrow layer handed to a row-block kernel
@@ -339,25 +397,32 @@ __global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
     const int NT = a.ncols / 32;
     const int m0 = ((int)blockIdx.x / NT) * 32, n0 = ((int)blockIdx.x % NT) * 32;
     const float* arow = a.x.p + (size_t)min(m0 + (lane & 31), a.M - 1) * a.x.ld;   // rows >= M alias the last row (never stored)
+    // the epilogue's operands (bias / ReLU mask / the value accumulated onto) depend on nothing this kernel computes: their loads are
+    // issued here, beside the tile operands, instead of as one more memory round trip behind the barrier (the step is a chain of
+    // these launches, each a handful of dependent round trips long)
+    const int r = tid >> 3, c4 = (tid & 7) * 4, m = m0 + r, n = n0 + c4, mc = min(m, a.M - 1);
+    float* o = a.out + (size_t)mc * a.ldo + n;
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!DX) e0 = *reinterpret_cast<const f32x4*>(a.bias + n);
+    else {
+        if (a.mask) e0 = *reinterpret_cast<const f32x4*>(a.mask + (size_t)mc * a.ldm + n);
+        if (a.accum) e1 = *reinterpret_cast<const f32x4*>(o);
+    }
     dense_small_tile<DX>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, a.w, a.w_ld, n0, a.kred, wave, lane, red);
     __syncthreads();
-    const int r = tid >> 3, c4 = (tid & 7) * 4, m = m0 + r, n = n0 + c4;
     if (m >= a.M) return;
     f32x4 v;
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = dense_small_sum(red, r, c4 + q);
-    float* o = a.out + (size_t)m * a.ldo + n;
     if constexpr (!DX) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] += b[q]; if (a.relu) v[q] = v[q] > 0.f ? v[q] : 0.f; }
+        for (int q = 0; q < 4; ++q) { v[q] += e0[q]; if (a.relu) v[q] = v[q] > 0.f ? v[q] : 0.f; }
     } else {
         if (a.mask) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + (size_t)m * a.ldm + n);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (!(mk[q] > 0.f)) v[q] = 0.f;
+            for (int q = 0; q < 4; ++q) if (!(e0[q] > 0.f)) v[q] = 0.f;
         }
-        if (a.accum) { const f32x4 old = *reinterpret_cast<const f32x4*>(o); v += old; }
+        if (a.accum) v += e1;
     }
     *reinterpret_cast<f32x4*>(o) = v;
 }

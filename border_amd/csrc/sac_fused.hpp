@@ -55,22 +55,28 @@ __global__ __launch_bounds__(512) void k_sac_heads_action(SacHeadsActionArgs p)
     const int m0 = (int)blockIdx.x * 32;
     const float* arow = p.h + (size_t)min(m0 + (lane & 31), p.B - 1) * p.ldh;
     const HeadRef& hd = team ? p.hs : p.hm;
+    // operands of the row arithmetic that do not depend on the tiles: loaded beside the tile operands, not behind the barrier
+    const float bias_m = p.hm.bias[lane & 31], bias_s = p.hs.bias[lane & 31];
+    float zrow[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) zrow[rr] = lane < p.A ? p.z[(size_t)min(m0 + wave * 4 + rr, p.B - 1) * p.A + lane] : 0.f;
     dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, hd.w, p.w_ld, 0, p.kred, w4, lane, red[team]);
     __syncthreads();
     // one wave per row, lanes over the action dimension: k_sac_action's arithmetic and its butterfly sums
+#pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int r = wave * 4 + rr, row = m0 + r;
         if (row >= p.B) break;
         float nl = 0.f, sl = 0.f;
         if (lane < 32) {   // columns of tile 0 (the rest of the padded width stays zero from allocation)
-            float mv = dense_small_sum(red[0], r, lane) + p.hm.bias[lane];
-            float ev = dense_small_sum(red[1], r, lane) + p.hs.bias[lane];
+            float mv = dense_small_sum(red[0], r, lane) + bias_m;
+            float ev = dense_small_sum(red[1], r, lane) + bias_s;
             if (p.hm.relu) mv = mv > 0.f ? mv : 0.f;
             if (p.hs.relu) ev = ev > 0.f ? ev : 0.f;
             const size_t q = (size_t)row * p.ld + lane;
             p.mean[q] = mv; p.e[q] = ev;
             if (lane < p.A) {
-                const float z = p.z[(size_t)row * p.A + lane];
+                const float z = zrow[rr];
                 const float s = expf(ev);
                 const float cl = fminf(fmaxf(s, p.lo), p.hi);
                 const float sd = expf(cl);
@@ -148,6 +154,14 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < p.NC) last_layer_dx_load(dxr[i], p.hin[i], p.w_last[i], p.w_ld, p.ldh, y * 64, m0, p.B, tid);
+    // everything else the kernel reads that it does not compute itself, issued now: each of these was one more dependent memory round
+    // trip (1-2 us) behind a barrier.  The scalars are only used by the last workgroup - which one that will be is not known yet.
+    float bias_pre[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias_pre[i] = i < p.NC ? p.wl[jb + i].bias[tid & 31] : 0.f;
+    const float lp_pre = (!act_pass && tid < 32) ? p.logp[min(m0 + tid, p.B - 1)] : 0.f;
+    const float la_pre = p.log_alpha[0], out_pre = p.accumulate ? p.out[0] : 0.f;
+    const float am_pre = p.auto_alpha ? p.al_m[0] : 0.f, av_pre = p.auto_alpha ? p.al_v[0] : 0.f;
     for (int j0 = 0; j0 < p.NC; j0 += 2) {
         const int j = j0 + team;
         if (j < p.NC && !(SF_ABL & 4)) {   // team-uniform
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
         for (int e = tid; e < 2 * 32 * 32; e += 512) {
             const int t = e >> 10, r = (e >> 5) & 31, c = e & 31, jj = j0 + t;
             if (jj >= p.NC || m0 + r >= p.B) continue;
-            float v = dense_small_sum(red[t], r, c) + p.wl[jb + jj].bias[c];
+            float v = dense_small_sum(red[t], r, c) + (jj == 0 ? bias_pre[0] : jj == 1 ? bias_pre[1] : jj == 2 ? bias_pre[2] : bias_pre[3]);   // (c == tid & 31; selects, not a dynamically indexed register array)
             if (p.wl[jb + jj].relu) v = v > 0.f ? v : 0.f;
             if (c == 0) qv[jj][r] = v;
             if (!writer) continue;
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
                 qm = qv[0][tid];
                 for (int i = 1; i < p.NC; ++i) { const float v = qv[i][tid]; if (v < qm) { qm = v; im = i; } }
                 for (int i = 0; i < p.NC; ++i) { const float d = i == im ? 1.0f : 0.0f; sel[i][tid] = d; if (writer) p.dout[i][(size_t)(m0 + tid) * p.ldq] = d; }
-                lp = p.logp[m0 + tid];
+                lp = lp_pre;
             }
             if (writer) {
                 const int nb = (p.B + 31) / 32;
@@ -184,22 +198,25 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
                 if (tid == 0) { st_agent(p.part + blockIdx.x, p1); st_agent(p.part + nb + blockIdx.x, p2); st_agent(p.part + 2 * nb + blockIdx.x, p3); }
             }
         }
-        __syncthreads();
+    }
+    if (SF_ABL & 1) return;
+    // the partials are out: take the ticket now (its barrier also publishes `sel`) and let its round trip run under the gradient stores
+    ticket_take(p.ticket, gridDim.x * gridDim.y, &s_last);
+    if (!act_pass) {
         // d qmin / d h2 = relu'(h2) * dout * W_last[:, 0]   (what the last layer's dX launch computes: its only non-zero term)
         if (!(SF_ABL & 2))
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < p.NC) last_layer_dx_store(dxr[i], sel[i], p.dh[i], p.ldh, y * 64, m0, p.B, tid);
     }
-    if (SF_ABL & 1) return;
-    if (!last_workgroup(p.ticket, gridDim.x * gridDim.y, &s_last)) return;
+    if (!ticket_last(&s_last)) return;
     // ---- k_sac_select's batch-wide part, by the last workgroup to finish: the block partials in block order
     const int nb = (p.B + 31) / 32;
-    float log_alpha = p.log_alpha[0];
+    float log_alpha = la_pre;
     if (p.auto_alpha) {
         const float g = -(sum_partials(p.part, nb, lsum) / (float)p.B);
-        const float mm = p.al_m[0] * p.s.b1 + g * p.s.omb1;
-        const float vv = p.al_v[0] * p.s.b2 + p.s.omb2 * g * g;
+        const float mm = am_pre * p.s.b1 + g * p.s.omb1;
+        const float vv = av_pre * p.s.b2 + p.s.omb2 * g * g;
         const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
         log_alpha = log_alpha + p.s.neg_step * mm / denom;
         __syncthreads();
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
     const float alpha = expf(log_alpha);
     const float s_logp = sum_partials(p.part + nb, nb, lsum);
     const float s_qm = sum_partials(p.part + 2 * nb, nb, lsum);
-    if (tid == 0) p.out[0] = actor_loss_sum(p.accumulate ? p.out[0] : 0.f, alpha, s_logp, s_qm, p.scale);
+    if (tid == 0) p.out[0] = actor_loss_sum(out_pre, alpha, s_logp, s_qm, p.scale);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -234,6 +251,23 @@ __global__ __launch_bounds__(512) void k_sac_actor_bwd(SacActorBwdArgs p)
     const int team = wave >> 2, w4 = wave & 3;
     const int m0 = (int)blockIdx.x * 32, n0 = (int)blockIdx.y * 32;
     const int r = (tid & 255) >> 3, c4 = (tid & 7) * 4;          // epilogue element of threads 0..255
+    // ---- operands that depend on nothing this kernel computes, issued now (see k_sac_q_last): the heads' weights of the second tile,
+    // the action / sigma / noise values of the tanh-Gaussian backward, the ReLU mask of the output, the entropy coefficient
+    f32x4 bh[8];
+    dense_small_load_b<true>(team ? p.ws : p.wm, p.wh_ld, n0, p.kredh, w4, lane, bh);   // kredh = the heads' padded width <= 64
+    const float la_pre = p.log_alpha[0];
+    float a_pre[4] = {0.f, 0.f, 0.f, 0.f}, s_pre[4] = {0.f, 0.f, 0.f, 0.f}, sd_pre[4] = {0.f, 0.f, 0.f, 0.f}, z_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 256 && m0 + r < p.B) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = p.n0a + c4 + q - p.col0;
+            if (j < 0 || j >= p.A) continue;
+            const size_t t = (size_t)(m0 + r) * p.ld + j;
+            a_pre[q] = p.a[t]; s_pre[q] = p.s[t]; sd_pre[q] = p.sd[t]; z_pre[q] = p.z[(size_t)(m0 + r) * p.A + j];
+        }
+        mk = *reinterpret_cast<const f32x4*>(p.hmask + (size_t)(m0 + r) * p.ldh + n0 + c4);
+    }
     // ---- sum over the critics of d qmin / d a, critic by critic (k_sac_actor_grad's order, starting from 0); two critics per round
     float dq[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i0 = 0; i0 < p.NC; i0 += 2) {
@@ -254,19 +288,18 @@ __global__ __launch_bounds__(512) void k_sac_actor_bwd(SacActorBwdArgs p)
     for (int e = tid; e < 32 * p.ld; e += 512) { gm[e / p.ld][e % p.ld] = 0.f; gs[e / p.ld][e % p.ld] = 0.f; }
     __syncthreads();
     if (tid < 256) {
-        const float alpha = expf(p.log_alpha[0]);
+        const float alpha = expf(la_pre);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = p.n0a + c4 + q - p.col0, b = m0 + r;
             if (j < 0 || j >= p.A || b >= p.B) continue;
-            const size_t t = (size_t)b * p.ld + j;
-            const float a = p.a[t], s = p.s[t], sd = p.sd[t];
+            const float a = a_pre[q], s = s_pre[q], sd = sd_pre[q];
             const float dlogp = (2.0f * a) / ((1.0f - a * a) + p.eps);
             const float ga = (alpha * dlogp - dq[q]) / (float)p.B;
             const float gu = ga * (1.0f - a * a);
             const float inr = (s >= p.lo && s <= p.hi) ? 1.0f : 0.0f;
             gm[r][j] = gu;
-            gs[r][j] = gu * p.z[(size_t)b * p.A + j] * sd * inr * s;
+            gs[r][j] = gu * z_pre[q] * sd * inr * s;
         }
     }
     __syncthreads();
@@ -278,11 +311,10 @@ __global__ __launch_bounds__(512) void k_sac_actor_bwd(SacActorBwdArgs p)
     // ---- both heads' input gradient for the 32 trunk features of this column block: team 0 gmean Wml^T, team 1 ge Wsl^T
     const int i32 = lane & 31;
     const float (*ga)[SF_LDG] = team ? gs : gm;
-    dense_small_tile<true>([&](int k) { return *reinterpret_cast<const f32x4*>(&ga[i32][k]); }, team ? p.ws : p.wm, p.wh_ld, n0, p.kredh, w4, lane, red[team]);
+    dense_small_tile_pre([&](int k) { return *reinterpret_cast<const f32x4*>(&ga[i32][k]); }, bh, p.kredh, w4, lane, red[team]);
     __syncthreads();
     if (tid >= 256 || m0 + r >= p.B) return;
     const size_t o = (size_t)(m0 + r) * p.ldh + n0 + c4;
-    const f32x4 mk = *reinterpret_cast<const f32x4*>(p.hmask + o);
     f32x4 out;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -321,6 +353,17 @@ __global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < p.NC) last_layer_dx_load(dxr[i], p.hin[i], p.w_last[i], p.w_ld, p.ldh, (int)blockIdx.y * 64, m0, p.B, tid);
+    // the row arithmetic's operands and the last workgroup's scalar, issued now (see k_sac_q_last)
+    float bias_pre[4], q_pre[4];
+    const int b_pre = min(m0 + (tid & 31), p.B - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bias_pre[i] = i < p.NC ? p.wl_t[i].bias[tid & 31] : 0.f;
+        q_pre[i] = (i < p.NC && tid < 64) ? p.q[i][(size_t)b_pre * p.ldq] : 0.f;
+    }
+    const float la_pre = p.log_alpha[0], out_pre = p.accumulate ? p.out[0] : 0.f;
+    float rew_pre = 0.f, term_pre = 0.f, lp_pre = 0.f;
+    if (tid < 64) { rew_pre = p.reward[b_pre]; term_pre = (float)p.term[b_pre]; lp_pre = p.logp[b_pre]; }
     for (int j0 = 0; j0 < p.NC; j0 += 2) {
         const int j = j0 + team;
         if (j < p.NC) {
@@ -331,7 +374,7 @@ __global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
         for (int e = tid; e < 2 * 32 * 32; e += 512) {
             const int t = e >> 10, r = (e >> 5) & 31, c = e & 31, jj = j0 + t;
             if (jj >= p.NC || m0 + r >= p.B) continue;
-            float v = dense_small_sum(red[t], r, c) + p.wl_t[jj].bias[c];
+            float v = dense_small_sum(red[t], r, c) + (jj == 0 ? bias_pre[0] : jj == 1 ? bias_pre[1] : jj == 2 ? bias_pre[2] : bias_pre[3]);   // (c == tid & 31)
             if (p.wl_t[jj].relu) v = v > 0.f ? v : 0.f;
             if (writer) p.qt[jj][(size_t)(m0 + r) * p.ldq + c] = v;
             if (c == 0) qtv[jj][r] = v;
@@ -342,14 +385,16 @@ __global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
     if (tid < 64) {
         const bool ok = tid < 32 && m0 + tid < p.B;
         const int b = min(m0 + tid, p.B - 1);
-        const float alpha = expf(p.log_alpha[0]);
+        const float alpha = expf(la_pre);
         float qm = qtv[0][tid & 31];
         for (int i = 1; i < p.NC; ++i) qm = fminf(qm, qtv[i][tid & 31]);
-        const float tgt = sac_td_target(p.reward_scale, p.reward[b], (float)p.term[b], p.gamma, qm, alpha, p.logp[b]);
+        const float tgt = sac_td_target(p.reward_scale, rew_pre, term_pre, p.gamma, qm, alpha, lp_pre);
         if (ok && writer) p.tgt[b] = tgt;
-        for (int i = 0; i < p.NC; ++i) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= p.NC) break;
             float l, g;
-            sac_td_loss(p.q[i][(size_t)b * p.ldq], tgt, p.loss_kind, l, g);
+            sac_td_loss(q_pre[i], tgt, p.loss_kind, l, g);
             const float dv = g / (float)p.B;
             if (ok) { dl[i][tid] = dv; if (writer) p.dout[i][(size_t)b * p.ldq] = dv; }
             if (writer) {
@@ -358,13 +403,14 @@ __global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
             }
         }
     }
-    __syncthreads();
+    // the partials are out: ticket first (its barrier also publishes `dl`), its round trip runs under the gradient stores
+    ticket_take(p.ticket, gridDim.x * gridDim.y, &s_last);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < p.NC) last_layer_dx_store(dxr[i], dl[i], p.dh[i], p.ldh, (int)blockIdx.y * 64, m0, p.B, tid);
-    if (!last_workgroup(p.ticket, gridDim.x * gridDim.y, &s_last)) return;
+    if (!ticket_last(&s_last)) return;
     const int nb = (p.B + 31) / 32;
-    float total = p.accumulate ? p.out[0] : 0.f;
+    float total = out_pre;
     for (int i = 0; i < p.NC; ++i) total = add_scaled(total, sum_partials(p.part + (size_t)i * nb, nb, lsum), p.scale);
     if (tid == 0) p.out[0] = total;
 }

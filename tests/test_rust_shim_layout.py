@@ -308,3 +308,56 @@ def test_the_crate_has_complete_sources_and_integration_md_points_at_them():
     assert "rust/border-amd-agent/src/ffi.rs" in integ and "rust/border-amd-agent/src/async_trainer.rs" in integ
     # no Rust struct literal of the ABI survives in the document (it went stale once): the crate is the source
     assert "reserved: 0 };" not in integ and "device: 0, reserved: 0" not in integ
+
+
+def _rust_code_only(src: str) -> str:
+    """Rust source with comments, string / char literals removed (lifetimes kept): enough for delimiter accounting."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("//", i):
+            i = src.find("\n", i) if src.find("\n", i) >= 0 else n
+        elif src.startswith("/*", i):
+            depth, i = 1, i + 2
+            while i < n and depth:
+                if src.startswith("/*", i): depth += 1; i += 2
+                elif src.startswith("*/", i): depth -= 1; i += 2
+                else: i += 1
+        elif c == '"' or (c == "r" and re.match(r'r#*"', src[i:])) or (c == "b" and src.startswith('b"', i)):
+            m = re.match(r'b?r(#*)"', src[i:])
+            if m:   # raw string: ends at "#*
+                end = src.find('"' + m.group(1), i + m.end())
+                i = (end + 1 + len(m.group(1))) if end >= 0 else n
+            else:
+                i += 2 if c == "b" else 1
+                while i < n and src[i] != '"':
+                    i += 2 if src[i] == "\\" else 1
+                i += 1
+        elif c == "'":
+            m = re.match(r"'(\\.[^']*|[^'\\])'", src[i:])
+            if m: i += m.end()           # a char literal
+            else: out.append(c); i += 1  # a lifetime
+        else:
+            out.append(c); i += 1
+    return "".join(out)
+
+
+def test_every_rust_source_has_balanced_delimiters_and_declared_modules():
+    """No cargo here: the cheapest structural check a compiler would make first - (), [], {} balance in every .rs file of the shim
+    crate and of tools/upstream_kat, and every `mod x;` of lib.rs has its file."""
+    roots = [os.path.join(ROOT, "rust", "border-amd-agent", "src"), os.path.join(ROOT, "tools", "upstream_kat", "src")]
+    files = [os.path.join(r, f) for r in roots for f in sorted(os.listdir(r)) if f.endswith(".rs")]
+    assert len(files) >= 13
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for path in files:
+        code = _rust_code_only(open(path).read())
+        stack = []
+        for k, ch in enumerate(code):
+            if ch in "([{": stack.append(ch)
+            elif ch in ")]}":
+                assert stack and stack[-1] == pairs[ch], (path, code[max(0, k - 80):k + 1])
+                stack.pop()
+        assert not stack, (path, stack[-3:])
+    lib = open(os.path.join(roots[0], "lib.rs")).read()
+    for m in re.finditer(r"^\s*(?:pub\s+)?mod\s+(\w+)\s*;", lib, re.M):
+        assert os.path.exists(os.path.join(roots[0], m.group(1) + ".rs")), m.group(1)

@@ -748,7 +748,11 @@ struct Sac : bdr_agent, SacBatch {
     }
 
     const char* kind() const override { return "sac"; }
-    void on_gate_timeout() override { two_queues = false; }   // a flag wait timed out: back to one queue
+    void on_gate_timeout() override   // a flag wait timed out: back to one queue
+    {
+        if (two_queues) fprintf(stderr, "border_amd: a cross-queue wait of the SAC step timed out; this agent continues on one queue\n");
+        two_queues = false;
+    }
     // the launch sequence of one opt() (Sac::opt_, sac/base.rs:175-192)
     // does this opt() take the two-queue sequence?
     bool side_queue_for(const bdr_replay* r) const { return two_queues && !prof && graph_policy.mode != 1 && gather_in_pack && !r->per && !r->frame_stack; }   // (BDR_STEP_GRAPH=1: the captured step, one queue)

@@ -344,6 +344,8 @@ struct Sac : bdr_agent, SacBatch {
     unsigned* sig = nullptr;                  // [4] flag words
     unsigned epoch = 0;                       // update counter of the two-queue sequence
     bool two_queues = false;                  // the streams exist and sit on different hardware queues
+    unsigned long long flag_limit = FLAG_WAIT_LIMIT;   // 100 MHz ticks (10 s; BDR_GATE_LIMIT_MS for tests)
+    long long stall_at = -1;                  // tests (BDR_SAC_STALL_AT=n): update n does not publish PRO - its consumer's wait has to time out
     bool main_ahead = true;                   // `stream` carries work the flags do not cover (a one-queue update, a parameter exchange,
                                               // set_params, the buffers' first memset): the side queue waits for it once, with an event
 
@@ -771,11 +773,11 @@ struct Sac : bdr_agent, SacBatch {
                 BDR_TRY(replay_flip_batch(r, Bn));
                 epoch += 1;
                 GatherArgs plan{};
-                BDR_TRY(flag_wait(side, sig + SIG_PI, epoch - 1, dev_err + ERR_GATE, 1u + SIG_PI));   // the actor parameters of update n-1 are final
+                BDR_TRY(flag_wait(side, sig + SIG_PI, epoch - 1, dev_err + ERR_GATE, 1u + SIG_PI, flag_limit));   // the actor parameters of update n-1 are final
                 BDR_TRY(replay_sample_plan(r, Bn, side, &plan));
                 BDR_TRY(prologue(side, Bn, (const float*)r->b_obs, (const float*)r->b_act, (const float*)r->b_next, z_a, z_a + (size_t)Bn * A, true, &plan));
-                BDR_TRY(flag_set(side, sig + SIG_PRO, epoch));
-                BDR_TRY(flag_wait(stream, sig + SIG_PRO, epoch, dev_err + ERR_GATE, 1u + SIG_PRO));
+                if ((long long)epoch != stall_at) BDR_TRY(flag_set(side, sig + SIG_PRO, epoch));
+                BDR_TRY(flag_wait(stream, sig + SIG_PRO, epoch, dev_err + ERR_GATE, 1u + SIG_PRO, flag_limit));
                 BDR_TRY(update_rest(Bn, r->b_reward, r->b_term, z_a, z_a + (size_t)Bn * A, u == 0, true));
                 continue;
             }
@@ -982,6 +984,8 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
             BDR_HIP(hipMalloc((void**)&a->sig, 4 * sizeof(unsigned)));
             BDR_HIP(hipMemset(a->sig, 0, 4 * sizeof(unsigned)));
             BDR_TRY(flag_queues_independent(a->stream, a->side, a->sig + Sac::SIG_SCRATCH, &a->two_queues));
+            if (const char* l = getenv("BDR_GATE_LIMIT_MS")) a->flag_limit = (unsigned long long)std::max(1, atoi(l)) * 100000ull;
+            if (const char* l = getenv("BDR_SAC_STALL_AT")) a->stall_at = atoll(l);
         }
     }
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};

@@ -357,3 +357,46 @@ np.save(sys.argv[1], np.concatenate([a.get_params(n).ravel() for n in ("pi", "qn
     assert so[1] == "LOSS True", so
     assert "continues on one queue" in se, se[-500:]
     assert (sp == cp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("od,ad,pu,qu,nc,Bsz,ent,n_upd", [
+    (11, 3, [96, 40], [72, 136], 3, 72, ("Auto", -3.0, 1e-3), 1),        # three critics, nothing a multiple of a tile
+    (5, 2, [64], [300], 1, 200, ("Fix", 0.2), 3),                          # one trunk layer, one critic, three updates per opt
+    (23, 7, [128, 64, 32], [64, 64, 64], 4, 33, ("Auto", -7.0, 3e-4), 2),  # three trunk layers, four critics, 33 rows
+    (30, 8, [64, 64], [64, 64], 2, 64, ("Fix", 1.0), 1),                   # a shape the row-block kernels do not cover (layer-by-layer launches on two queues)
+])
+def test_sac_two_queue_sequence_equals_one_queue_on_ragged_shapes(B, monkeypatch, od, ad, pu, qu, nc, Bsz, ent, n_upd):
+    """Agent::opt over the ring, eager launches: the two-queue sequence (next update's sample + actor forward on the side queue, two
+    buffer sets, device flags) against everything on one queue - pushes between opts, records, every parameter, target, Adam moment and
+    the buffer's next indices bit for bit."""
+    def run(side):
+        for k in ("BDR_STEP_GRAPH", "BDR_NO_STEP_GRAPH", "BDR_SAC_SIDE_QUEUE"): monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("BDR_NO_STEP_GRAPH", "1")
+        if not side: monkeypatch.setenv("BDR_SAC_SIDE_QUEUE", "0")
+        rng = np.random.default_rng(23)
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=700, seed=9), (od,), np.float32, (ad,), np.float32)
+        def push(n):
+            rb.push(rng.standard_normal((n, od)).astype(np.float32), rng.uniform(-1, 1, (n, ad)).astype(np.float32),
+                    rng.standard_normal((n, od)).astype(np.float32), rng.standard_normal(n).astype(np.float32),
+                    (rng.random(n) < .05).astype(np.int8), np.zeros(n, np.int8))
+        push(500)
+        a = B.Sac.build(B.SacConfig(obs_dim=od, act_dim=ad, pi_units=tuple(pu), q_units=tuple(qu), n_critics=nc, batch_size=Bsz,
+                                    ent_coef_mode=ent, n_updates_per_opt=n_upd, critic_loss="SmoothL1", device=0, seed=3))
+        a.train()
+        recs = []
+        for k in range(9):
+            recs.append(a.opt_with_record(rb) if k % 4 == 3 else (a.opt(rb), None)[1])
+            if k % 2 == 0: push(37)        # the ring wraps (capacity 700) while updates are in flight
+        names = ["pi", "log_alpha"] + [f"qnet_{i}" for i in range(nc)] + [f"qnet_tgt_{i}" for i in range(nc)]
+        out = {n: a.get_params(n) for n in names}
+        out["pi/exp_avg_sq"] = a.get_params("pi", "exp_avg_sq")
+        out["next_indices"] = rb.sample_indices(40)
+        a.close(); rb.close()
+        return out, recs
+    two, trec = run(True)
+    one, orec = run(False)
+    assert trec == orec
+    for k in two:
+        assert (two[k] == one[k]).all(), k
+    assert np.isfinite(two["pi"]).all()

@@ -227,9 +227,9 @@ int32_t bdr_agent::err_report(const unsigned* w)
     memset(host_err, 0, ERR_WORDS * sizeof(unsigned));
     if (gate) {
         on_gate_timeout();
-        return fail(BDR_ERR_HIP, "cross-queue wait %u of a %s agent timed out (its producer kernel never arrived): the agent continues on its "
-                                 "fallback schedule (DqnCnn: event ordering, the parameter updates behind the failed gate were skipped; "
-                                 "Sac: one queue, the update the wait belonged to is undefined)", gate - 1, kind());
+        return fail(BDR_ERR_HIP, "cross-queue gate %u of a %s agent timed out (the producer kernel it waits for never arrived): the agent continues on its "
+                                 "fallback schedule (DqnCnn: event ordering; "
+                                 "Sac: one queue; in both the parameter updates behind the failed wait were skipped)", gate - 1, kind());
     }
     if (act) return fail(BDR_ERR_INVALID, "an action index outside [0, n_actions) reached the TD step (the reference's gather raises "
                                           "an index error); it was clamped");

@@ -668,12 +668,14 @@ struct ReduceAdamArgs {
     float* p[RA_INST]; float* g[RA_INST]; float* m[RA_INST]; float* v[RA_INST]; float* tgt[RA_INST];
     AdamScalars s[RA_INST]; unsigned n4; float tau, omt; int track;
     int grads_only;   // 1: sum the partials into the gradient arena and stop (synchronous-DP mode: the all-reduce comes before Adam)
+    const unsigned* poison;   // optional: a cross-queue wait of the step timed out (queue_flags.hpp) - the inputs may be incomplete, leave everything alone
 };
 __global__ __launch_bounds__(256) void k_dense_reduce_adam(ReduceAdamArgs a)
 {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     const int z = blockIdx.y;
     if (i >= a.n4) return;
+    if (a.poison && *a.poison) return;
     int k = 0;
     for (int q = 1; q < a.nseg; ++q) k += i >= a.seg[q].off4 ? 1 : 0;
     const DenseReduceSeg sg = a.seg[k];

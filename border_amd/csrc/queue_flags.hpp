@@ -11,7 +11,7 @@
 // Every wait of the SAC step is for work submitted EARLIER than the waiting kernel (the previous update's actor step, this
 // update's prologue), so streams that alias one hardware queue (GPU_MAX_HW_QUEUES) run the same packets in submission order
 // and no wait can be for something queued behind it: slower, never a deadlock.  A producer that never arrives trips the time
-// limit instead of hanging the queue; the agent's error word reports it at the next synchronisation.
+// limit instead of hanging the queue; the agent's error word reports it at the next synchronisation (and see k_flag_wait).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,13 +24,18 @@ static __global__ __launch_bounds__(64) void k_flag_set(unsigned* flag, unsigned
     if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// limit in ticks of the 100 MHz wall clock; on a timeout *err_word = err_code (when given) and the kernel returns
+// limit in ticks of the 100 MHz wall clock; on a timeout *err_word = err_code (when given) and the kernel returns.  The error word is
+// also the agent's POISON: while it is up every later wait returns at once (no second time limit), the kernels behind a failed wait
+// run unordered, and the kernels that write parameters, moments and targets skip their update (agent_base.hpp, dense.hpp) - the state
+// stays that of the last good update until the host has seen the error and cleared the word.
 static __global__ __launch_bounds__(64) void k_flag_wait(const unsigned* flag, unsigned epoch, unsigned long long limit, unsigned* err_word, unsigned err_code)
 {
     if (threadIdx.x != 0) return;
+    if (err_word && __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // poisoned
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {   // wrap-safe
         __builtin_amdgcn_s_sleep(4);
+        if (err_word && __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // another wait failed first
         if (wall_clock64() - t0 > limit) {
             if (err_word) __hip_atomic_store(err_word, err_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;

@@ -69,6 +69,7 @@ struct SacSelectArgs {
     int B, NC;
     // EntCoef::update (ent_coef.rs:69-75) first: loss = -(log_alpha * (logp + H)).mean(); Adam on the scalar
     int auto_alpha; float target; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
+    const unsigned* poison;              // a cross-queue wait timed out: no EntCoef step
 };
 // Sums over the batch rows, in an order that does not depend on who computes it (the row-block kernels of sac_fused.hpp form the
 // block partials in their own workgroups): rows in blocks of 32, a block's partial = the 32-lane butterfly (xor 16, 8, 4, 2, 1) of
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_sac_select(SacSelectArgs p)
         const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
         log_alpha = log_alpha + p.s.neg_step * mm / denom;
         __syncthreads();                                          // all reads of al_m / al_v / log_alpha are done
-        if (threadIdx.x == 0) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; }
+        if (threadIdx.x == 0 && !(p.poison && *p.poison)) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; }
     }
     const float alpha = expf(log_alpha);
     const float s_logp = row_sum_1024(p.B, [&](int b) { return p.logp[b]; }, red);
@@ -548,6 +549,7 @@ struct Sac : bdr_agent, SacBatch {
         }
         for (int i = 0; i < ninst; ++i) { ra.p[i] = p[i]; ra.g[i] = g[i]; ra.m[i] = m[i]; ra.v[i] = v[i]; ra.tgt[i] = tgt_p ? tgt_p[i] : nullptr; ra.s[i] = sc[i]; }
         ra.n4 = (unsigned)(net.total / 4); ra.track = tgt_p ? 1 : 0; ra.tau = (float)cfg.tau; ra.omt = (float)(1.0 - cfg.tau);
+        ra.poison = dev_err + ERR_GATE;
         BDR_HIP(step_launch(stream, true, k_dense_reduce_adam, dim3((ra.n4 + 255) / 256, ninst), dim3(256), ra));
         return BDR_OK;
     }
@@ -614,7 +616,7 @@ struct Sac : bdr_agent, SacBatch {
             p.auto_alpha = cfg.ent_coef_auto ? 1 : 0;
             if (cfg.ent_coef_auto) {
                 step_al += 1;
-                p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v;
+                p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v; p.poison = dev_err + ERR_GATE;
                 p.s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
             }
             Bracket br(a, "sac_q_last");
@@ -627,7 +629,7 @@ struct Sac : bdr_agent, SacBatch {
             p.auto_alpha = cfg.ent_coef_auto ? 1 : 0;
             if (cfg.ent_coef_auto) {
                 step_al += 1;
-                p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v;
+                p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v; p.poison = dev_err + ERR_GATE;
                 p.s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
             }
             Bracket br(a, "sac_select");

@@ -312,12 +312,15 @@ def test_device_noise_stream_moments_reproducibility_and_disjointness(B):
 
 @pytest.mark.gpu
 def test_sac_flag_wait_timeout_is_reported_and_the_agent_continues_on_one_queue(B):
-    """The two-queue SAC step orders its queues with device flags (csrc/queue_flags.hpp).  Forced failure (BDR_SAC_STALL_AT): the side
-    queue does not publish one update's prologue, so the main queue's wait for it must time out (20 ms limit).  Required: no hang; the
-    failure is reported by the next synchronisation as a gate error and cleared; the agent says it continues on one queue and trains on -
-    and, because the prologue itself did run, ends with the parameters of an undisturbed run, bit for bit."""
+    """The two-queue SAC step orders its queues with device flags (csrc/queue_flags.hpp).  Forced failure (BDR_SAC_STALL_AT=3): the side
+    queue does not publish the third update's prologue, so the main queue's wait for it must time out (20 ms limit).  Required: no hang;
+    the error word poisons the agent - later waits return at once and every kernel that writes parameters, moments, targets or the
+    entropy coefficient skips its update, so the state stays that of the last good update (bit for bit the state of an undisturbed run
+    after two updates) however the unordered kernels behind the failed wait interleave; the next synchronisation reports the failure
+    as a gate error and clears it; the agent says it continues on one queue and trains on."""
     import subprocess
     import sys
+    import tempfile
     script = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -328,35 +331,38 @@ rb.fill_synthetic(3000, seed=1, kind=1, n_actions=0)
 a = B.Sac.build(B.SacConfig(obs_dim=od, act_dim=ad, pi_units=(64, 64), q_units=(64, 64), n_critics=2, batch_size=128,
                             ent_coef_mode=("Auto", -6.0, 3e-4), device=0, seed=5))
 a.train()
-for _ in range(6): a.opt(rb)
+names = ("pi", "qnet_0", "qnet_1", "qnet_tgt_0", "qnet_tgt_1", "log_alpha")
+state = lambda: np.concatenate([a.get_params(n).ravel() for n in names] + [a.get_params("pi", "exp_avg").ravel(), a.get_params("qnet_1", "exp_avg_sq").ravel()])
+n_first = int(sys.argv[2])
+for _ in range(n_first): a.opt(rb)
 try:
     a.sync(); print("NO_ERROR")
 except B.BdrError as e:
-    print("ERR", e.code, "wait" in str(e) and "sac" in str(e))
+    print("ERR", e.code, "gate" in str(e) and "sac" in str(e))
 a.sync()
+s0 = state()
+np.save(sys.argv[1], s0)
 for _ in range(6): a.opt(rb)
 rec = a.opt_with_record(rb)
-print("LOSS", bool(np.isfinite(rec["loss_critic"])))
-np.save(sys.argv[1], np.concatenate([a.get_params(n).ravel() for n in ("pi", "qnet_0", "qnet_1", "qnet_tgt_0", "log_alpha")]))
+print("LOSS", bool(np.isfinite(rec["loss_critic"])), "MOVED", bool((state() != s0).any()))
 """ % os.path.join(os.path.dirname(__file__), "..")
-    import tempfile
     outs = {}
     with tempfile.TemporaryDirectory() as d:
-        for name, extra in (("stalled", {"BDR_SAC_STALL_AT": "3", "BDR_GATE_LIMIT_MS": "20"}), ("clean", {})):
+        for name, extra, n_first in (("stalled", {"BDR_SAC_STALL_AT": "3", "BDR_GATE_LIMIT_MS": "20"}, 7), ("clean", {}, 2)):
             env = dict(os.environ)
             for k in ("BDR_SAC_SIDE_QUEUE", "BDR_STEP_GRAPH", "BDR_NO_STEP_GRAPH", "BDR_SAC_STALL_AT"): env.pop(k, None)
             env.update(extra)
             path = os.path.join(d, name + ".npy")
-            r = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([sys.executable, "-c", script, path, str(n_first)], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-1500:]
             outs[name] = (r.stdout.split("\n"), r.stderr, np.load(path))
     so, se, sp = outs["stalled"]
     co, ce, cp = outs["clean"]
-    assert co[0] == "NO_ERROR" and co[1] == "LOSS True", co
+    assert co[0] == "NO_ERROR" and co[1] == "LOSS True MOVED True", co
     assert so[0].startswith("ERR") and " 3 " in so[0] + " " and so[0].endswith("True"), (so, se[-500:])
-    assert so[1] == "LOSS True", so
+    assert so[1] == "LOSS True MOVED True", so
     assert "continues on one queue" in se, se[-500:]
-    assert (sp == cp).all()
+    assert (sp == cp).all()          # seven updates enqueued, the third one's wait failed: the state is the one after two
 
 
 @pytest.mark.gpu

@@ -556,7 +556,9 @@ struct Sac : bdr_agent, SacBatch {
 
     // One iteration of the Sac::opt_ loop on a device-resident batch (obs/next_obs/act rows are f32).  The order of the reference is
     // kept where it matters (actor first, the critic target from the UPDATED actor, tracking after every critic step); launches that
-    // do not depend on each other are merged: 34 launches for twin critics instead of one per layer and tensor (70).
+    // do not depend on each other are merged and the narrow layers ride in row-block kernels (sac_fused.hpp): 21 launches for twin
+    // critics instead of one per layer and tensor (70).  update() = prologue() + update_rest(); the two-queue sequence (opt_enqueue) runs
+    // the prologue of the NEXT update on the side queue.
     // draw_noise: z_actor / z_next ([Bn][A] each, contiguous) are drawn on the device inside the first launch
     int32_t update(int Bn, const float* obs, const float* act, const float* next_obs, const float* reward, const int8_t* term,
                    float* z_actor, float* z_next, bool first, bool draw_noise = false, const GatherArgs* gather = nullptr)
@@ -801,8 +803,9 @@ struct Sac : bdr_agent, SacBatch {
         BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
         const int Bn = (int)cfg.batch_size;
         BDR_TRY(ensure_batch(Bn));
-        // ~70 kernels of 2-8 us: replayed from a captured graph (step_graph.hpp).  Profiling brackets and prioritized replay
-        // (tree kernels with their own host state) take the eager path - the same sequence, launched one by one.
+        // 21 kernels of 4-14 us.  Default: eager launches on two queues (opt_enqueue).  Without the side queue the sequence can be
+        // replayed from a captured graph (step_graph.hpp; the policy measures whether that pays).  Profiling brackets and prioritized
+        // replay (tree kernels with their own host state) take the eager one-queue path - the same sequence, launched one by one.
         if (prof || r->per || side_queue_for(r)) return opt_enqueue(r, Bn);
         {
             const int w = graph_policy.want(stream);

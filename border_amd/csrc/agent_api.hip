@@ -222,6 +222,7 @@ int32_t bdr_agent::err_report(const unsigned* w)
 {
     if (!(w[ERR_ACTION] | w[ERR_GATE] | w[ERR_NONFINITE])) return BDR_OK;
     const unsigned act = w[ERR_ACTION], gate = w[ERR_GATE], nonf = w[ERR_NONFINITE];
+    if (gate) drain_queues();   // all of the agent's queues idle before the poison word goes down
     (void)hipMemsetAsync(dev_err, 0, ERR_WORDS * sizeof(unsigned), stream);
     (void)hipStreamSynchronize(stream);
     memset(host_err, 0, ERR_WORDS * sizeof(unsigned));
@@ -229,7 +230,9 @@ int32_t bdr_agent::err_report(const unsigned* w)
         on_gate_timeout();
         return fail(BDR_ERR_HIP, "cross-queue gate %u of a %s agent timed out (the producer kernel it waits for never arrived): the agent continues on its "
                                  "fallback schedule (DqnCnn: event ordering; "
-                                 "Sac: one queue; in both the parameter updates behind the failed wait were skipped)", gate - 1, kind());
+                                 "Sac: one queue; in both the parameter updates behind the failed wait were skipped on the device, while the host's "
+                                 "counters - n_opts, the Adam step numbers - kept counting them: bias corrections from here on are those of a slightly "
+                                 "later step)", gate - 1, kind());
     }
     if (act) return fail(BDR_ERR_INVALID, "an action index outside [0, n_actions) reached the TD step (the reference's gather raises "
                                           "an index error); it was clamped");
@@ -242,10 +245,10 @@ int32_t bdr_agent::err_check()
     unsigned w[ERR_WORDS];
     BDR_HIP(hipMemcpy(w, dev_err, sizeof w, hipMemcpyDeviceToHost));
     BDR_TRY(err_report(w));
-    if (bdr_replay* lr = replay_lookup(last_replay_uid)) {
-        if (lr->per) BDR_TRY(per_check(lr->per));
-    } else last_replay_uid = 0;
-    return BDR_OK;
+    bool alive = false;
+    const int32_t st = replay_per_check(last_replay_uid, &alive);   // (lookup + check under the registry lock)
+    if (!alive) last_replay_uid = 0;
+    return st;
 }
 
 int32_t bdr_agent::err_poll()
@@ -346,6 +349,7 @@ int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* r, bdr_dqn_record* r
     BDR_REQUIRE(a && r && rec, "null argument");
     BDR_REQUIRE(is_dqn(a), "bdr_agent_opt_with_record(bdr_dqn_record) needs a DQN agent; use bdr_agent_opt_with_scalars");
     BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(a->err_poll());   // as bdr_agent_opt: a failure of an earlier step is reported before this one is enqueued
     a->last_replay_uid = r->uid;
     BDR_TRY(a->opt(r));
     prof_collect(a);
@@ -364,6 +368,7 @@ int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* r, float* out, int3
 {
     BDR_REQUIRE(a && r && out && n_out, "null argument");
     BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(a->err_poll());
     a->last_replay_uid = r->uid;
     BDR_TRY(a->opt(r));
     prof_collect(a);

@@ -108,6 +108,10 @@ struct bdr_agent {
     int32_t err_check();   // the stream has just been synchronised: read, report, clear
     int32_t err_poll();    // no synchronisation: look at the last asynchronous read-back, enqueue the next one when due
     virtual void on_gate_timeout() {}   // DqnCnn: fall back to event ordering
+    // Called by err_report BEFORE it clears the error words: every queue of the agent must be idle by then.  While the words are up
+    // the waits queued on the other queues return at once (poison); cleared under them they would start a fresh time limit and
+    // could poison the agent a second time, and kernels still queued there would write the batch sets the fallback schedule reads.
+    virtual void drain_queues() { (void)hipStreamSynchronize(stream); }
     // Synchronous data-parallel mode (SURVEY.md 8(e) "Collective", last sentence): opt() = backward -> all-reduce of the
     // gradient arena over the communicator (sum, then 1/N) -> optimizer step, so that N ranks with batch B/N each take exactly
     // the step one rank takes on the concatenated batch.  grad_reduce is installed by bdr_agent_set_grad_comm (comm.hip).

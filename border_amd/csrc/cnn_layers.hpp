@@ -11,8 +11,11 @@
 namespace {
 
 constexpr int MAXZ = 3;       // network instances per forward launch
+#ifndef BDR_L1_XSPLIT
+#define BDR_L1_XSPLIT 1   // l1 forward: split-K slice = XCD (FwdL1X); 0: the round-2/3 maps (FwdL1 / FwdL1Z2, split 7)
+#endif
 #ifndef BDR_L1_SPLIT
-#define BDR_L1_SPLIT 7
+#define BDR_L1_SPLIT (BDR_L1_XSPLIT ? 8 : 7)
 #endif
 constexpr int L1_SPLIT = BDR_L1_SPLIT;   // split-K of the 3136-deep l1 contraction (98 k-tiles)
 constexpr float INV255 = 1.0f / 255.0f;
@@ -88,14 +91,22 @@ struct FwdP {
     }
 };
 // (conv1 runs on the bf16 matrix cores with exact operands: conv1_bf16.hpp forward, conv1_dw_bf16.hpp weight gradient)
-using FwdC2 = FwdP<GeomC2, AFwd<GeomC2>, 2, 2, false>;     // 64x64,  M = B*81
-using FwdC3 = FwdP<GeomC3, AFwd<GeomC3>, 2, 2, false>;     // 64x64,  M = B*49
+#ifndef BDR_FWDC2_SHAPE
+#define BDR_FWDC2_SHAPE 2, 2, 1, 1
+#endif
+template <class G, int WM, int WN, int TM, int TN> using FwdConvP = FwdP<G, AFwd<G>, WM, WN, false, 0, TM, TN>;
+using FwdC2 = FwdConvP<GeomC2, BDR_FWDC2_SHAPE>;     // 64x64,  M = B*81
+using FwdC3 = FwdConvP<GeomC3, 2, 2, 1, 1>;          // 64x64,  M = B*49
 
 // l1: [B][3136] x [3136][512], split-K over blockIdx.y, raw partials (bias/relu in the head kernel)
-struct FwdL1 {
+#ifndef BDR_FWDL1_SHAPE
+#define BDR_FWDL1_SHAPE 2, 2, 1, 1
+#endif
+template <int WM_, int WN_, int TM_, int TN_>
+struct FwdL1P {
     using A = AFwd<GeomL1>;
     using Args = FwdArgs;
-    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int RPI = 1, RPIP = 0;
     static constexpr int NC = 512;
     static constexpr bool B_TR = false;
@@ -115,8 +126,14 @@ struct FwdL1 {
     __device__ static float epi_load(const Epi&, int, int) { return 0.f; }
     __device__ static void store(const Epi& e, int m, int n, float v, float) { e.out[(size_t)m * NC + n] = v; }
 };
+using FwdL1 = FwdL1P<BDR_FWDL1_SHAPE>;
 // even instance counts (the online + target pair): XCD = (instance parity, pair of n-tiles); grid (16 m-tiles, splits, nz/2)
 struct FwdL1Z2 : FwdL1 { static constexpr int XMAP = 2; };
+// eight k-slices, slice = XCD (98 k-tiles: 12 or 13 per slice); grid (8 * m-tiles * 8 n-tiles, 1, nz); L1_SPLIT == 8
+struct FwdL1X : FwdL1 {
+    static constexpr int XMAP = 3;
+    __device__ static void kt_range(const Args&, int y, int& k0, int& k1) { k0 = (y * A::NKT) >> 3; k1 = ((y + 1) * A::NKT) >> 3; }
+};
 
 // ================================================================================================
 // input-gradient policies (transposed conv as gather; epilogue applies relu'(previous activation))
@@ -132,11 +149,15 @@ struct DxArgs {
 };
 
 // l1: dh0[b][k] = sum_n dh1[b][n] W4[k][n];  treated as 1x1 "conv" with CIN=512 -> N'=3136
-struct DxL1 {
+#ifndef BDR_DXL1_SHAPE
+#define BDR_DXL1_SHAPE 2, 2, 1, 1
+#endif
+template <int WM_, int WN_, int TM_, int TN_>
+struct DxL1P {
     using G = Geom<1, 1, 512, 1, 1, 1, 1, 1, 3136>;
     using A = AFwd<G>;     // dense rows of dh1
     using Args = DxArgs;
-    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int RPI = 1, RPIP = 0;
     static constexpr int NC = 3136;    // N' (columns of the result)
     static constexpr bool B_TR = true;
@@ -157,6 +178,11 @@ struct DxL1 {
         e.out[(size_t)m * NC + n] = mask > 0.f ? v : 0.f;
     }
 };
+
+using DxL1 = DxL1P<BDR_DXL1_SHAPE>;
+
+// column tiles of a launch
+template <class P> constexpr int n_tiles() { return P::NC / (P::WN * P::TN * 32); }
 
 // conv3 (3x3, stride 1): rows over the 9x9 input grid, K' = 9 taps * 64, N' = 64
 template <int WM_, int WN_, int RPIP_ = 0, int TM_ = 1, int TN_ = 1>
@@ -197,11 +223,15 @@ static __device__ __constant__ unsigned char c3_pos_by_taps[81] = {
     20, 21, 22, 23, 24, 29, 30, 31, 32, 33, 38, 39, 40, 41, 42, 47, 48, 49, 50, 51, 56, 57, 58, 59, 60, 11, 12, 13, 14, 15, 19, 25, 28, 34, 37, 43, 46,
     52, 55, 61, 65, 66, 67, 68, 69, 10, 16, 64, 70, 2, 3, 4, 5, 6, 18, 26, 27, 35, 36, 44, 45, 53, 54, 62, 74, 75, 76, 77, 78, 1, 7, 9, 17, 63, 71, 73,
     79, 0, 8, 72, 80};
-struct DxC3Pos {
+#ifndef BDR_DXC3_SHAPE
+#define BDR_DXC3_SHAPE 2, 2, 1, 1
+#endif
+template <int WM_, int WN_, int TM_, int TN_>
+struct DxC3PosP {
     using G = GeomC3;
     using A = ADxS1Pos<G>;
     using Args = DxArgs;          // M = B * 81
-    static constexpr int WM = 2, WN = 2, TM = 1, TN = 1;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int RPI = 1, RPIP = 0;
     static constexpr int NC = G::CIN;
     static constexpr bool B_TR = true;
@@ -240,6 +270,8 @@ struct DxC3Pos {
     __device__ static float epi_load(const Epi& e, int m, int n) { return e.mask[(size_t)m * NC + n]; }
     __device__ static void store(const Epi& e, int m, int n, float v, float mask) { e.out[(size_t)m * NC + n] = mask > 0.f ? v : 0.f; }
 };
+
+using DxC3Pos = DxC3PosP<BDR_DXC3_SHAPE>;
 
 // conv2 (4x4, stride 2): blockIdx.y = parity class (ph,pw); rows (b, ih/2, iw/2); K' = 4 taps * 64
 template <int WM_, int WN_, int RPIP_ = 0, int TM_ = 1, int TN_ = 1>
@@ -280,6 +312,48 @@ struct DxC2P {
     }
 };
 using DxC2 = DxC2P<4, 1>;      // 128x32 flat tiles per class, M = B*100
+
+// The four parity classes as ONE GEMM.  Row (b, ih/2, iw/2) of class (ph, pw) reads dY[b][ih/2 - a][iw/2 - b2][:] for tap (a, b2):
+// the A operand does not depend on the class at all - only the weight row does (kh = ph + 2a, kw = pw + 2*b2).  So the classes
+// are 4 x 32 = 128 COLUMNS of one [B*100][256] x [256][128] product: a dY tile is staged once instead of four times (PMC, round 3:
+// the per-class launch fetched 20.1 MB for 5.4 MB of dY) and every A fragment read from LDS feeds both classes of its wave.
+// Per output element the k order (tap, cout) is that of DxC2P: bit-identical results.
+template <int WM_, int WN_, int TM_, int TN_>
+struct DxC2MP {
+    using G = GeomC2;
+    using A = ADxS2<G>;
+    using Args = DxArgs;          // M = B * 100 (rows of ONE class)
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int RPI = (G::IH / 2) * (G::IW / 2), RPIP = 0;
+    static constexpr int NC = 4 * G::CIN;          // columns n = class * 32 + cin
+    static constexpr bool B_TR = true;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.M, mv, mr); }
+    __device__ static constexpr int N(const Args&) { return NC; }
+    __device__ static constexpr int KP(const Args&) { return G::COUT; }
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
+    __device__ static const float* w(const Args& a, int, int) { return a.w; }
+    __device__ static int tap_index(int cls, int t) { return ((cls >> 1) + 2 * (t >> 1)) * 4 + (cls & 1) + 2 * (t & 1); }
+    // weight row of column n for tap t: W2 is [(kh,kw,cin)][cout]
+    __device__ static int b_row(int, int t, int n) { return tap_index(n >> 5, t) * G::CIN + (n & 31); }
+    __device__ static void kt_range(const Args&, int, int& k0, int& k1) { k0 = 0; k1 = A::NKT; }
+    __device__ static size_t out_index(int m, int n)
+    {
+        constexpr int HH = G::IH / 2, WH = G::IW / 2;
+        const int cls = n >> 5;
+        const int b = m / (HH * WH), rem = m % (HH * WH);
+        const int ih = 2 * (rem / WH) + (cls >> 1), iw = 2 * (rem % WH) + (cls & 1);
+        return ((size_t)(b * G::IH + ih) * G::IW + iw) * G::CIN + (n & 31);
+    }
+    struct Epi { gptr<const float> mask; gptr<float> out; };
+    __device__ static Epi epi(const Args& a, int, int) { return Epi{pin_sgpr(a.mask), pin_sgpr(a.out)}; }
+    __device__ static float epi_load(const Epi& e, int m, int n) { return e.mask[out_index(m, n)]; }
+    __device__ static void store(const Epi& e, int m, int n, float v, float mask) { e.out[out_index(m, n)] = mask > 0.f ? v : 0.f; }
+};
+#ifndef BDR_DXC2M_SHAPE
+#define BDR_DXC2M_SHAPE 2, 2, 1, 2     // 64 x 128 tiles: 400 workgroups at B = 256
+#endif
+using DxC2M = DxC2MP<BDR_DXC2M_SHAPE>;
 
 // ================================================================================================
 // weight-gradient policies

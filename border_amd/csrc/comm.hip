@@ -63,16 +63,18 @@ int32_t load_rccl()
 // Hardware queues for the N>1 path.  The overlapped parameter exchange adds a communication queue to the agent's three
 // streams and the replay buffer's: five streams that must not share an in-order HSA queue, and HIP multiplexes streams onto
 // GPU_MAX_HW_QUEUES (default 4) queues per process.  The variable is read when the HIP runtime initialises (its first API
-// call), so it is the LIBRARY that asks for the queues, when it is loaded - before any HIP call of a process that links it or
-// imports it first - whenever the process is one rank of several (torchrun / mpirun / BDR_NRANKS say so).  A host that
-// initialises HIP before loading the library sets it itself; the agent detects aliased queues and
-// falls back to the in-stream exchange, and bdr_comm_init_rank says so.
+// call) and it is process-wide - it changes the queue allocation of every HIP user in the process, torch under torchrun
+// included - so the library only touches it on an EXPLICIT request of the host: BDR_REQUEST_HW_QUEUES=<n> (or BDR_NRANKS > 1,
+// the library's own variable) in the environment when the library is loaded, before the process's first HIP call.  It never
+// infers the request from a launcher's WORLD_SIZE / PMI_SIZE.  Hosts normally export GPU_MAX_HW_QUEUES=8 themselves (bench.py,
+// tests/test_gpu_multi.py); without enough queues the agent detects the aliasing and falls back to the
+// in-stream exchange, and bdr_comm_init_rank says so.
 namespace {
 int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; }
-bool multi_rank_env() { return env_int("WORLD_SIZE") > 1 || env_int("OMPI_COMM_WORLD_SIZE") > 1 || env_int("PMI_SIZE") > 1 || env_int("BDR_NRANKS") > 1; }
 __attribute__((constructor)) void bdr_request_hw_queues()
 {
-    if (multi_rank_env()) setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+    const int want = env_int("BDR_REQUEST_HW_QUEUES") > 0 ? env_int("BDR_REQUEST_HW_QUEUES") : (env_int("BDR_NRANKS") > 1 ? 8 : 0);
+    if (want > 0) { char v[16]; snprintf(v, sizeof v, "%d", want); setenv("GPU_MAX_HW_QUEUES", v, /*overwrite=*/0); }
 }
 }  // namespace
 
@@ -111,8 +113,8 @@ int32_t bdr_comm_init_rank(const uint8_t id[BDR_UNIQUE_ID_BYTES], int32_t nranks
         if (!noted && q < 5) {
             noted = true;
             fprintf(stderr, "border_amd: GPU_MAX_HW_QUEUES=%s with %d ranks: the overlapped parameter exchange needs 5 hardware queues; "
-                            "set GPU_MAX_HW_QUEUES=8 before the process's first HIP call (the library does so itself when it is loaded "
-                            "first and WORLD_SIZE / BDR_NRANKS > 1); agents fall back to the in-stream exchange\n",
+                            "export GPU_MAX_HW_QUEUES=8 before the process's first HIP call (or BDR_REQUEST_HW_QUEUES=8 before the library is "
+                            "loaded); agents fall back to the in-stream exchange\n",
                     getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset (4)", nranks);
         }
     }

@@ -137,6 +137,7 @@ void stream_register(hipStream_t s);
 void stream_retire(hipStream_t s);
 bool stream_alive(hipStream_t s);
 bdr_replay* replay_lookup(uint64_t uid);   // live handle with this uid, or nullptr once it was destroyed
+int32_t replay_per_check(uint64_t uid, bool* alive);   // per_check of that handle while the registry lock is held
 // the host state a sample advances (uniform ring): snapshot / restore around a step-graph pass that may have to be re-enqueued
 struct ReplaySnap {
     uint64_t word_pos, batch_n; bool read_pending; hipStream_t read_stream;

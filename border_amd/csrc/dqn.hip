@@ -47,8 +47,23 @@ namespace {
 #ifndef BDR_TEAMS_FWD_L1
 #define BDR_TEAMS_FWD_L1 1
 #endif
-constexpr int TEAMS_FWD_C2 = 1, TEAMS_FWD_C3 = BDR_TEAMS_FWD_C3, TEAMS_FWD_L1 = BDR_TEAMS_FWD_L1, TEAMS_DX_L1 = BDR_TEAMS_DX_L1,
-              TEAMS_DX_C3 = BDR_TEAMS_DX_C3, TEAMS_DX_C2 = 1;
+#ifndef BDR_TEAMS_FWD_C2
+#define BDR_TEAMS_FWD_C2 1
+#endif
+#ifndef BDR_TEAMS_DX_C2
+#define BDR_TEAMS_DX_C2 1
+#endif
+#ifndef BDR_DXC2_MERGED
+#define BDR_DXC2_MERGED 1   // conv2 input gradient: the four parity classes as one GEMM (DxC2M); 0: one launch slice per class (DxC2)
+#endif
+// conv3 forward of the DQN step: 32x64 tiles, two k-split teams (392 workgroups per instance instead of 196: with the split forward every
+// launch is ONE instance, and 196 tiles left a quarter of the CUs idle; round 4, same box: 4 700 vs 4 647 opt-steps/s)
+#ifndef BDR_FWDC3_SHAPE
+#define BDR_FWDC3_SHAPE 1, 2, 1, 1
+#endif
+using FwdC3D = FwdConvP<GeomC3, BDR_FWDC3_SHAPE>;
+constexpr int TEAMS_FWD_C2 = BDR_TEAMS_FWD_C2, TEAMS_FWD_C3 = BDR_TEAMS_FWD_C3, TEAMS_FWD_L1 = BDR_TEAMS_FWD_L1, TEAMS_DX_L1 = BDR_TEAMS_DX_L1,
+              TEAMS_DX_C3 = BDR_TEAMS_DX_C3, TEAMS_DX_C2 = BDR_TEAMS_DX_C2;
 
 // ================================================================================================
 // head: l1 finish + l2, one wave per (row, instance)
@@ -366,6 +381,13 @@ struct DqnCnn : bdr_agent {
     const char* kind() const override { return "dqn_cnn"; }
     int32_t opt(bdr_replay* r) override;
     void on_gate_timeout() override;
+    void drain_queues() override
+    {
+        (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);
+        if (aux) (void)hipStreamSynchronize(aux);
+        if (comm_st) (void)hipStreamSynchronize(comm_st);
+    }
     int32_t after_sync() override
     {
         if (!(xchg_pending_conv || xchg_pending_fc)) return BDR_OK;
@@ -570,17 +592,22 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
     }
     f.M = B * 81;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a1[inst[z].slot]; f.w[z] = inst[z].params + ar.w2; f.bias[z] = inst[z].params + ar.b2; f.out[z] = a->a2[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv2"); BDR_HIP((launch_igemm<FwdC2, TEAMS_FWD_C2>(st, dim3((f.M + 63) / 64, 1, nz), f))); }
+    { Bracket br(a, "fwd_conv2"); BDR_HIP((launch_igemm<FwdC2, TEAMS_FWD_C2>(st, dim3(m_tiles<FwdC2>(f.M) * n_tiles<FwdC2>(), 1, nz), f))); }
     f.M = B * 49;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a2[inst[z].slot]; f.w[z] = inst[z].params + ar.w3; f.bias[z] = inst[z].params + ar.b3; f.out[z] = a->a3[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3, TEAMS_FWD_C3>(st, dim3((f.M + 63) / 64, 1, nz), f))); }
+    { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3D, TEAMS_FWD_C3>(st, dim3(m_tiles<FwdC3D>(f.M) * n_tiles<FwdC3D>(), 1, nz), f))); }
     f.M = B; f.nkt_per_split = (98 + L1_SPLIT - 1) / L1_SPLIT;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a3[inst[z].slot]; f.w[z] = inst[z].params + ar.w4; f.bias[z] = nullptr; f.out[z] = a->p1[inst[z].slot]; }
     if (uses_q) BDR_TRY(a->join_exchange(false, true));
     {
         Bracket br(a, "fwd_l1");
+#if BDR_L1_XSPLIT
+        static_assert(L1_SPLIT == 8, "FwdL1X: one k-slice per XCD");
+        BDR_HIP((launch_igemm<FwdL1X, TEAMS_FWD_L1>(st, dim3(m_tiles<FwdL1X>(B) * n_tiles<FwdL1X>() * 8, 1, nz), f)));
+#else
         if (nz % 2 == 0) BDR_HIP((launch_igemm<FwdL1Z2, TEAMS_FWD_L1>(st, dim3(((B + 63) / 64) * 16, L1_SPLIT, nz / 2), f)));
         else BDR_HIP((launch_igemm<FwdL1, TEAMS_FWD_L1>(st, dim3(((B + 63) / 64) * 8, L1_SPLIT, nz), f)));
+#endif
     }
     HeadArgs h{};
     h.B = B; h.A = ar.A; h.S = L1_SPLIT;
@@ -739,7 +766,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     auto l1_dx = [&]() -> int32_t {
         DxArgs d{a->dh1, a->q + ar.w4, a->a3[0], a->dy3, B, sigf(SIG_HEAD), epoch};   // its start publishes "head done"
         Bracket br(a, "bwd_l1_dx");
-        BDR_HIP((launch_igemm<DxL1, TEAMS_DX_L1>(a->stream, dim3((((B + 63) / 64) * 49 + 7) / 8 * 8, 1, 1), d, 0, kev(1))));
+        BDR_HIP((launch_igemm<DxL1, TEAMS_DX_L1>(a->stream, dim3((m_tiles<DxL1>(B) * n_tiles<DxL1>() + 7) / 8 * 8, 1, 1), d, 0, kev(1))));
         return BDR_OK;
     };
     // :150 backward_step -> Adam.  The l1 / l2 parameters (95 % of the arena) have their gradients (k_head_bwd, DwL1) and
@@ -763,7 +790,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     auto c3_dx = [&]() -> int32_t {
         DxArgs d{a->dy3, a->q + ar.w3, a->a2[0], a->dy2, B * 81, sigf(SIG_DXL1), epoch};
         Bracket br(a, "bwd_conv3_dx");
-        BDR_HIP((launch_igemm<DxC3Pos, TEAMS_DX_C3>(a->stream, dim3((B + 63) / 64, 81, 1), d, 0, kev(2))));
+        BDR_HIP((launch_igemm<DxC3Pos, TEAMS_DX_C3>(a->stream, dim3(((B + DxC3Pos::WM * DxC3Pos::TM * 32 - 1) / (DxC3Pos::WM * DxC3Pos::TM * 32)) * n_tiles<DxC3Pos>(), 81, 1), d, 0, kev(2))));
         return BDR_OK;
     };
     auto c2_dw = [&]() -> int32_t {
@@ -776,7 +803,11 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     auto c2_dx = [&]() -> int32_t {
         DxArgs d{a->dy2, a->q + ar.w2, a->a1[0], a->dy1, B * 100, sigf(SIG_DXC3), epoch};
         Bracket br(a, "bwd_conv2_dx");
+#if BDR_DXC2_MERGED
+        BDR_HIP((launch_igemm<DxC2M, TEAMS_DX_C2>(a->stream, dim3(m_tiles<DxC2M>(d.M) * n_tiles<DxC2M>(), 1, 1), d)));
+#else
         BDR_HIP((launch_igemm<DxC2, TEAMS_DX_C2>(a->stream, dim3((d.M + 127) / 128, 4, 1), d)));
+#endif
         return BDR_OK;
     };
     auto c1_dw = [&]() -> int32_t {   // conv1 has no input gradient

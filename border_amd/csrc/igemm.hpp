@@ -30,10 +30,6 @@ namespace bdr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef IGEMM_ABL    // tools/probes only: timing ablations (results are wrong when non-zero)
-#define IGEMM_ABL 0  // 1: no global prefetch in the loop, 2: no LDS commit, 4: no barrier, 8: no LDS fragment reads
-#endif
-
 constexpr int BK = 32;        // k-tile
 constexpr int LDA = BK + 4;   // A tile row stride (floats): conflict-free ds_read_b128, 16B aligned
 
@@ -282,6 +278,10 @@ __device__ __forceinline__ bool vrow_img(int M, int mv, int& mr)
 template <class P, class = void> struct xmap_of { static constexpr int value = 0; };
 template <class P> struct xmap_of<P, std::void_t<decltype(P::XMAP)>> { static constexpr int value = P::XMAP; };
 
+// transposed-weight policies may map (y, tap, column) to a weight row themselves (`b_row`): the default is row tap_index(y, tap) * N + n
+template <class P, class = void> struct has_b_row : std::false_type {};
+template <class P> struct has_b_row<P, std::void_t<decltype(P::b_row(0, 0, 0))>> : std::true_type {};
+
 // m-tiles of a launch: RPIP == 0 -> flat
 template <class P>
 inline int m_tiles(int M)
@@ -310,8 +310,7 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
         f32x4 a[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
-            a[tm] = (IGEMM_ABL & 8) ? f32x4{1.f * lane, 2.f, 3.f, 4.f}
-                                    : *reinterpret_cast<const f32x4*>(&As[(arow0 + tm * 32 + i) * LDA + 8 * u + 4 * h]);
+            a[tm] = *reinterpret_cast<const f32x4*>(&As[(arow0 + tm * 32 + i) * LDA + 8 * u + 4 * h]);
         f32x4 bq[TN];
         if constexpr (B_KMAJOR) {
 #pragma unroll
@@ -324,7 +323,7 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 if constexpr (B_KMAJOR) b[tn] = bq[tn][s];
-                else b[tn] = (IGEMM_ABL & 8) ? 0.5f * lane : Bs[(8 * u + 4 * h + s) * LDB + bcol0 + tn * 32 + i];
+                else b[tn] = Bs[(8 * u + 4 * h + s) * LDB + bcol0 + tn * 32 + i];
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
@@ -356,21 +355,6 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
 // Virtual rows: a policy may pad every image's rows to a multiple of the tile height
 // (P::vrow(args, mv, m_real) -> valid), so that one workgroup == one image and a B-image batch maps
 // onto the 256 CUs without the round-robin tail of a flat row tiling (81 conv2 rows -> 96, 49 -> 64).
-#ifdef IGEMM_TRACE   // tools/probes only: per-workgroup phase timestamps (100 MHz wall clock)
-__device__ unsigned long long* g_igemm_trace;
-#define IGEMM_TP(slot) do { if (threadIdx.x == 0 && g_igemm_trace) { \
-    unsigned long long* t_ = g_igemm_trace + ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
-    t_[slot] = wall_clock64(); t_[4 + (slot)] = clock64(); } } while (0)
-#else
-#define IGEMM_TP(slot) do { } while (0)
-#endif
-#ifdef IGEMM_TRACE2  // tools/probes only: cycles of one wave inside the k loop, per phase (s_memtime)
-__device__ unsigned long long* g_igemm_phase;
-#define IGEMM_PH(var) const long long var = clock64()
-#else
-#define IGEMM_PH(var) do { } while (0)
-#endif
-
 // Cross-queue progress flags (see DqnCnn::update_critic, schedule 3).  A kernel whose Args carry `sig_flag` / `sig_epoch`
 // publishes "everything queued before me on my stream is complete" the moment its first workgroup starts: the dispatch
 // packet's barrier bit has already waited for the predecessors and their end-of-kernel release, so a consumer on another
@@ -398,7 +382,6 @@ __device__ inline bool vrow_of(const typename P::Args& a, int y, int mv, int& mr
 template <class P, int TEAMS = 1>
 __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P::Args args)
 {
-    IGEMM_TP(0);
     if constexpr (has_start_signal<typename P::Args>::value) start_signal(args.sig_flag, args.sig_epoch);
     using A = typename P::A;
     constexpr int NW = P::WM * P::WN, NT = 64 * NW;          // waves / threads per team
@@ -427,8 +410,15 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
     // block -> (m-tile, n-tile, instance) map.  Workgroup b runs on XCD b % 8 and every XCD has its own L2, so which tiles
     // share an XCD decides how often an operand crosses the fabric (PMC: l1 forward moved 71.6 MB for 26.5 MB of operands
     // and results with the plain map, every XCD streaming all of A).
-    int mt, nt, z = blockIdx.z;
-    if constexpr (xmap_of<P>::value == 1) {
+    int mt, nt, z = blockIdx.z, y = blockIdx.y;
+    if constexpr (xmap_of<P>::value == 3) {
+        // split-K slice = XCD: XCD j multiplies k-slice j of every output tile, so each XCD's L2 sees 1/8 of A's columns and 1/8
+        // of B's rows exactly once (PMC, round 3: the (instance, n-tile pair) map fetched 38.6 MB for 19.3 MB of operands - every A
+        // element crossed the fabric four times).  grid: (8 * m-tiles * n-tiles, 1, instances)
+        y = blockIdx.x & 7;
+        const int j = blockIdx.x >> 3;
+        nt = j % NT_N; mt = j / NT_N;
+    } else if constexpr (xmap_of<P>::value == 1) {
         // contiguous runs of tiles per XCD, m fastest: the m-tiles of one n-tile (same B columns) meet in one L2
         const int MT = (M + BM - 1) / BM, per = gridDim.x >> 3;   // (flat rows: RPIP == 0)
         const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -444,7 +434,6 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
         mt = blockIdx.x / NT_N; nt = blockIdx.x % NT_N;
     }
     const int m0 = mt * BM, n0 = nt * BN;                    // m0: virtual row
-    const int y = blockIdx.y;
 
     // per-thread staging coordinates: element e = tid + p*NT of the A tile -> (row e / APR, k-quad e % APR)
     const int a_q = tid % APR, a_r = tid / APR;
@@ -494,7 +483,10 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
                 const int TPT = P::KP(args) / BK;
                 const int tap = kt / TPT, c0 = (kt % TPT) * BK;
                 const int kq = e % 8, np = e / 8;
-                rb[S][v] = *reinterpret_cast<const f32x4*>(w + ((size_t)P::tap_index(y, tap) * P::N(args) + n0 + np) * P::KP(args) + c0 + kq * 4);
+                size_t wrow;
+                if constexpr (has_b_row<P>::value) wrow = (size_t)P::b_row(y, tap, n0 + np);
+                else wrow = (size_t)P::tap_index(y, tap) * P::N(args) + n0 + np;
+                rb[S][v] = *reinterpret_cast<const f32x4*>(w + wrow * P::KP(args) + c0 + kq * 4);
             }
         }
     };
@@ -571,51 +563,24 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
         }
     }
     __syncthreads();
-    IGEMM_TP(1);
     int cur = 0;
-#ifdef IGEMM_TRACE2
-    long long ph[6] = {0, 0, 0, 0, 0, 0};
-#endif
     auto step = [&](auto set, int it) {   // set = (it+1)&1: holds tile it+1; refilled with tile it+3
-        IGEMM_PH(t_a);
-#ifdef IGEMM_TRACE2
-        long long t_b = t_a, t_c = t_a, t_d = t_a;
-#endif
         if (it < my_n) {                  // team-uniform
             const float* As = smem + cur * STAGE;
             const int k3 = tile(it + 3);
             mfma_ktile<P::TM, P::TN, LDB, P::B_TR>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc, [&](int u) {
-#ifdef IGEMM_TRACE2
-                if (u == 0) t_b = clock64();
-                if (u == 3) t_d = clock64();
-#endif
-                if (u == 0) { if (!(IGEMM_ABL & 2)) { commit_a(set, cur ^ 1); commit_b(set, cur ^ 1); } }   // tile it+1 -> idle stage
-                else if (u == 1) { if (!(IGEMM_ABL & 1)) prefetch_a(set, k3); }                       // tile it+3 global loads
-                else if (u == 2) { if (!(IGEMM_ABL & 1)) prefetch_b(set, k3); }
-#ifdef IGEMM_TRACE2
-                if (u == 0) t_c = clock64();
-#endif
+                if (u == 0) { commit_a(set, cur ^ 1); commit_b(set, cur ^ 1); }   // tile it+1 -> idle stage
+                else if (u == 1) prefetch_a(set, k3);                             // tile it+3 global loads
+                else if (u == 2) prefetch_b(set, k3);
             });
         }
-        IGEMM_PH(t_e);
-        if (!(IGEMM_ABL & 4)) __syncthreads();
-#ifdef IGEMM_TRACE2
-        const long long t_f = clock64();
-        ph[0] += t_b - t_a; ph[1] += t_c - t_b; ph[2] += t_d - t_c; ph[3] += t_e - t_d; ph[4] += t_f - t_e; ph[5] += 1;
-#endif
+        __syncthreads();
         cur ^= 1;
     };
     for (int it = 0; it < iters; it += 2) {
         step(Set1{}, it);
         if (it + 1 < iters) step(Set0{}, it + 1);
     }
-    IGEMM_TP(2);
-#ifdef IGEMM_TRACE2
-    if (threadIdx.x == 0 && g_igemm_phase) {
-        unsigned long long* o = g_igemm_phase + ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
-        for (int q = 0; q < 6; ++q) o[q] = (unsigned long long)ph[q];
-    }
-#endif
     if constexpr (TEAMS == 2) {   // acc(team 0) += acc(team 1), through team 1's (now idle) stages
         constexpr int PER_WAVE = P::TM * P::TN * 16 * 64;
         static_assert(2 * STAGE >= NW * PER_WAVE, "team reduction buffer");
@@ -651,7 +616,6 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
             for (int r = 0; r < 16; ++r)
                 if (okmask[tm] >> r & 1) P::store(epi, mrow[tm][r], n, acc[tm][tn][r], aux[tm][tn][r]);
         }
-    IGEMM_TP(3);
 }
 
 

@@ -24,6 +24,7 @@ struct TdDenseArgs {
     int B, A; float gamma; int loss_kind;
     const float* weight; float* td_abs; int has_clip; float clip_min, clip_max;   // PER (dqn/base.rs:123-145)
     unsigned* err;    // bdr_agent::dev_err
+    int relu_out;     // MlpConfig::activation_out (mlp/base.rs:36): the Q rows are post-ReLU, dL/dz = dL/dQ * [Q > 0]
 };
 __global__ __launch_bounds__(256) void k_td_dense(TdDenseArgs a)
 {
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256) void k_td_dense(TdDenseArgs a)
     const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
     float lossb, td;
     const float dl = td_loss_row(pred, tgt, li, lossb, td);
-    const float dq = dl / (float)a.B;
+    float dq = dl / (float)a.B;
+    if (a.relu_out && !(pred > 0.f)) dq = 0.f;
     if (lane == 0) { a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb; if (a.td_abs) a.td_abs[row] = td; }
     for (int c = lane; c < a.ld; c += 64) a.dq_rows[(size_t)row * a.ld + c] = c == act ? dq : 0.f;
 }
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(512) void k_mlp_head_td(MlpHeadTdArgs p)
         const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
         float lossb, td;
         const float dl = td_loss_row(pred, tgt, li, lossb, td);
-        const float dq = dl / (float)a.B;
+        float dq = dl / (float)a.B;
+        if (a.relu_out && !(pred > 0.f)) dq = 0.f;
         if (lane == 0) {
             s_dq[r] = dq; s_act[r] = (int)act;
             if (writer) { a.pred[row] = pred; a.tgt[row] = tgt; st_agent(a.loss_row + row, lossb); if (a.td_abs) a.td_abs[row] = td; }
@@ -388,7 +391,7 @@ struct DqnMlp : bdr_agent {
         t.B = Bn; t.A = net.out_dim; t.gamma = (float)cfg.discount_factor; t.loss_kind = cfg.critic_loss;
         t.weight = weight; t.td_abs = td_abs;
         t.has_clip = cfg.has_clip_td_err; t.clip_min = (float)cfg.clip_td_err_min; t.clip_max = (float)cfg.clip_td_err_max;
-        t.err = dev_err;
+        t.err = dev_err; t.relu_out = net.L[L - 1].relu;
         if (lat && head_fused) {
             const DenseLayer& ll = net.L[L - 1];
             const int nz = cfg.double_dqn ? 3 : 2;
@@ -622,10 +625,9 @@ int32_t dqn_mlp_create(const bdr_dqn_config* cfg, bdr_agent** out)
 {
     BDR_REQUIRE(cfg->net.in_dim >= 1 && cfg->net.n_units >= 0 && cfg->net.n_units <= BDR_MAX_UNITS, "bad Mlp config");
     BDR_REQUIRE(cfg->net.out_dim >= 1 && cfg->net.out_dim <= 64, "out_dim must be in [1,64]");
-    BDR_REQUIRE(!cfg->net.activation_out, "a DQN Q-network has no output activation");
     DqnMlp* a = new DqnMlp();
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
-    a->net = make_mlp(cfg->net.in_dim, cfg->net.units, cfg->net.n_units, cfg->net.out_dim, false);
+    a->net = make_mlp(cfg->net.in_dim, cfg->net.units, cfg->net.n_units, cfg->net.out_dim, cfg->net.activation_out != 0);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     BDR_TRY(a->err_init());
     a->fused = getenv("BDR_NO_MLP_FUSED") == nullptr;

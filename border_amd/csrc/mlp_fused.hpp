@@ -263,7 +263,8 @@ __global__ __launch_bounds__(512) void k_dqn_mlp_step(MlpFusedArgs a)
             const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
             float lossb, td;
             const float dl = td_loss_row(pred, tgt, li, lossb, td);
-            const float dq = dl / (float)B;
+            float dq = dl / (float)B;
+            if (a.relu[L - 1] && !(pred > 0.f)) dq = 0.f;   // MlpConfig::activation_out (mlp/base.rs:36): Q = relu(z), dL/dz = dL/dQ * [Q > 0]
             if (sub == 0) { a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb; if (a.td_abs) a.td_abs[row] = td; }
             for (int c = sub; c < ld; c += 16) a.dy[L - 1][(size_t)row * ld + c] = c == act ? dq : 0.f;
         }
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(512) void k_dqn_mlp_step_lds(MlpFusedArgs a)
             const TdLossIn li{a.loss_kind, a.weight != nullptr, a.weight ? a.weight[row] : 1.f, a.has_clip, a.clip_min, a.clip_max};
             float lossb, td;
             const float dl = td_loss_row(pred, tgt, li, lossb, td);
-            const float dq = dl / (float)B;
+            float dq = dl / (float)B;
+            if (a.relu[L - 1] && !(pred > 0.f)) dq = 0.f;   // MlpConfig::activation_out (mlp/base.rs:36): Q = relu(z), dL/dz = dL/dQ * [Q > 0]
             if (sub == 0) { a.pred[row] = pred; a.tgt[row] = tgt; a.loss_row[row] = lossb; s_loss[row] = lossb; if (a.td_abs) a.td_abs[row] = td; }
             for (int c = sub; c < ld; c += 16) {
                 const float g = c == act ? dq : 0.f;

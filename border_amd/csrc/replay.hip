@@ -272,6 +272,18 @@ bdr_replay* replay_lookup(uint64_t uid)
     auto it = g_replays.find(uid);
     return it == g_replays.end() ? nullptr : it->second;
 }
+// per_check of the live buffer with this uid, under the registry lock: a concurrent bdr_replay_destroy on another thread (the Rust
+// handles are Send) cannot free the handle between the lookup and the dereference.  *alive = false once the buffer is gone.
+int32_t replay_per_check(uint64_t uid, bool* alive)
+{
+    *alive = false;
+    if (!uid) return BDR_OK;
+    std::lock_guard<std::mutex> l(g_replays_mu);
+    auto it = g_replays.find(uid);
+    if (it == g_replays.end()) return BDR_OK;
+    *alive = true;
+    return it->second->per ? per_check(it->second->per) : BDR_OK;
+}
 }  // namespace bdr
 
 // `written` was just recorded on some stream: consumers have to wait for it again

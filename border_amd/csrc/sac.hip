@@ -754,10 +754,16 @@ struct Sac : bdr_agent, SacBatch {
     }
 
     const char* kind() const override { return "sac"; }
+    void drain_queues() override
+    {
+        (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);   // prologue kernels / flag waits still queued there (they return at once while poisoned)
+    }
     void on_gate_timeout() override   // a flag wait timed out: back to one queue
     {
         if (two_queues) fprintf(stderr, "border_amd: a cross-queue wait of the SAC step timed out; this agent continues on one queue\n");
         two_queues = false;
+        main_ahead = true;   // whatever ran on `stream` since the failed wait is not covered by the flags
     }
     // the launch sequence of one opt() (Sac::opt_, sac/base.rs:175-192)
     // does this opt() take the two-queue sequence?

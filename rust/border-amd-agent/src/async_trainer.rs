@@ -239,6 +239,18 @@ unsafe extern "C" fn observer_cb(ctx: *mut c_void, _actor: u32, _a: u64, opt_ste
     }));
 }
 
+/// The device mailbox between a learner and its actors, destroyed on every exit path of `train_async` (an early `?` included).
+/// Declared BEFORE the actors in `train_async`, so it is dropped after them: the actors' streams may still hold copies out of it
+/// until their handles have synchronised and gone.
+struct Mailbox(*mut ffi::bdr_model_mailbox);
+impl Drop for Mailbox {
+    fn drop(&mut self) {
+        if !self.0.is_null() {
+            unsafe { ffi::bdr_model_mailbox_destroy(self.0) };
+        }
+    }
+}
+
 fn record_keys(agent: *mut ffi::bdr_agent) -> Result<Vec<String>> {
     let mut buf = vec![0u8; 16384];
     let mut n = 0i32;
@@ -284,6 +296,7 @@ where
     let _ = <AmdReplayBuffer<O, Ab> as ReplayBufferBase>::build; // (same Config type as the reference's R)
     let act_row_bytes = learner.act_row_bytes();
 
+    let mut mailbox_guard = Mailbox(std::ptr::null_mut());   // (first: dropped last)
     // one agent per actor, each from its own config (actor/base.rs:127)
     let actors: Vec<A> = agent_configs.iter().map(|c| A::build(c.clone())).collect();
     let n_actors = actors.len();
@@ -294,6 +307,7 @@ where
     check(unsafe { ffi::bdr_agent_arena_device_ptr(learner.raw(), 0, &mut dev_ptr, &mut n_floats) })?;
     let mut mailbox = std::ptr::null_mut();
     check(unsafe { ffi::bdr_model_mailbox_create(device, n_floats, n_actors as u32, &mut mailbox) })?;
+    mailbox_guard.0 = mailbox;
 
     // environments behind vtables; built lazily on the actor threads
     let mut env_ctxs: Vec<Box<EnvCtx<E, A>>> = (0..n_actors)
@@ -356,15 +370,16 @@ where
             astats.as_mut_ptr(),
         )
     };
-    // the loop's own status first; the mailbox is destroyed whatever happened (the actor threads have been joined)
+    // the loop's own status first; the mailbox is destroyed whatever happened (the actor threads have been joined): by its guard,
+    // after the actors' handles - here and on every early return above
     let run = check(rc);
     let wait = run.is_ok().then(|| check(unsafe { ffi::bdr_agent_sync(learner.raw()) }));
     for a in &actors {
         unsafe { ffi::bdr_agent_sync(a.raw()) };
     }
-    unsafe { ffi::bdr_model_mailbox_destroy(mailbox) };
     drop(actors);
     drop(env_ctxs.drain(..));
+    drop(mailbox_guard);
     run?;
     if let Some(w) = wait {
         w?;

@@ -147,7 +147,7 @@ where
 
     /// dqn/base.rs:345-356: `qnet.pt.tch`, `qnet_tgt.pt.tch` in the container tch's `VarStore::save` writes for these names.
     fn save_params(&self, path: &Path) -> Result<Vec<PathBuf>> {
-        self.a.save_params(path, &["qnet.pt.tch".to_string(), "qnet_tgt.pt.tch".to_string()])
+        self.a.save_params(path, &["qnet".to_string(), "qnet_tgt".to_string()])
     }
 
     fn load_params(&mut self, path: &Path) -> Result<()> {

@@ -14,6 +14,12 @@ use std::{
 pub(crate) struct AgentHandle {
     pub(crate) h: *mut ffi::bdr_agent,
     keys: Vec<String>,
+    /// `*.safetensors` instead of the default `*.pt.tch` (set through `set_checkpoint_format`, mirrored here so that
+    /// `save_params` can name the files the library actually wrote)
+    safetensors: bool,
+    /// A device-side failure reported by `Agent::opt` (which returns `()` in the reference's trait): logged when it happens and
+    /// returned by the next call that can return an error (`sync`, `save_params`, `load_params`).
+    deferred: Option<anyhow::Error>,
 }
 
 // SAFETY: one HIP stream set per handle, hipSetDevice on every entry; `Send`, not `Sync` (all device work behind `&mut`).
@@ -21,7 +27,7 @@ unsafe impl Send for AgentHandle {}
 
 impl AgentHandle {
     pub(crate) fn new(h: *mut ffi::bdr_agent) -> Self {
-        Self { h, keys: Vec::new() }
+        Self { h, keys: Vec::new(), safetensors: false, deferred: None }
     }
 
     pub(crate) fn set_train(&mut self, on: bool) {
@@ -35,8 +41,29 @@ impl AgentHandle {
     }
 
     /// `Agent::opt`: enqueues the step on the agent's streams and returns without waiting for the device.
+    ///
+    /// The library reports device-side conditions of EARLIER steps here without synchronising (an action index outside
+    /// `[0, n_actions)`, a cross-queue wait that timed out).  They must not panic the learner thread: the state stays that of the
+    /// last good update and training can go on, so the error is logged and kept for the next fallible call.
     pub(crate) fn opt(&mut self, buffer: *mut ffi::bdr_replay) {
-        expect(unsafe { ffi::bdr_agent_opt(self.h, buffer) }, "Agent::opt");
+        if let Err(e) = check(unsafe { ffi::bdr_agent_opt(self.h, buffer) }) {
+            log::error!("Agent::opt: {e:#}");
+            self.deferred.get_or_insert(e);
+        }
+    }
+
+    fn take_deferred(&mut self) -> Result<()> {
+        match self.deferred.take() {
+            Some(e) => Err(e),
+            None => Ok(()),
+        }
+    }
+
+    /// `VarStore::save`'s other container for the files `save_params` writes (`BDR_CKPT_SAFETENSORS` = 1, `BDR_CKPT_PT_TCH` = 0).
+    pub(crate) fn set_checkpoint_format(&mut self, safetensors: bool) -> Result<()> {
+        check(unsafe { ffi::bdr_agent_set_checkpoint_format(self.h, safetensors as i32) })?;
+        self.safetensors = safetensors;
+        Ok(())
     }
 
     /// Names of the scalars `opt_with_record` returns, in order (the keys of the reference's `Record`).
@@ -74,7 +101,9 @@ impl AgentHandle {
     }
 
     pub(crate) fn sync(&mut self) -> Result<()> {
-        check(unsafe { ffi::bdr_agent_sync(self.h) })
+        let now = check(unsafe { ffi::bdr_agent_sync(self.h) });
+        self.take_deferred()?;
+        now
     }
 
     pub(crate) fn n_opts(&self) -> usize {
@@ -101,14 +130,18 @@ impl AgentHandle {
         expect(unsafe { ffi::bdr_agent_set_params(self.h, which, p.as_ptr(), p.len() as u64) }, "bdr_agent_set_params");
     }
 
-    /// `fs::create_dir_all(path)` + the model files under it, in the reference's container (`*.pt.tch`, VarStore::save).
-    pub(crate) fn save_params(&self, path: &Path, files: &[String]) -> Result<Vec<PathBuf>> {
+    /// `fs::create_dir_all(path)` + the model files under it, in the reference's container (`*.pt.tch`, VarStore::save) or
+    /// `*.safetensors` when that format was selected.  `stems`: the file names without extension (`qnet`, `qnet_tgt`, ...); the
+    /// returned paths are the files the library wrote.
+    pub(crate) fn save_params(&self, path: &Path, stems: &[String]) -> Result<Vec<PathBuf>> {
         let dir = CString::new(path.to_str().ok_or_else(|| anyhow!("non-UTF-8 path"))?)?;
         check(unsafe { ffi::bdr_agent_save_params(self.h, dir.as_ptr()) })?;
-        Ok(files.iter().map(|f| path.join(f)).collect())
+        let ext = if self.safetensors { "safetensors" } else { "pt.tch" };
+        Ok(stems.iter().map(|f| path.join(format!("{f}.{ext}"))).collect())
     }
 
     pub(crate) fn load_params(&mut self, path: &Path) -> Result<()> {
+        self.take_deferred()?;
         let dir = CString::new(path.to_str().ok_or_else(|| anyhow!("non-UTF-8 path"))?)?;
         check(unsafe { ffi::bdr_agent_load_params(self.h, dir.as_ptr()) })
     }

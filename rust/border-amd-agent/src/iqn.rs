@@ -139,7 +139,7 @@ where
 
     /// iqn/base.rs:303-311: `iqn.pt.tch`, `iqn_tgt.pt.tch`.
     fn save_params(&self, path: &Path) -> Result<Vec<PathBuf>> {
-        self.a.save_params(path, &["iqn.pt.tch".to_string(), "iqn_tgt.pt.tch".to_string()])
+        self.a.save_params(path, &["iqn".to_string(), "iqn_tgt".to_string()])
     }
 
     fn load_params(&mut self, path: &Path) -> Result<()> {

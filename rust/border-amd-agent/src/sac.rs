@@ -143,11 +143,11 @@ where
     fn save_params(&self, path: &Path) -> Result<Vec<PathBuf>> {
         let mut files = Vec::new();
         for i in 0..self.n_critics {
-            files.push(format!("qnet_{}.pt.tch", i));
-            files.push(format!("qnet_tgt_{}.pt.tch", i));
+            files.push(format!("qnet_{}", i));
+            files.push(format!("qnet_tgt_{}", i));
         }
-        files.push("pi.pt.tch".to_string());
-        files.push("ent_coef.pt.tch".to_string());
+        files.push("pi".to_string());
+        files.push("ent_coef".to_string());
         self.a.save_params(path, &files)
     }
 

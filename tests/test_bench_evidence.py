@@ -56,6 +56,42 @@ def test_stale_traffic_is_withheld(tmp_path, monkeypatch):
     assert bench.kernel_source_hash() != h
 
 
+def test_fp32_gemm_sum_and_traffic_ratios_are_in_the_line(tmp_path, monkeypatch):
+    """What the round-3 review had to recompute by hand: all FP32-MFMA GEMM launches together on the rocprofv3 durations of the
+    committed trace, and measured / algorithmic HBM bytes for every kernel with a byte model."""
+    root, h = _tree(tmp_path, True, monkeypatch)
+    fl = bench.dqn_kernel_flops(256, 2)
+    ab = bench.dqn_kernel_bytes(256, 2)
+    us = {k: 20.0 for k in fl}
+    (root / "profiles" / "kernel_trace_c2_serial.json").write_text(json.dumps({"kernel_source_sha16": h, "kernels_us": us}))
+    (root / "profiles" / "hbm_traffic.json").write_text(json.dumps({"fwd_conv2": 42938982, "bwd_conv2_dx": 2 * ab["bwd_conv2_dx"], "fwd_l1": 45964288,
+                                                                     "_source": {"kernel_source_sha16": h, "pmc_tables": "profiles/x_pmc.md"}}))
+    conf = {"flops": fl, "bytes": {"sample": 14454272}, "step_flops": sum(fl.values()), "batch": 256, "name": "c2",
+            "flops_per_instance": bench.dqn_kernel_flops(256, 1), "alg_bytes": ab}
+    prof = {k: 0.02 for k in fl}
+    r = bench.roofline(conf, prof, {k: 1 for k in prof}, 0.0026, 0.221)
+    g = r["fp32_gemm_sum"]
+    fp32 = [k for k in fl if k not in bench.BF16_KERNELS]
+    assert g["kernels"] == sorted(fp32) and abs(g["rocprofv3_us"] - 20.0 * len(fp32)) < 1e-6 and g["same_kernel_sources"] is True
+    assert abs(g["gflop"] - sum(fl[k] for k in fp32) / 1e9) < 1e-2 and abs(g["frac"] - g["gflop"] / (g["rocprofv3_us"] * 1e-3) / 157.3) < 1e-3
+    t = r["traffic_vs_algorithmic"]
+    assert t["bwd_conv2_dx"]["ratio"] == 2.0 and t["fwd_l1"]["alg_bytes"] == ab["fwd_l1"] and "fwd_conv3" not in t
+    # conv2 forward, both networks: 2 x (a1 13.1 MB + W2 0.13 MB + a2 5.3 MB)
+    assert ab["fwd_conv2"] == 2 * (256 * 400 * 32 * 4 + 512 * 64 * 4 + 256 * 81 * 64 * 4)
+    # a PMC pass of other kernel sources is withheld here too
+    (root / "profiles" / "hbm_traffic.json").write_text(json.dumps({"fwd_conv2": 1, "_source": {"kernel_source_sha16": "0" * 16}}))
+    assert bench.roofline(conf, prof, {k: 1 for k in prof}, 0.0026, 0.221)["traffic_vs_algorithmic"] == {"stale": True}
+
+
+def test_committed_kernel_trace_and_pmc_pass_are_of_the_same_kernel_sources():
+    """The evidence pack of a round is ONE set of kernel sources: profiles/kernel_trace_c2_serial.json (rocprofv3 durations) and
+    profiles/hbm_traffic.json (PMC bytes) must name the same source hash, or the per-kernel table mixes two binaries."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kt = json.load(open(os.path.join(root, "profiles", "kernel_trace_c2_serial.json")))
+    tr = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
+    assert kt["kernel_source_sha16"] == tr["_source"]["kernel_source_sha16"], (kt["kernel_source_sha16"], tr["_source"])
+
+
 def test_committed_evidence_files_are_stamped():
     """What is committed under profiles/ names the sources it was measured on (it may be stale - then bench says so - but never unlabelled)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

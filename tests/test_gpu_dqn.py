@@ -114,21 +114,25 @@ def test_golden_cnn_b8_mse_double_dqn(B, golden_dir):
                 lr=1e-4, critic_loss="Mse", double_dqn=True, tau=0.005, soft_update_interval=1)
 
 
-def test_full_batch_256_vs_oracle(B):
-    """BASELINE config: B=256, A=6, SmoothL1.  One step against the C oracle (fixed minibatch)."""
+# Atari's minimal action sets go from 3 to 18 actions (border-atari-env/src/env.rs:97-103); k_head / k_head_bwd are compiled for
+# register blocks of 8, 24 and 64 actions (csrc/dqn.hip forward()): 4 and 6 take <.., 8>, 9 and 18 <.., 24>, 33 <.., 64>
+@pytest.mark.parametrize("A", [6, 4, 9, 18, 33])
+def test_full_batch_256_vs_oracle(B, A):
+    """BASELINE config: B=256, SmoothL1 (A=6 is the headline shape).  One step against the C oracle (fixed minibatch)."""
     from oracle import oracle as O
     from oracle import torch_ref as T
-    shapes = T.cnn_shapes(6)
+    shapes = T.cnn_shapes(A)
     p0 = T.init_params(shapes, 7)
-    obs, act, nobs, rew, term = T.synthetic_atari_batch(256, 6, 77)
+    obs, act, nobs, rew, term = T.synthetic_atari_batch(256, A, 77)
+    assert act.max() == A - 1 and act.min() == 0   # every column of the head's register block is selected by some row
     term[:8] = 1  # make sure the (1 - is_terminated) branch is exercised
-    a = make_agent(B, batch_size=256, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000)
+    a = make_agent(B, A=A, batch_size=256, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000)
     a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
-    ref = O.DqnOracle(O.cnn_cfg(6), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000)
+    ref = O.DqnOracle(O.cnn_cfg(A), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000)
     rec = a.update_on_batch(obs, act, nobs, rew, term)
     r = ref.update(obs, act, nobs, rew, term, probe=True)
-    assert rel(a.probe("q_pred_all", 256 * 6), r["q_pred_all"].ravel()) < QTOL
-    assert rel(a.probe("q_next_all", 256 * 6), r["q_next_all"].ravel()) < QTOL
+    assert rel(a.probe("q_pred_all", 256 * A), r["q_pred_all"].ravel()) < QTOL
+    assert rel(a.probe("q_next_all", 256 * A), r["q_next_all"].ravel()) < QTOL
     assert rel(a.probe("pred", 256), r["pred"]) < QTOL and rel(a.probe("tgt", 256), r["tgt"]) < QTOL
     assert abs(rec["loss"] - r["loss"]) <= QTOL * abs(r["loss"])
     assert_grads_close(a.get_params("grad"), r["grads"], shapes)
@@ -365,6 +369,45 @@ def test_mlp_layer_by_layer_path_vs_oracle(B, units, Bsz, double, monkeypatch):
         assert (g[0] == lat[0]).all() and (g[1] == lat[1]).all(), env
 
 
+@pytest.mark.parametrize("units,Bsz,env", [((64, 64), 32, {}), ((64, 64), 32, {"BDR_NO_MLP_LDS": "1"}), ((64, 64), 32, {"BDR_NO_MLP_FUSED": "1"}),
+                                           ((128, 96), 100, {"BDR_STEP_GRAPH": "0"}), ((128, 96), 100, {"BDR_STEP_GRAPH": "0", "BDR_NO_MLP_HEAD_FUSE": "1"})])
+def test_mlp_activation_out_on_the_q_network_vs_oracle(B, units, Bsz, env, monkeypatch):
+    """MlpConfig::activation_out = true on a DQN Q-network (mlp/base.rs:36: `seq.add_fn(|x| x.relu())` behind the last layer; the
+    reference accepts it, rounds 1-3 of this library refused it): Q = relu(z), so rows whose selected Q is clamped to 0 pass no
+    gradient.  Every step kernel of the Mlp agent (one-workgroup LDS step, one-workgroup global step, layer-by-layer with the
+    row-block head and with the four separate launches) against the C oracle, three updates."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    for k in ("BDR_NO_MLP_LDS", "BDR_NO_MLP_FUSED", "BDR_STEP_GRAPH", "BDR_NO_MLP_HEAD_FUSE", "BDR_NO_SMALL_GEMM"): monkeypatch.delenv(k, raising=False)
+    for k, v in env.items(): monkeypatch.setenv(k, v)
+    A = 3
+    shapes = T.mlp_shapes(4, list(units), A)
+    p0 = T.init_params(shapes, 23)
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.MlpConfig(in_dim=4, units=units, out_dim=A, activation_out=True),
+                                                    opt_config=B.OptimizerConfig.Adam(1e-3)),
+                      device=0, batch_size=Bsz, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, double_dqn=True)
+    a = B.Dqn.build(cfg)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    ref = O.DqnOracle(O.mlp_cfg(4, list(units), A, activation_out=True), p0, lr=1e-3, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, double_dqn=True)
+    clamped = 0
+    for step in range(3):
+        rng = np.random.default_rng(900 + step)
+        obs = rng.standard_normal((Bsz, 4)).astype(np.float32); nobs = rng.standard_normal((Bsz, 4)).astype(np.float32)
+        act = rng.integers(0, A, Bsz); rew = rng.standard_normal(Bsz).astype(np.float32); term = (rng.random(Bsz) < 0.1).astype(np.int8)
+        rec = a.update_on_batch(obs, act, nobs, rew, term)
+        r = ref.update(obs, act, nobs, rew, term, probe=True)
+        q = a.probe("q_pred_all", Bsz * A)
+        assert q.min() >= 0.0 and rel(q, r["q_pred_all"].ravel()) < 3e-4, step
+        clamped += int((r["pred"] == 0).sum())
+        assert rel(a.probe("pred", Bsz), r["pred"]) < 3e-4 and rel(a.probe("tgt", Bsz), r["tgt"]) < 3e-4
+        assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-7
+        assert_grads_close(a.get_params("grad"), r["grads"], shapes, tol=5e-4)
+    assert clamped > 0                     # the masked branch was exercised
+    assert np.abs(a.get_params("qnet") - ref.q).max() < 0.3 * 1e-3 and rel(a.get_params("qnet_tgt"), ref.q_tgt) < 1e-3
+    assert rel(a.qvalues(obs[:5]), O.net_forward(O.mlp_cfg(4, list(units), A, activation_out=True), a.get_params("qnet"), obs[:5])) < 3e-4
+    a.close()
+
+
 def test_mlp_adamw_matches_aten(B):
     """OptimizerConfig::AdamW (opt.rs:20-27,38-55): decoupled weight decay, custom betas / eps, 5 steps vs ATen."""
     from oracle import torch_ref as T
@@ -471,28 +514,30 @@ def test_n_updates_per_opt_and_soft_update_counter(B):
     a.close(); rb.close()
 
 
-@pytest.mark.parametrize("Bsz,ddqn", [(1, False), (3, True), (33, False), (100, True), (300, False)])   # 300: conv1-dW workgroups take two images
-def test_ragged_batch_sizes_vs_oracle(B, Bsz, ddqn):
+@pytest.mark.parametrize("Bsz,ddqn,A", [(1, False, 6), (3, True, 6), (33, False, 6), (100, True, 6), (300, False, 6),   # 300: conv1-dW workgroups take two images
+                                        (7, True, 4), (3, False, 9), (33, True, 18), (100, False, 33), (65, True, 64)])   # the head kernels' 24- and 64-action blocks
+def test_ragged_batch_sizes_vs_oracle(B, Bsz, ddqn, A):
     """Batch sizes that are not multiples of any tile (rows 81*B / 49*B / B, one image per conv1-dW workgroup, two
-    rows per head workgroup): Q-values, targets, loss and gradients against the C oracle."""
+    rows per head workgroup) and action counts in every register block of the head kernels: Q-values, targets, loss and
+    gradients against the C oracle."""
     from oracle import oracle as O
     from oracle import torch_ref as T
-    shapes = T.cnn_shapes(6)
+    shapes = T.cnn_shapes(A)
     p0 = T.init_params(shapes, 40 + Bsz)
-    obs, act, nobs, rew, term = T.synthetic_atari_batch(Bsz, 6, 500 + Bsz)
+    obs, act, nobs, rew, term = T.synthetic_atari_batch(Bsz, A, 500 + Bsz)
     term[0] = 1
-    a = make_agent(B, batch_size=Bsz, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, double_dqn=ddqn)
+    a = make_agent(B, A=A, batch_size=Bsz, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, double_dqn=ddqn)
     a.set_params(p0, "qnet")
     a.set_params(T.init_params(shapes, 41 + Bsz), "qnet_tgt")
-    ref = O.DqnOracle(O.cnn_cfg(6), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, double_dqn=ddqn)
+    ref = O.DqnOracle(O.cnn_cfg(A), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, double_dqn=ddqn)
     ref.q_tgt[:] = T.init_params(shapes, 41 + Bsz)
     rec = a.update_on_batch(obs, act, nobs, rew, term)
     r = ref.update(obs, act, nobs, rew, term, probe=True)
-    assert rel(a.probe("q_pred_all", Bsz * 6), r["q_pred_all"].ravel()) < QTOL
+    assert rel(a.probe("q_pred_all", Bsz * A), r["q_pred_all"].ravel()) < QTOL
     assert rel(a.probe("pred", Bsz), r["pred"]) < QTOL and rel(a.probe("tgt", Bsz), r["tgt"]) < QTOL
     assert abs(rec["loss"] - r["loss"]) <= QTOL * abs(r["loss"]) + 1e-9
     assert_grads_close(a.get_params("grad"), r["grads"], shapes)
-    assert rel(a.qvalues(obs[:1]), O.net_forward(O.cnn_cfg(6), a.get_params("qnet"), obs[:1])) < QTOL
+    assert rel(a.qvalues(obs[:1]), O.net_forward(O.cnn_cfg(A), a.get_params("qnet"), obs[:1])) < QTOL
     a.close()
 
 

@@ -68,15 +68,17 @@ def test_iqn_golden_cnn_b2(B, golden_dir):
     _run(B, "iqn_cnn_b2", golden_dir)
 
 
-def test_iqn_cnn_64_quantiles_vs_oracle(B):
-    """BASELINE config 4 shape at a reduced batch (B=16, 64 pred/tgt quantiles, Nature trunk): one update vs the C oracle."""
+@pytest.mark.parametrize("A", [6, 4, 9, 18, 33])
+def test_iqn_cnn_64_quantiles_vs_oracle(B, A):
+    """BASELINE config 4 shape at a reduced batch (B=16, 64 pred/tgt quantiles, Nature trunk): one update vs the C oracle, at
+    action counts on both sides of the merge head's 32- and 64-column padding (Atari: 3...18 actions, env.rs:97-103)."""
     from oracle import oracle as O
     from oracle import torch_ref as T
-    sh = T.iqn_shapes("cnn", 3136, 64, [512], 6)
+    sh = T.iqn_shapes("cnn", 3136, 64, [512], A)
     p0 = T.init_params(sh[0] + sh[1] + sh[2], 31)
-    a = _agent(B, "cnn", 3136, 64, [512], 6, None, [], 16, 1e-4, p0, tau=1.0, soft_update_interval=10000)
-    ref = O.IqnOracle("cnn", p0, lr=1e-4, feature_dim=3136, embed_dim=64, f_units=[512], n_actions=6, tau=1.0, soft_update_interval=10000)
-    batch = T.iqn_batch(16, "cnn", 6, 64, 64, 77)
+    a = _agent(B, "cnn", 3136, 64, [512], A, None, [], 16, 1e-4, p0, tau=1.0, soft_update_interval=10000)
+    ref = O.IqnOracle("cnn", p0, lr=1e-4, feature_dim=3136, embed_dim=64, f_units=[512], n_actions=A, tau=1.0, soft_update_interval=10000)
+    batch = T.iqn_batch(16, "cnn", A, 64, 64, 77)
     rec = a.update_on_batch(*batch)
     r = ref.update(*batch)
     assert abs(rec["loss_critic"] - r["loss"]) <= QTOL * abs(r["loss"])

@@ -70,6 +70,33 @@ def test_softmax_sequence_matches_oracle_and_softmax_law(B):
     a.close()
 
 
+@pytest.mark.parametrize("A", [4, 9, 18, 33])
+def test_eps_greedy_sequence_of_the_cnn_agent_matches_oracle_exactly(B, A):
+    """The Nature-CNN agent's Policy::sample at action counts in each register block of its head kernel (8 / 24 / 64;
+    Atari's minimal action sets have 3...18 actions, border-atari-env/src/env.rs:97-103): argmax rows, random rows, the
+    epsilon schedule and the counters against the CPU restatement, exactly."""
+    from oracle.oracle import Explorer
+    from oracle import torch_ref as T
+    rng = np.random.default_rng(A)
+    a = _cnn_agent(B, A=A, train=True)
+    a.set_params(T.init_params(T.cnn_shapes(A), 5), "qnet")
+    a.set_explorer(B.EpsilonGreedy(final_step=40), seed=11 + A)
+    ref = Explorer("eps_greedy", final_step=40, seed=11 + A)
+    seen = set()
+    for call in range(120):
+        obs = rng.integers(0, 256, (3, 4, 1, 84, 84), dtype=np.uint8)
+        q = a.qvalues(obs)
+        assert q.shape == (3, A)
+        act, info = a.sample(obs, return_info=True)
+        ract, reps, rrand = ref.sample(q, train=True)
+        assert act.tolist() == ract.tolist(), call
+        assert info["is_random"] == rrand and abs(info["eps"] - reps) < 1e-15
+        seen.update(act.tolist())
+    assert info["n_samples_act"] == 120 == ref.n_samples_act and info["n_samples_best_act"] == ref.n_samples_best_act
+    assert max(seen) < A and len(seen) > 1
+    a.close()
+
+
 def test_eval_mode_cnn_greedy_with_one_percent_random(B):
     from oracle.oracle import Explorer
     from oracle import torch_ref as T

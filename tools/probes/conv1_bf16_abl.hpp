@@ -1,53 +1,12 @@
-// conv1 forward on the bf16 matrix cores with EXACT operands.
-//
-// conv1's input is u8 pixels 0..255: exactly representable in bf16 (8-bit significand).  Each f32
-// weight is split into three bf16 terms w = hi + mid + lo (truncation split, exact: 3 x 8 bits cover
-// the 24-bit significand), so every product x*hi, x*mid, x*lo is exact in f32 and the MFMA only
-// rounds in its f32 accumulation -- the same error class as the FP32 MFMA / an fmaf chain, at
-// 3 bf16 MFMAs (32 cycles each, K=16) instead of 8 f32 MFMAs (64 cycles each, K=2) per 16 k:
-// 5.3x fewer matrix-pipe cycles.  cnn/base.rs:26-28 (x/255 -> conv(4->32,k8,s4) -> relu); the 1/255
-// is applied to the f32 accumulator in the epilogue.
-//
-// v_mfma_f32_32x32x16_bf16 operand maps: A lane l: A[i=l&31][k=8*(l>>5)+0..7], B lane l:
-// B[k=8*(l>>5)+0..7][j=l&31], D as the f32 form.  k-step s covers channel c=s/4, patch rows
-// kh=(s%4)*2+h: a lane's 8 k-values are the 8 contiguous pixels of one patch row = ONE 8-byte
-// load straight from the NCHW u8 batch, no LDS staging for A.  The three weight planes live in
-// LDS for the lifetime of a (persistent) workgroup in exactly the B-fragment order, so a lane
-// fetches a fragment with one conflict-free ds_read_b128.  No barrier inside the item loop.
+// Copy of the product's k_conv1_bf16 (border_amd/csrc/conv1_bf16.hpp) with the timing ablations of tools/probes/conv1_probe.hip:
+//   -DC1_NOLOAD no pixel loads, -DC1_PRESPLIT weight planes copied from a pre-split buffer, -DC1_NOMFMA no matrix instructions,
+//   -DC1_NOSTORE no output stores  (results are WRONG with any of them).  Namespace bdr_abl; the product header carries none of this.
+// Snapshot of the round-3/4 kernel body - re-copy when the product kernel changes.
 #pragma once
-#include <hip/hip_runtime.h>
+#include "../../border_amd/csrc/conv1_bf16.hpp"
 
-#include "igemm.hpp"
-
-namespace bdr {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int C1_PLANE_VECS = 16 * 2 * 32;   // uint4 per plane: [s][h][n] x 8 bf16
-
-struct Conv1Args {
-    const uint8_t* x[3];     // [B][4][84][84] u8
-    const float* w1[3];      // [256][32] f32, k=(c,kh,kw)
-    const float* bias[3];
-    float* out[3];           // [M][32] f32 (NHWC)
-    int M;                   // B*400
-    int nz;
-};
-
-__device__ __forceinline__ bf16x8 u8x8_to_bf16(uint32_t lo, uint32_t hi)
-{
-    // integers 0..255 are exact in bf16: the bf16 pattern is the upper half of the f32 pattern
-    const uint32_t f0 = __float_as_uint((float)(lo & 255u)), f1 = __float_as_uint((float)((lo >> 8) & 255u));
-    const uint32_t f2 = __float_as_uint((float)((lo >> 16) & 255u)), f3 = __float_as_uint((float)(lo >> 24));
-    const uint32_t f4 = __float_as_uint((float)(hi & 255u)), f5 = __float_as_uint((float)((hi >> 8) & 255u));
-    const uint32_t f6 = __float_as_uint((float)((hi >> 16) & 255u)), f7 = __float_as_uint((float)(hi >> 24));
-    uint4 v;
-    v.x = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
-    v.y = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
-    v.z = __builtin_amdgcn_perm(f5, f4, 0x07060302u);
-    v.w = __builtin_amdgcn_perm(f7, f6, 0x07060302u);
-    return __builtin_bit_cast(bf16x8, v);
-}
+namespace bdr_abl {
+using namespace bdr;
 
 // grid: nz * G workgroups of 512 threads (8 waves, 2 workgroups per CU); workgroup b serves
 // instance b % nz.  Prologue: split the instance's f32 weights into the three bf16 planes directly
@@ -72,7 +31,11 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const uint32_t* q = reinterpret_cast<const uint32_t*>(p + (s >> 2) * 7056 + ((s & 3) * 2) * 84);
+#ifdef C1_NOLOAD
+            r[s] = uint2{(uint32_t)(size_t)q, (uint32_t)lane};
+#else
             r[s] = uint2{q[0], q[1]};
+#endif
         }
     };
 
@@ -80,6 +43,12 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
     uint2 nxt[16];
     int item = wg * 8 + wave;
     if (item < items) load_item(item, nxt);
+#ifdef C1_PRESPLIT   // tools/probes only (timing): the three planes copied as they are from a pre-split buffer
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(a.w1[z]);
+        for (int t = tid; t < 3 * C1_PLANE_VECS; t += 512) wl[t] = wp[t % 2048];
+    }
+#else
     {
         const float* w1 = a.w1[z];
         for (int t = tid; t < C1_PLANE_VECS; t += 512) {
@@ -99,6 +68,7 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
             wl[2 * C1_PLANE_VECS + t] = uint4{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3], (lo[4] >> 16) | lo[5], (lo[6] >> 16) | lo[7]};
         }
     }
+#endif
     __syncthreads();
 
     const float bias = a.bias[z][i];
@@ -128,7 +98,11 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
             const bf16x8 av = u8x8_to_bf16(cur[s].x, cur[s].y);
 #pragma unroll
             for (int pl = 2; pl >= 0; --pl)   // small terms first
+#ifdef C1_NOMFMA
+                acc[pl] += (float)av[0] * (float)__builtin_bit_cast(bf16x8, bq[pl])[1];
+#else
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bq[pl]), acc, 0, 0, 0);
+#endif
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bq[pl] = bn[pl];
             __builtin_amdgcn_sched_barrier(0);
@@ -142,7 +116,11 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
             for (int r = 0; r < 16; ++r) {
                 const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float v = acc[r] * (1.0f / 255.0f) + bias;
+#ifdef C1_NOSTORE
+                if (v == 123.456f) out[(size_t)mo * 32 + i] = v;
+#else
                 out[(size_t)mo * 32 + i] = v > 0.f ? v : 0.f;
+#endif
             }
         } else {
 #pragma unroll
@@ -155,4 +133,4 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
     }
 }
 
-}  // namespace bdr
+}  // namespace bdr_abl

@@ -2,8 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../../border_amd/csrc/conv1_bf16.hpp"
-using namespace bdr;
+#include "conv1_bf16_abl.hpp"   // k_conv1_bf16 with the ablation switches (namespace bdr_abl)
+using namespace bdr_abl;
 __global__ void k_copy(const uint4* s, uint4* d, size_t n) { size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i < n) d[i] = s[i]; }
 int main(int argc, char** argv)
 {
@@ -28,7 +28,7 @@ int main(int argc, char** argv)
         for (int k = 0; k < 20; ++k) {
             for (int z = 0; z < nz; ++z) hipLaunchKernelGGL(k_copy, dim3((B * 28224 / 16 + 255) / 256), dim3(256), 0, 0, (const uint4*)shadow[z], (uint4*)c.x[z], (size_t)B * 28224 / 16);
             hipEventRecord(e0);
-            hipLaunchKernelGGL(k_conv1_bf16, dim3(256 * nz), dim3(512), 0, 0, c);
+            hipLaunchKernelGGL(bdr_abl::k_conv1_bf16, dim3(256 * nz), dim3(512), 0, 0, c);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (k >= 5) tot += ms;
         }
@@ -38,7 +38,7 @@ int main(int argc, char** argv)
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
-            for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(k_conv1_bf16, dim3(g * nz), dim3(512), 0, 0, c);
+            for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(bdr_abl::k_conv1_bf16, dim3(g * nz), dim3(512), 0, 0, c);
             hipEventRecord(e1); hipEventSynchronize(e1);
         }
         float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -59,6 +59,25 @@ int main()
     DX2(1, 1, 0, 2, 1, 1)   // 64x32 one wave
     DX2(1, 1, 0, 4, 1, 1)   // 128x32 one wave
     DX2(1, 1, 0, 4, 1, 2)
-    DX2(4, 1, 100, 1, 1, 1) // per-image rows (100 -> 128)?
+    // round 4: the four classes as 128 columns of ONE GEMM (DxC2MP): dY staged once, checksums must equal the per-class kernels'
+#define DX2M(WM, WN, TM, TN, T) { using P = DxC2MP<WM, WN, TM, TN>; \
+    CK(hipMemset(dx1, 0, n1 * 4)); run<P, T>("dx_c2 merged w" #WM "x" #WN " t" #TM "x" #TN " teams" #T, dim3(m_tiles<P>(d2.M) * (128 / (WN * TN * 32)), 1, 1), d2, dx1, n1); }
+    DX2M(2, 2, 1, 2, 1)     // 64 x 128, 400 workgroups
+    DX2M(2, 2, 1, 2, 2)
+    DX2M(2, 2, 2, 2, 1)     // 128 x 128, 200
+    DX2M(2, 2, 2, 2, 2)
+    DX2M(1, 4, 1, 1, 1)     // 32 x 128, 800
+    DX2M(1, 4, 2, 1, 1)     // 64 x 128, waves own a class
+    DX2M(1, 4, 2, 1, 2)
+    DX2M(2, 4, 1, 1, 1)     // 64 x 128 with 8 waves
+    DX2M(4, 2, 1, 2, 1)     // 128 x 128 with 8 waves
+    DX2M(2, 2, 1, 1, 1)     // 64 x 64: two column tiles (dY staged twice)
+    DX2M(2, 2, 1, 1, 2)
+    DX2M(4, 1, 1, 2, 1)     // 128 x 64
+    DX2M(1, 2, 1, 2, 1)     // 32 x 128 with two waves
+    DX2M(1, 2, 1, 2, 2)
+    DX2M(1, 4, 1, 1, 2)     // 32 x 128, two teams
+    DX2M(4, 4, 1, 1, 1)     // 128 x 128 with 16 waves
+    DX2M(2, 4, 2, 1, 1)     // 128 x 128 with 8 waves, waves own a class
     return 0;
 }

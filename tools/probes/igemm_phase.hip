@@ -1,10 +1,11 @@
 // Where do the cycles of one wave go inside the k loop of k_igemm?  (s_memtime phase sums, conv2 forward, B = 256)
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIGEMM_TRACE2 -Iinclude -Iborder_amd/csrc tools/probes/igemm_phase.hip -o tools/probes/igemm_phase.bin
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIGEMM_TRACE2 -Iinclude -Iborder_amd/csrc -Itools/probes tools/probes/igemm_phase.hip -o tools/probes/igemm_phase.bin
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "cnn_layers.hpp"
+#include "igemm_abl.hpp"   // instrumented copy of k_igemm (namespace bdr_abl)
 using namespace bdr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 static float* dev_rand(size_t n, float lo, float hi, unsigned seed)
@@ -20,17 +21,17 @@ static void phases(const char* name, dim3 grid, const typename P::Args& args)
 {
     const size_t nwg = (size_t)grid.x * grid.y * grid.z;
     unsigned long long* d; CK(hipMalloc(&d, nwg * 64)); CK(hipMemset(d, 0, nwg * 64));
-    for (int i = 0; i < 3; ++i) CK((launch_igemm<P, TEAMS>(0, grid, args)));
+    for (int i = 0; i < 3; ++i) CK((bdr_abl::launch_igemm<P, TEAMS>(0, grid, args)));
     CK(hipDeviceSynchronize());
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_phase), &d, sizeof(d)));
-    CK((launch_igemm<P, TEAMS>(0, grid, args)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(bdr_abl::g_igemm_phase), &d, sizeof(d)));
+    CK((bdr_abl::launch_igemm<P, TEAMS>(0, grid, args)));
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(nwg * 8); CK(hipMemcpy(h.data(), d, nwg * 64, hipMemcpyDeviceToHost));
     double s[5] = {0, 0, 0, 0, 0}, n = 0;
     for (size_t i = 0; i < nwg; ++i) { for (int q = 0; q < 5; ++q) s[q] += (double)h[i * 8 + q]; n += (double)h[i * 8 + 5]; }
     printf("%-30s %zu WGs, cycles per k-tile (wave 0):  frag-wait+4 MFMA %6.0f | commit %6.0f | 12 MFMA+prefetch %6.0f | tail %5.0f | barrier %6.0f | total %6.0f\n",
            name, nwg, s[0] / n, s[1] / n, s[2] / n, s[3] / n, s[4] / n, (s[0] + s[1] + s[2] + s[3] + s[4]) / n);
-    unsigned long long* null = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_phase), &null, sizeof(null)));
+    unsigned long long* null = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(bdr_abl::g_igemm_phase), &null, sizeof(null)));
     CK(hipFree(d));
 }
 int main()

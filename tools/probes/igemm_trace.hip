@@ -1,12 +1,13 @@
 // Phase timeline of one k_igemm launch: when does each workgroup start, finish its prologue, its k loop,
 // its epilogue?  (100 MHz wall clock, comparable across CUs.)
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIGEMM_TRACE -Iinclude -Iborder_amd/csrc tools/probes/igemm_trace.hip -o tools/probes/igemm_trace.bin
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIGEMM_TRACE -Iinclude -Iborder_amd/csrc -Itools/probes tools/probes/igemm_trace.hip -o tools/probes/igemm_trace.bin
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "cnn_layers.hpp"
+#include "igemm_abl.hpp"   // instrumented copy of k_igemm (namespace bdr_abl)
 #include "igemm_dl.hpp"
 
 using namespace bdr;
@@ -24,14 +25,14 @@ static float* dev_rand(size_t n, float lo, float hi, unsigned seed)
 template <class P, int TEAMS, bool DL = false>
 static void trace(const char* name, dim3 grid, const typename P::Args& args)
 {
-    auto launch = [&]() { if constexpr (DL) return launch_igemm_dl<P, TEAMS>(0, grid, args); else return launch_igemm<P, TEAMS>(0, grid, args); };
+    auto launch = [&]() { if constexpr (DL) return launch_igemm_dl<P, TEAMS>(0, grid, args); else return bdr_abl::launch_igemm<P, TEAMS>(0, grid, args); };
     const size_t nwg = (size_t)grid.x * grid.y * grid.z;
     unsigned long long* d; CK(hipMalloc(&d, nwg * 8 * 8)); CK(hipMemset(d, 0, nwg * 8 * 8));
     unsigned long long* null = nullptr;
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_trace), &null, sizeof(d)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(bdr_abl::g_igemm_trace), &null, sizeof(d)));
     for (int i = 0; i < 3; ++i) CK(launch());
     CK(hipDeviceSynchronize());
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_trace), &d, sizeof(d)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(bdr_abl::g_igemm_trace), &d, sizeof(d)));
     CK(launch());
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(nwg * 8); CK(hipMemcpy(h.data(), d, nwg * 8 * 8, hipMemcpyDeviceToHost));

@@ -9,7 +9,7 @@ from .dqn import AtariCnnConfig, Dqn, DqnConfig, DqnModelConfig, EpsilonGreedy, 
 from .sac import Sac, SacConfig  # noqa: F401
 from .iqn import Iqn, IqnConfig  # noqa: F401
 from . import checkpoint  # noqa: F401
-from .atari import AtariPreprocessor  # noqa: F401
+from .atari import AtariDeviceEnv, AtariPreprocessor  # noqa: F401
 from .trainer import (NativeTrainer, ParamExchange, Sampler, SimpleStepProcessor, Step, SyntheticEnv, Trainer, TrainerConfig,  # noqa: F401
                       shard_seed)
 from .async_trainer import (ActorManagerConfig, ActorStat, AsyncTrainer, AsyncTrainerConfig, AsyncTrainStat, ModelMailbox,  # noqa: F401

@@ -101,13 +101,20 @@ PUSH_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
 OBSERVER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_float), C.c_int32)
 
 
+SAMPLE_DEV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p)
+PUSH_DEV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_int8),
+                          C.POINTER(C.c_int8))
+
+
 class EnvVtable(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("reset", ENV_RESET_FN), ("step_with_reset", ENV_STEP_FN)]
+    # obs_on_device != 0: obs_out / init_obs_out of the callbacks are device buffers on GPU `device` (device-resident observations)
+    _fields_ = [("ctx", C.c_void_p), ("reset", ENV_RESET_FN), ("step_with_reset", ENV_STEP_FN), ("obs_on_device", C.c_int32), ("device", C.c_int32)]
 
 
 class TrainerOps(C.Structure):
     _fields_ = [("agent", C.c_void_p), ("buffer", C.c_void_p), ("agent_set_train", SET_TRAIN_FN), ("agent_sample", SAMPLE_FN),
-                ("agent_opt", OPT_FN), ("agent_opt_with_record", OPT_REC_FN), ("buffer_push", PUSH_FN)]
+                ("agent_opt", OPT_FN), ("agent_opt_with_record", OPT_REC_FN), ("buffer_push", PUSH_FN),
+                ("agent_sample_device", SAMPLE_DEV_FN), ("buffer_push_device", PUSH_DEV_FN)]
 
 
 class TrainerConfigC(C.Structure):
@@ -130,24 +137,24 @@ class DeviceBatch(C.Structure):
 # every symbol include/border_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "bdr_last_error", "bdr_device_count", "bdr_version",
-    "bdr_replay_create", "bdr_replay_destroy", "bdr_replay_push", "bdr_replay_len", "bdr_replay_head", "bdr_replay_frames_used",
+    "bdr_replay_create", "bdr_replay_destroy", "bdr_replay_push", "bdr_replay_push_device", "bdr_replay_len", "bdr_replay_head", "bdr_replay_frames_used",
     "bdr_replay_sample_indices", "bdr_replay_batch", "bdr_replay_last_batch", "bdr_replay_fill_synthetic",
     "bdr_replay_read_rows",
     "bdr_per_config_default", "bdr_replay_enable_per", "bdr_replay_update_priority", "bdr_replay_batch_weights",
     "bdr_replay_per_info", "bdr_replay_per_read", "bdr_replay_per_get", "bdr_dqn_update_on_batch_weighted",
     "bdr_dqn_config_default", "bdr_dqn_create", "bdr_agent_destroy", "bdr_agent_set_train", "bdr_agent_is_train",
     "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_agent_opt_with_scalars", "bdr_agent_record_keys", "bdr_agent_draw_noise", "bdr_agent_param_count_of", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
-    "bdr_explorer_config_default", "bdr_agent_set_explorer", "bdr_agent_get_explorer", "bdr_agent_sample",
+    "bdr_explorer_config_default", "bdr_agent_set_explorer", "bdr_agent_get_explorer", "bdr_agent_sample", "bdr_agent_sample_device", "bdr_agent_qvalues_device",
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
     "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_agent_set_checkpoint_format",
     "bdr_checkpoint_write", "bdr_checkpoint_read", "bdr_dqn_probe",
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
     "bdr_iqn_config_default", "bdr_iqn_create", "bdr_iqn_update_on_batch", "bdr_iqn_forward", "bdr_iqn_qvalues",
-    "bdr_sac_config_default", "bdr_sac_create", "bdr_sac_update_on_batch", "bdr_sac_sample",
+    "bdr_sac_config_default", "bdr_sac_create", "bdr_sac_update_on_batch", "bdr_sac_sample", "bdr_sac_sample_device",
     "bdr_comm_get_unique_id", "bdr_comm_init_rank", "bdr_comm_destroy", "bdr_comm_agree", "bdr_sac_probe", "bdr_agent_allreduce_params",
     "bdr_agent_broadcast_params", "bdr_agent_set_grad_comm", "bdr_dqn_grads_on_batch", "bdr_agent_apply_grads",
     "bdr_atari_prep_create", "bdr_atari_prep_destroy", "bdr_atari_prep_reset", "bdr_atari_prep_step", "bdr_atari_prep_obs",
-    "bdr_atari_prep_device_stacks", "bdr_atari_clip_reward",
+    "bdr_atari_prep_device_stacks", "bdr_atari_prep_device_prev_stacks", "bdr_atari_prep_copy_stack", "bdr_atari_clip_reward",
     "bdr_trainer_config_default", "bdr_trainer_ops_default", "bdr_trainer_train", "bdr_trainer_train_offline",
     "bdr_model_mailbox_create", "bdr_model_mailbox_destroy", "bdr_agent_publish_model", "bdr_agent_sync_model_from",
     "bdr_async_trainer_config_default", "bdr_learner_ops_default", "bdr_actor_ops_default", "bdr_async_train",
@@ -195,6 +202,7 @@ def lib() -> C.CDLL:
     L.bdr_replay_create.argtypes = [C.POINTER(ReplayConfig), C.POINTER(vp)]
     L.bdr_replay_destroy.argtypes = [vp]
     L.bdr_replay_push.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
+    L.bdr_replay_push_device.argtypes = [vp, u64, vp, u64, vp, vp, u64, vp, vp, vp]
     L.bdr_replay_len.argtypes = [vp, C.POINTER(u64)]
     L.bdr_replay_head.argtypes = [vp, C.POINTER(u64)]
     L.bdr_replay_frames_used.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -216,6 +224,9 @@ def lib() -> C.CDLL:
     L.bdr_agent_param_count_of.argtypes = [vp, i32, C.POINTER(u64)]
     L.bdr_dqn_update_on_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, C.POINTER(DqnRecordC)]
     L.bdr_agent_qvalues.argtypes = [vp, u64, vp, vp, vp]
+    L.bdr_agent_sample_device.argtypes = [vp, u64, vp, u64, vp, vp]
+    L.bdr_agent_qvalues_device.argtypes = [vp, u64, vp, u64, vp, vp]
+    L.bdr_sac_sample_device.argtypes = [vp, u64, vp, u64, vp]
     L.bdr_agent_sync.argtypes = [vp]
     L.bdr_agent_n_opts.argtypes = [vp, C.POINTER(u64)]
     L.bdr_agent_param_count.argtypes = [vp, C.POINTER(u64)]

@@ -90,7 +90,7 @@ class LearnerOps(C.Structure):
 
 class ActorOps(C.Structure):
     _fields_ = [("agent", C.c_void_p), ("mailbox", C.c_void_p), ("agent_set_train", _lib.SET_TRAIN_FN), ("agent_sample", _lib.SAMPLE_FN),
-                ("sync_model", SYNC_FN), ("env", _lib.EnvVtable)]
+                ("sync_model", SYNC_FN), ("agent_sample_device", _lib.SAMPLE_DEV_FN), ("env", _lib.EnvVtable)]
 
 
 class AsyncStatsC(C.Structure):
@@ -186,10 +186,31 @@ def env_vtable(env, obs_shape, obs_dtype, act_row_bytes=8, act_dtype=np.int64, k
         except Exception:  # noqa: BLE001
             return 91
 
+    if getattr(env, "device_obs", False):
+        # device-resident observations (bdr_env_vtable::obs_on_device): obs_out / init_out are device buffers the environment
+        # fills itself (AtariDeviceEnv: a copy of its frame stack inside HBM)
+        def reset(_ctx, obs_out):   # noqa: F811
+            try:
+                env.reset_into(obs_out)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 90
+
+        def step(_ctx, act, obs_out, reward, term, trunc, init_out):   # noqa: F811
+            try:
+                a = np.frombuffer((C.c_char * act_row_bytes).from_address(act), act_dtype).copy()
+                reward[0], term[0], trunc[0] = env.step_into(a, obs_out, init_out)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 91
+
     fns = (_lib.ENV_RESET_FN(reset), _lib.ENV_STEP_FN(step))
     if keep is not None:
         keep.append(fns)
-    return _lib.EnvVtable(None, *fns)
+    vt = _lib.EnvVtable(None, *fns)
+    if getattr(env, "device_obs", False):
+        vt.obs_on_device, vt.device = 1, int(getattr(env, "device", 0))
+    return vt
 
 
 class AsyncTrainer:

@@ -605,6 +605,43 @@ int32_t bdr_agent_sample(bdr_agent* a, uint64_t n, const void* obs, int64_t* act
     return BDR_OK;
 }
 
+// Policy::sample / action values for observation rows that already live in HBM ("batched across many vectorised
+// envs on device"): row i at obs_dev + i * row_stride bytes, e.g. the frame stacks of a bdr_atari_prep.  Same forward, same
+// exploration stream, same counters as the host-row calls - only the host -> device copy of the rows is gone (contiguous rows are
+// read in place).  The rows must be complete when the call is made (their producer synchronised, as bdr_atari_prep_step does) and
+// stay untouched until it returns.
+static int32_t check_device_rows(const bdr_agent* a, const void* obs_dev, uint64_t row_stride)
+{
+    BDR_REQUIRE(a && obs_dev, "null argument");
+    BDR_REQUIRE(row_stride > 0 && row_stride % 4 == 0, "row_stride must be a positive multiple of 4 bytes");
+    hipPointerAttribute_t at{};
+    BDR_REQUIRE(hipPointerGetAttributes(&at, obs_dev) == hipSuccess && at.type == hipMemoryTypeDevice && at.device == a->device,
+                "obs_dev is not device memory of the agent's GPU (host rows go through bdr_agent_sample / bdr_agent_qvalues)");
+    return BDR_OK;
+}
+
+int32_t bdr_agent_sample_device(bdr_agent* a, uint64_t n, const void* obs_dev, uint64_t row_stride, int64_t* act_out, bdr_sample_info* info)
+{
+    BDR_REQUIRE(a && act_out, "null argument");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(check_device_rows(a, obs_dev, row_stride));
+    a->obs_rows_on_device = true; a->obs_row_stride = row_stride;
+    const int32_t st = bdr_agent_sample(a, n, obs_dev, act_out, info);
+    a->obs_rows_on_device = false;
+    return st;
+}
+
+int32_t bdr_agent_qvalues_device(bdr_agent* a, uint64_t n, const void* obs_dev, uint64_t row_stride, float* q_out, int64_t* argmax_out)
+{
+    BDR_REQUIRE(a, "null argument");
+    BDR_HIP(hipSetDevice(a->device));
+    BDR_TRY(check_device_rows(a, obs_dev, row_stride));
+    a->obs_rows_on_device = true; a->obs_row_stride = row_stride;
+    const int32_t st = bdr_agent_qvalues(a, n, obs_dev, q_out, argmax_out);
+    a->obs_rows_on_device = false;
+    return st;
+}
+
 int32_t bdr_agent_param_count(const bdr_agent* a, uint64_t* n)
 {
     BDR_REQUIRE(a && n, "null argument");

@@ -42,6 +42,27 @@ struct ProfSlot { std::string name; hipEvent_t e0, e1; double ms = 0; uint64_t c
 
 // The opaque `bdr_agent` of include/border_amd.h.  Concrete agents: DqnCnn (dqn.hip), DqnMlp / Sac
 // (mlp_agents.hip), Iqn (iqn.hip).
+// One observation row of a compiled loop (trainer.hip, async_trainer.hip): host bytes, or - for environments with device-resident
+// observations (bdr_env_vtable::obs_on_device) - a device buffer of the same size.
+struct ObsRow {
+    bool dev = false; size_t bytes = 0; int device = 0;
+    std::vector<uint8_t> h; uint8_t* d = nullptr;
+    ObsRow() = default;
+    ObsRow(const ObsRow&) = delete; ObsRow& operator=(const ObsRow&) = delete;
+    ~ObsRow() { if (d) { (void)hipSetDevice(device); (void)hipFree(d); } }
+    int32_t init(bool on_device, int dev_ix, size_t n)
+    {
+        dev = on_device; device = dev_ix; bytes = n;
+        if (!dev) { h.assign(n, 0); return BDR_OK; }
+        BDR_HIP(hipSetDevice(device));
+        BDR_HIP(hipMalloc((void**)&d, n));
+        return BDR_OK;
+    }
+    void* p() { return dev ? (void*)d : (void*)h.data(); }
+    const void* p() const { return dev ? (const void*)d : (const void*)h.data(); }
+    void swap(ObsRow& o) { std::swap(h, o.h); std::swap(d, o.d); }   // `a = b` of the reference where b is dead afterwards
+};
+
 struct bdr_agent {
     int32_t device = 0;
     hipStream_t stream = nullptr;
@@ -144,6 +165,19 @@ struct bdr_agent {
         *out = act_stage;
         return BDR_OK;
     }
+    // Observation rows of an acting call -> dst (device, contiguous).  Host rows by default; inside a *_device entry point
+    // (bdr_agent_sample_device ...) the rows already live in HBM, obs_row_stride bytes apart, and never touch the host.
+    bool obs_rows_on_device = false;
+    uint64_t obs_row_stride = 0;
+    int32_t stage_obs(void* dst, const void* src, size_t row_bytes, uint64_t n, hipStream_t st)
+    {
+        if (!obs_rows_on_device) BDR_HIP(hipMemcpyAsync(dst, src, n * row_bytes, hipMemcpyHostToDevice, st));
+        else if (obs_row_stride == row_bytes) BDR_HIP(hipMemcpyAsync(dst, src, n * row_bytes, hipMemcpyDeviceToDevice, st));
+        else BDR_HIP(hipMemcpy2DAsync(dst, row_bytes, src, obs_row_stride, row_bytes, n, hipMemcpyDeviceToDevice, st));
+        return BDR_OK;
+    }
+    // the rows can be read in place (device rows that are already contiguous)
+    bool obs_in_place(size_t row_bytes) const { return obs_rows_on_device && obs_row_stride == row_bytes; }
     virtual const char* kind() const = 0;
     virtual int32_t opt(bdr_replay* r) = 0;                       // Agent::opt, asynchronous
     virtual int32_t after_sync() { return BDR_OK; }               // device-side error flags, checked by bdr_agent_sync

@@ -137,6 +137,24 @@ struct Message {
     std::vector<uint8_t> obs, act, next_obs;
     std::vector<float> reward;
     std::vector<int8_t> term, trunc;
+    // device-resident environments (bdr_env_vtable::obs_on_device): the observation rows of the message stay in HBM -
+    // [n_buffer][obs_row_bytes] each, allocated by the actor, pushed with buffer_push_device and freed by the learner
+    uint8_t* d_obs = nullptr; uint8_t* d_next = nullptr; int device = 0;
+    Message() = default;
+    Message(const Message&) = delete; Message& operator=(const Message&) = delete;
+    Message(Message&& o) noexcept { *this = std::move(o); }
+    Message& operator=(Message&& o) noexcept
+    {
+        if (this != &o) {
+            release();
+            id = o.id; n = o.n; obs = std::move(o.obs); act = std::move(o.act); next_obs = std::move(o.next_obs);
+            reward = std::move(o.reward); term = std::move(o.term); trunc = std::move(o.trunc);
+            d_obs = o.d_obs; d_next = o.d_next; device = o.device; o.d_obs = o.d_next = nullptr; o.n = 0;
+        }
+        return *this;
+    }
+    ~Message() { release(); }
+    void release() { if (d_obs || d_next) { (void)hipSetDevice(device); (void)hipFree(d_obs); (void)hipFree(d_next); d_obs = d_next = nullptr; } }
 };
 
 // crossbeam bounded(cap): try_send fails when full (replay_buffer_proxy.rs:63-68), try_iter drains what is there
@@ -190,18 +208,29 @@ void actor_run(Shared* sh, const bdr_actor_ops* ops, uint32_t id, bdr_actor_stat
     const bdr_async_trainer_config& c = *sh->c;
     const auto t_start = Clock::now();
     uint64_t env_steps = 0, n_opt_steps = 0;
-    std::vector<uint8_t> prev_obs(c.obs_row_bytes), proc_prev(c.obs_row_bytes), obs_new(c.obs_row_bytes), init_obs(c.obs_row_bytes), act(c.act_row_bytes);
+    const bool dev = ops->env.obs_on_device != 0;   // observations stay in HBM from the environment to the learner's ring
+    // (the sampler's prev_obs and the step processor's are the same observation at the top of every iteration: one buffer)
+    ObsRow prev, obs_new, init_obs;
+    std::vector<uint8_t> act(c.act_row_bytes);
     Message buf;
-    auto reset_buf = [&]() {
+    auto reset_buf = [&]() -> bool {
         buf = Message();
         buf.id = id;
-        buf.obs.reserve(c.n_buffer * c.obs_row_bytes); buf.next_obs.reserve(c.n_buffer * c.obs_row_bytes);
         buf.act.reserve(c.n_buffer * c.act_row_bytes);
+        if (!dev) { buf.obs.reserve(c.n_buffer * c.obs_row_bytes); buf.next_obs.reserve(c.n_buffer * c.obs_row_bytes); return true; }
+        buf.device = ops->env.device;
+        if (hipSetDevice(buf.device) != hipSuccess || hipMalloc((void**)&buf.d_obs, c.n_buffer * c.obs_row_bytes) != hipSuccess ||
+            hipMalloc((void**)&buf.d_next, c.n_buffer * c.obs_row_bytes) != hipSuccess) {
+            (void)fail(BDR_ERR_HIP, "actor %u: device rows of a message (2 x %llu bytes) could not be allocated", id, (unsigned long long)(c.n_buffer * c.obs_row_bytes));
+            return false;
+        }
+        return true;
     };
-    reset_buf();
     auto finish = [&]() {
         if (stat) { stat->env_steps = env_steps; stat->duration_s = std::chrono::duration<double>(Clock::now() - t_start).count(); }
     };
+    if (prev.init(dev, ops->env.device, c.obs_row_bytes) != BDR_OK || obs_new.init(dev, ops->env.device, c.obs_row_bytes) != BDR_OK ||
+        init_obs.init(dev, ops->env.device, c.obs_row_bytes) != BDR_OK || !reset_buf()) { sh->fail_from("actor", id); finish(); return; }
     // "Waits and syncs the initial model" (:148-153)
     while (!sh->model_ready.load() && !sh->stop.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
     if (sh->stop.load()) { finish(); return; }
@@ -217,25 +246,34 @@ void actor_run(Shared* sh, const bdr_actor_ops* ops, uint32_t id, bdr_actor_stat
         if (updated) { if (stat) stat->n_syncs += 1; sh->notify(id, env_steps, n_opt_steps, BDR_ASYNC_EVENT_ACTOR_SYNC, nullptr, 0); }
         // ---- sampler.sample_and_push(&mut agent, &mut buffer) (:170)
         if (!have_prev) {
-            if (ops->env.reset(ops->env.ctx, prev_obs.data()) != BDR_OK) { sh->fail_from("actor env", id); break; }
-            proc_prev = prev_obs;
+            if (ops->env.reset(ops->env.ctx, prev.p()) != BDR_OK) { sh->fail_from("actor env", id); break; }
             have_prev = true;
         }
-        if (ops->agent_sample(ops->agent, 1, prev_obs.data(), act.data()) != BDR_OK) { sh->fail_from("actor", id); break; }
+        if ((dev ? ops->agent_sample_device(ops->agent, 1, prev.p(), c.obs_row_bytes, act.data()) : ops->agent_sample(ops->agent, 1, prev.p(), act.data())) != BDR_OK) {
+            sh->fail_from("actor", id); break;
+        }
         float reward = 0; int8_t term = 0, trunc = 0;
-        if (ops->env.step_with_reset(ops->env.ctx, act.data(), obs_new.data(), &reward, &term, &trunc, init_obs.data()) != BDR_OK) { sh->fail_from("actor env", id); break; }
+        if (ops->env.step_with_reset(ops->env.ctx, act.data(), obs_new.p(), &reward, &term, &trunc, init_obs.p()) != BDR_OK) { sh->fail_from("actor env", id); break; }
         const bool is_done = term == 1 || trunc == 1;
-        prev_obs = is_done ? init_obs : obs_new;
         // ReplayBufferProxy::push: buffer the item; at n_buffer items swap the Vec out and try_send it
-        buf.obs.insert(buf.obs.end(), proc_prev.begin(), proc_prev.end());
+        if (dev) {
+            if (hipMemcpy(buf.d_obs + buf.n * c.obs_row_bytes, prev.p(), c.obs_row_bytes, hipMemcpyDeviceToDevice) != hipSuccess ||
+                hipMemcpy(buf.d_next + buf.n * c.obs_row_bytes, obs_new.p(), c.obs_row_bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+                (void)fail(BDR_ERR_HIP, "actor %u: device copy of a transition's rows failed", id);
+                sh->fail_from("actor", id); break;
+            }
+        } else {
+            const uint8_t* po = static_cast<const uint8_t*>(prev.p()); const uint8_t* pn = static_cast<const uint8_t*>(obs_new.p());
+            buf.obs.insert(buf.obs.end(), po, po + c.obs_row_bytes);
+            buf.next_obs.insert(buf.next_obs.end(), pn, pn + c.obs_row_bytes);
+        }
         buf.act.insert(buf.act.end(), act.begin(), act.end());
-        buf.next_obs.insert(buf.next_obs.end(), obs_new.begin(), obs_new.end());
         buf.reward.push_back(reward); buf.term.push_back(term); buf.trunc.push_back(trunc);
         buf.n += 1;
-        proc_prev = is_done ? init_obs : obs_new;
+        prev.swap(is_done ? init_obs : obs_new);   // prev_obs = init_obs / obs for the sampler and the step processor alike
         if (buf.n == c.n_buffer) {
             Message m = std::move(buf);
-            reset_buf();
+            if (!reset_buf()) { sh->fail_from("actor", id); break; }
             if (!sh->ch.try_send(std::move(m))) {   // Err(SendMsgForPush): the reference's actor thread panics on the unwrap (:170)
                 (void)fail(BDR_ERR_INVALID, "ReplayBufferProxy::push: the bounded channel (%llu messages) is full (SendMsgForPush)",
                            (unsigned long long)c.channel_capacity);
@@ -271,8 +309,8 @@ int32_t bdr_async_train(const bdr_async_trainer_config* c, const bdr_learner_ops
     BDR_REQUIRE(L->t.agent_set_train && L->t.agent_opt && L->t.agent_opt_with_record && L->t.buffer_push && L->buffer_len && L->publish_model,
                 "learner function table is incomplete");
     for (uint32_t i = 0; i < n_actors; ++i)
-        BDR_REQUIRE(actors[i].agent_set_train && actors[i].agent_sample && actors[i].sync_model && actors[i].env.reset && actors[i].env.step_with_reset,
-                    "actor %u: function table is incomplete", i);
+        BDR_REQUIRE(actors[i].agent_set_train && actors[i].agent_sample && actors[i].sync_model && actors[i].env.reset && actors[i].env.step_with_reset &&
+                    (!actors[i].env.obs_on_device || actors[i].agent_sample_device), "actor %u: function table is incomplete", i);
     Shared sh;
     sh.c = c; sh.ch.cap = c->channel_capacity; sh.observer = observer; sh.observer_ctx = observer_ctx;
     if (actor_stats) memset(actor_stats, 0, sizeof(bdr_actor_stat) * n_actors);
@@ -318,7 +356,12 @@ int32_t bdr_async_train(const bdr_async_trainer_config* c, const bdr_learner_ops
         sh.ch.drain(msgs);
         for (auto& m : msgs) {
             samples_counter += m.n; samples_total += m.n; n_messages += 1;
-            BDR_TRY(L->t.buffer_push(L->t.buffer, m.n, m.obs.data(), m.act.data(), m.next_obs.data(), m.reward.data(), m.term.data(), m.trunc.data()));
+            if (m.d_obs) {   // a device-resident actor: HBM -> ring inside the device
+                BDR_REQUIRE(L->t.buffer_push_device, "a device-resident actor needs the learner's buffer_push_device");
+                BDR_TRY(L->t.buffer_push_device(L->t.buffer, m.n, m.d_obs, c->obs_row_bytes, m.act.data(), m.d_next, c->obs_row_bytes, m.reward.data(), m.term.data(), m.trunc.data()));
+            } else {
+                BDR_TRY(L->t.buffer_push(L->t.buffer, m.n, m.obs.data(), m.act.data(), m.next_obs.data(), m.reward.data(), m.term.data(), m.trunc.data()));
+            }
             sh.notify(m.id, samples_total, opt_steps, BDR_ASYNC_EVENT_PUSH, nullptr, (int32_t)m.n);
         }
         return BDR_OK;
@@ -417,6 +460,20 @@ int32_t d_sync(void* a, void* mailbox, uint32_t reader, int32_t first, uint64_t*
 
 extern "C" {
 
+namespace {
+int32_t d_sample_dev(void* a, uint64_t n, const void* obs_dev, uint64_t stride, void* act)
+{
+    bdr_agent* ag = (bdr_agent*)a;
+    if (ag && !strcmp(ag->kind(), "sac")) return bdr_sac_sample_device(ag, n, obs_dev, stride, (float*)act);
+    return bdr_agent_sample_device(ag, n, obs_dev, stride, (int64_t*)act, nullptr);
+}
+int32_t d_push_dev(void* b, uint64_t n, const void* obs_dev, uint64_t os, const void* act, const void* next_dev, uint64_t ns, const float* rew,
+                   const int8_t* term, const int8_t* trunc)
+{
+    return bdr_replay_push_device((bdr_replay*)b, n, obs_dev, os, act, next_dev, ns, rew, term, trunc);
+}
+}  // namespace
+
 void bdr_learner_ops_default(bdr_learner_ops* ops, bdr_agent* agent, bdr_replay* buffer, bdr_model_mailbox* mailbox)
 {
     if (!ops) return;
@@ -424,6 +481,7 @@ void bdr_learner_ops_default(bdr_learner_ops* ops, bdr_agent* agent, bdr_replay*
     ops->t.agent = agent; ops->t.buffer = buffer;
     ops->t.agent_set_train = d_set_train; ops->t.agent_sample = d_sample; ops->t.agent_opt = d_opt; ops->t.agent_opt_with_record = d_opt_rec;
     ops->t.buffer_push = d_push;
+    ops->t.agent_sample_device = d_sample_dev; ops->t.buffer_push_device = d_push_dev;
     ops->buffer_len = d_len; ops->publish_model = d_publish; ops->mailbox = mailbox;
 }
 
@@ -433,6 +491,7 @@ void bdr_actor_ops_default(bdr_actor_ops* ops, bdr_agent* agent, bdr_model_mailb
     memset(ops, 0, sizeof *ops);
     ops->agent = agent; ops->mailbox = mailbox;
     ops->agent_set_train = d_set_train; ops->agent_sample = d_sample; ops->sync_model = d_sync;
+    ops->agent_sample_device = d_sample_dev;
     if (env) ops->env = *env;
 }
 

@@ -25,6 +25,8 @@ struct bdr_atari_prep {
     uint32_t n_envs = 0, width = 0, height = 0;
     hipStream_t stream = nullptr;
     uint8_t* stacks = nullptr;      // [n_envs][4][84][84]
+    uint8_t* prev = nullptr;        // [n_envs][4][84][84]: every environment's stack as it was BEFORE its last step (obs_t of the
+                                    // transition whose next_obs is `stacks`) - what a device-side push needs (bdr_replay_push_device)
     uint8_t* d_frames = nullptr;    // staging: [cap][2][H][W][3]
     uint32_t* d_ixs = nullptr;
     uint8_t* h_stage = nullptr;     // pinned
@@ -81,6 +83,7 @@ struct PrepArgs {
     const uint8_t* frames;   // [n][2][H][W][3] (reset: both copies equal)
     const uint32_t* env_ixs; // [n]
     uint8_t* stacks;
+    uint8_t* prev;
     int W, H;
     int reset;               // 1: all four slots <- the new frame
 };
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_atari_prep(PrepArgs a)
     const uint8_t* fa = a.frames + (size_t)e * 2 * fsz;
     const uint8_t* fb = fa + fsz;
     uint8_t* stack = a.stacks + (size_t)a.env_ixs[e] * 4 * OUT * OUT;
+    uint8_t* prev = a.prev + (size_t)a.env_ixs[e] * 4 * OUT * OUT;
 
     if (tid < OUT) vt[tid] = taps_of(tid, a.H);
     else if (tid < 2 * OUT) ht[tid - OUT] = taps_of(tid - OUT, a.W);
@@ -155,9 +159,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_atari_prep(PrepArgs a)
     // stack_frame (env.rs:197-209): slots 1..3 <- slots 0..2, every thread moves its own pixels (oldest first)
     if (!a.reset) {
         for (int p = tid; p < OUT * OUT; p += PREP_THREADS) {
-            stack[3 * OUT * OUT + p] = stack[2 * OUT * OUT + p];
-            stack[2 * OUT * OUT + p] = stack[1 * OUT * OUT + p];
-            stack[1 * OUT * OUT + p] = stack[p];
+            const uint8_t s0 = stack[p], s1 = stack[1 * OUT * OUT + p], s2 = stack[2 * OUT * OUT + p], s3 = stack[3 * OUT * OUT + p];
+            prev[p] = s0; prev[1 * OUT * OUT + p] = s1; prev[2 * OUT * OUT + p] = s2; prev[3 * OUT * OUT + p] = s3;   // obs_t, kept for the push
+            stack[3 * OUT * OUT + p] = s2;
+            stack[2 * OUT * OUT + p] = s1;
+            stack[1 * OUT * OUT + p] = s0;
         }
     }
     // pass 2: horizontal_sample + luma; one thread per output pixel (the same pixels it just moved)
@@ -210,7 +216,7 @@ int32_t run(bdr_atari_prep* h, uint32_t n, const uint32_t* env_ixs, const uint8_
     }
     BDR_HIP(hipMemcpyAsync(h->d_frames, h->h_stage, (size_t)n * 2 * fsz, hipMemcpyHostToDevice, h->stream));
     BDR_HIP(hipMemcpyAsync(h->d_ixs, env_ixs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    PrepArgs a{h->d_frames, h->d_ixs, h->stacks, (int)h->width, (int)h->height, reset};
+    PrepArgs a{h->d_frames, h->d_ixs, h->stacks, h->prev, (int)h->width, (int)h->height, reset};
     hipLaunchKernelGGL(k_atari_prep, dim3(n), dim3(PREP_THREADS), (((size_t)OUT * h->width * 3 + 15) & ~(size_t)15) + 2 * OUT * sizeof(Taps), h->stream, a);
     BDR_HIP(hipGetLastError());
     BDR_HIP(hipStreamSynchronize(h->stream));   // env_ixs / frames may be reused by the caller
@@ -231,9 +237,12 @@ int32_t bdr_atari_prep_create(int32_t device, uint32_t n_envs, uint32_t width, u
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&h->stacks, (size_t)n_envs * 4 * OUT * OUT);
     if (e == hipSuccess) e = hipMemsetAsync(h->stacks, 0, (size_t)n_envs * 4 * OUT * OUT, h->stream);   // frames: vec![0; 4*84*84]
+    if (e == hipSuccess) e = hipMalloc((void**)&h->prev, (size_t)n_envs * 4 * OUT * OUT);
+    if (e == hipSuccess) e = hipMemsetAsync(h->prev, 0, (size_t)n_envs * 4 * OUT * OUT, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         if (h->stacks) (void)hipFree(h->stacks);
+        if (h->prev) (void)hipFree(h->prev);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         delete h;
         return fail(BDR_ERR_HIP, "atari_prep allocation failed: %s", hipGetErrorString(e));
@@ -247,7 +256,7 @@ int32_t bdr_atari_prep_destroy(bdr_atari_prep* h)
     if (!h) return BDR_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->stacks); (void)hipFree(h->d_frames); (void)hipFree(h->d_ixs); (void)hipHostFree(h->h_stage);
+    (void)hipFree(h->stacks); (void)hipFree(h->prev); (void)hipFree(h->d_frames); (void)hipFree(h->d_ixs); (void)hipHostFree(h->h_stage);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return BDR_OK;
@@ -280,6 +289,23 @@ int32_t bdr_atari_prep_device_stacks(bdr_atari_prep* h, const uint8_t** stacks)
 {
     BDR_REQUIRE(h && stacks, "null argument");
     *stacks = h->stacks;
+    return BDR_OK;
+}
+
+int32_t bdr_atari_prep_copy_stack(bdr_atari_prep* h, uint32_t env_ix, void* dst_dev)
+{
+    BDR_REQUIRE(h && dst_dev, "null argument");
+    BDR_REQUIRE(env_ix < h->n_envs, "environment index out of range");
+    BDR_HIP(hipSetDevice(h->device));
+    BDR_HIP(hipMemcpyAsync(dst_dev, h->stacks + (size_t)env_ix * 4 * OUT * OUT, 4 * OUT * OUT, hipMemcpyDeviceToDevice, h->stream));
+    BDR_HIP(hipStreamSynchronize(h->stream));
+    return BDR_OK;
+}
+
+int32_t bdr_atari_prep_device_prev_stacks(bdr_atari_prep* h, const uint8_t** prev)
+{
+    BDR_REQUIRE(h && prev, "null argument");
+    *prev = h->prev;
     return BDR_OK;
 }
 

@@ -83,6 +83,7 @@ struct bdr_replay {
     // pinned staging for push
     uint8_t* stage = nullptr;
     uint64_t stage_records = 0;
+    uint8_t* d_tails = nullptr; uint64_t tails_cap = 0;   // bdr_replay_push_device: device copy of a run's act / reward / flags
     // device batch buffers (lazily sized)
     uint64_t batch_cap = 0, batch_n = 0;
     uint64_t uid = 0, batch_gen = 0;   // process-unique handle id; bumped whenever the batch buffers are re-allocated or flipped

@@ -1418,9 +1418,13 @@ int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     DqnCnn* a = static_cast<DqnCnn*>(base);
     BDR_TRY(ensure_batch(a, (int)n));
     const size_t ob = (size_t)a->cfg.net.n_stack * 84 * 84;
-    uint8_t* d = nullptr;
-    BDR_TRY(a->act_buffer(n * ob, (void**)&d));
-    BDR_HIP(hipMemcpyAsync(d, obs, n * ob, hipMemcpyHostToDevice, a->stream));
+    const uint8_t* d = static_cast<const uint8_t*>(obs);
+    if (!a->obs_in_place(ob)) {   // host rows, or device rows with a stride: into the agent's contiguous staging buffer
+        uint8_t* stage = nullptr;
+        BDR_TRY(a->act_buffer(n * ob, (void**)&stage));
+        BDR_TRY(a->stage_obs(stage, obs, ob, n, a->stream));
+        d = stage;
+    }
     NetInst inst[1] = {{d, a->q, 0}};
     int32_t st = forward(a, inst, 1, (int)n);
     if (st == BDR_OK) {

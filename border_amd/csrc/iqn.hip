@@ -565,7 +565,7 @@ struct Iqn : bdr_agent {
             BDR_HIP(hipMalloc((void**)&u_act, n * 8)); BDR_HIP(hipMalloc((void**)&u_rew, n * 4)); BDR_HIP(hipMalloc((void**)&u_term, round_up(n, 16)));
             u_cap = n;
         }
-        BDR_HIP(hipMemcpyAsync(u_obs, obs, n * ob, hipMemcpyHostToDevice, stream));
+        BDR_TRY(stage_obs(u_obs, obs, ob, n, stream));   // (host rows; device rows inside bdr_agent_sample_device)
         if (next_obs) BDR_HIP(hipMemcpyAsync(u_next, next_obs, n * ob, hipMemcpyHostToDevice, stream));
         if (act) BDR_HIP(hipMemcpyAsync(u_act, act, n * 8, hipMemcpyHostToDevice, stream));
         if (reward) BDR_HIP(hipMemcpyAsync(u_rew, reward, n * 4, hipMemcpyHostToDevice, stream));

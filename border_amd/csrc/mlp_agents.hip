@@ -706,7 +706,7 @@ int32_t dqn_mlp_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     const size_t ob = (size_t)a->net.in_dim * 4;
     uint8_t* d = nullptr;
     BDR_TRY(a->act_buffer(n * ob, (void**)&d));
-    BDR_HIP(hipMemcpyAsync(d, obs, n * ob, hipMemcpyHostToDevice, a->stream));
+    BDR_TRY(a->stage_obs(d, obs, ob, n, a->stream));
     int32_t st = a->forward(0, a->q, d, (int)n);
     const int L = (int)a->net.L.size(), ld = a->net.L[L - 1].Np, A = a->net.out_dim;
     std::vector<float> tmp(n * ld);

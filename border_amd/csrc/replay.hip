@@ -530,6 +530,7 @@ int32_t bdr_replay_destroy(bdr_replay* r)
     (void)hipFree(r->b_reward); (void)hipFree(r->b_term); (void)hipFree(r->b_trunc); (void)hipFree(r->b_ixs);
     (void)hipFree(r->alt.obs); (void)hipFree(r->alt.next); (void)hipFree(r->alt.act); (void)hipFree(r->alt.reward);
     (void)hipFree(r->alt.term); (void)hipFree(r->alt.trunc); (void)hipFree(r->alt.ixs);
+    (void)hipFree(r->d_tails);
     per_destroy(r->per);
     (void)hipEventDestroy(r->written); (void)hipEventDestroy(r->read);
     (void)hipStreamDestroy(r->stream);
@@ -596,6 +597,92 @@ int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, const void* 
     BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
     BDR_HIP(hipStreamSynchronize(r->stream));  // caller may reuse its host buffers; staging reusable
     // base.rs:308-312
+    r->i = (r->i + n) % r->capacity;
+    r->size += n;
+    if (r->size >= r->capacity) r->size = r->capacity;
+    return BDR_OK;
+}
+
+// ExperienceBufferBase::push for transitions whose observation rows already live in HBM (the frame stacks of a bdr_atari_prep:
+// obs = the stacks before the step, next_obs = after it).  One workgroup per record copies the two rows inside HBM (16-byte lanes
+// where the addresses allow) and writes act / reward / flags from a small staged array - the rows never cross PCIe.
+struct PushDevArgs {
+    uint8_t* ring; uint64_t stride, obs_bytes, act_bytes, next_off, act_off, tail_off, pos;
+    const uint8_t* obs; uint64_t obs_stride; const uint8_t* next; uint64_t next_stride;
+    const uint8_t* tails;   // [m][act_bytes + 8]: act | reward f32 | is_terminated | is_truncated | 2 pad
+};
+__global__ __launch_bounds__(256) void k_push_device(PushDevArgs a)
+{
+    const uint64_t k = blockIdx.x;
+    uint8_t* rec = a.ring + (a.pos + k) * a.stride;
+    const uint8_t* src[2] = {a.obs + k * a.obs_stride, a.next + k * a.next_stride};
+    uint8_t* dst[2] = {rec, rec + a.next_off};
+    for (int w = 0; w < 2; ++w) {
+        if ((((uintptr_t)src[w] | (uintptr_t)dst[w] | a.obs_bytes) & 15) == 0) {
+            const uint4* s4 = reinterpret_cast<const uint4*>(src[w]); uint4* d4 = reinterpret_cast<uint4*>(dst[w]);
+            for (uint64_t i = threadIdx.x; i < a.obs_bytes / 16; i += 256) d4[i] = s4[i];
+        } else if ((((uintptr_t)src[w] | (uintptr_t)dst[w] | a.obs_bytes) & 3) == 0) {
+            const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src[w]); uint32_t* d1 = reinterpret_cast<uint32_t*>(dst[w]);
+            for (uint64_t i = threadIdx.x; i < a.obs_bytes / 4; i += 256) d1[i] = s1[i];
+        } else {
+            for (uint64_t i = threadIdx.x; i < a.obs_bytes; i += 256) dst[w][i] = src[w][i];
+        }
+    }
+    const uint8_t* t = a.tails + k * (a.act_bytes + 8);
+    for (uint64_t i = threadIdx.x; i < a.act_bytes; i += 256) rec[a.act_off + i] = t[i];
+    if (threadIdx.x < 6) rec[a.tail_off + threadIdx.x] = t[a.act_bytes + threadIdx.x];
+}
+
+int32_t bdr_replay_push_device(bdr_replay* r, uint64_t n, const void* obs_dev, uint64_t obs_stride, const void* act, const void* next_obs_dev,
+                               uint64_t next_obs_stride, const float* reward, const int8_t* term, const int8_t* trunc)
+{
+    BDR_REQUIRE(r, "null replay handle");
+    if (n == 0) return BDR_OK;
+    BDR_REQUIRE(obs_dev && act && next_obs_dev && reward && term && trunc, "null transition field");
+    BDR_REQUIRE(obs_stride >= r->obs_bytes && next_obs_stride >= r->obs_bytes, "row strides must be >= the observation row size");
+    BDR_REQUIRE(!r->frame_stack, "the single-frame store finds shared frames by comparing host rows: push host rows (bdr_replay_push) into a "
+                                 "buffer with frame_stack > 0");
+    BDR_HIP(hipSetDevice(r->device));
+    for (const void* p : {obs_dev, next_obs_dev}) {
+        hipPointerAttribute_t at{};
+        BDR_REQUIRE(hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice && at.device == r->device,
+                    "observation rows must be device memory of the buffer's GPU (host rows go through bdr_replay_push)");
+    }
+    BDR_TRY(wait_for_reader(r, r->stream));  // WAR: do not overwrite rows a consumer's gather may still be reading
+    const uint64_t tw = r->act_bytes + 8;
+    const uint8_t* a = (const uint8_t*)act;
+    uint64_t done = 0;
+    while (done < n) {
+        const uint64_t pos = (r->i + done) % r->capacity;
+        // the pinned staging buffer (stage_records * stride bytes) holds the small fields of a run
+        const uint64_t fit = std::max<uint64_t>(1, r->stage_records * r->stride / tw);
+        const uint64_t m = std::min(std::min(n - done, fit), r->capacity - pos);
+        BDR_HIP(hipStreamSynchronize(r->stream));  // staging buffer free again
+        if (m > r->tails_cap) {
+            (void)hipFree(r->d_tails); r->d_tails = nullptr; r->tails_cap = 0;
+            BDR_HIP(hipMalloc((void**)&r->d_tails, std::max<uint64_t>(m, 256) * tw));
+            r->tails_cap = std::max<uint64_t>(m, 256);
+        }
+        for (uint64_t k = 0; k < m; ++k) {
+            uint8_t* t = r->stage + k * tw;
+            const uint64_t s = done + k;
+            memcpy(t, a + s * r->act_bytes, r->act_bytes);
+            memcpy(t + r->act_bytes, &reward[s], 4);
+            t[r->act_bytes + 4] = (uint8_t)term[s]; t[r->act_bytes + 5] = (uint8_t)trunc[s]; t[r->act_bytes + 6] = t[r->act_bytes + 7] = 0;
+        }
+        BDR_HIP(hipMemcpyAsync(r->d_tails, r->stage, m * tw, hipMemcpyHostToDevice, r->stream));
+        PushDevArgs pa{r->ring, r->stride, r->obs_bytes, r->act_bytes, r->next_off, r->act_off, r->tail_off, pos,
+                       (const uint8_t*)obs_dev + done * obs_stride, obs_stride, (const uint8_t*)next_obs_dev + done * next_obs_stride, next_obs_stride, r->d_tails};
+        hipLaunchKernelGGL(k_push_device, dim3((uint32_t)m), dim3(256), 0, r->stream, pa);
+        BDR_HIP(hipGetLastError());
+        done += m;
+    }
+    if (r->per) {   // base.rs:304-306 set_priority(len), as bdr_replay_push
+        BDR_HIP(hipStreamWaitEvent(r->stream, r->written, 0));
+        BDR_TRY(per_push(r->per, r->i, n, r->stream));
+    }
+    BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
+    BDR_HIP(hipStreamSynchronize(r->stream));  // the caller's device rows may be overwritten by its next environment step
     r->i = (r->i + n) % r->capacity;
     r->size += n;
     if (r->size >= r->capacity) r->size = r->capacity;

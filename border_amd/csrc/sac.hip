@@ -1142,8 +1142,8 @@ int32_t bdr_sac_sample(bdr_agent* base, uint64_t n, const float* obs, float* act
     BDR_TRY(a->ensure_batch((int)n));
     float* d = nullptr;
     BDR_HIP(hipMalloc((void**)&d, n * a->O * 4));
-    BDR_HIP(hipMemcpyAsync(d, obs, n * a->O * 4, hipMemcpyHostToDevice, a->stream));
-    int32_t st = pack_rows(a->stream, d, a->O, a->O, a->x_o, a->pi.L[0].Kp, 0, (int)n);
+    int32_t st = a->stage_obs(d, obs, (size_t)a->O * 4, n, a->stream);
+    if (st == BDR_OK) st = pack_rows(a->stream, d, a->O, a->O, a->x_o, a->pi.L[0].Kp, 0, (int)n);
     if (st == BDR_OK) {
         if (a->train) st = a->gen_noise(a->z_a, n * a->A);
         else { hipError_t e = hipMemsetAsync(a->z_a, 0, n * a->A * 4, a->stream); if (e != hipSuccess) st = fail(BDR_ERR_HIP, "memset failed"); }
@@ -1161,6 +1161,18 @@ int32_t bdr_sac_sample(bdr_agent* base, uint64_t n, const float* obs, float* act
     BDR_TRY(st);
     for (uint64_t i = 0; i < n; ++i) for (int j = 0; j < a->A; ++j) act_out[i * a->A + j] = tmp[i * Ap + j];
     return BDR_OK;
+}
+
+// bdr_sac_sample for observation rows that are already in HBM (row i at obs_dev + i * row_stride bytes)
+int32_t bdr_sac_sample_device(bdr_agent* base, uint64_t n, const void* obs_dev, uint64_t row_stride, float* act_out)
+{
+    BDR_REQUIRE(base && obs_dev && act_out, "null argument");
+    BDR_REQUIRE(!strcmp(base->kind(), "sac"), "not a SAC agent");
+    BDR_REQUIRE(row_stride >= (uint64_t)static_cast<Sac*>(base)->O * 4 && row_stride % 4 == 0, "row_stride must be >= the row size and a multiple of 4");
+    base->obs_rows_on_device = true; base->obs_row_stride = row_stride;
+    const int32_t st = bdr_sac_sample(base, n, static_cast<const float*>(obs_dev), act_out);
+    base->obs_rows_on_device = false;
+    return st;
 }
 
 }  // extern "C"

@@ -95,6 +95,18 @@ int32_t d_push(void* b, uint64_t n, const void* obs, const void* act, const void
 {
     return bdr_replay_push((bdr_replay*)b, n, obs, act, next_obs, rew, term, trunc);
 }
+// the same two for device-resident observations (bdr_env_vtable::obs_on_device)
+int32_t d_sample_dev(void* a, uint64_t n, const void* obs_dev, uint64_t stride, void* act)
+{
+    bdr_agent* ag = (bdr_agent*)a;
+    if (ag && !strcmp(ag->kind(), "sac")) return bdr_sac_sample_device(ag, n, obs_dev, stride, (float*)act);
+    return bdr_agent_sample_device(ag, n, obs_dev, stride, (int64_t*)act, nullptr);
+}
+int32_t d_push_dev(void* b, uint64_t n, const void* obs_dev, uint64_t os, const void* act, const void* next_dev, uint64_t ns, const float* rew,
+                   const int8_t* term, const int8_t* trunc)
+{
+    return bdr_replay_push_device((bdr_replay*)b, n, obs_dev, os, act, next_dev, ns, rew, term, trunc);
+}
 }  // namespace
 
 extern "C" {
@@ -113,6 +125,7 @@ void bdr_trainer_ops_default(bdr_trainer_ops* ops, bdr_agent* agent, bdr_replay*
     ops->agent = agent; ops->buffer = buffer;
     ops->agent_set_train = d_set_train; ops->agent_sample = d_sample; ops->agent_opt = d_opt;
     ops->agent_opt_with_record = d_opt_rec; ops->buffer_push = d_push;
+    ops->agent_sample_device = d_sample_dev; ops->buffer_push_device = d_push_dev;
 }
 
 int32_t bdr_trainer_train(const bdr_trainer_config* c, const bdr_trainer_ops* ops, const bdr_env_vtable* env,
@@ -122,30 +135,35 @@ int32_t bdr_trainer_train(const bdr_trainer_config* c, const bdr_trainer_ops* op
     BDR_REQUIRE(env && env->reset && env->step_with_reset, "environment function table is incomplete");
     BDR_REQUIRE(ops->agent_sample && ops->buffer_push, "the online loop needs agent_sample and buffer_push");
     BDR_REQUIRE(c->obs_row_bytes > 0 && c->act_row_bytes > 0, "obs_row_bytes / act_row_bytes must be set");
+    const bool dev = env->obs_on_device != 0;   // the environment's observations live in HBM: act and push through the *_device entries
+    BDR_REQUIRE(!dev || (ops->agent_sample_device && ops->buffer_push_device), "a device-resident environment needs agent_sample_device and buffer_push_device");
     State s; s.c = c; s.ops = ops;
-    // Sampler state (sampler.rs:61-75) + SimpleStepProcessor::prev_obs (step_proc.rs:86-101)
-    std::vector<uint8_t> prev_obs(c->obs_row_bytes), proc_prev(c->obs_row_bytes), obs_new(c->obs_row_bytes), init_obs(c->obs_row_bytes),
-        act(c->act_row_bytes);
+    // Sampler state (sampler.rs:61-75) + SimpleStepProcessor::prev_obs (step_proc.rs:86-101).  The sampler's prev_obs and the step
+    // processor's are the same observation at the top of every iteration (both become init_obs after a terminal step, obs otherwise):
+    // one buffer, host or device
+    ObsRow prev, obs_new, init_obs;
+    BDR_TRY(prev.init(dev, env->device, c->obs_row_bytes)); BDR_TRY(obs_new.init(dev, env->device, c->obs_row_bytes)); BDR_TRY(init_obs.init(dev, env->device, c->obs_row_bytes));
+    std::vector<uint8_t> act(c->act_row_bytes);
     bool have_prev = false;
     BDR_TRY(ops->agent_set_train(ops->agent, 1));   // trainer.rs:283
     for (;;) {
         const auto t0 = Clock::now();
         // ---- Sampler::sample_and_push (sampler.rs:99-144)
         if (!have_prev) {
-            BDR_TRY(env->reset(env->ctx, prev_obs.data()));
-            proc_prev = prev_obs;                       // step_processor.reset(prev_obs.clone())
+            BDR_TRY(env->reset(env->ctx, prev.p()));    // (+ step_processor.reset(prev_obs.clone()))
             have_prev = true;
         }
-        BDR_TRY(ops->agent_sample(ops->agent, 1, prev_obs.data(), act.data()));
+        if (dev) BDR_TRY(ops->agent_sample_device(ops->agent, 1, prev.p(), c->obs_row_bytes, act.data()));
+        else BDR_TRY(ops->agent_sample(ops->agent, 1, prev.p(), act.data()));
         float reward = 0; int8_t term = 0, trunc = 0;
-        BDR_TRY(env->step_with_reset(env->ctx, act.data(), obs_new.data(), &reward, &term, &trunc, init_obs.data()));
+        BDR_TRY(env->step_with_reset(env->ctx, act.data(), obs_new.p(), &reward, &term, &trunc, init_obs.p()));
         const bool is_done = term == 1 || trunc == 1;   // step.rs:136-138
-        prev_obs = is_done ? init_obs : obs_new;
         // SimpleStepProcessor::process (step_proc.rs:103-137): (prev_obs, act, obs, reward, flags); next transition starts
         // from obs, or from init_obs after a terminal step
-        BDR_TRY(ops->buffer_push(ops->buffer, 1, proc_prev.data(), act.data(), obs_new.data(), &reward, &term, &trunc));
-        proc_prev = is_done ? init_obs : obs_new;
-        if (is_done) { proc_prev = prev_obs; s.n_episodes += 1; }   // sampler.rs:137-141
+        if (dev) BDR_TRY(ops->buffer_push_device(ops->buffer, 1, prev.p(), c->obs_row_bytes, act.data(), obs_new.p(), c->obs_row_bytes, &reward, &term, &trunc));
+        else BDR_TRY(ops->buffer_push(ops->buffer, 1, prev.p(), act.data(), obs_new.p(), &reward, &term, &trunc));
+        prev.swap(is_done ? init_obs : obs_new);        // prev_obs = init_obs / obs (sampler.rs:137-141, step_proc.rs:131-135)
+        if (is_done) s.n_episodes += 1;
         const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
         s.timer_for_samples += dt; s.total_sample += dt;
         s.samples_counter += 1;

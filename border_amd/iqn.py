@@ -143,6 +143,21 @@ class Iqn:
         _lib.check(_lib.lib().bdr_iqn_forward(self._h, self.WHICH[which], n, _p(obs), _p(tau), nt, _p(z)))
         return z
 
+    def sample_device(self, obs_dev: int, n: int, row_stride: int, return_info: bool = False):
+        """Policy::sample for observation rows already in HBM (`bdr_agent_sample_device`): row i at obs_dev + i * row_stride bytes."""
+        a = np.empty(n, np.int64)
+        info = _lib.SampleInfoC()
+        _lib.check(_lib.lib().bdr_agent_sample_device(self._h, n, C.c_void_p(obs_dev), row_stride, _p(a), C.byref(info)))
+        if return_info:
+            return a, {"eps": info.eps, "is_random": bool(info.is_random), "n_samples_act": info.n_samples_act,
+                       "n_samples_best_act": info.n_samples_best_act}
+        return a
+
+    def qvalues_device(self, obs_dev: int, n: int, row_stride: int) -> np.ndarray:
+        q = np.empty((n, self.config.n_actions), np.float32)
+        _lib.check(_lib.lib().bdr_agent_qvalues_device(self._h, n, C.c_void_p(obs_dev), row_stride, _p(q), None))
+        return q
+
     def qvalues(self, obs) -> np.ndarray:
         obs = np.ascontiguousarray(obs)
         q = np.empty((obs.shape[0], self.config.n_actions), np.float32)

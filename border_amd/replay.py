@@ -128,6 +128,19 @@ class SimpleReplayBuffer:
         _lib.check(_lib.lib().bdr_replay_push(self._h, n, _p(obs), _p(act), _p(next_obs), _p(reward), _p(term),
                                               _p(trunc)))
 
+    def push_device(self, obs_dev: int, obs_stride: int, act, next_obs_dev: int, next_obs_stride: int, reward, is_terminated, is_truncated) -> None:
+        """The same push for observation rows that already live in HBM (`bdr_replay_push_device`): obs_dev / next_obs_dev are device
+        addresses (e.g. `AtariPreprocessor.device_prev_stacks()` / `.device_stacks()`), row k at address + k * stride; act / reward /
+        flags are host arrays."""
+        reward = np.ascontiguousarray(reward, dtype=np.float32).reshape(-1)
+        n = reward.shape[0]
+        act = np.ascontiguousarray(act, dtype=self.act_dtype).reshape(n, -1)
+        term = np.ascontiguousarray(is_terminated, dtype=np.int8).reshape(n)
+        trunc = np.ascontiguousarray(is_truncated, dtype=np.int8).reshape(n)
+        assert act.nbytes == n * self.act_bytes
+        _lib.check(_lib.lib().bdr_replay_push_device(self._h, n, C.c_void_p(obs_dev), obs_stride, _p(act), C.c_void_p(next_obs_dev), next_obs_stride,
+                                                     _p(reward), _p(term), _p(trunc)))
+
     def len(self) -> int:
         n = C.c_uint64()
         _lib.check(_lib.lib().bdr_replay_len(self._h, C.byref(n)))

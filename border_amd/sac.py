@@ -160,6 +160,12 @@ class Sac:
         _lib.check(_lib.lib().bdr_sac_sample(self._h, obs.shape[0], _p(obs), _p(out)))
         return out
 
+    def sample_device(self, obs_dev: int, n: int, row_stride: int) -> np.ndarray:
+        """`sample` for observation rows already in HBM (`bdr_sac_sample_device`): row i at obs_dev + i * row_stride bytes."""
+        out = np.empty((n, self.config.act_dim), np.float32)
+        _lib.check(_lib.lib().bdr_sac_sample_device(self._h, n, C.c_void_p(obs_dev), row_stride, _p(out)))
+        return out
+
     def sync(self):
         _lib.check(_lib.lib().bdr_agent_sync(self._h))
 

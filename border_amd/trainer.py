@@ -241,6 +241,10 @@ class NativeTrainer:
             return 0
 
         vt = _lib.EnvVtable(None, _lib.ENV_RESET_FN(reset), _lib.ENV_STEP_FN(step))
+        if getattr(env, "device_obs", False):   # device-resident observations: the callbacks get device buffers (see async_trainer.env_vtable)
+            from .async_trainer import env_vtable
+            self._keep = []
+            vt = env_vtable(env, obs_shape, obs_dtype, act_row_bytes, act_dtype, keep=self._keep)
         if ops is None:
             ops = _lib.TrainerOps()
             _lib.lib().bdr_trainer_ops_default(C.byref(ops), agent.handle, buffer.handle)

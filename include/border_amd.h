@@ -82,6 +82,16 @@ BDR_API int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, cons
                                 const void* next_obs, const float* reward,
                                 const int8_t* is_terminated, const int8_t* is_truncated);
 
+/* The same push for transitions whose observation rows already live in HBM - the frame stacks of a bdr_atari_prep (obs = its
+ * stacks before the step, bdr_atari_prep_device_prev_stacks; next_obs = after it, bdr_atari_prep_device_stacks), or any device
+ * rows `*_stride` bytes apart: trainer/sampler.rs:99-144 + border-atari-env/src/env.rs:197-209,312-324 without the HBM -> host ->
+ * HBM round trip of the stacks.  act / reward / flags are host arrays (they come from the host side: exploration, the emulator).
+ * Ring rows, cursor, size and PER priorities are exactly those of bdr_replay_push on the same bytes.  Not for frame_stack > 0
+ * buffers (their push compares host rows): BDR_ERR_INVALID.  Returns when the rows have been copied. */
+BDR_API int32_t bdr_replay_push_device(bdr_replay* r, uint64_t n, const void* obs_dev, uint64_t obs_stride, const void* act,
+                                       const void* next_obs_dev, uint64_t next_obs_stride, const float* reward,
+                                       const int8_t* is_terminated, const int8_t* is_truncated);
+
 /* ExperienceBufferBase::len (base.rs:318-320) and the write cursor `i`. */
 BDR_API int32_t bdr_replay_len(const bdr_replay* r, uint64_t* len);
 BDR_API int32_t bdr_replay_head(const bdr_replay* r, uint64_t* head);
@@ -308,6 +318,15 @@ typedef struct {
 } bdr_sample_info;
 BDR_API int32_t bdr_agent_sample(bdr_agent* a, uint64_t n_procs, const void* obs, int64_t* act_out,
                                  bdr_sample_info* info);
+/* Policy::sample for observations that are already on the device (trainer/sampler.rs:99-144 with the
+ * observation of border-atari-env/src/env.rs:197-209 kept in HBM): row i at obs_dev + i * row_stride bytes, e.g.
+ * bdr_atari_prep_device_stacks with row_stride = 4*84*84.  Forward, exploration stream, counters and results are those of
+ * bdr_agent_sample on the same bytes; contiguous rows are read in place.  The rows must be complete when the call is made and
+ * stay untouched until it returns.  bdr_agent_qvalues_device: the action values themselves (bdr_agent_qvalues). */
+BDR_API int32_t bdr_agent_sample_device(bdr_agent* a, uint64_t n_procs, const void* obs_dev, uint64_t row_stride, int64_t* act_out,
+                                        bdr_sample_info* info);
+BDR_API int32_t bdr_agent_qvalues_device(bdr_agent* a, uint64_t n, const void* obs_dev, uint64_t row_stride, float* q_out,
+                                         int64_t* argmax_out);
 
 /* Block until everything enqueued on the agent's stream has finished.  Device-side error flags raised since the last check
  * (an action index outside [0, n_actions) in a TD step, a NaN priority in update_priority, a timed-out cross-queue gate) are
@@ -361,6 +380,12 @@ typedef struct bdr_env_vtable {             /* single-process Env (border-core/s
     /* Env::step_with_reset(&act) (env.rs:137-161): writes obs, reward, flags; when the step is done also init_obs */
     int32_t (*step_with_reset)(void* ctx, const void* act, void* obs_out, float* reward, int8_t* is_terminated,
                                int8_t* is_truncated, void* init_obs_out);
+    /* Device-resident observations (zero-initialised tables keep the host convention): with obs_on_device != 0
+     * obs_out / init_obs_out are DEVICE buffers of obs_row_bytes on GPU `device` - the environment keeps its observation in HBM
+     * (a bdr_atari_prep: bdr_atari_prep_copy_stack writes an environment's stack there) - and the loops act and push through the
+     * *_device entries of their function tables: the observation never visits the host. */
+    int32_t obs_on_device;
+    int32_t device;
 } bdr_env_vtable;
 
 typedef struct bdr_trainer_ops {
@@ -372,6 +397,12 @@ typedef struct bdr_trainer_ops {
     int32_t (*agent_opt_with_record)(void* agent, void* buffer, float* scalars, int32_t cap, int32_t* n_scalars);
     int32_t (*buffer_push)(void* buffer, uint64_t n, const void* obs, const void* act, const void* next_obs,
                            const float* reward, const int8_t* is_terminated, const int8_t* is_truncated);
+    /* used instead of agent_sample / buffer_push when the environment's observations are device-resident (bdr_env_vtable::obs_on_device):
+     * bdr_agent_sample_device / bdr_replay_push_device by default; act_out, act, reward and the flags stay host memory */
+    int32_t (*agent_sample_device)(void* agent, uint64_t n_procs, const void* obs_dev, uint64_t row_stride, void* act_out);
+    int32_t (*buffer_push_device)(void* buffer, uint64_t n, const void* obs_dev, uint64_t obs_stride, const void* act,
+                                  const void* next_obs_dev, uint64_t next_obs_stride, const float* reward,
+                                  const int8_t* is_terminated, const int8_t* is_truncated);
 } bdr_trainer_ops;
 
 typedef struct bdr_trainer_config {         /* trainer/config.rs:30-87; an interval of 0 means "never" */
@@ -457,6 +488,7 @@ typedef struct bdr_actor_ops {              /* one Actor: its own agent (built f
     int32_t (*agent_set_train)(void* agent, int32_t train);
     int32_t (*agent_sample)(void* agent, uint64_t n_procs, const void* obs, void* act_out);
     int32_t (*sync_model)(void* agent, void* mailbox, uint32_t actor_id, int32_t first, uint64_t* n_opts_inout, int32_t* updated);
+    int32_t (*agent_sample_device)(void* agent, uint64_t n_procs, const void* obs_dev, uint64_t row_stride, void* act_out);   /* env.obs_on_device */
     bdr_env_vtable env;
 } bdr_actor_ops;
 
@@ -509,6 +541,12 @@ BDR_API int32_t bdr_atari_prep_step(bdr_atari_prep* h, uint32_t n, const uint32_
 BDR_API int32_t bdr_atari_prep_obs(bdr_atari_prep* h, uint32_t n, const uint32_t* env_ixs, uint8_t* obs_out);
 /* device address of all stacks, [n_envs][4][84][84] u8 */
 BDR_API int32_t bdr_atari_prep_device_stacks(bdr_atari_prep* h, const uint8_t** stacks);
+/* one environment's current stack -> dst_dev (device memory, 4*84*84 bytes), complete when the call returns: what an environment
+ * with bdr_env_vtable::obs_on_device writes into obs_out / init_obs_out */
+BDR_API int32_t bdr_atari_prep_copy_stack(bdr_atari_prep* h, uint32_t env_ix, void* dst_dev);
+/* device address of every environment's stack as it was BEFORE its last step, [n_envs][4][84][84] u8: obs_t of the transition
+ * whose next_obs is device_stacks (what bdr_replay_push_device takes; unchanged by reset) */
+BDR_API int32_t bdr_atari_prep_device_prev_stacks(bdr_atari_prep* h, const uint8_t** prev);
 BDR_API float bdr_atari_clip_reward(float r, int32_t train);
 
 /* Host-side named-tensor files (no GPU involved): the container layer under save_params / load_params, for callers
@@ -608,6 +646,8 @@ BDR_API int32_t bdr_sac_update_on_batch(bdr_agent* a, uint64_t n, const float* o
 BDR_API int32_t bdr_sac_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
 /* Policy::sample (sac/base.rs:215-225). */
 BDR_API int32_t bdr_sac_sample(bdr_agent* a, uint64_t n, const float* obs, float* act_out);
+/* the same for observation rows in HBM (row i at obs_dev + i * row_stride bytes), see bdr_agent_sample_device */
+BDR_API int32_t bdr_sac_sample_device(bdr_agent* a, uint64_t n, const void* obs_dev, uint64_t row_stride, float* act_out);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU parameter exchange (replaces the learner->actors NamedTensors channel of

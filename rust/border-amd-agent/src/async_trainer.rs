@@ -338,6 +338,8 @@ where
             ctx: env_ctxs[i].as_mut() as *mut EnvCtx<E, A> as *mut c_void,
             reset: Some(env_reset::<E, A>),
             step_with_reset: Some(env_step::<E, A>),
+            obs_on_device: 0, // border's Env trait hands observations over as host values
+            device: 0,
         };
         let mut ops: ffi::bdr_actor_ops = unsafe { std::mem::zeroed() };
         unsafe { ffi::bdr_actor_ops_default(&mut ops, a.raw(), mailbox, &vt) };

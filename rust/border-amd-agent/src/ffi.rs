@@ -202,6 +202,8 @@ pub struct bdr_env_vtable {
             init_obs_out: *mut c_void,
         ) -> i32,
     >,
+    pub obs_on_device: i32,
+    pub device: i32,
 }
 
 #[repr(C)]
@@ -221,6 +223,22 @@ pub struct bdr_trainer_ops {
             obs: *const c_void,
             act: *const c_void,
             next_obs: *const c_void,
+            reward: *const f32,
+            is_terminated: *const i8,
+            is_truncated: *const i8,
+        ) -> i32,
+    >,
+    pub agent_sample_device:
+        Option<unsafe extern "C" fn(agent: *mut c_void, n_procs: u64, obs_dev: *const c_void, row_stride: u64, act_out: *mut c_void) -> i32>,
+    pub buffer_push_device: Option<
+        unsafe extern "C" fn(
+            buffer: *mut c_void,
+            n: u64,
+            obs_dev: *const c_void,
+            obs_stride: u64,
+            act: *const c_void,
+            next_obs_dev: *const c_void,
+            next_obs_stride: u64,
             reward: *const f32,
             is_terminated: *const i8,
             is_truncated: *const i8,
@@ -291,6 +309,8 @@ pub struct bdr_actor_ops {
     pub sync_model: Option<
         unsafe extern "C" fn(agent: *mut c_void, mailbox: *mut c_void, actor_id: u32, first: i32, n_opts_inout: *mut u64, updated: *mut i32) -> i32,
     >,
+    pub agent_sample_device:
+        Option<unsafe extern "C" fn(agent: *mut c_void, n_procs: u64, obs_dev: *const c_void, row_stride: u64, act_out: *mut c_void) -> i32>,
     pub env: bdr_env_vtable,
 }
 
@@ -398,6 +418,18 @@ extern "C" {
         is_terminated: *const i8,
         is_truncated: *const i8,
     ) -> i32;
+    pub fn bdr_replay_push_device(
+        r: *mut bdr_replay,
+        n: u64,
+        obs_dev: *const c_void,
+        obs_stride: u64,
+        act: *const c_void,
+        next_obs_dev: *const c_void,
+        next_obs_stride: u64,
+        reward: *const f32,
+        is_terminated: *const i8,
+        is_truncated: *const i8,
+    ) -> i32;
     pub fn bdr_replay_len(r: *const bdr_replay, len: *mut u64) -> i32;
     pub fn bdr_replay_head(r: *const bdr_replay, head: *mut u64) -> i32;
     pub fn bdr_replay_frames_used(r: *const bdr_replay, allocated: *mut u64, capacity: *mut u64) -> i32;
@@ -485,6 +517,8 @@ extern "C" {
     pub fn bdr_agent_set_explorer(a: *mut bdr_agent, e: *const bdr_explorer_config) -> i32;
     pub fn bdr_agent_get_explorer(a: *const bdr_agent, e: *mut bdr_explorer_config) -> i32;
     pub fn bdr_agent_sample(a: *mut bdr_agent, n_procs: u64, obs: *const c_void, act_out: *mut i64, info: *mut bdr_sample_info) -> i32;
+    pub fn bdr_agent_sample_device(a: *mut bdr_agent, n_procs: u64, obs_dev: *const c_void, row_stride: u64, act_out: *mut i64, info: *mut bdr_sample_info) -> i32;
+    pub fn bdr_agent_qvalues_device(a: *mut bdr_agent, n: u64, obs_dev: *const c_void, row_stride: u64, q_out: *mut f32, argmax_out: *mut i64) -> i32;
     pub fn bdr_agent_sync(a: *mut bdr_agent) -> i32;
     pub fn bdr_agent_n_opts(a: *const bdr_agent, n: *mut u64) -> i32;
     pub fn bdr_agent_param_count(a: *const bdr_agent, n: *mut u64) -> i32;
@@ -549,6 +583,8 @@ extern "C" {
     pub fn bdr_atari_prep_step(h: *mut bdr_atari_prep, n: u32, env_ixs: *const u32, frames_a: *const u8, frames_b: *const u8) -> i32;
     pub fn bdr_atari_prep_obs(h: *mut bdr_atari_prep, n: u32, env_ixs: *const u32, obs_out: *mut u8) -> i32;
     pub fn bdr_atari_prep_device_stacks(h: *mut bdr_atari_prep, stacks: *mut *const u8) -> i32;
+    pub fn bdr_atari_prep_copy_stack(h: *mut bdr_atari_prep, env_ix: u32, dst_dev: *mut c_void) -> i32;
+    pub fn bdr_atari_prep_device_prev_stacks(h: *mut bdr_atari_prep, prev: *mut *const u8) -> i32;
     pub fn bdr_atari_clip_reward(r: f32, train: i32) -> f32;
 
     // ---- checkpoints, probes, profiling
@@ -595,6 +631,7 @@ extern "C" {
         rec3: *mut f32,
     ) -> i32;
     pub fn bdr_sac_sample(a: *mut bdr_agent, n: u64, obs: *const f32, act_out: *mut f32) -> i32;
+    pub fn bdr_sac_sample_device(a: *mut bdr_agent, n: u64, obs_dev: *const c_void, row_stride: u64, act_out: *mut f32) -> i32;
 
     // ---- multi-GPU parameter exchange (RCCL over xGMI)
     pub fn bdr_comm_get_unique_id(id: *mut u8) -> i32;

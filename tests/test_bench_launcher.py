@@ -32,6 +32,18 @@ def test_plain_command_spawns_its_own_ranks():
     assert line["gpu_max_hw_queues"] == "8"          # the N>1 path asks for its hardware queues before the first HIP call
 
 
+def test_eight_ranks_the_size_of_config_c3():
+    """BASELINE config 3 is 8 actors x 8 MI355X: the launcher, the gloo rendezvous on 127.0.0.1, the barrier and the MAX-reduce of
+    the timing with eight ranks (no GPU is touched: --dry-run)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=_clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == list(range(8)) and line["gpu_max_hw_queues"] == "8"
+
+
 def test_driver_form_under_torchrun_runs_the_ranks_it_is_given():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

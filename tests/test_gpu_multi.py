@@ -14,7 +14,15 @@ Parity statements (8(e) "Parity at G>1"), each against something that IS parity-
        single-GPU runs of the same seeds bit for bit;
  (iii) broadcast == the root's parameters, bit for bit (the reference's learner -> actors sync, async_trainer/base.rs:268-272);
  (iv)  the overlapped per-segment exchange (communication queue beside the backward) == the in-stream exchange, bit for bit;
- (v)   bdr_comm_agree: MIN of the ranks' ok flags on every rank."""
+ (v)   bdr_comm_agree: MIN of the ranks' ok flags on every rank;
+ (vi)  the SAC handle: SyncModel ships `pi` only (sac/base.rs:377-386) - after K local steps on different shards the exchange leaves
+       `pi` == fl(fl(pi0 + pi1) * 0.5) on both ranks and every critic, target critic and log_alpha exactly as it was;
+ (vii) the IQN handle: its whole model (`iqn`) is averaged, `iqn_tgt` and the Adam moments stay local;
+ (viii) bdr_async_train per rank (learner + actor + local shard) with the `exchange` + `agree` hooks over the two real ranks
+       (async_trainer/base.rs:268-272, 299-388): both ranks stop after max_opts, sync the same number of times, and - the run ends with a
+       sync - hold bit-identical learner parameters.
+The rank script itself also runs with ONE rank on the 1-GPU box (test_rank_script_runs_on_one_rank: every collective is then the
+identity), so that what only a 2-GPU node can check is at least free of programming errors before it gets there."""
 import os
 import socket
 import sys
@@ -69,6 +77,13 @@ def _rank_main(rank, world, port, out):
         return bytes(t.tolist())
     ex = B.ParamExchange.rccl_or_raise(world, rank, 1, dev, bcast_bytes, ("qnet",))
     comm = ex._comm
+    own_comm = None
+    if world == 1:   # the one-rank run of this script: a real 1-rank RCCL communicator for the direct calls (every collective = identity)
+        uid = (C.c_uint8 * B._lib.BDR_UNIQUE_ID_BYTES)()
+        B._lib.check(L.bdr_comm_get_unique_id(uid))
+        own_comm = C.c_void_p()
+        B._lib.check(L.bdr_comm_init_rank(uid, 1, 0, dev, C.byref(own_comm)))
+        comm = own_comm
     res = {"rank": rank}
 
     # (v) agreement
@@ -139,34 +154,107 @@ def _rank_main(rank, world, port, out):
     res["overlap_equals_instream"] = bool((ov[0] == ins[0]).all() and (ov[1] == ins[1]).all() and (ov[2] == ins[2]).all())
     res["exchanged_every_3"] = ov[0]
 
-    # (iii) broadcast from rank 1
+    # (vi) SAC: only `pi` crosses the ranks
+    sac_rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=2000, seed=B.shard_seed(42, rank)), (17,), np.float32, (6,), np.float32, device=dev)
+    sac_rb.fill_synthetic(2000, seed=20 + rank, kind=1, n_actions=0)
+    sac = B.Sac.build(B.SacConfig(obs_dim=17, act_dim=6, pi_units=(64, 64), q_units=(64, 64), n_critics=2, batch_size=64,
+                                  ent_coef_mode=("Auto", -6.0, 3e-4), lr_actor=3e-4, lr_critic=3e-4, device=dev, seed=5))
+    for _ in range(6):
+        sac.opt(sac_rb)
+    sac.sync()
+    names = ["pi", "qnet_0", "qnet_1", "qnet_tgt_0", "qnet_tgt_1", "log_alpha"]
+    before = {n: sac.get_params(n) for n in names}
+    B._lib.check(L.bdr_agent_allreduce_params(sac.handle, comm, sac.WHICH["pi"]))   # (the process's one communicator)
+    sac.sync()
+    res["sac_before"], res["sac_after"] = before, {n: sac.get_params(n) for n in names}
+    sac.opt(sac_rb); sac.sync()          # the step after an exchange runs (one-queue / two-queue hand-over)
+    res["sac_n_opts"] = sac.n_opts
+    sac.close(); sac_rb.close()
+
+    # (vii) IQN: the whole model is averaged, target and moments stay local
+    irb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=500, seed=B.shard_seed(42, rank)), (4,), np.float32, device=dev)
+    irb.fill_synthetic(500, seed=30 + rank, kind=1, n_actions=3)
+    iqn = B.Iqn.build(B.IqnConfig(f_config=B.MlpConfig(in_dim=4, units=(32,), out_dim=16, activation_out=True), feature_dim=16, embed_dim=8, m_units=(32,),
+                                  n_actions=3, lr=1e-3, batch_size=16, device=dev, seed=3, tau=0.5, soft_update_interval=3))
+    for _ in range(5):
+        iqn.opt(irb)
+    iqn.sync()
+    ib = {n: iqn.get_params(n) for n in ("iqn", "iqn_tgt", "exp_avg")}
+    B._lib.check(L.bdr_agent_allreduce_params(iqn.handle, comm, iqn.WHICH["iqn"]))
+    iqn.sync()
+    res["iqn_before"], res["iqn_after"] = ib, {n: iqn.get_params(n) for n in ("iqn", "iqn_tgt", "exp_avg")}
+    iqn.close(); irb.close()
+
+    # (viii) the async trainer on every rank, learners averaged at every sync point, agreement before every collective
+    arb = _ring(B, dev, B.shard_seed(42, rank), 40 + rank, 400)
+    learner = _cnn(B, 16, dev, tau=1.0, soft_update_interval=10000, param_seed=9)
+    actor = _cnn(B, 16, dev, param_seed=9)
+    actor.set_explorer(B.EpsilonGreedy(final_step=100), seed=50 + rank)
+    env = B.SyntheticEnv((4, 1, 84, 84), np.uint8, seed=60 + rank, p_term=0.05)
+    ex.which = ("qnet",)
+    events = []
+    tr = B.AsyncTrainer(B.AsyncTrainerConfig(max_opts=7, warmup_period=0, sync_interval=3, record_agent_info_interval=0, record_compute_cost_interval=0,
+                                             warmup_sleep_ms=1), B.ActorManagerConfig(n_buffer=4))
+    st = tr.train(learner, arb, [actor], [env], (4, 1, 84, 84), np.uint8, exchange=lambda s: ex.average(learner), agree=lambda ok: ex.agree(ok),
+                  on_event=lambda actor_id, a_, b_, ev, v: events.append((ev, b_)) if ev == "sync" else None)
+    learner.sync()
+    res["async_stat"] = (st.opt_steps, st.n_syncs, [b_ for ev, b_ in events])
+    res["async_qnet"] = learner.get_params("qnet")
+    learner.close(); actor.close(); arb.close()
+
+    # (iii) broadcast from rank 1 (rank 0 when there is one rank)
     a = _cnn(B, 32, dev, tau=1.0, soft_update_interval=10000, param_seed=100 + rank)
     mine = a.get_params("qnet")
-    B._lib.check(L.bdr_agent_broadcast_params(a.handle, comm, 0, 1))
+    B._lib.check(L.bdr_agent_broadcast_params(a.handle, comm, 0, world - 1))
     a.sync()
     res["bcast_mine"], res["bcast_after"] = mine, a.get_params("qnet")
     a.close()
 
     ex.close()
+    if own_comm is not None:
+        B._lib.check(L.bdr_comm_destroy(own_comm))
     out.put(res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def two_ranks():
+def _spawn(world):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=900) for _ in range(2)), key=lambda r: r["rank"])
+    res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda r: r["rank"])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     return res
+
+
+@pytest.fixture(scope="module")
+def two_ranks():
+    return _spawn(2)
+
+
+def test_rank_script_runs_on_one_rank():
+    """The whole rank script over a 1-rank RCCL communicator (runs on the 1-GPU box): every collective is the identity, so each
+    'after' equals its 'before' bit for bit, the async trainer finishes with its sync points, and nothing in the script that only
+    a 2-GPU node exercises is left untried for plain programming errors."""
+    if _n_gpus() < 1:
+        pytest.fail("no MI355X visible: the HIP path must run on the GPU box")
+    (r,) = _spawn(1)
+    assert r["agree_all_ok"] is True and r["agree_one_failed"] is True          # (rank 0 never says "failed" here)
+    assert r["grad_comm_identity"] and r["avg_own_equals_solo"] and r["avg_moments_local"] and r["overlap_equals_instream"]
+    assert (r["avg_after"] == r["avg_own_before"]).all() and (r["bcast_after"] == r["bcast_mine"]).all()
+    for n, v in r["sac_before"].items():
+        assert (r["sac_after"][n] == v).all(), n
+    assert r["sac_n_opts"] == 7
+    for n, v in r["iqn_before"].items():
+        assert (r["iqn_after"][n] == v).all(), n
+    opt_steps, n_syncs, at = r["async_stat"]
+    assert opt_steps == 7 and at == [0, 3, 6, 7] and n_syncs == 4                # first, every sync_interval, last (util.rs:31-92)
 
 
 @needs_two
@@ -221,3 +309,32 @@ def test_broadcast_equals_the_root(two_ranks):
     root = two_ranks[1]["bcast_mine"]
     assert not (two_ranks[0]["bcast_mine"] == root).all()
     assert (two_ranks[0]["bcast_after"] == root).all() and (two_ranks[1]["bcast_after"] == root).all()
+
+
+@needs_two
+def test_sac_exchange_ships_pi_only(two_ranks):
+    b0, b1 = two_ranks[0]["sac_before"], two_ranks[1]["sac_before"]
+    assert not (b0["pi"] == b1["pi"]).all()                                       # different shards diverged
+    mean = (b0["pi"] + b1["pi"]) * np.float32(0.5)
+    for r in two_ranks:
+        assert (r["sac_after"]["pi"] == mean).all()
+        for n in ("qnet_0", "qnet_1", "qnet_tgt_0", "qnet_tgt_1", "log_alpha"):   # sac/base.rs:377-386: the critics and alpha stay local
+            assert (r["sac_after"][n] == r["sac_before"][n]).all(), n
+        assert r["sac_n_opts"] == 7
+
+
+@needs_two
+def test_iqn_exchange_averages_the_model_and_leaves_target_and_moments_local(two_ranks):
+    b0, b1 = two_ranks[0]["iqn_before"], two_ranks[1]["iqn_before"]
+    assert not (b0["iqn"] == b1["iqn"]).all()
+    mean = (b0["iqn"] + b1["iqn"]) * np.float32(0.5)
+    for r in two_ranks:
+        assert (r["iqn_after"]["iqn"] == mean).all()
+        assert (r["iqn_after"]["iqn_tgt"] == r["iqn_before"]["iqn_tgt"]).all() and (r["iqn_after"]["exp_avg"] == r["iqn_before"]["exp_avg"]).all()
+
+
+@needs_two
+def test_async_trainers_on_two_ranks_average_at_every_sync_point_and_end_identical(two_ranks):
+    s0, s1 = two_ranks[0]["async_stat"], two_ranks[1]["async_stat"]
+    assert s0 == s1 and s0[0] == 7 and s0[2] == [0, 3, 6, 7] and s0[1] == 4       # same sync points on both ranks (agree + exchange at each)
+    assert (two_ranks[0]["async_qnet"] == two_ranks[1]["async_qnet"]).all()        # the run ends with a sync: averaged learners

@@ -21,7 +21,7 @@ constexpr int L1_SPLIT = BDR_L1_SPLIT;   // split-K of the 3136-deep l1 contract
 constexpr float INV255 = 1.0f / 255.0f;
 
 // ---- flat parameter arena (internal layouts; every segment 16-byte aligned) ----------------------
-//   W1 [256][32]  k=(c,kh,kw)      b1[32]
+//   W1 [64 * n_stack][32]  k=(c,kh,kw)      b1[32]      (n_stack = 4: [256][32])
 //   W2 [512][64]  k=(kh,kw,c)      b2[64]
 //   W3 [576][64]  k=(kh,kw,c)      b3[64]
 //   W4 [3136][512] k=(h,w,c)       b4[512]      (NHWC flatten of conv3's output)
@@ -29,13 +29,16 @@ constexpr float INV255 = 1.0f / 255.0f;
 struct Arena {
     size_t w1, b1, w2, b2, w3, b3, w4, b4, w5, b5, total;  // offsets in floats
     int A;
+    int ns;        // AtariCnnConfig::n_stack (cnn/config.rs:14-24): conv1 has 64 * ns rows
+    size_t n_w1() const { return (size_t)64 * ns * 32; }
 };
-Arena make_arena(int A)
+Arena make_arena(int A, int ns = 4)
 {
     Arena a{};
     size_t o = 0;
     auto seg = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
-    a.w1 = seg(256 * 32); a.b1 = seg(32);
+    a.ns = ns;
+    a.w1 = seg((size_t)64 * ns * 32); a.b1 = seg(32);
     a.w2 = seg(512 * 64); a.b2 = seg(64);
     a.w3 = seg(576 * 64); a.b3 = seg(64);
     a.w4 = seg((size_t)3136 * 512); a.b4 = seg(512);
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials3(Reduce3Args a)
 
 // chunk counts of the weight-gradient reductions (rows M split across workgroups)
 struct DwPlan { int chunks_c1, chunks_c2, chunks_c3; size_t stride_c1, stride_c2, stride_c3, off_c1, off_c2, off_c3, total; };
-DwPlan dw_plan(int B)
+DwPlan dw_plan(int B, int ns = 4)
 {
     DwPlan p{};
     auto mt = [](int M) { return (M + 31) / 32; };
@@ -462,7 +465,7 @@ DwPlan dw_plan(int B)
             if (c3 > 0) p.chunks_c3 = std::min(p.chunks_c3, c3);
         }
     }
-    p.stride_c1 = 256 * 32 + 32; p.stride_c2 = 512 * 64 + 64; p.stride_c3 = 576 * 64 + 64;
+    p.stride_c1 = (size_t)64 * ns * 32 + 32; p.stride_c2 = 512 * 64 + 64; p.stride_c3 = 576 * 64 + 64;
     p.off_c1 = 0;
     p.off_c2 = p.off_c1 + p.chunks_c1 * p.stride_c1;
     p.off_c3 = p.off_c2 + p.chunks_c2 * p.stride_c2;

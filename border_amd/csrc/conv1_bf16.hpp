@@ -23,11 +23,12 @@ namespace bdr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int C1_PLANE_VECS = 16 * 2 * 32;   // uint4 per plane: [s][h][n] x 8 bf16
+constexpr int C1_MAX_STACK = 8;   // AtariCnnConfig::n_stack values the conv1 kernels are instantiated for: 1 ... 8 (cnn/config.rs:14-24; 4 in every example)
+constexpr int c1_plane_vecs(int ns) { return 4 * ns * 2 * 32; }   // uint4 per plane: [s][h][n] x 8 bf16, s = 4 * n_stack k-steps of 16
 
 struct Conv1Args {
-    const uint8_t* x[3];     // [B][4][84][84] u8
-    const float* w1[3];      // [256][32] f32, k=(c,kh,kw)
+    const uint8_t* x[3];     // [B][n_stack][84][84] u8
+    const float* w1[3];      // [64 * n_stack][32] f32, k=(c,kh,kw)
     const float* bias[3];
     float* out[3];           // [M][32] f32 (NHWC)
     int M;                   // B*400
@@ -53,9 +54,12 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint32_t lo, uint32_t hi)
 // instance b % nz.  Prologue: split the instance's f32 weights into the three bf16 planes directly
 // into LDS (each thread 2 fragments of 8 k).  Then every wave walks 32-pixel items with stride G*8;
 // the next item's pixels are prefetched into registers, no barrier inside the item loop.
-static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
+// NS = n_stack (input channels): K = 64 * NS, 4 * NS k-steps of 16.
+template <int NS>
+static __global__ __launch_bounds__(512, NS <= 4 ? 4 : 2) void k_conv1_bf16(Conv1Args a)
 {
-    __shared__ uint4 wl[3 * C1_PLANE_VECS];   // 48 KiB: three bf16 weight planes in B-fragment order
+    constexpr int C1_PLANE_VECS = c1_plane_vecs(NS), KS = 4 * NS;
+    __shared__ uint4 wl[3 * C1_PLANE_VECS];   // 12 KiB x n_stack: three bf16 weight planes in B-fragment order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.x % a.nz, wg = blockIdx.x / a.nz, nwg = gridDim.x / a.nz;
     const int i = lane & 31, h = lane >> 5;
@@ -63,21 +67,21 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
     const uint8_t* x = a.x[z];
 
     // gather of one item: 16 patch rows of 8 pixels per lane (lane = pixel i, row parity h)
-    auto load_item = [&](int item, uint2 (&r)[16]) {
+    auto load_item = [&](int item, uint2 (&r)[KS]) {
         int m = item * 32 + i;
         m = m < a.M ? m : a.M - 1;
         const int b = m / 400, rem = m - b * 400;
         const int oh = rem / 20, ow = rem - oh * 20;
-        const uint8_t* p = x + (size_t)b * 28224 + (oh * 4 + h) * 84 + ow * 4;
+        const uint8_t* p = x + (size_t)b * (NS * 7056) + (oh * 4 + h) * 84 + ow * 4;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const uint32_t* q = reinterpret_cast<const uint32_t*>(p + (s >> 2) * 7056 + ((s & 3) * 2) * 84);
             r[s] = uint2{q[0], q[1]};
         }
     };
 
     // first item's pixels are in flight while the weights are split
-    uint2 nxt[16];
+    uint2 nxt[KS];
     int item = wg * 8 + wave;
     if (item < items) load_item(item, nxt);
     {
@@ -106,9 +110,9 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
     asm volatile("" ::"v"(bias));   // land the bias load here: otherwise the epilogue's first store waits vmcnt(0), i.e. for the NEXT item's pixel loads
 
     for (; item < items; item += stride) {
-        uint2 cur[16];
+        uint2 cur[KS];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) cur[s] = nxt[s];
+        for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
         if (item + stride < items) load_item(item + stride, nxt);   // next item in flight during the MFMAs
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
@@ -120,8 +124,8 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bq[pl] = wl[pl * C1_PLANE_VECS + h * 32 + i];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            if (s + 1 < 16) {
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bn[pl] = wl[pl * C1_PLANE_VECS + ((s + 1) * 2 + h) * 32 + i];
             }
@@ -153,6 +157,18 @@ static __global__ __launch_bounds__(512, 4) void k_conv1_bf16(Conv1Args a)
             }
         }
     }
+}
+
+// the instantiation for a run-time n_stack
+inline hipError_t launch_conv1_bf16(int ns, dim3 grid, hipStream_t st, const Conv1Args& c)
+{
+    switch (ns) {
+#define BDR_C1_CASE(N) case N: hipLaunchKernelGGL(k_conv1_bf16<N>, grid, dim3(512), 0, st, c); break;
+        BDR_C1_CASE(1) BDR_C1_CASE(2) BDR_C1_CASE(3) BDR_C1_CASE(4) BDR_C1_CASE(5) BDR_C1_CASE(6) BDR_C1_CASE(7) BDR_C1_CASE(8)
+#undef BDR_C1_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 }  // namespace bdr

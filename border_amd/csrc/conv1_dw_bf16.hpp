@@ -22,10 +22,10 @@
 namespace bdr {
 
 struct Conv1DwArgs {
-    const uint8_t* x;     // [B][4][84][84] u8
+    const uint8_t* x;     // [B][n_stack][84][84] u8
     const float* dy;      // [B*400][32] f32
     float* part;          // [gridDim.x][part_stride]
-    size_t part_stride;   // floats (256*32 + 32)
+    size_t part_stride;   // floats (64*n_stack*32 + 32)
     int B;
 };
 
@@ -48,40 +48,54 @@ __device__ unsigned long long* g_c1dw_trace;
 #define C1DW_TP(slot) do { } while (0)
 #endif
 
+// NS = n_stack.  The 2 * NS (input channel, kh half) row tiles of the image are dealt to the 8 waves: one each for NS = 4 (the
+// reference's examples), TPW = 2 per wave for NS = 5 ... 8, idle waves (they still split dY and meet the barriers) below 4.
+template <int NS>
 static __global__ __launch_bounds__(512) void k_conv1_dw_bf16(Conv1DwArgs a)
 {
     C1DW_TP(0);
+    constexpr int TASKS = 2 * NS, TPW = (TASKS + 7) / 8;
     __shared__ __attribute__((aligned(16))) uint16_t planes[3 * 32 * C1DW_LDM];   // 78 336 B
     __shared__ float sred[16][32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = wave >> 1, tile = wave & 1;                     // wave = (input channel, kh half): one 32-row tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
     const int pn = tid & 31, pmg = tid >> 5;                      // prologue role: column n, quad group (16 groups)
 
-    f32x16 acc;
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
 
-    // per-lane A geometry: kh = 4*tile + i/8, kw = i%8
+    // per-lane A geometry of task t = wave + 8 * j -> (input channel c = t / 2, kh half tile = t % 2): kh = 4*tile + i/8, kw = i%8
     const uint32_t sh = 8u * (uint32_t)(i & 3);
-    const int rowoff = (4 * tile + (i >> 3)) * 84 + (i & 4);
+    int c_of[TPW], rowoff[TPW]; bool live[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int task = wave + 8 * t;
+        live[t] = task < TASKS;
+        c_of[t] = (live[t] ? task : 0) >> 1;
+        rowoff[t] = (4 * (task & 1) + (i >> 3)) * 84 + (i & 4);
+    }
 
     for (int img = blockIdx.x; img < a.B; img += gridDim.x) {
-        const uint8_t* xc = a.x + (size_t)img * 28224 + c * 7056;
-        auto load_step = [&](int s, U32x4A4 (&d)[2]) {   // step s: quads 4s + 2g, 4s + 2g + 1
+        const uint8_t* ximg = a.x + (size_t)img * (NS * 7056);
+        auto load_step = [&](int t, int s, U32x4A4 (&d)[2]) {   // step s: quads 4s + 2g, 4s + 2g + 1
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int quad = 4 * s + 2 * g + q;
                 const int oh = quad / 5, ow0 = 4 * (quad - 5 * oh);
-                d[q] = *reinterpret_cast<const U32x4A4*>(xc + (4 * oh) * 84 + 4 * ow0 + rowoff);
+                d[q] = *reinterpret_cast<const U32x4A4*>(ximg + c_of[t] * 7056 + (4 * oh) * 84 + 4 * ow0 + rowoff[t]);
             }
         };
         // pixel fragments run C1DW_PF k-steps ahead of the MFMAs through a register ring (a step is ~0.15 us of
         // matrix work, an L2 hit is longer); the first ones are in flight while dY is split
-        U32x4A4 ring[C1DW_PF + 1][2];
+        U32x4A4 ring[TPW][C1DW_PF + 1][2];
 #pragma unroll
-        for (int s0 = 0; s0 < C1DW_PF; ++s0) load_step(s0, ring[s0]);
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int s0 = 0; s0 < C1DW_PF; ++s0) load_step(t, s0, ring[t][s0]);
 
         // ---- dY block of this image -> three k-major bf16 planes; bias partial sums
         {
@@ -118,21 +132,24 @@ static __global__ __launch_bounds__(512) void k_conv1_dw_bf16(Conv1DwArgs a)
         // ---- 25 k-steps of 16 positions
 #pragma unroll
         for (int s = 0; s < 25; ++s) {
-            U32x4A4 (&cur)[2] = ring[s % (C1DW_PF + 1)];
-            if (s + C1DW_PF < 25) load_step(s + C1DW_PF, ring[(s + C1DW_PF) % (C1DW_PF + 1)]);
             uint4 bq[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
                 bq[pl] = *reinterpret_cast<const uint4*>(&planes[(pl * 32 + i) * C1DW_LDM + 16 * s + 8 * g]);
-            uint4 av;
-            av.x = u8pair_to_bf16(cur[0].x, cur[0].y, sh);
-            av.y = u8pair_to_bf16(cur[0].z, cur[0].w, sh);
-            av.z = u8pair_to_bf16(cur[1].x, cur[1].y, sh);
-            av.w = u8pair_to_bf16(cur[1].z, cur[1].w, sh);
-            const bf16x8 af = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
-            for (int pl = 2; pl >= 0; --pl)   // small terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bq[pl]), acc, 0, 0, 0);
+            for (int t = 0; t < TPW; ++t) {
+                U32x4A4 (&cur)[2] = ring[t][s % (C1DW_PF + 1)];
+                if (s + C1DW_PF < 25) load_step(t, s + C1DW_PF, ring[t][(s + C1DW_PF) % (C1DW_PF + 1)]);
+                uint4 av;
+                av.x = u8pair_to_bf16(cur[0].x, cur[0].y, sh);
+                av.y = u8pair_to_bf16(cur[0].z, cur[0].w, sh);
+                av.z = u8pair_to_bf16(cur[1].x, cur[1].y, sh);
+                av.w = u8pair_to_bf16(cur[1].z, cur[1].w, sh);
+                const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)   // small terms first
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bq[pl]), acc[t], 0, 0, 0);
+            }
         }
         C1DW_TP(2);
         __syncthreads();   // planes / sred are rewritten by the next image
@@ -140,12 +157,28 @@ static __global__ __launch_bounds__(512) void k_conv1_dw_bf16(Conv1DwArgs a)
 
     float* part = a.part + (size_t)blockIdx.x * a.part_stride;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
-        part[(size_t)(c * 64 + tile * 32 + row) * 32 + i] = acc[r];
+    for (int t = 0; t < TPW; ++t) {
+        if (!live[t]) continue;   // (wave-uniform)
+        const int task = wave + 8 * t;                            // rows [32 * task, 32 * task + 32) = (c * 64 + tile * 32 + row)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+            part[(size_t)(task * 32 + row) * 32 + i] = acc[t][r];
+        }
     }
-    if (tid < 32) part[256 * 32 + tid] = bsum;
+    if (tid < 32) part[64 * NS * 32 + tid] = bsum;
     C1DW_TP(3);
+}
+
+inline hipError_t launch_conv1_dw_bf16(int ns, dim3 grid, hipStream_t st, const Conv1DwArgs& d)
+{
+    switch (ns) {
+#define BDR_C1DW_CASE(N) case N: hipLaunchKernelGGL(k_conv1_dw_bf16<N>, grid, dim3(512), 0, st, d); break;
+        BDR_C1DW_CASE(1) BDR_C1DW_CASE(2) BDR_C1DW_CASE(3) BDR_C1DW_CASE(4) BDR_C1DW_CASE(5) BDR_C1DW_CASE(6) BDR_C1DW_CASE(7) BDR_C1DW_CASE(8)
+#undef BDR_C1DW_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 }  // namespace bdr

@@ -447,7 +447,7 @@ int32_t ensure_batch(DqnCnn* a, int B)
     BDR_TRY(alloc_f(&a->dy1, (size_t)B * 400 * 32));
     BDR_TRY(alloc_f(&a->dq, B)); BDR_TRY(alloc_f(&a->pred, B)); BDR_TRY(alloc_f(&a->tgt, B));
     BDR_TRY(alloc_f(&a->loss_row, B));
-    const DwPlan p = dw_plan(B);
+    const DwPlan p = dw_plan(B, a->ar.ns);
     BDR_TRY(alloc_f(&a->part, p.total));
     a->part_floats = p.total;
     a->B = B;
@@ -587,8 +587,7 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         const int items = (c.M + 31) / 32;
         const int g = std::max(1, std::min(512 / nz, (items + 7) / 8));
         Bracket br(a, "fwd_conv1");
-        hipLaunchKernelGGL(k_conv1_bf16, dim3(g * nz), dim3(512), 0, st, c);
-        BDR_HIP(hipGetLastError());
+        BDR_HIP(launch_conv1_bf16(ar.ns, dim3(g * nz), st, c));
     }
     f.M = B * 81;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a1[inst[z].slot]; f.w[z] = inst[z].params + ar.w2; f.bias[z] = inst[z].params + ar.b2; f.out[z] = a->a2[inst[z].slot]; }
@@ -746,7 +745,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         BDR_HIP(hipStreamWaitEvent(a->side, a->ev_fork[k], 0));
         return BDR_OK;
     };
-    const DwPlan pl = dw_plan(a->B);   // buffer layout follows the allocated batch capacity
+    const DwPlan pl = dw_plan(a->B, ar.ns);   // buffer layout follows the allocated batch capacity
     const bool defer = a->defer_adam;  // backward only: the optimizer step is apply_grads()
     if (!defer) a->adam_step += 1;
     const AdamScalars adam_s = adam_scalars(c, std::max<uint64_t>(a->adam_step, 1));
@@ -814,8 +813,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         const int chunks = std::min(pl.chunks_c1, B);
         Conv1DwArgs d{obs, a->dy1, a->part + pl.off_c1, pl.stride_c1, B};
         Bracket br(a, "bwd_conv1_dw");
-        hipLaunchKernelGGL(k_conv1_dw_bf16, dim3(chunks), dim3(512), 0, a->stream, d);
-        BDR_HIP(hipGetLastError());
+        BDR_HIP(launch_conv1_dw_bf16(ar.ns, dim3(chunks), a->stream, d));
         return BDR_OK;
     };
 
@@ -882,7 +880,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         const int plc[3] = {pl.chunks_c1, pl.chunks_c2, pl.chunks_c3};
         const size_t offs[3] = {pl.off_c1, pl.off_c2, pl.off_c3}, strides[3] = {pl.stride_c1, pl.stride_c2, pl.stride_c3};
         const size_t gw[3] = {ar.w1, ar.w2, ar.w3};
-        const int nw[3] = {256 * 32, 512 * 64, 576 * 64}, nb[3] = {32, 64, 64};
+        const int nw[3] = {(int)ar.n_w1(), 512 * 64, 576 * 64}, nb[3] = {32, 64, 64};
         int wg = 0;
         for (int k = 0; k < 3; ++k) {
             const int nchunks = k == 0 ? std::min(plc[0], B) : std::min(plc[k], (Ms[k] + 31) / 32);   // conv1: one partial per workgroup
@@ -1036,16 +1034,17 @@ int32_t fill_record(DqnCnn* a, int B, const float* reward_dev, bdr_dqn_record* r
 }
 
 // ---- reference <-> internal parameter layouts ------------------------------------------------------
-// reference order: c1.weight[32][4][8][8] c1.bias c2.weight[64][32][4][4] c2.bias c3.weight[64][64][3][3]
+// reference order: c1.weight[32][n_stack][8][8] c1.bias c2.weight[64][32][4][4] c2.bias c3.weight[64][64][3][3]
 // c3.bias l1.weight[512][3136 (c,h,w)] l1.bias l2.weight[A][512] l2.bias   (cnn/base.rs:23-36)
-size_t ref_param_count(int A) { return 8192 + 32 + 32768 + 64 + 36864 + 64 + (size_t)512 * 3136 + 512 + (size_t)A * 512 + A; }
+size_t ref_param_count(int A, int ns) { return (size_t)2048 * ns + 32 + 32768 + 64 + 36864 + 64 + (size_t)512 * 3136 + 512 + (size_t)A * 512 + A; }
 
 void to_internal(const Arena& ar, const float* ref, float* in)
 {
     std::fill(in, in + ar.total, 0.f);
     const float* p = ref;
-    for (int o = 0; o < 32; ++o) for (int k = 0; k < 256; ++k) in[ar.w1 + (size_t)k * 32 + o] = p[(size_t)o * 256 + k];
-    p += 8192; std::copy(p, p + 32, in + ar.b1); p += 32;
+    const int K1 = 64 * ar.ns;   // (c, kh, kw) of c1.weight[o] is the internal k order
+    for (int o = 0; o < 32; ++o) for (int k = 0; k < K1; ++k) in[ar.w1 + (size_t)k * 32 + o] = p[(size_t)o * K1 + k];
+    p += (size_t)32 * K1; std::copy(p, p + 32, in + ar.b1); p += 32;
     for (int o = 0; o < 64; ++o) for (int c = 0; c < 32; ++c) for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw)
         in[ar.w2 + (size_t)((kh * 4 + kw) * 32 + c) * 64 + o] = p[((size_t)(o * 32 + c) * 4 + kh) * 4 + kw];
     p += 32768; std::copy(p, p + 64, in + ar.b2); p += 64;
@@ -1062,8 +1061,9 @@ void to_internal(const Arena& ar, const float* ref, float* in)
 void to_reference(const Arena& ar, const float* in, float* ref)
 {
     float* p = ref;
-    for (int o = 0; o < 32; ++o) for (int k = 0; k < 256; ++k) p[(size_t)o * 256 + k] = in[ar.w1 + (size_t)k * 32 + o];
-    p += 8192; std::copy(in + ar.b1, in + ar.b1 + 32, p); p += 32;
+    const int K1 = 64 * ar.ns;
+    for (int o = 0; o < 32; ++o) for (int k = 0; k < K1; ++k) p[(size_t)o * K1 + k] = in[ar.w1 + (size_t)k * 32 + o];
+    p += (size_t)32 * K1; std::copy(in + ar.b1, in + ar.b1 + 32, p); p += 32;
     for (int o = 0; o < 64; ++o) for (int c = 0; c < 32; ++c) for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw)
         p[((size_t)(o * 32 + c) * 4 + kh) * 4 + kw] = in[ar.w2 + (size_t)((kh * 4 + kw) * 32 + c) * 64 + o];
     p += 32768; std::copy(in + ar.b2, in + ar.b2 + 64, p); p += 64;
@@ -1088,11 +1088,11 @@ float* arena_ptr(DqnCnn* a, int which)
 
 // the library's own initialiser: uniform(+-1/sqrt(fan_in)) from splitmix64 (init scheme is irrelevant to
 // parity: tests inject weights through bdr_agent_set_params)
-void init_reference_params(int A, uint64_t seed, std::vector<float>& ref)
+void init_reference_params(int A, int ns, uint64_t seed, std::vector<float>& ref)
 {
-    ref.resize(ref_param_count(A));
-    const size_t sizes[10] = {8192, 32, 32768, 64, 36864, 64, (size_t)512 * 3136, 512, (size_t)A * 512, (size_t)A};
-    const int fan[10] = {256, 256, 512, 512, 576, 576, 3136, 3136, 512, 512};
+    ref.resize(ref_param_count(A, ns));
+    const size_t sizes[10] = {(size_t)2048 * ns, 32, 32768, 64, 36864, 64, (size_t)512 * 3136, 512, (size_t)A * 512, (size_t)A};
+    const int fan[10] = {64 * ns, 64 * ns, 512, 512, 576, 576, 3136, 3136, 512, 512};
     uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
     size_t o = 0;
     for (int t = 0; t < 10; ++t) {
@@ -1214,7 +1214,7 @@ int32_t DqnCnn::apply_grads()
     return after_updates(this);
 }
 
-static std::vector<NamedTensor> cnn_meta(int A);
+static std::vector<NamedTensor> cnn_meta(int A, int ns);
 
 // Agent::opt_with_record (dqn/base.rs:316-342): "loss"; with record_verbose_level >= 2 also pred_mean, reward_mean, tgt_mean,
 // tgt_minus_pred_mean (update_critic :107-121), then - only from opt_with_record - qnet.param_stats() (`<var>_mean`,
@@ -1228,9 +1228,9 @@ int32_t DqnCnn::record(float* out, int cap, int* n)
     if (rec.has_verbose) {
         v.insert(v.end(), {rec.pred_mean, rec.reward_mean, rec.tgt_mean, rec.tgt_minus_pred_mean});
         if (rec_opt) {
-            std::vector<float> ref(ref_param_count(ar.A));
+            std::vector<float> ref(ref_param_count(ar.A, ar.ns));
             BDR_TRY(get_params(0, ref.data(), ref.size()));
-            param_stats(cnn_meta(ar.A), ref.data(), v);
+            param_stats(cnn_meta(ar.A, ar.ns), ref.data(), v);
             v.push_back(n_samples_act == 0 ? 0.f : (float)n_samples_best_act / (float)n_samples_act);
             n_samples_act = 0; n_samples_best_act = 0;
         }
@@ -1245,20 +1245,20 @@ void DqnCnn::record_keys(std::vector<std::string>& keys)
     keys = {"loss"};
     if (cfg.record_verbose_level >= 2) {
         keys.insert(keys.end(), {"pred_mean", "reward_mean", "tgt_mean", "tgt_minus_pred_mean"});
-        param_stat_keys(cnn_meta(ar.A), keys);
+        param_stat_keys(cnn_meta(ar.A, ar.ns), keys);
         keys.push_back("ratio_best_act");
     }
 }
 
-uint64_t DqnCnn::param_count(int which) { return which == -1 ? (uint64_t)ar.A : ref_param_count(ar.A); }
+uint64_t DqnCnn::param_count(int which) { return which == -1 ? (uint64_t)ar.A : ref_param_count(ar.A, ar.ns); }
 
 int32_t DqnCnn::get_params(int which, float* out, uint64_t n)
 {
     BDR_TRY(join_exchange(true, true));
     float* src = arena_ptr(this, which);
     BDR_REQUIRE(src, "which must be 0..4");
-    BDR_REQUIRE(n == ref_param_count(ar.A), "parameter count mismatch (%llu vs %llu)", (unsigned long long)n,
-                (unsigned long long)ref_param_count(ar.A));
+    BDR_REQUIRE(n == ref_param_count(ar.A, ar.ns), "parameter count mismatch (%llu vs %llu)", (unsigned long long)n,
+                (unsigned long long)ref_param_count(ar.A, ar.ns));
     std::vector<float> in(ar.total);
     BDR_HIP(hipMemcpyAsync(in.data(), src, ar.total * 4, hipMemcpyDeviceToHost, stream));
     BDR_HIP(hipStreamSynchronize(stream));
@@ -1271,7 +1271,7 @@ int32_t DqnCnn::set_params(int which, const float* inp, uint64_t n)
     BDR_TRY(join_exchange(true, true));
     float* dst = arena_ptr(this, which);
     BDR_REQUIRE(dst, "which must be 0..4");
-    BDR_REQUIRE(n == ref_param_count(ar.A), "parameter count mismatch");
+    BDR_REQUIRE(n == ref_param_count(ar.A, ar.ns), "parameter count mismatch");
     std::vector<float> in(ar.total);
     to_internal(ar, inp, in.data());
     BDR_HIP(hipMemcpyAsync(dst, in.data(), ar.total * 4, hipMemcpyHostToDevice, stream));
@@ -1286,9 +1286,9 @@ float* DqnCnn::arena(int which, size_t* n)
     return arena_ptr(this, which);
 }
 
-static std::vector<NamedTensor> cnn_meta(int A)
+static std::vector<NamedTensor> cnn_meta(int A, int ns)
 {
-    return {{"c1.weight", {32, 4, 8, 8}}, {"c1.bias", {32}}, {"c2.weight", {64, 32, 4, 4}}, {"c2.bias", {64}},
+    return {{"c1.weight", {32, (uint64_t)ns, 8, 8}}, {"c1.bias", {32}}, {"c2.weight", {64, 32, 4, 4}}, {"c2.bias", {64}},
             {"c3.weight", {64, 64, 3, 3}}, {"c3.bias", {64}}, {"l1.weight", {512, 3136}}, {"l1.bias", {512}},
             {"l2.weight", {(uint64_t)A, 512}}, {"l2.bias", {(uint64_t)A}}};
 }
@@ -1296,30 +1296,31 @@ static std::vector<NamedTensor> cnn_meta(int A)
 int32_t DqnCnn::save(const char* dir)
 {
     // dqn/base.rs:348-356: qnet.pt.tch, qnet_tgt.pt.tch
-    std::vector<float> ref(ref_param_count(ar.A));
+    std::vector<float> ref(ref_param_count(ar.A, ar.ns));
     BDR_TRY(get_params(0, ref.data(), ref.size()));
-    BDR_TRY(save_named(ckpt_save_path(this, dir, "qnet"), cnn_meta(ar.A), ref.data(), ref.size()));
+    BDR_TRY(save_named(ckpt_save_path(this, dir, "qnet"), cnn_meta(ar.A, ar.ns), ref.data(), ref.size()));
     BDR_TRY(get_params(1, ref.data(), ref.size()));
-    return save_named(ckpt_save_path(this, dir, "qnet_tgt"), cnn_meta(ar.A), ref.data(), ref.size());
+    return save_named(ckpt_save_path(this, dir, "qnet_tgt"), cnn_meta(ar.A, ar.ns), ref.data(), ref.size());
 }
 
 int32_t DqnCnn::load(const char* dir)
 {
-    std::vector<float> ref(ref_param_count(ar.A));
-    BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet"), cnn_meta(ar.A), ref.data(), ref.size()));
+    std::vector<float> ref(ref_param_count(ar.A, ar.ns));
+    BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet"), cnn_meta(ar.A, ar.ns), ref.data(), ref.size()));
     BDR_TRY(set_params(0, ref.data(), ref.size()));
-    BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet_tgt"), cnn_meta(ar.A), ref.data(), ref.size()));
+    BDR_TRY(load_named(ckpt_load_path(this, dir, "qnet_tgt"), cnn_meta(ar.A, ar.ns), ref.data(), ref.size()));
     return set_params(1, ref.data(), ref.size());
 }
 
 namespace bdr {
 int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
 {
-    BDR_REQUIRE(cfg->net.n_stack == 4, "AtariCnn kernels are specialised for n_stack = 4");
+    BDR_REQUIRE(cfg->net.n_stack >= 1 && cfg->net.n_stack <= bdr::C1_MAX_STACK, "AtariCnnConfig::n_stack must be in [1, %d] (conv1's kernels are instantiated "
+                "for these; the reference's examples use 4)", bdr::C1_MAX_STACK);
     BDR_REQUIRE(cfg->net.out_dim >= 1 && cfg->net.out_dim <= 64, "out_dim must be in [1,64]");
     DqnCnn* a = new DqnCnn();
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
-    a->ar = make_arena(cfg->net.out_dim);
+    a->ar = make_arena(cfg->net.out_dim, cfg->net.n_stack);
     BDR_HIP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     BDR_HIP(hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking));
     for (auto& e : a->ev_fork) BDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -1347,7 +1348,7 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     if (a->amsgrad) { BDR_TRY(alloc_f(&a->vmax, a->ar.total)); BDR_HIP(hipMemsetAsync(a->vmax, 0, a->ar.total * 4, a->stream)); }
     BDR_TRY(alloc_f(&a->loss, 4));
     std::vector<float> ref, in(a->ar.total);
-    init_reference_params(a->ar.A, cfg->param_seed, ref);
+    init_reference_params(a->ar.A, a->ar.ns, cfg->param_seed, ref);
     to_internal(a->ar, ref.data(), in.data());
     BDR_HIP(hipMemcpyAsync(a->q, in.data(), a->ar.total * 4, hipMemcpyHostToDevice, a->stream));
     BDR_HIP(hipMemcpyAsync(a->q_tgt, in.data(), a->ar.total * 4, hipMemcpyHostToDevice, a->stream));  // DqnModel::clone

@@ -232,7 +232,7 @@ struct Iqn : bdr_agent {
             Conv1Args c{}; c.M = Bn * 400; c.nz = 1;
             c.x[0] = obs; c.w1[0] = params + conv.w1; c.bias[0] = params + conv.b1; c.out[0] = a1;
             const int items = (c.M + 31) / 32, g = std::max(1, std::min(512, (items + 7) / 8));
-            { Bracket br(a, "psi_conv1"); hipLaunchKernelGGL(k_conv1_bf16, dim3(g), dim3(512), 0, stream, c); BDR_HIP(hipGetLastError()); }
+            { Bracket br(a, "psi_conv1"); BDR_HIP(launch_conv1_bf16(4, dim3(g), stream, c)); }
             FwdArgs f{};
             f.M = Bn * 81; f.x[0] = a1; f.w[0] = params + conv.w2; f.bias[0] = params + conv.b2; f.out[0] = a2;
             { Bracket br(a, "psi_conv2"); LAUNCH(k_igemm<FwdC2>, dim3((f.M + 63) / 64, 1, 1), f); }
@@ -345,7 +345,7 @@ struct Iqn : bdr_agent {
             {
                 const int chunks = std::min(pl.chunks_c1, Bn);
                 Conv1DwArgs d{obs, dy1, part_conv + pl.off_c1, pl.stride_c1, Bn};
-                { Bracket br(a, "psi_conv1_dw"); hipLaunchKernelGGL(k_conv1_dw_bf16, dim3(chunks), dim3(512), 0, a->stream, d); BDR_HIP(hipGetLastError()); }
+                { Bracket br(a, "psi_conv1_dw"); BDR_HIP(launch_conv1_dw_bf16(4, dim3(chunks), a->stream, d)); }
                 const int n = 256 * 32 + 32;
                 hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, stream, part_conv + pl.off_c1, pl.stride_c1, chunks, grad + conv.w1, n, 256 * 32, INV255);
                 BDR_HIP(hipGetLastError());
@@ -603,7 +603,7 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     a->F = cfg->feature_dim; a->E = cfg->embed_dim; a->A = cfg->n_actions;
     size_t o = 0;
     if (a->cnn) {
-        BDR_REQUIRE(cfg->feature_dim == 3136 && cfg->psi.n_stack == 4, "AtariCnn{skip_linear} yields 3136 features (n_stack 4)");
+        BDR_REQUIRE(cfg->feature_dim == 3136 && cfg->psi.n_stack == 4, "the IQN agent's AtariCnn{skip_linear} trunk is built for n_stack = 4 and yields 3136 features (the DQN agent takes n_stack 1 ... 8)");
         a->conv = make_arena(1);
         o = CONV_FLOATS; a->ref_total = CONV_FLOATS;
     } else {

@@ -541,6 +541,58 @@ def test_ragged_batch_sizes_vs_oracle(B, Bsz, ddqn, A):
     a.close()
 
 
+@pytest.mark.parametrize("ns,Bsz,A", [(1, 33, 6), (2, 40, 4), (3, 7, 9), (5, 36, 6), (8, 19, 18)])
+def test_other_frame_stack_depths_vs_oracle(B, ns, Bsz, A, tmp_path):
+    """AtariCnnConfig::n_stack is a parameter of the reference (cnn/config.rs:14-24, cnn/base.rs:27: conv2d(n_stack, 32, 8, stride 4));
+    rounds 1-3 only accepted 4.  conv1's K is 64 * n_stack: the bf16 forward kernel walks 4 * n_stack k-steps, the weight-gradient
+    kernel deals 2 * n_stack (channel, kh half) row tiles to its eight waves (idle waves below 4, two tiles per wave above).  One
+    update on a fixed minibatch, an opt over a replay buffer of n_stack-frame rows, and the checkpoint's c1.weight shape."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    shapes = T.cnn_shapes(A, ns)
+    p0 = T.init_params(shapes, 60 + ns)
+    rng = np.random.default_rng(70 + ns)
+    obs = rng.integers(0, 256, (Bsz, ns, 1, 84, 84), dtype=np.uint8); nobs = rng.integers(0, 256, (Bsz, ns, 1, 84, 84), dtype=np.uint8)
+    act = rng.integers(0, A, Bsz).astype(np.int64); rew = rng.standard_normal(Bsz).astype(np.float32); term = (rng.random(Bsz) < 0.1).astype(np.int8)
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=ns, out_dim=A), opt_config=B.OptimizerConfig.Adam(1e-4)),
+                      device=0, batch_size=Bsz, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, double_dqn=True)
+    a = B.Dqn.build(cfg)
+    assert a.param_count() == sum(int(np.prod(sh)) for sh in shapes)
+    a.set_params(p0, "qnet"); a.set_params(T.init_params(shapes, 61 + ns), "qnet_tgt")
+    assert (a.get_params("qnet") == p0).all()
+    ref = O.DqnOracle(O.cnn_cfg(A, ns), p0, lr=1e-4, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, double_dqn=True)
+    ref.q_tgt[:] = T.init_params(shapes, 61 + ns)
+    rec = a.update_on_batch(obs, act, nobs, rew, term)
+    r = ref.update(obs, act, nobs, rew, term, probe=True)
+    assert rel(a.probe("q_pred_all", Bsz * A), r["q_pred_all"].ravel()) < QTOL
+    assert rel(a.probe("pred", Bsz), r["pred"]) < QTOL and rel(a.probe("tgt", Bsz), r["tgt"]) < QTOL
+    assert abs(rec["loss"] - r["loss"]) <= QTOL * abs(r["loss"]) + 1e-9
+    assert_grads_close(a.get_params("grad"), r["grads"], shapes)
+    assert rel(a.qvalues(obs[:3]), O.net_forward(O.cnn_cfg(A, ns), a.get_params("qnet"), obs[:3])) < QTOL
+    # Agent::opt over a ring of n_stack-frame rows (the schedules with two queues), then the checkpoint
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=200, seed=42), (ns, 1, 84, 84), np.uint8)
+    rb.fill_synthetic(200, seed=3, kind=0, n_actions=A)
+    for _ in range(3):
+        a.opt(rb)
+    a.sync()
+    assert np.isfinite(a.get_params("qnet")).all() and a.n_opts == 4
+    a.save_params(str(tmp_path / "m"))
+    from border_amd import checkpoint as ck
+    names = [("c1.weight", (32, ns, 8, 8)), ("c1.bias", (32,)), ("c2.weight", (64, 32, 4, 4)), ("c2.bias", (64,)), ("c3.weight", (64, 64, 3, 3)),
+             ("c3.bias", (64,)), ("l1.weight", (512, 3136)), ("l1.bias", (512,)), ("l2.weight", (A, 512)), ("l2.bias", (A,))]
+    t = ck.read(str(tmp_path / "m" / "qnet.pt.tch"), names)                 # the reference's variable names, c1.weight [32][n_stack][8][8]
+    assert t["c1.weight"].shape == (32, ns, 8, 8)
+    assert (np.concatenate([t[n].ravel() for n, _ in names]) == a.get_params("qnet")).all()
+    b = B.Dqn.build(cfg)
+    b.load_params(str(tmp_path / "m"))
+    assert (b.get_params("qnet") == a.get_params("qnet")).all()
+    with pytest.raises(B.BdrError, match="do not match the AtariCnn input"):   # rows of another depth are refused, not misread
+        wrong = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=20, seed=1), (ns + 1, 1, 84, 84), np.uint8)
+        wrong.fill_synthetic(20, seed=1, kind=0, n_actions=A)
+        a.opt(wrong)
+    a.close(); b.close(); rb.close()
+
+
 def test_checkpoints_are_safetensors_with_reference_names(B, tmp_path):
     """save_params / load_params (dqn/base.rs:345-371) use the safetensors container tch's VarStore reads and writes
     for *.safetensors paths: the official `safetensors` package must read what the library wrote (reference variable

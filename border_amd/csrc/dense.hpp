@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "agent_base.hpp"
+#include "igemm_b3.hpp"
 
 namespace bdr {
 
@@ -185,6 +186,22 @@ struct DenseDx {
         *o = a.accum ? *o + v : v;
     }
 };
+
+// The same two layers on the bf16 matrix cores with split operands (igemm_b3.hpp: six of the nine exact bf16 partial products):
+// the weights come from pre-split bf16 planes [plane][ncols][kred] (k contiguous: W^T for the forward, W itself for dX).
+struct DenseB3Args : DenseArgs { const uint16_t* wpl; };
+template <class Base, int WM_, int WN_, int TM_, int TN_>
+struct DenseB3 : Base {
+    using Args = DenseB3Args;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int MAXW = TM_ * TN_ >= 4 ? 1 : 2;
+    __device__ static const uint4* b_chunk(const Args& a, int, int, int pl, int kt, int n, int kq)
+    {
+        return reinterpret_cast<const uint4*>(a.wpl + (size_t)pl * a.ncols * a.kred + (size_t)n * a.kred + kt * 32 + kq * 8);
+    }
+};
+using DenseFwdHadB3 = DenseB3<DenseFwdHad, 2, 2, 2, 2>;   // 128 x 128 tiles (ncols % 128 == 0)
+using DenseDxB3 = DenseB3<DenseDx, 2, 2, 2, 1>;           // 128 x 64 tiles  (ncols % 64 == 0)
 
 struct DenseDxZ : DenseDx {
     using Args = DenseArgsZ;
@@ -461,6 +478,34 @@ inline int32_t dense_forward_had(hipStream_t st, const DenseLayer& l, const floa
     d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
     d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np;
     BDR_HIP(launch_dense<DenseFwdHad>(st, dim3(((M + 63) / 64) * (l.Np / 64), 1, 1), d));
+    return BDR_OK;
+}
+
+// Split-operand forms of the two calls above (igemm_b3.hpp).  planes_tr / planes_nat: the layer's weights as three bf16 planes,
+// [plane][Np][Kp] and [plane][Kp][Np] (dense_split_planes).  Shapes: Np % 128 == 0 for the forward, Kp % 64 == 0 for dX.
+inline int32_t dense_split_planes(hipStream_t st, const DenseLayer& l, const float* params_base, uint16_t* planes_nat, uint16_t* planes_tr)
+{
+    hipLaunchKernelGGL(k_split_planes2, dim3((l.Np + 31) / 32, (l.Kp + 31) / 32), dim3(256), 0, st, params_base + l.w, l.Np, planes_nat, planes_tr, l.Kp, l.Np);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+inline int32_t dense_forward_had_b3(hipStream_t st, const DenseLayer& l, const float* params_base, const uint16_t* planes_tr, DenseSrc x, const float* had,
+                                    int had_ld, int had_group, float* out, int M)
+{
+    DenseB3Args d{};
+    d.x = x; d.xhad = had; d.xhad_ld = had_ld; d.xhad_group = had_group;
+    d.w = params_base + l.w; d.bias = params_base + l.b; d.out = out; d.ldo = l.Np;
+    d.M = M; d.ncols = l.Np; d.kred = l.Kp; d.relu = l.relu; d.w_ld = l.Np; d.wpl = planes_tr;
+    BDR_HIP((launch_igemm_b3<DenseFwdHadB3, 6>(st, dim3(((M + 127) / 128) * (l.Np / 128), 1, 1), d)));
+    return BDR_OK;
+}
+inline int32_t dense_dx_b3(hipStream_t st, const DenseLayer& l, const float* params_base, const uint16_t* planes_nat, const float* dy, float* dx,
+                           const float* mask, int M)
+{
+    DenseB3Args d{};
+    d.x = DenseSrc{dy, l.Np}; d.w = params_base + l.w; d.out = dx; d.ldo = l.Kp; d.mask = mask; d.ldm = l.Kp;
+    d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np; d.wpl = planes_nat;
+    BDR_HIP((launch_igemm_b3<DenseDxB3, 6>(st, dim3(((M + 127) / 128) * (l.Kp / 64), 1, 1), d)));
     return BDR_OK;
 }
 

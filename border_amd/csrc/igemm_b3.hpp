@@ -1,0 +1,326 @@
+// GEMM on the bf16 matrix cores with SPLIT f32 operands ("3 x bf16"), for the layers that ARE matrix-bound: IQN's
+// [B * N quantiles][3136] x [3136][512] forward and its input gradient at config C4 (M = 32 768 rows, 0.74-0.79 of the FP32-MFMA
+// peak with the exact kernel: csrc/iqn.hip).  The B = 256 conv layers of the DQN step are operand-delivery bound and gain nothing
+// from it (tools/probes/bp_probe.hip); they stay on the FP32 MFMA.
+//
+// Every f32 operand x is split exactly into three bf16 terms x = hi + mid + lo (8 + 8 + 8 significant bits, truncation
+// split), so a product a*b is the sum of nine exact bf16 x bf16 products.  TERMS = 9 keeps all of them: the MFMA then
+// only rounds in its f32 accumulation, the error class of the FP32 MFMA / an fmaf chain.  TERMS = 6 drops the three
+// products below 2^-24 |a||b| (mid*lo, lo*mid, lo*lo): measured 4e-6 relative on the C4 layer against the exact kernel
+// (the parity bar is 1e-4 on quantile values; tests/test_gpu_iqn.py holds both kernels to it and to each other).  v_mfma_f32_32x32x16_bf16 retires 16 k in 32 cycles, the FP32
+// v_mfma_f32_32x32x2_f32 2 k in 64: 9 terms cost 288 matrix cycles per 16 k instead of 512, 6 terms 192.
+//
+// Same contraction, policies and epilogue as k_igemm (igemm.hpp).  Differences:
+//  * both operands are k-major in LDS as three bf16 planes ([rows][32 k], row stride 80 B: conflict-free ds_read_b128
+//    fragments of 8 k);
+//  * A (activations / gradients, f32 in HBM) is split by the staging threads on its way into LDS;
+//  * B (weights) is read from pre-split bf16 planes in HBM (policy hook b_chunk), k-major: the forward wants [n][k] (the
+//    transpose of W[k][n]), the input gradient W's own [k][n] rows.  The planes are re-split from the f32 weights at the start
+//    of every update (k_split_planes: ~10 us against a 5 ms step), so no parameter writer has to keep them fresh;
+//  * an A operand that is a Hadamard product (ADenseHad: IQN's merge m = relu(phi) * psi(x)[b]) is multiplied before the split.
+#pragma once
+#include "igemm.hpp"
+
+namespace bdr {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // plain vector types keep the staging registers out of scratch
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int B3_LDR = 40;   // row stride of a bf16 plane tile in u16 units (32 k + 8 pad = 80 B)
+
+// exact 3-way split of four floats into packed bf16 pairs: p[plane] = {pair(x0,x1), pair(x2,x3)}
+__device__ __forceinline__ void split3_f32x4(const f32x4& x, u32x2_t (&p)[3])
+{
+    uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = __float_as_uint(x[j]) & 0xffff0000u;
+        const float r1 = x[j] - __uint_as_float(hi[j]);            // exact
+        mid[j] = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mid[j]);             // exact, <= 8 significant bits
+        lo[j] = __float_as_uint(r2) & 0xffff0000u;
+    }
+    p[0] = u32x2_t{(hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]};
+    p[1] = u32x2_t{(mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]};
+    p[2] = u32x2_t{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]};
+}
+
+// weights -> three bf16 planes in BOTH orders from one read of the f32 matrix src[R][C] (row stride ld): nat[plane][R][C] and
+// tr[plane][C][R] (either may be null).  32 x 32 tiles through LDS so that both writes are contiguous runs.
+static __global__ __launch_bounds__(256) void k_split_planes2(const float* __restrict__ src, int ld, uint16_t* __restrict__ nat, uint16_t* __restrict__ tr, int R, int C)
+{
+    __shared__ uint16_t t[3][32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+    const size_t n = (size_t)R * C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        const float x = (r < R && c < C) ? src[(size_t)r * ld + c] : 0.f;
+        const uint32_t hi = __float_as_uint(x) & 0xffff0000u;
+        const float r1 = x - __uint_as_float(hi);
+        const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mid);
+        const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
+        const uint16_t v[3] = {(uint16_t)(hi >> 16), (uint16_t)(mid >> 16), (uint16_t)(lo >> 16)};
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            t[pl][ty + 8 * j][tx] = v[pl];
+            if (nat && r < R && c < C) nat[pl * n + (size_t)r * C + c] = v[pl];
+        }
+    }
+    __syncthreads();
+    if (!tr) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;   // transposed: consecutive threads walk r
+        if (c < C && r < R)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) tr[pl * n + (size_t)c * R + r] = t[pl][tx][ty + 8 * j];
+    }
+}
+
+// (probe form) weights -> three bf16 planes, optionally transposed: src [R][C] f32 -> dst[plane][R][C] (T = 0) or dst[plane][C][R] (T = 1)
+static __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ src, uint16_t* __restrict__ dst, int R, int C, int T)
+{
+    const size_t n = (size_t)R * C;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = (int)(i / C), c = (int)(i % C);
+    const float x = src[i];
+    const uint32_t hi = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hi);
+    const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
+    const size_t o = T ? (size_t)c * R + r : i;
+    dst[o] = (uint16_t)(hi >> 16); dst[n + o] = (uint16_t)(mid >> 16); dst[2 * n + o] = (uint16_t)(lo >> 16);
+}
+
+// P: as for k_igemm, plus
+//   b_chunk(args, z, y, plane, kt, n, kq) -> const uint4*   the 8 bf16 (k = kt*32 + kq*8 ..) of B column n (global column index)
+//   P::MAXW   (optional, default 2) waves per SIMD the kernel is compiled for: 1 = 512 VGPRs for 128 x 128 tiles, 2 = 256
+template <class P, class = void> struct b3_maxw { static constexpr int value = 2; };
+template <class P> struct b3_maxw<P, std::void_t<decltype(P::MAXW)>> { static constexpr int value = P::MAXW; };
+template <class P, int TERMS = 9>
+__global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per_eu(1, b3_maxw<P>::value))) void k_igemm_b3(typename P::Args args)
+{
+    using A = typename P::A;
+    static_assert(A::VEC == 4, "f32 A operands");
+    static_assert(TERMS == 6 || TERMS == 9, "6 or 9 partial products");
+    constexpr int NW = P::WM * P::WN, NT = 64 * NW;
+    constexpr int BM = P::WM * P::TM * 32, BN = P::WN * P::TN * 32;
+    constexpr int APR = BK / 4;                               // f32x4 loads per A row
+    static_assert(NT % APR == 0, "a thread keeps its k-quad across passes");
+    constexpr int A_ELEMS = BM * APR, A_PASSES = (A_ELEMS + NT - 1) / NT;
+    constexpr int B_CH = BN * 4, B_PASSES = (B_CH + NT - 1) / NT;   // 16-byte chunks per plane
+    constexpr int PLANE_A = BM * B3_LDR, PLANE_B = BN * B3_LDR;      // u16
+    constexpr int STAGE = 3 * (PLANE_A + PLANE_B);                   // u16
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / P::WN, wn = wave % P::WN;
+    const int NT_N = P::N(args) / BN;
+    const int mt = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.z, y = blockIdx.y;
+    const int M = P::M(args);
+
+    const int a_q = tid % APR, a_r = tid / APR;
+    typename A::Row rows[A_PASSES];
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+        int mr;
+        const bool ok = P::vrow(args, m0 + p * (NT / APR) + a_r, mr);
+        rows[p] = A::row(P::a_src(args, z), ok ? mr : M, M);
+    }
+    int kt0, kt1;
+    P::kt_range(args, y, kt0, kt1);
+    const int nkt = kt1 - kt0;
+    auto tile = [&](int it) { return kt0 + min(it, nkt - 1); };
+
+    f32x4 ra[2][A_PASSES];
+    constexpr bool HAD = a_has_had<A>::value;
+    f32x4 rh[2][HAD ? A_PASSES : 1];   // second factor of a Hadamard A operand
+    u32x4_t rb[2][B_PASSES][3];
+    // The staging work of a k-tile is cut into per-pass slices (one 16-byte A chunk or one 3-plane B chunk per thread each) so that
+    // the k loop can place them BETWEEN groups of MFMAs: a wave issues in order, and a block of 24 back-to-back MFMAs keeps it stalled
+    // on the matrix pipe for ~700 cycles before the split's VALU work behind it could start (first version: 36 % of the bf16 peak).
+    auto prefetch_a = [&](auto set, int kt, int p) {
+        constexpr int S = decltype(set)::value;
+        if (A_ELEMS % NT == 0 || tid + p * NT < A_ELEMS) {
+            A::load(rows[p], kt, a_q, &ra[S][p]);
+            if constexpr (HAD) rh[S][p] = A::load_had(rows[p], kt, a_q);
+        }
+    };
+    auto prefetch_b = [&](auto set, int kt, int p) {
+        constexpr int S = decltype(set)::value;
+        const int e = tid + p * NT;
+        if (B_CH % NT != 0 && e >= B_CH) return;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rb[S][p][pl] = *reinterpret_cast<const u32x4_t*>(P::b_chunk(args, z, y, pl, kt, n0 + e / 4, e % 4));
+    };
+    auto commit_a = [&](auto set, int stage, int p) {
+        constexpr int S = decltype(set)::value;
+        uint16_t* As = smem + stage * STAGE;
+        if (A_ELEMS % NT != 0 && tid + p * NT >= A_ELEMS) return;
+        u32x2_t sp[3];
+        f32x4 av = ra[S][p];
+        if constexpr (HAD) av *= rh[S][p];
+        split3_f32x4(av, sp);
+        const int o = (p * (NT / APR) + a_r) * B3_LDR + a_q * 4;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2_t*>(&As[pl * PLANE_A + o]) = sp[pl];
+    };
+    auto commit_b = [&](auto set, int stage, int p) {
+        constexpr int S = decltype(set)::value;
+        uint16_t* Bs = smem + stage * STAGE + 3 * PLANE_A;
+        const int e = tid + p * NT;
+        if (B_CH % NT != 0 && e >= B_CH) return;
+        const int o = (e / 4) * B3_LDR + (e % 4) * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(&Bs[pl * PLANE_B + o]) = rb[S][p][pl];
+    };
+    auto prefetch = [&](auto set, int kt) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) prefetch_a(set, kt, p);
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) prefetch_b(set, kt, p);
+    };
+    auto commit = [&](auto set, int stage) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) commit_a(set, stage, p);
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) commit_b(set, stage, p);
+    };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+
+    f32x16 acc[P::TM][P::TN];
+#pragma unroll
+    for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < P::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    if (nkt > 0) {
+        prefetch(Set0{}, tile(0));
+        prefetch(Set1{}, tile(1));
+        commit(Set0{}, 0);
+        prefetch(Set0{}, tile(2));
+    }
+
+    const int j = lane & 31, h = lane >> 5;
+    typename P::Epi epi = P::epi(args, z, y);
+    int mrow[P::TM][16];
+    unsigned okmask[P::TM];
+    float aux[P::TM][P::TN][16];
+#pragma unroll
+    for (int tm = 0; tm < P::TM; ++tm) {
+        okmask[tm] = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mv = m0 + (wm * P::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (P::vrow(args, mv, mrow[tm][r])) okmask[tm] |= 1u << r;
+            else mrow[tm][r] = 0;
+#pragma unroll
+            for (int tn = 0; tn < P::TN; ++tn)
+                aux[tm][tn][r] = P::epi_load(epi, mrow[tm][r], n0 + (wn * P::TN + tn) * 32 + j);
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    // Slices of a k-tile's staging work: the commit of tile it+1 (A passes, B passes) into the idle stage rides on the MFMA groups of
+    // the first k-step, the global loads of tile it+3 (into the registers the commit has just freed) on those of the second; one
+    // barrier per k-tile, BETWEEN the two k-steps: by then every wave has committed tile it+1 and has read all of tile it (the
+    // fragments of a k-step are fetched from LDS one k-step ahead), so the second k-step can already fetch tile it+1's first fragments
+    // and the next step may overwrite this stage.
+    constexpr int C_SLICES = A_PASSES + B_PASSES, PER = (C_SLICES + TERMS - 1) / TERMS;
+    bf16x8_t fa[2][P::TM][3], fb[2][P::TN][3];
+    auto load_frag = [&](auto buf, int stage, int s) {
+        constexpr int F = decltype(buf)::value;
+        const uint16_t* As = smem + stage * STAGE;
+        const uint16_t* Bs = As + 3 * PLANE_A;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int tm = 0; tm < P::TM; ++tm)
+                fa[F][tm][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl * PLANE_A + ((wm * P::TM + tm) * 32 + j) * B3_LDR + s * 16 + h * 8]);
+#pragma unroll
+            for (int tn = 0; tn < P::TN; ++tn)
+                fb[F][tn][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl * PLANE_B + ((wn * P::TN + tn) * 32 + j) * B3_LDR + s * 16 + h * 8]);
+        }
+    };
+    // partial products, smallest first: (a plane, b plane)
+    auto mfma_group = [&](auto buf, int t) {
+        constexpr int F = decltype(buf)::value;
+        constexpr int ORD9[9][2] = {{2, 2}, {2, 1}, {1, 2}, {2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+#pragma unroll
+        for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < P::TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[F][tm][ORD9[t][0]], fb[F][tn][ORD9[t][1]], acc[tm][tn], 0, 0, 0);
+    };
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, 1>;
+    if (nkt > 0) load_frag(Buf0{}, 0, 0);   // (stage 0 was committed before the prologue's barrier)
+    auto step = [&](auto set, int it) {   // set holds tile it+1; refilled with tile it+3
+        const int k3 = tile(it + 3);
+        load_frag(Buf1{}, cur, 1);
+#pragma unroll
+        for (int t = 9 - TERMS; t < 9; ++t) {
+            mfma_group(Buf0{}, t);
+            const int g = t - (9 - TERMS);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int q = g * PER + u;   // (compile-time after unrolling)
+                if (q < A_PASSES) commit_a(set, cur ^ 1, q);
+                else if (q < C_SLICES) commit_b(set, cur ^ 1, q - A_PASSES);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the slices between the MFMA groups (hipcc otherwise regroups them behind the block)
+        }
+        __syncthreads();
+        load_frag(Buf0{}, cur ^ 1, 0);
+#pragma unroll
+        for (int t = 9 - TERMS; t < 9; ++t) {
+            mfma_group(Buf1{}, t);
+            const int g = t - (9 - TERMS);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int q = g * PER + u;
+                if (q < A_PASSES) prefetch_a(set, k3, q);
+                else if (q < C_SLICES) prefetch_b(set, k3, q - A_PASSES);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+    };
+    for (int it = 0; it < nkt; it += 2) {
+        step(Set1{}, it);
+        if (it + 1 < nkt) step(Set0{}, it + 1);
+    }
+
+#pragma unroll
+    for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < P::TN; ++tn) {
+            const int n = n0 + (wn * P::TN + tn) * 32 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(aux[tm][tn][r]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (okmask[tm] >> r & 1) P::store(epi, mrow[tm][r], n, acc[tm][tn][r], aux[tm][tn][r]);
+        }
+}
+
+template <class P, int TERMS = 9>
+inline hipError_t launch_igemm_b3(hipStream_t st, dim3 grid, const typename P::Args& args)
+{
+    hipLaunchKernelGGL((k_igemm_b3<P, TERMS>), grid, dim3(64 * P::WM * P::WN), 0, st, args);
+    return hipGetLastError();
+}
+
+}  // namespace bdr

@@ -171,6 +171,24 @@ struct Iqn : bdr_agent {
     uint8_t *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr; float* u_rew = nullptr; int8_t* u_term = nullptr; uint64_t u_cap = 0;
     uint64_t adam_step = 0, soft_update_counter = 0, noise_counter = 0;
     int n_updates_done = 0;
+    // The merge layer f.L[1] ([B*N][F] x [F][units]) on the bf16 matrix cores with split operands (igemm_b3.hpp) when it is large
+    // enough to be matrix-bound (config C4: 32 768 x 3 136 x 512): forward of both networks and the input gradient.  The exact
+    // FP32-MFMA kernels stay selectable (BDR_IQN_F32_EXACT=1) and serve every smaller shape.
+    bool b3_allowed = true;
+    uint16_t *wpl_nat = nullptr, *wpl_tr = nullptr;   // [3][Kp][Np], [3][Np][Kp] bf16 planes of L[1]'s weights, re-split before every use
+    bool use_b3(int M) const
+    {
+        if (!b3_allowed || hd.L.size() < 2) return false;
+        const DenseLayer& l = hd.L[1];
+        return l.Np % 128 == 0 && l.Kp % 64 == 0 && (size_t)l.Kp * l.Np >= ((size_t)1 << 20) && M >= 4096;
+    }
+    int32_t split_l1(const float* params, bool need_nat)
+    {
+        const DenseLayer& l = hd.L[1];
+        const size_t n = (size_t)3 * l.Kp * l.Np;
+        if (!wpl_tr) { BDR_HIP(hipMalloc((void**)&wpl_tr, n * 2)); BDR_HIP(hipMalloc((void**)&wpl_nat, n * 2)); }
+        return dense_split_planes(stream, l, params, need_nat ? wpl_nat : nullptr, wpl_tr);
+    }
 
     ~Iqn() override
     {
@@ -179,6 +197,7 @@ struct Iqn : bdr_agent {
         free_batch();
         (void)hipFree(p); (void)hipFree(p_tgt); (void)hipFree(grad); (void)hipFree(am); (void)hipFree(av); (void)hipFree(loss);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
+        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr);
     }
     void free_batch()
     {
@@ -265,8 +284,13 @@ struct Iqn : bdr_agent {
         { Bracket br(a, "iqn_phi"); BDR_TRY(dense_forward(a, stream, hd.L[0], params, DenseSrc{cosv, Ep}, phi, M)); }
         DenseSrc in{phi, hd.L[0].Np};
         for (size_t i = 1; i < hd.L.size(); ++i) {
-            Bracket br(a, ("iqn_f_fwd" + std::to_string(i)).c_str());
-            if (i == 1) BDR_TRY(dense_forward_had(stream, hd.L[1], params, in, feat, ldf, N, f_act[0], M));
+            Bracket br(a, (i == 1 && use_b3(M)) ? "iqn_f_fwd1_3xbf16" : ("iqn_f_fwd" + std::to_string(i)).c_str());   // (the label names the arithmetic that ran)
+            if (i == 1 && use_b3(M)) {
+                // the planes are re-split from the f32 weights of THIS network right here (~10 us against a 5 ms step): whoever wrote
+                // the parameters last - Adam, track, set_params, a model sync, an all-reduce - nothing can leave them stale
+                BDR_TRY(split_l1(params, params == p));
+                BDR_TRY(dense_forward_had_b3(stream, hd.L[1], params, wpl_tr, in, feat, ldf, N, f_act[0], M));
+            } else if (i == 1) BDR_TRY(dense_forward_had(stream, hd.L[1], params, in, feat, ldf, N, f_act[0], M));
             else BDR_TRY(dense_forward(a, stream, hd.L[i], params, in, f_act[i - 1], M));
             in = DenseSrc{f_act[i - 1], hd.L[i].Np};
         }
@@ -312,7 +336,11 @@ struct Iqn : bdr_agent {
             if (i > 1) { Bracket br(a, ("iqn_f_dx" + std::to_string(i)).c_str()); BDR_TRY(dense_dx(stream, hd.L[i], p, f_dy[i - 1], f_dy[i - 2], f_act[i - 2], M)); }
         }
         // dm = dL/dm (no ReLU mask: m is a product, not an activation)
-        { Bracket br(a, "iqn_f_dx1"); BDR_TRY(dense_dx(stream, hd.L[1], p, f_dy[0], mrg, nullptr, M)); }
+        {   // (wpl_nat: split from the online weights by this update's forward; the parameters have not changed since)
+            Bracket br(a, use_b3(M) ? "iqn_f_dx1_3xbf16" : "iqn_f_dx1");
+            if (use_b3(M)) BDR_TRY(dense_dx_b3(stream, hd.L[1], p, wpl_nat, f_dy[0], mrg, nullptr, M));
+            else BDR_TRY(dense_dx(stream, hd.L[1], p, f_dy[0], mrg, nullptr, M));
+        }
         float* dpsi = cnn ? dy3 : psi_dy.back();
         const int mask_psi = cnn ? 1 : (cfg.psi.activation_out ? 1 : 0);
         {
@@ -600,6 +628,7 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     Iqn* a = new Iqn();
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
     a->cnn = cfg->psi.kind == BDR_NET_ATARI_CNN;
+    a->b3_allowed = getenv("BDR_IQN_F32_EXACT") == nullptr;
     a->F = cfg->feature_dim; a->E = cfg->embed_dim; a->A = cfg->n_actions;
     size_t o = 0;
     if (a->cnn) {

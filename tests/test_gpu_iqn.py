@@ -135,6 +135,43 @@ def test_iqn_baseline_config4_full_size_vs_oracle(B):
     a.close()
 
 
+def test_split_operand_merge_layer_equals_the_exact_kernels(B, monkeypatch):
+    """The merge layer f.L[1] at a matrix-bound size (M = B * N = 4096 rows x 3136 x 512) on the bf16 matrix cores with split operands
+    (igemm_b3.hpp: six of the nine exact bf16 partial products) against the exact FP32-MFMA kernels (BDR_IQN_F32_EXACT=1) on the same
+    update: quantile values 1e-5, loss 1e-5, every gradient 1e-4 of its variable's scale - an order tighter than the 1e-4 bar both
+    hold against the oracle - and the profile labels name the arithmetic that ran."""
+    from oracle import torch_ref as T
+    Bsz, NQ, A = 64, 64, 6
+    sh = T.iqn_shapes("cnn", 3136, 64, [512], A)
+    p0 = T.init_params(sh[0] + sh[1] + sh[2], 51)
+    batch = T.iqn_batch(Bsz, "cnn", A, NQ, NQ, 321)
+    out = {}
+    for mode in ("exact", "split"):
+        if mode == "exact":
+            monkeypatch.setenv("BDR_IQN_F32_EXACT", "1")
+        else:
+            monkeypatch.delenv("BDR_IQN_F32_EXACT", raising=False)
+        a = _agent(B, "cnn", 3136, 64, [512], A, None, [], Bsz, 1e-4, p0, tau=1.0, soft_update_interval=10000)
+        z = a.forward(batch[0], batch[5], "iqn")
+        a.profile_enable(True)
+        rec = a.update_on_batch(*batch)
+        import bench
+        labels = [l for l, _ in bench.read_profile(a)]
+        a.profile_enable(False)
+        out[mode] = (z, rec["loss_critic"], a.get_params("grad"), a.get_params("iqn"), labels)
+        a.close()
+    assert "iqn_f_fwd1_3xbf16" in out["split"][4] and "iqn_f_dx1_3xbf16" in out["split"][4] and "iqn_f_fwd1" in out["exact"][4]
+    assert not any(l.endswith("3xbf16") for l in out["exact"][4])
+    assert rel(out["split"][0], out["exact"][0]) < 1e-5, rel(out["split"][0], out["exact"][0])
+    assert abs(out["split"][1] - out["exact"][1]) <= 1e-5 * abs(out["exact"][1])
+    o = 0
+    for shp in sh[0] + sh[1] + sh[2]:
+        n = int(np.prod(shp))
+        g_s, g_e = out["split"][2][o:o + n].astype(np.float64), out["exact"][2][o:o + n].astype(np.float64)
+        assert np.abs(g_s - g_e).max() <= 1e-4 * max(np.abs(g_e).max(), 1e-30), (shp, np.abs(g_s - g_e).max() / np.abs(g_e).max())
+        o += n
+
+
 def test_iqn_opt_over_replay_and_qvalues(B, tmp_path):
     """Agent::opt over the HBM ring with device-drawn percent points (Uniform64, batch 32): finite loss, counters,
     checkpoint round trip; Policy::sample's averaged action values == mean over Const32's 33 points of forward()."""

@@ -21,9 +21,8 @@ static float* dev_rand(size_t n, float lo, float hi, unsigned seed)
     float* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
     return d;
 }
-struct DenseB3Args : DenseArgs { const uint16_t* wpl; };
 template <int WM_, int WN_, int TM_, int TN_>
-struct DenseFwdB3 : DenseFwd {
+struct DenseFwdB3P : DenseFwd {
     using Args = DenseB3Args;
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     __device__ static const uint4* b_chunk(const Args& a, int, int, int pl, int kt, int n, int kq)
@@ -72,31 +71,31 @@ int main()
         printf("f32 MFMA 64x64            : %8.1f us  %6.1f TFLOP/s\n", t, gflop / t * 1e-3);
     }
     {
-        using P = DenseFwdB3<2, 2, 1, 1>;
+        using P = DenseFwdB3P<2, 2, 1, 1>;
         const double t = time_us([&] { CK((launch_igemm_b3<P, 6>(0, dim3((M / 64) * (N / 64), 1, 1), db))); });
         printf("3xbf16 6 terms 64x64      : %8.1f us  %6.1f TFLOP/s (algorithmic)\n", t, gflop / t * 1e-3);
         compare("6 terms vs f32", ob, o, (size_t)M * N);
     }
     {
-        using P = DenseFwdB3<2, 2, 2, 1>;   // 128 x 64
+        using P = DenseFwdB3P<2, 2, 2, 1>;   // 128 x 64
         const double t = time_us([&] { CK((launch_igemm_b3<P, 6>(0, dim3((M / 128) * (N / 64), 1, 1), db))); });
         printf("3xbf16 6 terms 128x64     : %8.1f us  %6.1f TFLOP/s\n", t, gflop / t * 1e-3);
         compare("6 terms 128x64 vs f32", ob, o, (size_t)M * N);
     }
     {
-        using P = DenseFwdB3<2, 2, 2, 2>;   // 128 x 128
+        using P = DenseFwdB3P<2, 2, 2, 2>;   // 128 x 128
         const double t = time_us([&] { CK((launch_igemm_b3<P, 6>(0, dim3((M / 128) * (N / 128), 1, 1), db))); });
         printf("3xbf16 6 terms 128x128    : %8.1f us  %6.1f TFLOP/s\n", t, gflop / t * 1e-3);
         compare("6 terms 128x128 vs f32", ob, o, (size_t)M * N);
     }
     {
-        using P = DenseFwdB3<2, 2, 1, 2>;   // 64 x 128
+        using P = DenseFwdB3P<2, 2, 1, 2>;   // 64 x 128
         const double t = time_us([&] { CK((launch_igemm_b3<P, 6>(0, dim3((M / 64) * (N / 128), 1, 1), db))); });
         printf("3xbf16 6 terms 64x128     : %8.1f us  %6.1f TFLOP/s\n", t, gflop / t * 1e-3);
         compare("6 terms 64x128 vs f32", ob, o, (size_t)M * N);
     }
     {
-        using P = DenseFwdB3<2, 2, 1, 1>;
+        using P = DenseFwdB3P<2, 2, 1, 1>;
         const double t = time_us([&] { CK((launch_igemm_b3<P, 9>(0, dim3((M / 64) * (N / 64), 1, 1), db))); });
         printf("3xbf16 9 terms 64x64      : %8.1f us  %6.1f TFLOP/s\n", t, gflop / t * 1e-3);
     }

@@ -280,6 +280,13 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
                 if (q < A_PASSES) commit_a(set, cur ^ 1, q);
                 else if (q < C_SLICES) commit_b(set, cur ^ 1, q - A_PASSES);
             }
+            // within the group: one MFMA, then a run of the slice's VALU work, ... (a wave issues in order: four MFMAs back to back stall it
+            // on the matrix pipe and the split behind them starts only when the last one has issued; +1 % on the C4 step)
+#pragma unroll
+            for (int i = 0; i < P::TM * P::TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);   // keep the slices between the MFMA groups (hipcc otherwise regroups them behind the block)
         }
         __syncthreads();

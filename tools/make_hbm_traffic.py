@@ -9,11 +9,9 @@ import json
 import re
 import sys
 
-KEY = {"bdr::k_conv1_bf16": "fwd_conv1", "k_adam": "adam_l1_l2", "k_gather": "sample", "k_igemm<DxC2P>": "bwd_conv2_dx",
-       "k_igemm<DxC3P": "bwd_conv3_dx", "k_igemm<DxL1>": "bwd_l1_dx", "k_igemm<FwdL1>": "fwd_l1", "k_igemm<FwdL1Z2>": "fwd_l1", "k_igemm<FwdPC2>": "fwd_conv2",
-       "k_igemm<FwdPC3>": "fwd_conv3", "bdr::k_conv1_dw_bf16": "bwd_conv1_dw", "k_igemm_red<DwPC1>": "bwd_conv1_dw", "k_igemm_red<DwPC2>": "bwd_conv2_dw",
-       "k_igemm_red<DwPC3>": "bwd_conv3_dw", "k_igemm_red<DwPL1>": "bwd_l1_dw", "k_reduce_partials3": "bwd_conv_reduce", "k_reduce_adam": "reduce_adam",
-       "k_head<": "head_fwd_td", "k_head_fwd": "head_fwd", "k_head_bwd": "head_bwd", "k_td_rows": "td_rows"}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench   # noqa: E402  (kernel name -> profile label: bench.KERNEL_LABELS)
 
 
 def read(path, counter):
@@ -21,10 +19,9 @@ def read(path, counter):
     for line in open(path):
         m = re.match(r"\| (.+?) \| %s \| ([0-9.]+) \|" % counter, line)
         if m:
-            name = m.group(1).strip()
-            for k, v in KEY.items():
-                if name.startswith(k):
-                    out[v] = float(m.group(2))
+            lab = bench.kernel_label(m.group(1).strip())
+            if lab:
+                out[lab] = float(m.group(2))
     return out
 
 

@@ -51,14 +51,10 @@ def main():
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
-        label = {"k_igemm<FwdPC2>": "fwd_conv2", "k_igemm<FwdPC3>": "fwd_conv3", "k_igemm<FwdL1Z2>": "fwd_l1", "k_igemm<FwdL1>": "fwd_l1", "bdr::k_conv1_bf16": "fwd_conv1",
-                 "k_igemm<DxC2P>": "bwd_conv2_dx", "k_igemm<DxC3Pos>": "bwd_conv3_dx", "k_igemm<DxL1>": "bwd_l1_dx", "k_igemm_red<DwPC2>": "bwd_conv2_dw",
-                 "k_igemm_red<DwPC3>": "bwd_conv3_dw", "k_igemm_red<DwPL1>": "bwd_l1_dw", "bdr::k_conv1_dw_bf16": "bwd_conv1_dw", "k_adam": "adam_l1_l2",
-                 "k_reduce_adam": "reduce_adam", "k_head_bwd": "head_bwd"}
         out = {}
-        for k, v in stats.items():
-            lab = label.get(k) or ("sample" if k.startswith("k_gather") else ("head_fwd_td" if k.startswith("k_head<") else k))
-            out[lab] = round(v[1] / v[0], 2)
+        for k, v in stats.items():   # kernel name -> bench.py's profile label (bench.KERNEL_LABELS); several kernels of one label add up
+            lab = bench.kernel_label(k) or k
+            out[lab] = round(out.get(lab, 0.0) + v[1] / v[0], 2)
         with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
             json.dump({"kernel_source_sha16": bench.kernel_source_hash(), "source_db": path, "skip_first": skip, "kernels_us": out}, f, indent=1)
     # PMC counters if present

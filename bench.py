@@ -394,6 +394,9 @@ def roofline(conf, prof, cnt, null_ms, ms_step):
             "frac_of_fp32_peak": round(sf / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "serial_kernel_ms": round(sum(prof.values()), 5), "launches_per_step": int(sum(cnt.values()))}
     step["frac"] = step["frac_of_fp32_peak"]
+    if bf16:
+        step["note"] = ("algorithmic flops of ALL kernels over the FP32-MFMA peak: kernels on the bf16 pipes (exact / split operands) count with their "
+                        "algorithmic work, so the fraction can exceed 1 (C4); the two pipes apart: fp32_mfma, bf16_mfma_exact_split")
     if fp32:   # the two matrix pipes apart: FP32-MFMA kernels against the FP32 peak, exact-bf16 kernels against the bf16 peak
         f32_fl, f32_ms = sum(fl[k] for k in fp32), sum(prof[k] for k in fp32)
         step["fp32_mfma"] = {"gflop": round(f32_fl / 1e9, 3), "kernel_ms": round(f32_ms, 5),

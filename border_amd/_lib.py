@@ -25,7 +25,8 @@ class BdrError(RuntimeError):
 
 class ReplayConfig(C.Structure):
     _fields_ = [("capacity", C.c_uint64), ("seed", C.c_uint64), ("obs_row_bytes", C.c_uint64),
-                ("act_row_bytes", C.c_uint64), ("device", C.c_int32), ("frame_stack", C.c_int32), ("frame_capacity", C.c_uint64)]
+                ("act_row_bytes", C.c_uint64), ("device", C.c_int32), ("frame_stack", C.c_int32), ("frame_capacity", C.c_uint64),
+                ("index_rng", C.c_int32), ("reserved", C.c_int32)]
 
 
 class NetConfig(C.Structure):

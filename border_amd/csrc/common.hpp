@@ -67,6 +67,8 @@ struct bdr_replay {
     uint64_t capacity = 0, i = 0, size = 0;
     uint64_t obs_bytes = 0, act_bytes = 0;
     uint64_t next_off = 0, act_off = 0, tail_off = 0, stride = 0;
+    int32_t index_rng = 0;     // BDR_RNG_STDRNG / BDR_RNG_XOSHIRO256PP
+    uint64_t* xo_state = nullptr;   // xoshiro256++: [XO_LANES][4] generator states in HBM (lane j draws sample j of every batch)
     uint32_t key[8] = {0};     // ChaCha12 key = seed_from_u64(seed)
     uint64_t word_pos = 0;     // next u32 word of the key stream (host-tracked, passed by value)
     uint8_t* ring = nullptr;   // capacity * stride bytes in HBM

@@ -349,6 +349,7 @@ struct DqnCnn : bdr_agent {
     bool holds_gate_token = false;                   // see claim_gates()
     bool defer_adam = false;                         // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
     bool split_fwd = true;                           // schedule 3: target network forward on the other queue (BDR_NO_SPLIT_FWD=1: off)
+    bool noted_event_fallback = false;               // the one-line note of effective_sched() has been printed
     bool three_queues = false;                       // BDR_TQ=1: gather + target forward on the third stream when it is free (measured SLOWER)
     bool tgt_enqueued = false;                       // opt_inner has put this update's target forward on the other queue
     unsigned track_epoch = 0;                        // epoch of the last update that was followed by a soft update (SIG_TRACK)
@@ -681,7 +682,15 @@ bool claim_gates(DqnCnn* a)
 int effective_sched(DqnCnn* a)
 {
     if (a->prof) return 0;
-    if (a->sched == 3 && !claim_gates(a)) return 1;
+    if (a->sched == 3 && !claim_gates(a)) {
+        // (round-3 review: not silently) another agent of this process owns the flag-ordered schedule
+        if (!a->noted_event_fallback) {
+            a->noted_event_fallback = true;
+            fprintf(stderr, "border_amd: another DQN agent of this process already orders its two queues with device flags; this agent orders its "
+                            "queues with events (same results, ~10 %% slower steps) for as long as that agent lives\n");
+        }
+        return 1;
+    }
     return a->sched;
 }
 

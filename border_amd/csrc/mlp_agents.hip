@@ -510,7 +510,7 @@ struct DqnMlp : bdr_agent {
         for (uint64_t u = 0; u < cfg.n_updates_per_opt; ++u) {
             // a uniform sample over the plain ring is drawn by the step kernel itself when the step is one kernel anyway
             GatherArgs plan{};
-            const bool in_kernel = gather_in_step && fused_ok((int)cfg.batch_size) && !r->per && !r->frame_stack && cfg.batch_size <= 128 &&
+            const bool in_kernel = gather_in_step && fused_ok((int)cfg.batch_size) && !r->per && !r->frame_stack && !r->index_rng && cfg.batch_size <= 128 &&
                                    r->obs_bytes % 4 == 0;
             if (in_kernel) BDR_TRY(replay_sample_plan(r, cfg.batch_size, stream, &plan));
             else { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, cfg.batch_size, stream)); }

@@ -44,6 +44,40 @@ __global__ void k_sample_indices(ChaChaKey key, uint64_t word_pos, uint64_t size
 }
 
 // ------------------------------------------------------------------------------------------------
+// The optional device-native index generator (bdr_replay_config::index_rng = BDR_RNG_XOSHIRO256PP; north_star's wording): one
+// xoshiro256++ generator (Blackman / Vigna) per batch lane, states in HBM.  k_xo_init: lane j <- outputs 4j .. 4j+3 of SplitMix64(seed)
+// (the seeding its authors prescribe); k_xo_indices: lane j < n steps once, ix[j] = (result >> 32) % size.  Not the reference's StdRng
+// stream - no parity claim - but pinned on its own: oracle.py restates it, tests compare index streams and the generator's known answers.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t XO_LANES = 1u << 16;
+__host__ __device__ inline uint64_t splitmix64_at(uint64_t seed, uint64_t n)   // output n (0-based) of SplitMix64 seeded with `seed`
+{
+    uint64_t z = seed + (n + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_xo_init(uint64_t* __restrict__ st, uint64_t seed, uint32_t lanes)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= lanes) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st[(size_t)j * 4 + i] = splitmix64_at(seed, (uint64_t)j * 4 + i);
+}
+__global__ void k_xo_indices(uint64_t* __restrict__ st, uint64_t size, uint32_t n, uint64_t* __restrict__ ixs)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint64_t s0 = st[(size_t)j * 4], s1 = st[(size_t)j * 4 + 1], s2 = st[(size_t)j * 4 + 2], s3 = st[(size_t)j * 4 + 3];
+    const uint64_t sum = s0 + s3;
+    const uint64_t result = ((sum << 23) | (sum >> 41)) + s0;      // rotl(s0 + s3, 23) + s0
+    const uint64_t t = s1 << 17;
+    s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = (s3 << 45) | (s3 >> 19);
+    st[(size_t)j * 4] = s0; st[(size_t)j * 4 + 1] = s1; st[(size_t)j * 4 + 2] = s2; st[(size_t)j * 4 + 3] = s3;
+    ixs[j] = (uint64_t)(uint32_t)(result >> 32) % size;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: gather.  One workgroup copies one chunk of one sampled record's obs and next_obs with
 // 16-byte lanes (a wave instruction moves 1 KiB of a contiguous row); the tail fields
 // (act / reward / flags) of the record are transposed into the SoA batch arrays by chunk 0.
@@ -472,6 +506,8 @@ int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out)
     const uint64_t raw = r->tail_off + 8;
     r->stride = round_up(raw, raw >= 1024 ? 128 : 16);
     seed_from_u64(cfg->seed, r->key);
+    BDR_REQUIRE(cfg->index_rng == BDR_RNG_STDRNG || cfg->index_rng == BDR_RNG_XOSHIRO256PP, "index_rng must be BDR_RNG_STDRNG or BDR_RNG_XOSHIRO256PP");
+    r->index_rng = cfg->index_rng;
     if (cfg->frame_stack > 0) {   // single-frame store: small records + frame store
         const int k = cfg->frame_stack;
         if (k > 64 || r->obs_bytes % (uint64_t)k != 0 || (r->obs_bytes / k) % 16 != 0) {
@@ -508,6 +544,11 @@ int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out)
         r->fstage_frames = std::max<uint64_t>(2 * r->frame_stack, std::min<uint64_t>(1024, (8ull << 20) / r->frame_bytes));
         BDR_HIP(hipHostMalloc((void**)&r->fstage, r->fstage_frames * r->frame_bytes, hipHostMallocDefault));
     }
+    if (r->index_rng == BDR_RNG_XOSHIRO256PP) {
+        BDR_HIP(hipMalloc((void**)&r->xo_state, (size_t)XO_LANES * 4 * sizeof(uint64_t)));
+        hipLaunchKernelGGL(k_xo_init, dim3(XO_LANES / 256), dim3(256), 0, r->stream, r->xo_state, cfg->seed, XO_LANES);
+        BDR_HIP(hipGetLastError());
+    }
     BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);
     r->stage_records = std::max<uint64_t>(1, std::min<uint64_t>(256, (8ull << 20) / r->stride));
     BDR_HIP(hipHostMalloc((void**)&r->stage, r->stage_records * r->stride, hipHostMallocDefault));
@@ -530,7 +571,7 @@ int32_t bdr_replay_destroy(bdr_replay* r)
     (void)hipFree(r->b_reward); (void)hipFree(r->b_term); (void)hipFree(r->b_trunc); (void)hipFree(r->b_ixs);
     (void)hipFree(r->alt.obs); (void)hipFree(r->alt.next); (void)hipFree(r->alt.act); (void)hipFree(r->alt.reward);
     (void)hipFree(r->alt.term); (void)hipFree(r->alt.trunc); (void)hipFree(r->alt.ixs);
-    (void)hipFree(r->d_tails);
+    (void)hipFree(r->d_tails); (void)hipFree(r->xo_state);
     per_destroy(r->per);
     (void)hipEventDestroy(r->written); (void)hipEventDestroy(r->read);
     (void)hipStreamDestroy(r->stream);
@@ -826,6 +867,11 @@ int32_t replay_ensure_batch_capacity(bdr_replay* r, uint64_t n)
 
 static int32_t launch_indices(bdr_replay* r, uint64_t n, hipStream_t stream)
 {
+    if (r->index_rng == BDR_RNG_XOSHIRO256PP) {
+        BDR_REQUIRE(n <= XO_LANES, "xoshiro index generator: at most %u samples per batch (one generator per batch lane)", XO_LANES);
+        BDR_HIP(step_launch(stream, false, k_xo_indices, dim3((uint32_t)((n + 255) / 256)), dim3(256), r->xo_state, r->size, (uint32_t)n, r->b_ixs));
+        return BDR_OK;
+    }
     ChaChaKey key;
     memcpy(key.k, r->key, sizeof key.k);
     hipLaunchKernelGGL(k_sample_indices, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, key, r->word_pos,
@@ -867,6 +913,9 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
     if (r->per) {   // base.rs:377-383: sum-tree sampling + importance weights; one stream word per sample
         BDR_TRY(per_sample(r->per, r->key, r->word_pos, n, r->b_ixs, stream));
         a.given = 1;
+    } else if (r->index_rng == BDR_RNG_XOSHIRO256PP) {   // the device-native generator: its own kernel steps the lanes, the gather takes the indices
+        BDR_TRY(launch_indices(r, n, stream));
+        a.given = 1;
     }
     r->word_pos += n;  // one next_u32() per index
     if (r->frame_stack) {
@@ -901,7 +950,7 @@ int32_t replay_sample_on_stream(bdr_replay* r, uint64_t n, hipStream_t stream)
 // that fills the batch buffers exactly as k_gather would.
 int32_t replay_sample_plan(bdr_replay* r, uint64_t n, hipStream_t stream, GatherArgs* out)
 {
-    BDR_REQUIRE(!r->per && !r->frame_stack, "sample plans cover the plain uniform ring only");
+    BDR_REQUIRE(!r->per && !r->frame_stack && r->index_rng == BDR_RNG_STDRNG, "sample plans cover the plain uniform ring with the StdRng index stream only");
     BDR_TRY(replay_prepare_sample(r, n, stream));
     GatherArgs a{};
     a.ring = r->ring; a.stride = r->stride; a.obs_bytes = r->obs_bytes; a.act_bytes = r->act_bytes;
@@ -983,6 +1032,7 @@ int32_t bdr_replay_enable_per(bdr_replay* r, const bdr_per_config* c)
     BDR_REQUIRE(r && c, "null argument");
     BDR_REQUIRE(!r->per, "PER is already enabled");
     BDR_REQUIRE(r->size == 0 && r->i == 0, "PER must be enabled on an empty buffer");
+    BDR_REQUIRE(r->index_rng == BDR_RNG_STDRNG, "prioritized sampling draws from the StdRng stream (base.rs:377-383): index_rng must be BDR_RNG_STDRNG");
     BDR_HIP(hipSetDevice(r->device));
     BDR_TRY(per_create(c, r->capacity, r->stream, &r->per));
     BDR_HIP(hipEventRecord(r->written, r->stream)); mark_written(r);

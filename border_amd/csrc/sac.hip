@@ -767,7 +767,7 @@ struct Sac : bdr_agent, SacBatch {
     }
     // the launch sequence of one opt() (Sac::opt_, sac/base.rs:175-192)
     // does this opt() take the two-queue sequence?
-    bool side_queue_for(const bdr_replay* r) const { return two_queues && !prof && graph_policy.mode != 1 && gather_in_pack && !r->per && !r->frame_stack; }   // (BDR_STEP_GRAPH=1: the captured step, one queue)
+    bool side_queue_for(const bdr_replay* r) const { return two_queues && !prof && graph_policy.mode != 1 && gather_in_pack && !r->per && !r->frame_stack && !r->index_rng; }   // (BDR_STEP_GRAPH=1: the captured step, one queue)
     int32_t opt_enqueue(bdr_replay* r, int Bn)
     {
         const bool tq = side_queue_for(r) && step_graph_current() == nullptr;
@@ -794,7 +794,7 @@ struct Sac : bdr_agent, SacBatch {
             // a uniform sample over the plain ring is drawn by the pack kernel itself (replay_sample_plan); prioritized and
             // single-frame buffers keep their own gather launch
             GatherArgs plan{};
-            const bool in_pack = gather_in_pack && !r->per && !r->frame_stack;
+            const bool in_pack = gather_in_pack && !r->per && !r->frame_stack && !r->index_rng;
             if (in_pack) BDR_TRY(replay_sample_plan(r, Bn, stream, &plan));
             else { Bracket br(this, "sample"); BDR_TRY(replay_sample_on_stream(r, Bn, stream)); }
             // the noise of the actor pass, then of the target pass: 2*Bn*A consecutive draws of the agent's stream

@@ -44,6 +44,9 @@ class SimpleReplayBufferConfig:
     # (bdr_replay_config::frame_stack); frame_capacity 0 = capacity * 1.25 + 64 frames
     frame_stack: int = 0
     frame_capacity: int = 0
+    # "StdRng" (default): the reference's index stream bit for bit.  "xoshiro256++": the device-native generator (one per batch lane
+    # in HBM; bdr_replay_config::index_rng) - not the reference's stream, uniform sampling only
+    index_rng: str = "StdRng"
 
     def capacity_(self, v):  # builder-style setters like the reference's
         self.capacity = v
@@ -89,7 +92,8 @@ class SimpleReplayBuffer:
         self.act_shape, self.act_dtype = tuple(act_shape), np.dtype(act_dtype)
         self.obs_bytes = int(np.prod(self.obs_shape)) * self.obs_dtype.itemsize
         self.act_bytes = int(np.prod(self.act_shape)) * self.act_dtype.itemsize
-        cfg = _lib.ReplayConfig(config.capacity, config.seed, self.obs_bytes, self.act_bytes, device, config.frame_stack, config.frame_capacity)
+        cfg = _lib.ReplayConfig(config.capacity, config.seed, self.obs_bytes, self.act_bytes, device, config.frame_stack, config.frame_capacity,
+                                 {"StdRng": 0, "xoshiro256++": 1}[config.index_rng], 0)
         h = C.c_void_p()
         _lib.check(_lib.lib().bdr_replay_create(C.byref(cfg), C.byref(h)))
         self._h = h

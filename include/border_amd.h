@@ -69,7 +69,16 @@ typedef struct {
                              * and batches are identical to the plain ring's. */
     uint64_t frame_capacity;/* frames in the store (0: capacity + capacity / 4 + 64).  A push that would overwrite a frame a
                              * live transition still references fails with BDR_ERR_INVALID (raise frame_capacity). */
+    int32_t index_rng;      /* BDR_RNG_STDRNG (0, default): the index stream of the reference's StdRng::seed_from_u64(seed)
+                             * (base.rs:353, 386) bit for bit.  BDR_RNG_XOSHIRO256PP (1): north_star's "on-device xoshiro index
+                             * generator" - one xoshiro256++ generator per batch lane in HBM (lane j seeded with outputs 4j .. 4j+3
+                             * of SplitMix64(seed)), lane j draws sample j of every batch: ix = (next_u64() >> 32) % size.  NOT the
+                             * reference's stream (no parity claim: a device-native alternative for hosts that do not need one);
+                             * deterministic in (seed, the sequence of batch sizes).  Uniform sampling only. */
+    int32_t reserved;
 } bdr_replay_config;
+#define BDR_RNG_STDRNG 0
+#define BDR_RNG_XOSHIRO256PP 1
 
 /* ReplayBufferBase::build (base.rs:336-356).  The ring lives in HBM as one fused record per
  * transition: [obs | next_obs | act | reward f32 | is_terminated i8 | is_truncated i8 | pad]. */

@@ -547,3 +547,46 @@ class PerReplay:
         for ix, td in zip(ixs, td_errs):
             self.tree.update(int(ix), float(td))
         self.n_opts += 1
+
+
+# ---- the optional device-native index generator (bdr_replay_config::index_rng = BDR_RNG_XOSHIRO256PP) ---------------------------------
+# Not part of the reference (its stream is StdRng, above): xoshiro256++ 1.0 (Blackman / Vigna, public domain) restated, one generator
+# per batch lane, lane j seeded with outputs 4j .. 4j+3 of SplitMix64(seed).  Test infrastructure like everything in oracle/.
+_M64 = (1 << 64) - 1
+
+
+def splitmix64_at(seed: int, n: int) -> int:
+    z = (seed + (n + 1) * 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+class Xoshiro256pp:
+    def __init__(self, s):
+        self.s = [int(x) & _M64 for x in s]
+
+    def next_u64(self) -> int:
+        s = self.s
+        sm = (s[0] + s[3]) & _M64
+        result = ((((sm << 23) | (sm >> 41)) & _M64) + s[0]) & _M64
+        t = (s[1] << 17) & _M64
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t
+        s[3] = ((s[3] << 45) | (s[3] >> 19)) & _M64
+        return result
+
+
+class XoshiroLanes:
+    """Index stream of a replay buffer built with index_rng = xoshiro256++: lane j draws sample j of every batch."""
+
+    def __init__(self, seed: int):
+        self.seed, self.lanes = seed, {}
+
+    def sample_indices(self, size: int, n: int):
+        import numpy as np
+        out = np.empty(n, np.uint64)
+        for j in range(n):
+            if j not in self.lanes:
+                self.lanes[j] = Xoshiro256pp([splitmix64_at(self.seed, 4 * j + i) for i in range(4)])
+            out[j] = (self.lanes[j].next_u64() >> 32) % size
+        return out

@@ -291,7 +291,7 @@ where
     let mut learner = A::build(agent_config.clone());
     let buffer = AmdReplayBuffer::<O, Ab>::build_on(
         replay_buffer_config,
-        crate::replay::AmdReplayPlacement { device, frame_stack: 0, frame_capacity: 0 },
+        crate::replay::AmdReplayPlacement { device, frame_stack: 0, frame_capacity: 0, xoshiro_indices: false },
     )?;
     let _ = <AmdReplayBuffer<O, Ab> as ReplayBufferBase>::build; // (same Config type as the reference's R)
     let act_row_bytes = learner.act_row_bytes();

@@ -13,6 +13,8 @@ pub const BDR_ERR_EMPTY: i32 = 4;
 pub const BDR_ERR_IO: i32 = 5;
 pub const BDR_ERR_COMM: i32 = 6;
 
+pub const BDR_RNG_STDRNG: i32 = 0;
+pub const BDR_RNG_XOSHIRO256PP: i32 = 1;
 pub const BDR_PER_NORMALIZE_ALL: i32 = 0;
 pub const BDR_PER_NORMALIZE_BATCH: i32 = 1;
 pub const BDR_NET_ATARI_CNN: i32 = 0;
@@ -78,6 +80,8 @@ pub struct bdr_replay_config {
     pub device: i32,
     pub frame_stack: i32,
     pub frame_capacity: u64,
+    pub index_rng: i32,
+    pub reserved: i32,
 }
 
 #[repr(C)]

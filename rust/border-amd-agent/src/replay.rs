@@ -26,11 +26,14 @@ pub struct AmdReplayPlacement {
     pub frame_stack: i32,
     /// Frames in the store (`0`: `capacity + capacity / 4 + 64`).
     pub frame_capacity: u64,
+    /// `false`: the reference's `StdRng::seed_from_u64(seed)` index stream, bit for bit (`base.rs:353, 386`).  `true`: the
+    /// device-native xoshiro256++ generator (one per batch lane in HBM) - not the reference's stream, uniform sampling only.
+    pub xoshiro_indices: bool,
 }
 
 impl Default for AmdReplayPlacement {
     fn default() -> Self {
-        Self { device: 0, frame_stack: 0, frame_capacity: 0 }
+        Self { device: 0, frame_stack: 0, frame_capacity: 0, xoshiro_indices: false }
     }
 }
 
@@ -78,6 +81,8 @@ where
             device: place.device,
             frame_stack: place.frame_stack,
             frame_capacity: place.frame_capacity,
+            index_rng: if place.xoshiro_indices { ffi::BDR_RNG_XOSHIRO256PP } else { ffi::BDR_RNG_STDRNG },
+            reserved: 0,
         };
         let mut h = std::ptr::null_mut();
         check(unsafe { ffi::bdr_replay_create(&cfg, &mut h) })?;

@@ -283,6 +283,33 @@ def test_mlp_opt_over_replay(B):
     a.close(); rb.close()
 
 
+def test_mlp_opt_over_a_xoshiro_indexed_buffer(B):
+    """A buffer built with index_rng = xoshiro256++ (the device-native generator, replay.hip k_xo_indices): the step kernel's own
+    StdRng draw is not used, the buffer's gather names the rows, and the update on those rows equals the oracle's."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    rng = np.random.default_rng(6)
+    cap, Bsz, n = 600, 32, 500
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42, index_rng="xoshiro256++"), (4,), np.float32)
+    tr = (rng.standard_normal((n, 4)).astype(np.float32), rng.integers(0, 2, (n, 1)).astype(np.int64),
+          rng.standard_normal((n, 4)).astype(np.float32), rng.standard_normal(n).astype(np.float32), (rng.random(n) < .1).astype(np.int8),
+          np.zeros(n, np.int8))
+    rb.push(*tr)
+    lanes = O.XoshiroLanes(42)
+    p0 = T.init_params(T.mlp_shapes(4, [64, 64], 2), 11)
+    a = make_mlp_agent(B, batch_size=Bsz, lr=1e-3, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, double_dqn=True)
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    ref = O.DqnOracle(O.mlp_cfg(4, [64, 64], 2), p0, lr=1e-3, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, double_dqn=True)
+    for step in range(4):
+        rec = a.opt_with_record(rb)
+        ix = lanes.sample_indices(n, Bsz).astype(np.int64)
+        r = ref.update(tr[0][ix], tr[1][ix, 0], tr[2][ix], tr[3][ix], tr[4][ix], probe=True)
+        assert rel(a.probe("q_pred_all", Bsz * 2), r["q_pred_all"].ravel()) < 3e-4, step
+        assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-7
+    assert (rb.sample_indices(40) == lanes.sample_indices(n, 40)).all()      # four batches were drawn on both sides
+    a.close(); rb.close()
+
+
 def test_mlp_step_kernel_draws_its_own_batch(B, monkeypatch):
     """For nets that fit one workgroup the step kernel is also the replay buffer's sample (replay_sample_plan + the gather phase
     of k_dqn_mlp_step): same StdRng stream position, same rows as the separate gather launch - parameters after 12 opts with

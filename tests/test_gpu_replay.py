@@ -248,3 +248,37 @@ def test_sac_baseline_ring_one_million_f32_transitions(B):
     o, a, n, rw, tm, _ = rb.read_rows(0, 5)
     assert (o == pobs[3:]).all() and (n == pnext[3:]).all() and (rw == prew[3:]).all()
     rb.close()
+
+
+def test_xoshiro_index_generator_matches_its_restatement(B):
+    """bdr_replay_config::index_rng = BDR_RNG_XOSHIRO256PP: one xoshiro256++ generator per batch lane in HBM.  Not the reference's
+    StdRng stream (that is the default, pinned above) - checked bit for bit against oracle.XoshiroLanes, ragged batch sizes included,
+    and the gathered rows are the rows those indices name."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    cap, obs_shape = 1000, (6,)
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=77, index_rng="xoshiro256++"), obs_shape, np.float32)
+    obs = rng.standard_normal((700,) + obs_shape).astype(np.float32)
+    nxt = rng.standard_normal((700,) + obs_shape).astype(np.float32)
+    act = rng.integers(0, 3, (700, 1)).astype(np.int64)
+    rew = rng.standard_normal(700).astype(np.float32)
+    z = np.zeros(700, np.int8)
+    rb.push(obs, act, nxt, rew, z, z)
+    ref = O.XoshiroLanes(77)
+    for bs in (1, 64, 257, 32, 4096, 3):
+        want = ref.sample_indices(700, bs)
+        if bs % 2:
+            got = rb.sample_indices(bs)
+        else:
+            g = rb.batch(bs)
+            got = g.ix_sample
+            assert (g.obs.reshape(bs, -1) == obs[want.astype(np.int64)]).all() and (g.reward == rew[want.astype(np.int64)]).all()
+            assert (g.next_obs.reshape(bs, -1) == nxt[want.astype(np.int64)]).all() and (g.act.reshape(-1) == act[want.astype(np.int64), 0]).all()
+        assert (got == want).all(), bs
+    with pytest.raises(B.BdrError, match="at most"):
+        rb.sample_indices((1 << 16) + 1)
+    rb.close()
+    # prioritized sampling draws from the StdRng stream: the combination is refused, not silently ignored
+    with pytest.raises(B.BdrError, match="StdRng"):
+        B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=64, seed=1, index_rng="xoshiro256++", per_config=B.PerConfig()), (4,), np.float32)
+

@@ -60,3 +60,20 @@ def test_modulo_bias_is_kept():
     ixs = r.sample_indices(size, 64)
     raw = np.array([w.next_u32() for _ in range(64)], dtype=np.uint64)
     assert (ixs == raw % size).all()
+
+
+def test_xoshiro256pp_known_answers_and_lane_seeding():
+    """The optional device-native index generator (bdr_replay_config::index_rng = 1; not the reference's stream): xoshiro256++ 1.0's
+    published first outputs from state {1, 2, 3, 4}, SplitMix64's published first outputs from seed 1234567, and the lane layout."""
+    g = O.Xoshiro256pp([1, 2, 3, 4])
+    assert [g.next_u64() for _ in range(5)] == [41943041, 58720359, 3588806011781223, 3591011842654386, 9228616714210784205]
+    assert [O.splitmix64_at(1234567, i) for i in range(5)] == [6457827717110365317, 3203168211198807973, 9817491932198370423,
+                                                                  4593380528125082431, 16408922859458223821]
+    a, b = O.XoshiroLanes(7), O.XoshiroLanes(7)
+    first = a.sample_indices(1000, 16)
+    assert (first == b.sample_indices(1000, 32)[:16]).all()          # lane j is the same generator whatever the batch size
+    assert (first < 1000).all() and len(set(first.tolist())) > 8
+    second = a.sample_indices(1000, 16)
+    assert (second != first).any()
+    lane3 = O.Xoshiro256pp([O.splitmix64_at(7, 12 + i) for i in range(4)])
+    assert first[3] == (lane3.next_u64() >> 32) % 1000 and second[3] == (lane3.next_u64() >> 32) % 1000

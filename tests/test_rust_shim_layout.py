@@ -280,7 +280,7 @@ def test_sizes_and_offsets_from_the_rust_declarations_equal_gccs(both):
         r_size, _, r_offs = _layout(rs[n], rs, cache)
         assert r_size == int(size), f"{n}: {r_size} bytes from ffi.rs, {size} from the header"
         assert r_offs == [int(o) for o in offs], f"{n}: field offsets {r_offs} from ffi.rs, {offs} from the header"
-    assert int(dict((l.split()[0], l.split()[1]) for l in out.splitlines())["bdr_replay_config"]) == 48
+    assert int(dict((l.split()[0], l.split()[1]) for l in out.splitlines())["bdr_replay_config"]) == 56
 
 
 def test_the_crate_has_complete_sources_and_integration_md_points_at_them():

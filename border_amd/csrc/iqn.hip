@@ -146,7 +146,7 @@ void sample_const(int mode, std::vector<float>& t)
     else t.push_back(0.5f);
 }
 
-constexpr size_t CONV_FLOATS = 8192 + 32 + 32768 + 64 + 36864 + 64;
+inline size_t conv_floats(int ns) { return (size_t)2048 * ns + 32 + 32768 + 64 + 36864 + 64; }   // c1 [32][ns][8][8] .. c3.bias (cnn/base.rs:27-31)
 
 }  // namespace
 
@@ -223,7 +223,7 @@ struct Iqn : bdr_agent {
         if (cnn) {
             BDR_TRY(zalloc(&a1, (size_t)Bn * 400 * 32)); BDR_TRY(zalloc(&a2, (size_t)Bn * 81 * 64)); BDR_TRY(zalloc(&a3, (size_t)Bn * 49 * 64));
             BDR_TRY(zalloc(&dy3, (size_t)Bn * 49 * 64)); BDR_TRY(zalloc(&dy2, (size_t)Bn * 81 * 64)); BDR_TRY(zalloc(&dy1, (size_t)Bn * 400 * 32));
-            BDR_TRY(zalloc(&part_conv, dw_plan(Bn).total));
+            BDR_TRY(zalloc(&part_conv, dw_plan(Bn, conv.ns).total));
         } else {
             BDR_TRY(zalloc(&x_in, (size_t)Bn * psi_mlp.L[0].Kp));
             for (const auto& l : psi_mlp.L) { float *q = nullptr, *d = nullptr; BDR_TRY(zalloc(&q, (size_t)Bn * l.Np)); BDR_TRY(zalloc(&d, (size_t)Bn * l.Np)); psi_act.push_back(q); psi_dy.push_back(d); }
@@ -251,7 +251,7 @@ struct Iqn : bdr_agent {
             Conv1Args c{}; c.M = Bn * 400; c.nz = 1;
             c.x[0] = obs; c.w1[0] = params + conv.w1; c.bias[0] = params + conv.b1; c.out[0] = a1;
             const int items = (c.M + 31) / 32, g = std::max(1, std::min(512, (items + 7) / 8));
-            { Bracket br(a, "psi_conv1"); BDR_HIP(launch_conv1_bf16(4, dim3(g), stream, c)); }
+            { Bracket br(a, "psi_conv1"); BDR_HIP(launch_conv1_bf16(conv.ns, dim3(g), stream, c)); }
             FwdArgs f{};
             f.M = Bn * 81; f.x[0] = a1; f.w[0] = params + conv.w2; f.bias[0] = params + conv.b2; f.out[0] = a2;
             { Bracket br(a, "psi_conv2"); LAUNCH(k_igemm<FwdC2>, dim3((f.M + 63) / 64, 1, 1), f); }
@@ -351,7 +351,7 @@ struct Iqn : bdr_agent {
         { Bracket br(a, "iqn_cos_dw"); BDR_TRY(dense_dw(stream, hd.L[0], grad, DenseSrc{cosv, Ep}, mrg, M, part, ch)); }
         // psi backward
         if (cnn) {
-            const DwPlan pl = dw_plan(B);
+            const DwPlan pl = dw_plan(B, conv.ns);
             {
                 const int Mr = Bn * 49, chunks = std::min(pl.chunks_c3, (Mr + 31) / 32);
                 DwArgs d{a2, dy3, part_conv + pl.off_c3, pl.stride_c3, Mr};
@@ -373,9 +373,9 @@ struct Iqn : bdr_agent {
             {
                 const int chunks = std::min(pl.chunks_c1, Bn);
                 Conv1DwArgs d{obs, dy1, part_conv + pl.off_c1, pl.stride_c1, Bn};
-                { Bracket br(a, "psi_conv1_dw"); BDR_HIP(launch_conv1_dw_bf16(4, dim3(chunks), a->stream, d)); }
-                const int n = 256 * 32 + 32;
-                hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, stream, part_conv + pl.off_c1, pl.stride_c1, chunks, grad + conv.w1, n, 256 * 32, INV255);
+                { Bracket br(a, "psi_conv1_dw"); BDR_HIP(launch_conv1_dw_bf16(conv.ns, dim3(chunks), a->stream, d)); }
+                const int nw = (int)conv.n_w1(), n = nw + 32;
+                hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, stream, part_conv + pl.off_c1, pl.stride_c1, chunks, grad + conv.w1, n, nw, INV255);
                 BDR_HIP(hipGetLastError());
             }
         } else {
@@ -424,7 +424,7 @@ struct Iqn : bdr_agent {
     const char* kind() const override { return "iqn"; }
     int32_t opt(bdr_replay* r) override
     {
-        const uint64_t ob = cnn ? 28224ull : (uint64_t)in_dim * 4;
+        const uint64_t ob = cnn ? 7056ull * conv.ns : (uint64_t)in_dim * 4;
         BDR_REQUIRE(r->obs_bytes == ob && r->act_bytes >= 8, "replay rows do not match the IQN feature extractor input");
         BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
         const int Bn = (int)cfg.batch_size, Np = sample_points(cfg.sample_percents_pred), Nt = sample_points(cfg.sample_percents_tgt);
@@ -463,8 +463,9 @@ struct Iqn : bdr_agent {
         std::fill(in, in + total, 0.f);
         const float* q = ref;
         if (cnn) {
-            for (int o = 0; o < 32; ++o) for (int k = 0; k < 256; ++k) in[conv.w1 + (size_t)k * 32 + o] = q[(size_t)o * 256 + k];
-            q += 8192; std::copy(q, q + 32, in + conv.b1); q += 32;
+            const int K1 = 64 * conv.ns;
+            for (int o = 0; o < 32; ++o) for (int k = 0; k < K1; ++k) in[conv.w1 + (size_t)k * 32 + o] = q[(size_t)o * K1 + k];
+            q += (size_t)32 * K1; std::copy(q, q + 32, in + conv.b1); q += 32;
             for (int o = 0; o < 64; ++o) for (int c = 0; c < 32; ++c) for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw)
                 in[conv.w2 + (size_t)((kh * 4 + kw) * 32 + c) * 64 + o] = q[((size_t)(o * 32 + c) * 4 + kh) * 4 + kw];
             q += 32768; std::copy(q, q + 64, in + conv.b2); q += 64;
@@ -494,8 +495,9 @@ struct Iqn : bdr_agent {
     {
         float* q = ref;
         if (cnn) {
-            for (int o = 0; o < 32; ++o) for (int k = 0; k < 256; ++k) q[(size_t)o * 256 + k] = in[conv.w1 + (size_t)k * 32 + o];
-            q += 8192; std::copy(in + conv.b1, in + conv.b1 + 32, q); q += 32;
+            const int K1 = 64 * conv.ns;
+            for (int o = 0; o < 32; ++o) for (int k = 0; k < K1; ++k) q[(size_t)o * K1 + k] = in[conv.w1 + (size_t)k * 32 + o];
+            q += (size_t)32 * K1; std::copy(in + conv.b1, in + conv.b1 + 32, q); q += 32;
             for (int o = 0; o < 64; ++o) for (int c = 0; c < 32; ++c) for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw)
                 q[((size_t)(o * 32 + c) * 4 + kh) * 4 + kw] = in[conv.w2 + (size_t)((kh * 4 + kw) * 32 + c) * 64 + o];
             q += 32768; std::copy(in + conv.b2, in + conv.b2 + 64, q); q += 64;
@@ -552,7 +554,7 @@ struct Iqn : bdr_agent {
     {
         std::vector<NamedTensor> mt;
         if (cnn) {
-            mt = {{"c1.weight", {32, 4, 8, 8}}, {"c1.bias", {32}}, {"c2.weight", {64, 32, 4, 4}}, {"c2.bias", {64}}, {"c3.weight", {64, 64, 3, 3}}, {"c3.bias", {64}}};
+            mt = {{"c1.weight", {32, (uint64_t)conv.ns, 8, 8}}, {"c1.bias", {32}}, {"c2.weight", {64, 32, 4, 4}}, {"c2.bias", {64}}, {"c3.weight", {64, 64, 3, 3}}, {"c3.bias", {64}}};
         } else {
             for (size_t i = 0; i < psi_mlp.L.size(); ++i) {
                 mt.push_back({"psi.mlp.ln" + std::to_string(i) + ".weight", {(uint64_t)psi_mlp.L[i].out, (uint64_t)psi_mlp.L[i].in}});
@@ -585,7 +587,7 @@ struct Iqn : bdr_agent {
     }
     int32_t stage(uint64_t n, const void* obs, const int64_t* act, const void* next_obs, const float* reward, const int8_t* term)
     {
-        const size_t ob = cnn ? 28224 : (size_t)in_dim * 4;
+        const size_t ob = cnn ? (size_t)7056 * conv.ns : (size_t)in_dim * 4;
         if (n > u_cap) {
             BDR_HIP(hipStreamSynchronize(stream));
             (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
@@ -632,9 +634,10 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     a->F = cfg->feature_dim; a->E = cfg->embed_dim; a->A = cfg->n_actions;
     size_t o = 0;
     if (a->cnn) {
-        BDR_REQUIRE(cfg->feature_dim == 3136 && cfg->psi.n_stack == 4, "the IQN agent's AtariCnn{skip_linear} trunk is built for n_stack = 4 and yields 3136 features (the DQN agent takes n_stack 1 ... 8)");
-        a->conv = make_arena(1);
-        o = CONV_FLOATS; a->ref_total = CONV_FLOATS;
+        BDR_REQUIRE(cfg->feature_dim == 3136, "the AtariCnn{skip_linear} trunk yields 64 x 7 x 7 = 3136 features (cnn/base.rs:38-45)");
+        BDR_REQUIRE(cfg->psi.n_stack >= 1 && cfg->psi.n_stack <= bdr::C1_MAX_STACK, "AtariCnnConfig::n_stack must be in [1, %d] (conv1's kernels are instantiated per depth)", bdr::C1_MAX_STACK);
+        a->conv = make_arena(1, cfg->psi.n_stack);
+        o = a->ref_total = conv_floats(cfg->psi.n_stack);
     } else {
         BDR_REQUIRE(cfg->psi.out_dim == cfg->feature_dim, "psi.out_dim must equal feature_dim");
         a->in_dim = cfg->psi.in_dim;

@@ -1012,6 +1012,7 @@ ORC_API void orc_sac_update(const orc_sac_cfg* c, float* pi, float** qs, float**
 /* ========================================================================= */
 typedef struct {
     int32_t psi_kind;            /* 0 cnn, 1 mlp */
+    /* psi_in: the Mlp's input width; for the cnn the frame-stack depth n_stack (cnn/config.rs:14-24; 0 = the default 4) */
     int32_t psi_in, n_psi_units, psi_units[ORC_MAX_UNITS], psi_activation_out;
     int32_t feature_dim, embed_dim;
     int32_t n_f_units, f_units[ORC_MAX_UNITS];
@@ -1019,9 +1020,10 @@ typedef struct {
     double discount_factor;
 } orc_iqn_cfg;
 
+static int iqn_n_stack(const orc_iqn_cfg* c) { return c->psi_in > 0 ? c->psi_in : 4; }
 static int64_t iqn_psi_count(const orc_iqn_cfg* c)
 {
-    if (c->psi_kind == 0) return 8192 + 32 + 32768 + 64 + 36864 + 64;
+    if (c->psi_kind == 0) return 2048 * iqn_n_stack(c) + 32 + 32768 + 64 + 36864 + 64;
     return (int64_t)sac_mlp_make(c->psi_in, c->psi_units, c->n_psi_units, c->feature_dim, 1).total;
 }
 ORC_API int64_t orc_iqn_param_count(const orc_iqn_cfg* c)
@@ -1047,15 +1049,16 @@ static void iqn_forward(const orc_iqn_cfg* c, const float* p, const void* x, con
     const float* q = p;
     if (c->psi_kind == 0) {
         const uint8_t* u = (const uint8_t*)x;
-        const size_t n = (size_t)B * 4 * 84 * 84;
+        const int ns = iqn_n_stack(c);
+        const size_t n = (size_t)B * ns * 84 * 84, o2 = 2048 * (size_t)ns + 32, o3 = o2 + 32768 + 64;
         k->x0 = (float*)malloc(sizeof(float) * n);
         for (size_t i = 0; i < n; ++i) k->x0[i] = (float)u[i] / 255.0f;
         k->a1 = (float*)malloc(sizeof(float) * (size_t)B * 32 * 400);
         k->a2 = (float*)malloc(sizeof(float) * (size_t)B * 64 * 81);
         k->psi = (float*)malloc(sizeof(float) * (size_t)B * 3136);
-        conv2d_fwd(k->x0, q, q + 8192, k->a1, B, 4, 84, 84, 32, 8, 4, 1);
-        conv2d_fwd(k->a1, q + 8224, q + 8224 + 32768, k->a2, B, 32, 20, 20, 64, 4, 2, 1);
-        conv2d_fwd(k->a2, q + 41056, q + 41056 + 36864, k->psi, B, 64, 9, 9, 64, 3, 1, 1);
+        conv2d_fwd(k->x0, q, q + o2 - 32, k->a1, B, ns, 84, 84, 32, 8, 4, 1);
+        conv2d_fwd(k->a1, q + o2, q + o2 + 32768, k->a2, B, 32, 20, 20, 64, 4, 2, 1);
+        conv2d_fwd(k->a2, q + o3, q + o3 + 36864, k->psi, B, 64, 9, 9, 64, 3, 1, 1);
     } else {
         k->pm = sac_mlp_make(c->psi_in, c->psi_units, c->n_psi_units, c->feature_dim, 1);
         k->pm.relu[k->pm.n - 1] = c->psi_activation_out;
@@ -1170,11 +1173,13 @@ ORC_API float orc_iqn_update(const orc_iqn_cfg* c, float* iqn, const float* iqn_
         relu_bwd(k.psi, d3, (size_t)B * 3136);
         float* d2 = (float*)malloc(sizeof(float) * (size_t)B * 64 * 81);
         float* d1 = (float*)malloc(sizeof(float) * (size_t)B * 32 * 400);
-        conv2d_bwd(k.a2, iqn + 41056, d3, g + 41056, g + 41056 + 36864, d2, B, 64, 9, 9, 64, 3, 1);
+        const int ns = iqn_n_stack(c);
+        const size_t o2 = 2048 * (size_t)ns + 32, o3 = o2 + 32768 + 64;
+        conv2d_bwd(k.a2, iqn + o3, d3, g + o3, g + o3 + 36864, d2, B, 64, 9, 9, 64, 3, 1);
         relu_bwd(k.a2, d2, (size_t)B * 64 * 81);
-        conv2d_bwd(k.a1, iqn + 8224, d2, g + 8224, g + 8224 + 32768, d1, B, 32, 20, 20, 64, 4, 2);
+        conv2d_bwd(k.a1, iqn + o2, d2, g + o2, g + o2 + 32768, d1, B, 32, 20, 20, 64, 4, 2);
         relu_bwd(k.a1, d1, (size_t)B * 32 * 400);
-        conv2d_bwd(k.x0, iqn, d1, g, g + 8192, NULL, B, 4, 84, 84, 32, 8, 4);
+        conv2d_bwd(k.x0, iqn, d1, g, g + o2 - 32, NULL, B, ns, 84, 84, 32, 8, 4);
         free(d2); free(d1);
     } else {
         sac_mlp_bwd(&k.pm, iqn, k.px, B, k.pacts, dpsi, g, NULL);

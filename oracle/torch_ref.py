@@ -478,11 +478,11 @@ def sac_batch(B, obs_dim, act_dim, seed):
 # ================================================================================================
 # IQN  (border-tch-agent/src/iqn/base.rs:63-170, iqn/model/base.rs:162-234, util/quantile_loss.rs:7-13)
 # ================================================================================================
-def iqn_shapes(psi_kind, feature_dim, embed_dim, f_units, n_actions, psi_in=None, psi_units=()):
+def iqn_shapes(psi_kind, feature_dim, embed_dim, f_units, n_actions, psi_in=None, psi_units=(), n_stack=4):
     """IqnModel variables: psi (AtariCnn{skip_linear:true}: c1..c3 | Mlp in->units->feature_dim),
     iqn_cos_to_feature.weight/bias, f = Mlp(feature_dim -> f_units -> n_actions)."""
     if psi_kind == "cnn":
-        psi = [(32, 4, 8, 8), (32,), (64, 32, 4, 4), (64,), (64, 64, 3, 3), (64,)]
+        psi = [(32, n_stack, 8, 8), (32,), (64, 32, 4, 4), (64,), (64, 64, 3, 3), (64,)]
         assert feature_dim == 3136
     else:
         psi = mlp_shapes(psi_in, psi_units, feature_dim)
@@ -577,11 +577,11 @@ class TorchIqn:
                     tgt=tgt.squeeze(-1).numpy().copy(), grads=grads, params=flatten(self.p), tgt_params=flatten(self.p_tgt))
 
 
-def iqn_batch(B, psi_kind, n_actions, n_pred, n_tgt, seed, in_dim=None):
+def iqn_batch(B, psi_kind, n_actions, n_pred, n_tgt, seed, in_dim=None, n_stack=4):
     rng = np.random.default_rng(seed)
     if psi_kind == "cnn":
-        obs = rng.integers(0, 256, size=(B, 4, 1, 84, 84), dtype=np.uint8)
-        nobs = rng.integers(0, 256, size=(B, 4, 1, 84, 84), dtype=np.uint8)
+        obs = rng.integers(0, 256, size=(B, n_stack, 1, 84, 84), dtype=np.uint8)
+        nobs = rng.integers(0, 256, size=(B, n_stack, 1, 84, 84), dtype=np.uint8)
     else:
         obs = rng.standard_normal((B, in_dim)).astype(np.float32)
         nobs = rng.standard_normal((B, in_dim)).astype(np.float32)

@@ -26,8 +26,8 @@ def B():
     return border_amd
 
 
-def _agent(B, kind, F_, E, fu, A, pin, pu, Bsz, lr, p0, **kw):
-    f_cfg = B.AtariCnnConfig(n_stack=4, skip_linear=True) if kind == "cnn" else B.MlpConfig(in_dim=pin, units=tuple(pu), out_dim=F_, activation_out=True)
+def _agent(B, kind, F_, E, fu, A, pin, pu, Bsz, lr, p0, n_stack=4, **kw):
+    f_cfg = B.AtariCnnConfig(n_stack=n_stack, skip_linear=True) if kind == "cnn" else B.MlpConfig(in_dim=pin, units=tuple(pu), out_dim=F_, activation_out=True)
     cfg = B.IqnConfig(f_config=f_cfg, feature_dim=F_, embed_dim=E, m_units=tuple(fu), n_actions=A, lr=lr, batch_size=Bsz, device=0, **kw)
     a = B.Iqn.build(cfg)
     a.set_params(p0, "iqn"); a.set_params(p0, "iqn_tgt")
@@ -85,6 +85,39 @@ def test_iqn_cnn_64_quantiles_vs_oracle(B, A):
     g = a.get_params("grad")
     assert rel(g, r["grads"]) < 5e-4, rel(g, r["grads"])
     a.close()
+
+
+@pytest.mark.parametrize("ns", [1, 2, 8])
+def test_iqn_other_frame_stack_depths_vs_oracle(B, ns, tmp_path):
+    """AtariCnnConfig::n_stack (cnn/config.rs:14-24) on IQN's feature extractor, as on DQN's: conv1 has 64 * n_stack rows.  One update
+    vs the C oracle, an opt over a ring of n_stack-frame rows, and the checkpoint's c1.weight shape."""
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    A, Bsz = 6, 8
+    sh = T.iqn_shapes("cnn", 3136, 64, [512], A, n_stack=ns)
+    p0 = T.init_params(sh[0] + sh[1] + sh[2], 33 + ns)
+    a = _agent(B, "cnn", 3136, 64, [512], A, None, [], Bsz, 1e-4, p0, n_stack=ns, tau=1.0, soft_update_interval=10000)
+    assert a.param_count() == p0.size and (a.get_params("iqn") == p0).all()
+    ref = O.IqnOracle("cnn", p0, lr=1e-4, feature_dim=3136, embed_dim=64, f_units=[512], n_actions=A, psi_in=ns, tau=1.0, soft_update_interval=10000)
+    batch = T.iqn_batch(Bsz, "cnn", A, 32, 32, 78 + ns, n_stack=ns)
+    rec = a.update_on_batch(*batch)
+    r = ref.update(*batch)
+    assert abs(rec["loss_critic"] - r["loss"]) <= QTOL * abs(r["loss"])
+    g = a.get_params("grad")
+    assert rel(g, r["grads"]) < 5e-4, rel(g, r["grads"])
+    n1 = 2048 * ns
+    assert rel(g[:n1], r["grads"][:n1]) < 2e-3      # conv1's own weight gradient, on its own scale
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=100, seed=42), (ns, 1, 84, 84), np.uint8)
+    rb.fill_synthetic(100, seed=3, kind=0, n_actions=A)
+    for _ in range(2):
+        a.opt(rb)
+    a.sync()
+    assert np.isfinite(a.get_params("iqn")).all()
+    a.save_params(str(tmp_path / "m"))
+    from border_amd import checkpoint as ck
+    t = ck.read(str(tmp_path / "m" / "iqn.pt.tch"), [("c1.weight", (32, ns, 8, 8)), ("c1.bias", (32,))])     # shapes must match the file's
+    assert (t["c1.weight"].ravel() == a.get_params("iqn")[:n1]).all()
+    a.close(); rb.close()
 
 
 def test_iqn_baseline_config4_full_size_vs_oracle(B):

@@ -109,6 +109,7 @@ struct DenseArgs {
     int accum;           // dx: out += result (sum of several branches' input gradients)
     // optional second factor of the A operand (DenseFwdHad): A(m,k) = x[m][k] * xhad[m / xhad_group][k]
     const float* xhad; int xhad_ld, xhad_group;
+    float* gsum; int gmask;   // DenseDxHad: per-group column sums (row stride xhad_ld) and whether they are masked by xhad > 0
 };
 
 struct DenseFwd {
@@ -200,8 +201,20 @@ struct DenseB3 : Base {
         return reinterpret_cast<const uint4*>(a.wpl + (size_t)pl * a.ncols * a.kred + (size_t)n * a.kred + kt * 32 + kq * 8);
     }
 };
+// dX of the layer behind a Hadamard merge m[r] = g[r / group] * e[r] (e = a post-ReLU activation), with the merge's backward in the
+// epilogue (igemm_b3.hpp's row-group epilogue; group = the wave's TM * 32 rows):  d e_pre[r][n] = 1{e > 0} dm g[group][n]  and
+// d g[group][n] = sum_r dm[r][n] e[r][n]  (masked by g > 0 when g is itself a ReLU output).  mask = e, xhad = g.
+struct DenseDxHad : DenseDx {
+    static constexpr bool GROUP_EPI = true;
+    __device__ static float epi_load(const Epi& a, int m, int n) { return a.mask[(size_t)m * a.ldm + n]; }
+    __device__ static float group_scale(const Epi& a, int g, int n) { return a.xhad[(size_t)g * a.xhad_ld + n]; }
+    __device__ static void group_elem_store(const Epi& a, int m, int n, float v, float e, float gs) { a.out[(size_t)m * a.ldo + n] = e > 0.f ? v * gs : 0.f; }
+    __device__ static void group_store(const Epi& a, int g, int n, float s, float gs) { a.gsum[(size_t)g * a.xhad_ld + n] = (a.gmask && !(gs > 0.f)) ? 0.f : s; }
+};
 using DenseFwdHadB3 = DenseB3<DenseFwdHad, 2, 2, 2, 2>;   // 128 x 128 tiles (ncols % 128 == 0)
-using DenseDxB3 = DenseB3<DenseDx, 2, 2, 2, 1>;           // 128 x 64 tiles  (ncols % 64 == 0)
+using DenseDxB3 = DenseB3<DenseDx, 2, 2, 2, 2>;           // 128 x 128 tiles (ncols % 64 == 0: the last column tile may be half empty)
+using DenseDxHadB3 = DenseB3<DenseDxHad, 2, 2, 2, 2>;     // 128 x 128 tiles (a ragged last column tile when ncols % 128 = 64), row groups of 64:
+                                                          // a 128 x 64 tile reads 0.75 LDS fragments per MFMA and is LDS-bound (0.32 MFMA busy), this one 0.5
 
 struct DenseDxZ : DenseDx {
     using Args = DenseArgsZ;
@@ -505,7 +518,20 @@ inline int32_t dense_dx_b3(hipStream_t st, const DenseLayer& l, const float* par
     DenseB3Args d{};
     d.x = DenseSrc{dy, l.Np}; d.w = params_base + l.w; d.out = dx; d.ldo = l.Kp; d.mask = mask; d.ldm = l.Kp;
     d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np; d.wpl = planes_nat;
-    BDR_HIP((launch_igemm_b3<DenseDxB3, 6>(st, dim3(((M + 127) / 128) * (l.Kp / 64), 1, 1), d)));
+    BDR_HIP((launch_igemm_b3<DenseDxB3, 6>(st, dim3(((M + 127) / 128) * ((l.Kp + 127) / 128), 1, 1), d)));
+    return BDR_OK;
+}
+
+// ... with the Hadamard merge's backward in its epilogue (DenseDxHad): dx <- 1{e > 0} dm g[group], gsum[group] <- sum_rows dm e.
+// Rows come in groups of 64 (= the wave's rows) and M is a multiple of the 128-row tile: the caller checks both.
+inline int32_t dense_dx_had_b3(hipStream_t st, const DenseLayer& l, const float* params_base, const uint16_t* planes_nat, const float* dy, float* dx,
+                               const float* e, const float* g, int ldg, float* gsum, int gmask, int M)
+{
+    DenseB3Args d{};
+    d.x = DenseSrc{dy, l.Np}; d.w = params_base + l.w; d.out = dx; d.ldo = l.Kp; d.mask = e; d.ldm = l.Kp;
+    d.M = M; d.ncols = l.Kp; d.kred = l.Np; d.w_ld = l.Np; d.wpl = planes_nat;
+    d.xhad = g; d.xhad_ld = ldg; d.xhad_group = 64; d.gsum = gsum; d.gmask = gmask;
+    BDR_HIP((launch_igemm_b3<DenseDxHadB3, 6>(st, dim3((M / 128) * ((l.Kp + 127) / 128), 1, 1), d)));
     return BDR_OK;
 }
 

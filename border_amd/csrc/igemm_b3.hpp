@@ -101,6 +101,10 @@ static __global__ __launch_bounds__(256) void k_split_planes(const float* __rest
 // P: as for k_igemm, plus
 //   b_chunk(args, z, y, plane, kt, n, kq) -> const uint4*   the 8 bf16 (k = kt*32 + kq*8 ..) of B column n (global column index)
 //   P::MAXW   (optional, default 2) waves per SIMD the kernel is compiled for: 1 = 512 VGPRs for 128 x 128 tiles, 2 = 256
+// policies with a row-group epilogue declare `static constexpr bool GROUP_EPI = true` (+ group_scale / group_elem_store / group_store)
+template <class P, class = void> struct b3_group_epi : std::false_type {};
+template <class P> struct b3_group_epi<P, std::enable_if_t<P::GROUP_EPI>> : std::true_type {};
+
 template <class P, class = void> struct b3_maxw { static constexpr int value = 2; };
 template <class P> struct b3_maxw<P, std::void_t<decltype(P::MAXW)>> { static constexpr int value = P::MAXW; };
 template <class P, int TERMS = 9>
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / P::WN, wn = wave % P::WN;
-    const int NT_N = P::N(args) / BN;
+    const int NC = P::N(args), NT_N = (NC + BN - 1) / BN;   // a ragged last column tile computes clamped columns and stores none of them
     const int mt = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
     const int m0 = mt * BM, n0 = nt * BN;
     const int z = blockIdx.z, y = blockIdx.y;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
         const int e = tid + p * NT;
         if (B_CH % NT != 0 && e >= B_CH) return;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rb[S][p][pl] = *reinterpret_cast<const u32x4_t*>(P::b_chunk(args, z, y, pl, kt, n0 + e / 4, e % 4));
+        for (int pl = 0; pl < 3; ++pl) rb[S][p][pl] = *reinterpret_cast<const u32x4_t*>(P::b_chunk(args, z, y, pl, kt, min(n0 + e / 4, NC - 1), e % 4));
     };
     auto commit_a = [&](auto set, int stage, int p) {
         constexpr int S = decltype(set)::value;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
             else mrow[tm][r] = 0;
 #pragma unroll
             for (int tn = 0; tn < P::TN; ++tn)
-                aux[tm][tn][r] = P::epi_load(epi, mrow[tm][r], n0 + (wn * P::TN + tn) * 32 + j);
+                aux[tm][tn][r] = P::epi_load(epi, mrow[tm][r], min(n0 + (wn * P::TN + tn) * 32 + j, NC - 1));
         }
     }
     __syncthreads();
@@ -310,6 +314,28 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
         if (it + 1 < nkt) step(Set0{}, it + 1);
     }
 
+    if constexpr (b3_group_epi<P>::value) {
+        // Row-group epilogue: the wave's TM * 32 consecutive rows are ONE group (host-checked: group size = TM * 32, M a multiple of the
+        // tile); besides the element-wise store, a policy sums v * aux over the group's rows per column and stores one value per
+        // (group, column) - IQN's merge backward (d psi[b] = sum_n dm[b, n] phi[b, n]) without a second pass over dm.
+        const int g = (m0 + wm * P::TM * 32) / (P::TM * 32);
+#pragma unroll
+        for (int tn = 0; tn < P::TN; ++tn) {
+            const int n = n0 + (wn * P::TN + tn) * 32 + j;
+            if (n >= NC) continue;
+            const float gs = P::group_scale(epi, g, n);
+            float s = 0.f;
+#pragma unroll
+            for (int tm = 0; tm < P::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s = fmaf(acc[tm][tn][r], aux[tm][tn][r], s);
+                    P::group_elem_store(epi, mrow[tm][r], n, acc[tm][tn][r], aux[tm][tn][r], gs);
+                }
+            s += __shfl_xor(s, 32);
+            if (h == 0) P::group_store(epi, g, n, s, gs);
+        }
+    } else {
 #pragma unroll
     for (int tm = 0; tm < P::TM; ++tm)
 #pragma unroll
@@ -319,8 +345,9 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
             for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(aux[tm][tn][r]));
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (okmask[tm] >> r & 1) P::store(epi, mrow[tm][r], n, acc[tm][tn][r], aux[tm][tn][r]);
+                if ((okmask[tm] >> r & 1) && n < NC) P::store(epi, mrow[tm][r], n, acc[tm][tn][r], aux[tm][tn][r]);
         }
+    }
 }
 
 template <class P, int TERMS = 9>

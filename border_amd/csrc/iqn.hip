@@ -175,6 +175,7 @@ struct Iqn : bdr_agent {
     // enough to be matrix-bound (config C4: 32 768 x 3 136 x 512): forward of both networks and the input gradient.  The exact
     // FP32-MFMA kernels stay selectable (BDR_IQN_F32_EXACT=1) and serve every smaller shape.
     bool b3_allowed = true;
+    bool merge_epilogue = true;
     uint16_t *wpl_nat = nullptr, *wpl_tr = nullptr;   // [3][Kp][Np], [3][Np][Kp] bf16 planes of L[1]'s weights, re-split before every use
     bool use_b3(int M) const
     {
@@ -336,14 +337,20 @@ struct Iqn : bdr_agent {
             if (i > 1) { Bracket br(a, ("iqn_f_dx" + std::to_string(i)).c_str()); BDR_TRY(dense_dx(stream, hd.L[i], p, f_dy[i - 1], f_dy[i - 2], f_act[i - 2], M)); }
         }
         // dm = dL/dm (no ReLU mask: m is a product, not an activation)
-        {   // (wpl_nat: split from the online weights by this update's forward; the parameters have not changed since)
-            Bracket br(a, use_b3(M) ? "iqn_f_dx1_3xbf16" : "iqn_f_dx1");
-            if (use_b3(M)) BDR_TRY(dense_dx_b3(stream, hd.L[1], p, wpl_nat, f_dy[0], mrg, nullptr, M));
-            else BDR_TRY(dense_dx(stream, hd.L[1], p, f_dy[0], mrg, nullptr, M));
-        }
         float* dpsi = cnn ? dy3 : psi_dy.back();
         const int mask_psi = cnn ? 1 : (cfg.psi.activation_out ? 1 : 0);
-        {
+        bool merged_in_epilogue = false;
+        {   // (wpl_nat: split from the online weights by this update's forward; the parameters have not changed since)
+            // 64 percent points per sample (Uniform64, BASELINE config 4): a wave of the split-operand kernel owns one sample's rows, and
+            // the merge's backward (dlin = 1{phi > 0} dm psi, dpsi = sum_n dm phi) is its epilogue - dm never goes to HBM and back
+            const bool fuse_merge = use_b3(M) && Np == 64 && M % 128 == 0 && merge_epilogue;
+            Bracket br(a, use_b3(M) ? "iqn_f_dx1_3xbf16" : "iqn_f_dx1");
+            if (fuse_merge) BDR_TRY(dense_dx_had_b3(stream, hd.L[1], p, wpl_nat, f_dy[0], mrg, phi, feat, ldf, dpsi, mask_psi, M));
+            else if (use_b3(M)) BDR_TRY(dense_dx_b3(stream, hd.L[1], p, wpl_nat, f_dy[0], mrg, nullptr, M));
+            else BDR_TRY(dense_dx(stream, hd.L[1], p, f_dy[0], mrg, nullptr, M));
+            merged_in_epilogue = fuse_merge;
+        }
+        if (!merged_in_epilogue) {
             Bracket br(a, "iqn_merge_bwd");
             hipLaunchKernelGGL(k_iqn_merge_bwd, dim3((Bn * F + 255) / 256), dim3(256), 0, stream, mrg, phi, feat, ldf, dpsi, ldf, Bn, Np, F, Fp, mask_psi);
             BDR_HIP(hipGetLastError());
@@ -631,6 +638,7 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
     a->cnn = cfg->psi.kind == BDR_NET_ATARI_CNN;
     a->b3_allowed = getenv("BDR_IQN_F32_EXACT") == nullptr;
+    a->merge_epilogue = getenv("BDR_IQN_NO_MERGE_EPILOGUE") == nullptr;   // (A/B switch: the separate k_iqn_merge_bwd pass)
     a->F = cfg->feature_dim; a->E = cfg->embed_dim; a->A = cfg->n_actions;
     size_t o = 0;
     if (a->cnn) {

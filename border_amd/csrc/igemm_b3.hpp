@@ -27,7 +27,13 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // plain vector types keep the staging registers out of scratch
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr int B3_LDR = 40;   // row stride of a bf16 plane tile in u16 units (32 k + 8 pad = 80 B)
+constexpr int B3_LDR = 40;   // (probes: padded row stride of a bf16 plane tile in u16 units, 32 k + 8 pad = 80 B)
+// k_igemm_b3's plane tiles: rows of 32 k = 64 B, unpadded, the four 16-byte chunks of row r stored at chunk ^ ((r >> 2) & 3).  A fragment
+// read (16 lanes = 16 rows, one chunk index) then covers all 64 banks once, and the staging writes (4 rows x 64 B per 16 / 32 lanes)
+// are 256 contiguous bytes.  The padded 80-byte rows before it were conflict-free for the reads only: rows r and r + 3 overlap modulo 256 B
+// for the writes - SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE in the C4 kernels.
+constexpr int B3_ROW = 32;   // u16 per row
+__device__ __forceinline__ int b3_off(int row, int chunk) { return row * B3_ROW + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
 // exact 3-way split of four floats into packed bf16 pairs: p[plane] = {pair(x0,x1), pair(x2,x3)}
 __device__ __forceinline__ void split3_f32x4(const f32x4& x, u32x2_t (&p)[3])
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
     static_assert(NT % APR == 0, "a thread keeps its k-quad across passes");
     constexpr int A_ELEMS = BM * APR, A_PASSES = (A_ELEMS + NT - 1) / NT;
     constexpr int B_CH = BN * 4, B_PASSES = (B_CH + NT - 1) / NT;   // 16-byte chunks per plane
-    constexpr int PLANE_A = BM * B3_LDR, PLANE_B = BN * B3_LDR;      // u16
+    constexpr int PLANE_A = BM * B3_ROW, PLANE_B = BN * B3_ROW;      // u16
     constexpr int STAGE = 3 * (PLANE_A + PLANE_B);                   // u16
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * STAGE];
 
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
         f32x4 av = ra[S][p];
         if constexpr (HAD) av *= rh[S][p];
         split3_f32x4(av, sp);
-        const int o = (p * (NT / APR) + a_r) * B3_LDR + a_q * 4;
+        const int o = b3_off(p * (NT / APR) + a_r, a_q >> 1) + (a_q & 1) * 4;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2_t*>(&As[pl * PLANE_A + o]) = sp[pl];
     };
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
         uint16_t* Bs = smem + stage * STAGE + 3 * PLANE_A;
         const int e = tid + p * NT;
         if (B_CH % NT != 0 && e >= B_CH) return;
-        const int o = (e / 4) * B3_LDR + (e % 4) * 8;
+        const int o = b3_off(e / 4, e % 4);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(&Bs[pl * PLANE_B + o]) = rb[S][p][pl];
     };
@@ -252,10 +258,10 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
             for (int tm = 0; tm < P::TM; ++tm)
-                fa[F][tm][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl * PLANE_A + ((wm * P::TM + tm) * 32 + j) * B3_LDR + s * 16 + h * 8]);
+                fa[F][tm][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl * PLANE_A + b3_off((wm * P::TM + tm) * 32 + j, s * 2 + h)]);
 #pragma unroll
             for (int tn = 0; tn < P::TN; ++tn)
-                fb[F][tn][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl * PLANE_B + ((wn * P::TN + tn) * 32 + j) * B3_LDR + s * 16 + h * 8]);
+                fb[F][tn][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl * PLANE_B + b3_off((wn * P::TN + tn) * 32 + j, s * 2 + h)]);
         }
     };
     // partial products, smallest first: (a plane, b plane)

@@ -41,4 +41,5 @@ pmc FETCH_SIZE fetch
 pmc WRITE_SIZE write
 { echo "# rocprofv3 --pmc passes of round 4 (B=256 Atari DQN step, serial schedule BDR_NO_OVERLAP=1; separate passes, --kernel-trace only)"; echo; echo "## FETCH_SIZE (KiB per dispatch)"; echo; sed -n '3,$p' $O/pmc_${tag}_fetch.md; echo; echo "## WRITE_SIZE (KiB per dispatch)"; echo; sed -n '3,$p' $O/pmc_${tag}_write.md; } > $O/rocprof_${tag}_pmc.md
 python tools/make_hbm_traffic.py $O/pmc_${tag}_fetch.md $O/pmc_${tag}_write.md profiles/rocprof_${tag}_pmc.md > $O/hbm_traffic.json 2> $O/hbm_traffic.err
+bash tools/gpu_round4_mfma.sh $tag > $O/mfma_pass.log 2>&1
 ls $O | grep -E "$tag|hbm|kernel_trace" | head -60

@@ -215,6 +215,43 @@ def test_split_operand_merge_layer_equals_the_exact_kernels(B, monkeypatch, Bsz,
         o += n
 
 
+@pytest.mark.parametrize("act_out", [True, False])
+def test_split_operand_merge_layer_behind_an_mlp_feature_extractor(B, monkeypatch, act_out):
+    """The same comparison with psi = Mlp(8 -> [64] -> 2048): the fused merge backward masks d psi by psi > 0 only when psi ends in a
+    ReLU (MlpConfig::activation_out), and its feature rows have the Mlp's padded leading dimension."""
+    from oracle import torch_ref as T
+    Bsz, NQ, A, F_ = 64, 64, 5, 2048
+    sh = T.iqn_shapes("mlp", F_, 64, [512], A, psi_in=8, psi_units=[64])
+    p0 = T.init_params(sh[0] + sh[1] + sh[2], 57)
+    batch = T.iqn_batch(Bsz, "mlp", A, NQ, NQ, 322, in_dim=8)
+    out = {}
+    for mode in ("exact", "split"):
+        monkeypatch.delenv("BDR_IQN_F32_EXACT", raising=False)
+        if mode == "exact":
+            monkeypatch.setenv("BDR_IQN_F32_EXACT", "1")
+        f_cfg = B.MlpConfig(in_dim=8, units=(64,), out_dim=F_, activation_out=act_out)
+        cfg = B.IqnConfig(f_config=f_cfg, feature_dim=F_, embed_dim=64, m_units=(512,), n_actions=A, lr=1e-4, batch_size=Bsz, device=0, tau=1.0, soft_update_interval=10000)
+        a = B.Iqn.build(cfg)
+        a.set_params(p0, "iqn"); a.set_params(p0, "iqn_tgt")
+        a.profile_enable(True)
+        rec = a.update_on_batch(*batch)
+        import bench
+        labels = [l for l, _ in bench.read_profile(a)]
+        a.profile_enable(False)
+        out[mode] = (rec["loss_critic"], a.get_params("grad"), labels)
+        a.close()
+    assert "iqn_f_dx1_3xbf16" in out["split"][2] and "iqn_merge_bwd" not in out["split"][2] and "iqn_merge_bwd" in out["exact"][2]
+    assert abs(out["split"][0] - out["exact"][0]) <= 1e-5 * abs(out["exact"][0])
+    o = 0
+    for shp in sh[0] + sh[1] + sh[2]:
+        n = int(np.prod(shp))
+        g_s, g_e = out["split"][1][o:o + n].astype(np.float64), out["exact"][1][o:o + n].astype(np.float64)
+        d = np.abs(g_s - g_e) / max(np.abs(g_e).max(), 1e-30)
+        bad = (d > 1e-4).reshape(shp[0], -1).any(1)
+        assert bad.sum() <= 2 and d.max() < 5e-3, (shp, int(bad.sum()), d.max())
+        o += n
+
+
 def test_iqn_opt_over_replay_and_qvalues(B, tmp_path):
     """Agent::opt over the HBM ring with device-drawn percent points (Uniform64, batch 32): finite loss, counters,
     checkpoint round trip; Policy::sample's averaged action values == mean over Const32's 33 points of forward()."""

@@ -577,9 +577,16 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
         __syncthreads();
         cur ^= 1;
     };
-    for (int it = 0; it < iters; it += 2) {
-        step(Set1{}, it);
-        if (it + 1 < iters) step(Set0{}, it + 1);
+    // (pairs, then the odd tail: a conditional second step inside the loop gives the compiler a path "first step, straight back to the
+    //  header" on which the set the header consumes is the most recently loaded one, and its s_waitcnt insertion then drains the loads of
+    //  the previous step at every header - seen as vmcnt(3 .. 0) instead of vmcnt(7 .. 4) in the l1 forward kernel)
+    {
+        int it = 0;
+        for (; it + 1 < iters; it += 2) {
+            step(Set1{}, it);
+            step(Set0{}, it + 1);
+        }
+        if (it < iters) step(Set1{}, it);
     }
     if constexpr (TEAMS == 2) {   // acc(team 0) += acc(team 1), through team 1's (now idle) stages
         constexpr int PER_WAVE = P::TM * P::TN * 16 * 64;
@@ -692,36 +699,42 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
     const int a_q = tid % (BK / A::VEC), a_r = tid / (BK / A::VEC);  // a_r in [0, ROWS_PER_PASS)
     const float* ysrc = P::y_src(args);
 
-    f32x4 ra[A_PASSES][AV];
+    // two register sets (as in k_igemm): the loads of row tile mt + 3 are issued while tile mt is on the matrix pipe and are consumed a
+    // full tile later; with one set they were consumed six MFMAs (~400 cycles) after their issue and every tile waited out the rest of
+    // the memory latency (vmcnt(1), vmcnt(0) behind the first MFMAs of each tile; the dW kernels had the lowest MFMA-busy of the step)
+    f32x4 ra[2][A_PASSES][AV];
     constexpr bool HAD = a_has_had<A>::value;
-    f32x4 rh[HAD ? A_PASSES : 1];
-    f32x4 ry[Y_VECS];
+    f32x4 rh[2][HAD ? A_PASSES : 1];
+    f32x4 ry[2][Y_VECS];
     f32x4 bsum[Y_VECS];
 #pragma unroll
     for (int v = 0; v < Y_VECS; ++v) bsum[v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // pass p covers (row, ksub) pairs: idx = p*ROWS_PER_PASS + a_r; row = idx % 32, ksub = idx / 32
-    auto prefetch_a = [&](int mt) {
+    auto prefetch_a = [&](auto set, int mt) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
             const int idx = p * ROWS_PER_PASS + a_r;
             const int row = idx % 32, ksub = idx / 32;
             typename A::Row r = A::row(P::a_src(args), mt * 32 + row, M);
-            A::load(r, ko0 / BK + ksub, a_q, ra[p]);
-            if constexpr (HAD) rh[p] = A::load_had(r, ko0 / BK + ksub, a_q);
+            A::load(r, ko0 / BK + ksub, a_q, ra[S][p]);
+            if constexpr (HAD) rh[S][p] = A::load_had(r, ko0 / BK + ksub, a_q);
         }
     };
-    auto prefetch_y = [&](int mt) {   // rows >= M contribute zero (select, no branch)
+    auto prefetch_y = [&](auto set, int mt) {   // rows >= M contribute zero (select, no branch)
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int v = 0; v < Y_VECS; ++v) {
             const int e = tid + v * 256;
             const int row = e / (N_T / 4), n4 = e % (N_T / 4);
             const int m = mt * 32 + row;
             const f32x4 t = *reinterpret_cast<const f32x4*>(ysrc + (size_t)min(m, M - 1) * P::N(args) + n0 + n4 * 4);
-            ry[v] = m < M ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            ry[S][v] = m < M ? t : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto commit_a = [&](int stage) {
+    auto commit_a = [&](auto set, int stage) {
+        constexpr int S = decltype(set)::value;
         float* As = smem + stage * STAGE;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
@@ -729,20 +742,21 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
             const int row = idx % 32, ksub = idx / 32;
 #pragma unroll
             for (int j = 0; j < AV; ++j) {
-                f32x4 v = ra[p][j];
-                if constexpr (HAD) v *= rh[p];
+                f32x4 v = ra[S][p][j];
+                if constexpr (HAD) v *= rh[S][p];
                 *reinterpret_cast<f32x4*>(&As[row * LDAR + ksub * BK + a_q * A::VEC + j * 4]) = v;
             }
         }
     };
-    auto commit_y = [&](int stage, bool count) {
+    auto commit_y = [&](auto set, int stage, bool count) {
+        constexpr int S = decltype(set)::value;
         float* Ys = smem + stage * STAGE + 32 * LDAR;
 #pragma unroll
         for (int v = 0; v < Y_VECS; ++v) {
             const int e = tid + v * 256;
             const int row = e / (N_T / 4), n4 = e % (N_T / 4);
-            *reinterpret_cast<f32x4*>(&Ys[row * LDY + n4 * 4]) = ry[v];
-            if (count) bsum[v] += ry[v];
+            *reinterpret_cast<f32x4*>(&Ys[row * LDY + n4 * 4]) = ry[S][v];
+            if (count) bsum[v] += ry[S][v];
         }
     };
 
@@ -757,18 +771,21 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
     const int i = lane & 31, h = lane >> 5;
     // branch-free software pipeline (see k_igemm); the tail re-stages the last tile into the idle
     // stage, which must not be counted twice in the bias sums
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    auto tile_mt = [&](int k) { return min(mt0 + k, mt1 - 1); };
     if (mt0 < mt1) {
-        prefetch_a(mt0); prefetch_y(mt0);
-        commit_a(0); commit_y(0, true);
-        const int m1 = min(mt0 + 1, mt1 - 1);
-        prefetch_a(m1); prefetch_y(m1);
+        prefetch_a(Set0{}, mt0); prefetch_y(Set0{}, mt0);
+        prefetch_a(Set1{}, tile_mt(1)); prefetch_y(Set1{}, tile_mt(1));
+        commit_a(Set0{}, 0); commit_y(Set0{}, 0, true);
+        prefetch_a(Set0{}, tile_mt(2)); prefetch_y(Set0{}, tile_mt(2));
     }
     __syncthreads();
     int cur = 0;
-    for (int mt = mt0; mt < mt1; ++mt) {
+    auto step = [&](auto set, int mt) {   // set holds row tile mt + 1 (committed into the idle stage) and is refilled with tile mt + 3
         const float* As = smem + cur * STAGE;
         const float* Ys = As + 32 * LDAR;
-        const int m2 = min(mt + 2, mt1 - 1);
+        const int m3 = min(mt + 3, mt1 - 1);
         const bool fresh = mt + 1 < mt1;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -783,13 +800,21 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
 #pragma unroll
                 for (int tn = 0; tn < P::TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-            if (t == 1) commit_a(cur ^ 1);               // staging sliced into the MFMA shadows
-            else if (t == 5) commit_y(cur ^ 1, fresh);
-            else if (t == 8) prefetch_a(m2);
-            else if (t == 11) prefetch_y(m2);
+            if (t == 1) commit_a(set, cur ^ 1);               // staging sliced into the MFMA shadows
+            else if (t == 5) commit_y(set, cur ^ 1, fresh);
+            else if (t == 8) prefetch_a(set, m3);
+            else if (t == 11) prefetch_y(set, m3);
         }
         __syncthreads();
         cur ^= 1;
+    };
+    {
+        int mt = mt0;
+        for (; mt + 1 < mt1; mt += 2) {
+            step(Set1{}, mt);
+            step(Set0{}, mt + 1);
+        }
+        if (mt < mt1) step(Set1{}, mt);
     }
 
     float* part = P::part(args, chunk);

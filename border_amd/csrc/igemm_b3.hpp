@@ -33,6 +33,10 @@ constexpr int B3_LDR = 40;   // (probes: padded row stride of a bf16 plane tile 
 // are 256 contiguous bytes.  The padded 80-byte rows before it were conflict-free for the reads only: rows r and r + 3 overlap modulo 256 B
 // for the writes - SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE in the C4 kernels.
 constexpr int B3_ROW = 32;   // u16 per row
+#ifndef BDR_B3_XCD_MAP
+#define BDR_B3_XCD_MAP 1
+#endif
+constexpr bool b3_xcd_map = BDR_B3_XCD_MAP != 0;
 __device__ __forceinline__ int b3_off(int row, int chunk) { return row * B3_ROW + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
 // exact 3-way split of four floats into packed bf16 pairs: p[plane] = {pair(x0,x1), pair(x2,x3)}
@@ -132,7 +136,14 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / P::WN, wn = wave % P::WN;
     const int NC = P::N(args), NT_N = (NC + BN - 1) / BN;   // a ragged last column tile computes clamped columns and stores none of them
-    const int mt = blockIdx.x / NT_N, nt = blockIdx.x % NT_N;
+    // the NT_N column tiles of a row tile read the same A rows: keep them on one XCD (workgroup b runs on XCD b % 8), back to back in that
+    // XCD's dispatch order, so that its L2 serves all but the first read (linear order: four XCDs each fetch the rows from HBM / MALL)
+    int mt, nt;
+    {
+        const int MT = (int)gridDim.x / NT_N;
+        if ((MT & 7) == 0 && b3_xcd_map) { const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3; mt = (q / NT_N) * 8 + xcd; nt = q % NT_N; }
+        else { mt = blockIdx.x / NT_N; nt = blockIdx.x % NT_N; }
+    }
     const int m0 = mt * BM, n0 = nt * BN;
     const int z = blockIdx.z, y = blockIdx.y;
     const int M = P::M(args);
@@ -315,10 +326,15 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
         }
         cur ^= 1;
     };
-    for (int it = 0; it < nkt; it += 2) {
+    // (no conditional second step inside the loop: with it, the path "first step, then straight back to the header" makes the set the
+    //  header consumes the most recently loaded one as far as the compiler's s_waitcnt insertion can tell, and every iteration drained
+    //  the loads issued half a step earlier - vmcnt(12 .. 0) at the header instead of vmcnt(28 .. 16))
+    int it = 0;
+    for (; it + 1 < nkt; it += 2) {
         step(Set1{}, it);
-        if (it + 1 < nkt) step(Set0{}, it + 1);
+        step(Set0{}, it + 1);
     }
+    if (it < nkt) step(Set1{}, it);
 
     if constexpr (b3_group_epi<P>::value) {
         // Row-group epilogue: the wave's TM * 32 consecutive rows are ONE group (host-checked: group size = TM * 32, M a multiple of the

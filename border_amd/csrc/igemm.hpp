@@ -722,15 +722,15 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
             if constexpr (HAD) rh[S][p] = A::load_had(r, ko0 / BK + ksub, a_q);
         }
     };
-    auto prefetch_y = [&](auto set, int mt) {   // rows >= M contribute zero (select, no branch)
+    auto prefetch_y = [&](auto set, int mt) {   // rows >= M are clamped here and zeroed at the commit: a select behind the load makes the
+                                                // compiler wait for it where the select is scheduled, half a tile after its issue
         constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int v = 0; v < Y_VECS; ++v) {
             const int e = tid + v * 256;
             const int row = e / (N_T / 4), n4 = e % (N_T / 4);
             const int m = mt * 32 + row;
-            const f32x4 t = *reinterpret_cast<const f32x4*>(ysrc + (size_t)min(m, M - 1) * P::N(args) + n0 + n4 * 4);
-            ry[S][v] = m < M ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            ry[S][v] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)min(m, M - 1) * P::N(args) + n0 + n4 * 4);   // (masked at the commit)
         }
     };
     auto commit_a = [&](auto set, int stage) {
@@ -748,15 +748,16 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
             }
         }
     };
-    auto commit_y = [&](auto set, int stage, bool count) {
+    auto commit_y = [&](auto set, int stage, bool count, int mt) {   // mt: the row tile the set holds
         constexpr int S = decltype(set)::value;
         float* Ys = smem + stage * STAGE + 32 * LDAR;
 #pragma unroll
         for (int v = 0; v < Y_VECS; ++v) {
             const int e = tid + v * 256;
             const int row = e / (N_T / 4), n4 = e % (N_T / 4);
-            *reinterpret_cast<f32x4*>(&Ys[row * LDY + n4 * 4]) = ry[S][v];
-            if (count) bsum[v] += ry[S][v];
+            const f32x4 t = mt * 32 + row < M ? ry[S][v] : f32x4{0.f, 0.f, 0.f, 0.f};   // rows >= M contribute zero
+            *reinterpret_cast<f32x4*>(&Ys[row * LDY + n4 * 4]) = t;
+            if (count) bsum[v] += t;
         }
     };
 
@@ -777,7 +778,7 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
     if (mt0 < mt1) {
         prefetch_a(Set0{}, mt0); prefetch_y(Set0{}, mt0);
         prefetch_a(Set1{}, tile_mt(1)); prefetch_y(Set1{}, tile_mt(1));
-        commit_a(Set0{}, 0); commit_y(Set0{}, 0, true);
+        commit_a(Set0{}, 0); commit_y(Set0{}, 0, true, mt0);
         prefetch_a(Set0{}, tile_mt(2)); prefetch_y(Set0{}, tile_mt(2));
     }
     __syncthreads();
@@ -801,7 +802,7 @@ __device__ __forceinline__ void igemm_red_body(const typename P::Args& args, con
                 for (int tn = 0; tn < P::TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
             if (t == 1) commit_a(set, cur ^ 1);               // staging sliced into the MFMA shadows
-            else if (t == 5) commit_y(set, cur ^ 1, fresh);
+            else if (t == 5) commit_y(set, cur ^ 1, fresh, min(mt + 1, mt1 - 1));
             else if (t == 8) prefetch_a(set, m3);
             else if (t == 11) prefetch_y(set, m3);
         }

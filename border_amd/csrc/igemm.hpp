@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
     __syncthreads();
     int cur = 0;
     auto step = [&](auto set, int it) {   // set = (it+1)&1: holds tile it+1; refilled with tile it+3
-        if (it < my_n) {                  // team-uniform
+        if (TEAMS == 1 || it < my_n) {    // team-uniform; one team: my_n == iters, and a branch here costs the compiler its knowledge of which loads are outstanding
             const float* As = smem + cur * STAGE;
             const int k3 = tile(it + 3);
             mfma_ktile<P::TM, P::TN, LDB, P::B_TR>(As, As + BM * LDA, wm * P::TM * 32, wn * P::TN * 32, lane, acc, [&](int u) {

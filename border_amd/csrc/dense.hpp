@@ -9,6 +9,7 @@
 
 #include "agent_base.hpp"
 #include "igemm_b3.hpp"
+#include "igemm_red_b3.hpp"
 
 namespace bdr {
 
@@ -588,6 +589,22 @@ inline int32_t dense_dw(hipStream_t st, const DenseLayer& l, float* grad_base, D
     if (chunks > 1) {
         BDR_HIP(step_launch(st, false, k_dense_reduce, dim3((n + 63) / 64), dim3(256), part, (size_t)n, chunks, grad_base + l.w, n));
     }
+    return BDR_OK;
+}
+
+// The weight gradient on the bf16 matrix cores with split operands (igemm_red_b3.hpp): dy is split ONCE into transposed planes
+// (ytr: [3][Np][M] u16, caller-owned), X (x had[m / had_group]) in the kernel.  M % 64 == 0, Np % 128 == 0, Kp even, had_group % 8 == 0.
+inline int32_t dense_dw_b3(hipStream_t st, const DenseLayer& l, float* grad_base, DenseSrc x, const float* dy, uint16_t* ytr, int M, float* part, int chunks,
+                           const float* had = nullptr, int had_ld = 0, int had_group = 8)
+{
+    const int n = l.Kp * l.Np + l.Np;
+    hipLaunchKernelGGL(k_split_rows_tr, dim3(l.Np / 64, M / 64), dim3(256), 0, st, dy, l.Np, ytr, M, l.Np);
+    BDR_HIP(hipGetLastError());
+    RedB3Args a{x.p, x.ld, had, had_ld, had_group, ytr, part, (size_t)n, M, l.Kp, l.Np, chunks};
+    const int tiles = ((l.Kp + 127) / 128) * (l.Np / 128);
+    hipLaunchKernelGGL(k_igemm_red_b3<6>, dim3(tiles * chunks), dim3(256), 0, st, a);
+    BDR_HIP(hipGetLastError());
+    BDR_HIP(step_launch(st, false, k_dense_reduce, dim3((n + 63) / 64), dim3(256), part, (size_t)n, chunks, grad_base + l.w, n));
     return BDR_OK;
 }
 

@@ -1,14 +1,11 @@
-// Probe only (round 4, second attempt): the probe of igemm_red_b3.hpp with Y (the output gradient) pre-split ONCE into transposed bf16
-// planes by k_split_rows_tr, so that only X is split in the kernel.  Wired into csrc/iqn.hip it passed the 64-quantile parity test and
-// ran the C4 step at 250.5 opt-steps/s against 249.7 with the FP32-MFMA weight gradient on the same box: no gain - the transposed
-// staging of X (16 dword loads + Hadamard + split per thread and k-tile) is what bounds it, not the second split.  Not in the product.
 // Weight gradient of a dense layer on the bf16 matrix cores with split operands (six of the nine exact bf16 partial products, as
 // igemm_b3.hpp): G[ko][n] = sum_m X(m, ko) Y(m, n), the contraction running over the ROWS m.  gfx950 only.
 //   X (an activation, optionally times a per-row-group Hadamard factor: IQN's merged feature m = psi[b] * phi) is f32 in HBM and is
 //   split in the kernel; Y (the output gradient) comes as three bf16 planes ytr[plane][n][m] (m contiguous) that k_split_rows_tr
-//   writes ONCE per update - every one of the Kp / 128 row tiles of G would otherwise split the same Y rows again, and two in-kernel
-//   splits per k-tile cost the VALU what the six bf16 products save the matrix pipe (round-4 probe: 1.40 ms against 1.15 ms FP32
-//   at [32 768][3 136] x [32 768][512]).
+//   writes ONCE per update - every one of the Kp / 128 row tiles of G would otherwise split the same Y rows again.  Two round-4 probes
+//   (tools/probes/igemm_red_b3*.hpp) that staged X column by column (16 scalar loads per thread and k-tile) only matched the FP32 kernel;
+//   here a thread loads eight ROWS of two adjacent columns (wave-coalesced 512-byte row segments) and the transposition is just the
+//   choice of which eight values go into one 16-byte LDS chunk.
 #pragma once
 #include "igemm_b3.hpp"
 
@@ -42,13 +39,13 @@ static __global__ __launch_bounds__(256) void k_split_rows_tr(const float* __res
 
 // ------------------------------------------------------------------------------------------------
 // k_igemm_red_b3: G[ko][n] = sum_{m in chunk} X(m,ko) * Y(m,n)  (the contraction runs over the ROWS m).
-//   The MFMA wants, per lane, 8 consecutive contraction elements of its row: the LDS tiles are [ko][m] and [n][m] (m contiguous:
-//   exactly the plane layout of k_igemm_b3), so the staging transposes.  A thread owns one column (ko, or n) and four quads of
-//   four consecutive rows m: four dword loads per quad (a wave reads 256 contiguous bytes per row), the optional Hadamard factor
-//   once per quad (had[m / had_group][ko]; had_group % 4 == 0), one exact 3-way split, one ds_write_b64 per plane.
-//   Tile 128 x 128 (2 x 2 waves, 64 x 64 each), 32 rows of m per k-tile; per k-tile 16 staging slices (8 commits, 8 prefetches) ride
-//   between the 12 MFMA groups like in k_igemm_b3.  grid: (ko tiles * n tiles) * chunks workgroups, 1-D, chunk c on XCD c % 8
-//   (chunks % 8 == 0): all tiles of a row chunk read the same X / Y rows.
+//   The MFMA wants, per lane, 8 consecutive contraction elements of its row: the LDS tiles are [ko][m] and [n][m] (m contiguous, the
+//   swizzled 64-byte rows of k_igemm_b3).  X staging: wave w owns rows m0 + 8 w .. + 7 of the 32-row k-tile, lane l the columns
+//   ko0 + 2 l, + 1: eight 8-byte loads (a wave reads 512 contiguous bytes per row), the optional Hadamard factor once (had[m / had_group],
+//   had_group % 8 == 0), two exact 3-way splits per column, one ds_write_b128 per plane and column (chunk w of row ko).  Y staging: plain
+//   16-byte copies of the planes.  Tile 128 x 128 (2 x 2 waves, 64 x 64 each); per k-tile 10 staging slices ride between the 12 MFMA
+//   groups like in k_igemm_b3.  grid: (ko tiles * n tiles) * chunks workgroups, 1-D, chunk c on XCD c % 8 (chunks % 8 == 0): all tiles
+//   of a row chunk read the same X / Y rows.  M % 32 == 0.
 //   part[chunk][Kp * Np + Np]: the tile's sums, and the column sums of Y (bias gradient) from the ko-tile-0 workgroups.
 // ------------------------------------------------------------------------------------------------
 struct RedB3Args {
@@ -63,9 +60,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     static_assert(TERMS == 6 || TERMS == 9, "6 or 9 partial products");
     constexpr int TM = 2, TN = 2, BMK = 128, BN = 128;               // ko rows x n columns of the tile
-    constexpr int PLANE = 128 * B3_LDR;                               // u16 per plane and operand
+    constexpr int PLANE = 128 * B3_ROW;                               // u16 per plane and operand
     constexpr int STAGE = 6 * PLANE;
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * STAGE];   // 120 KB
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * STAGE];   // 96 KB
     __shared__ float sbq[512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -78,22 +75,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int mt0 = chunk * per, mt1 = min(n_mt, mt0 + per), nkt = max(mt1 - mt0, 0);
     auto tile_m = [&](int it) { return (mt0 + min(it, max(nkt - 1, 0))) * 32; };
 
-    // staging roles: column c = tid % 128 of the X tile (ko0 + c) and of the Y tile (n0 + c); quads mq, mq + 2, mq + 4, mq + 6 (mq = tid / 128)
-    const int c = tid & 127, mq = tid >> 7;
-    const bool x_ok = ko0 + c < a.Kp;
-    const float* xc = a.x + (x_ok ? ko0 + c : 0);
-    const float* hc = a.had ? a.had + (x_ok ? ko0 + c : 0) : nullptr;
-    f32x4 rx[2][4];
+    // staging roles (X): rows m0 + 8 wave + j (j = 0 .. 7), columns ko0 + 2 lane + {0, 1}
+    const int xc0 = ko0 + 2 * lane;
+    const bool x_ok = xc0 < a.Kp;                   // (Kp is even: both columns or none)
+    const float* xc = a.x + (x_ok ? xc0 : 0);
+    const float* hc = a.had ? a.had + (x_ok ? xc0 : 0) : nullptr;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t rx[2][8], rh[2];
     u32x4_t ry[2][2][3];
-    float rh[2][4];
     float bs[2] = {0.f, 0.f};   // column sums of Y over the chunks this thread stages (pass 0: column tid / 4, pass 1: column 64 + tid / 4)
     const bool count_bias = kot == 0;
-    auto prefetch_x = [&](auto set, int m0, int q) {
+    auto prefetch_x = [&](auto set, int m0, int q) {   // slice q: rows 2 q, 2 q + 1 of the wave's eight (+ the Hadamard factor with slice 0)
         constexpr int S = decltype(set)::value;
-        const int m = m0 + 4 * (mq + 2 * q);
+        const int m = m0 + 8 * wave + 2 * q;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rx[S][q][j] = (x_ok && m + j < a.M) ? xc[(size_t)(m + j) * a.x_ld] : 0.f;
-        if (hc) rh[S][q] = m < a.M ? hc[(size_t)(m / a.had_group) * a.had_ld] : 0.f;
+        for (int j = 0; j < 2; ++j) {
+            rx[S][2 * q + j] = *reinterpret_cast<const f32x2_t*>(xc + (size_t)(m + j) * a.x_ld);   // (columns beyond Kp: column 0's values, zeroed at the commit)
+        }
+        if (q == 0) rh[S] = hc ? *reinterpret_cast<const f32x2_t*>(hc + (size_t)((m0 + 8 * wave) / a.had_group) * a.had_ld) : f32x2_t{1.f, 1.f};
     };
     auto prefetch_y = [&](auto set, int m0, int p) {   // pass p: 16-byte chunk e = tid + 256 p of the [128 n][32 m] tile, three planes
         constexpr int S = decltype(set)::value;
@@ -102,16 +101,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) ry[S][p][pl] = *reinterpret_cast<const u32x4_t*>(src + (size_t)pl * a.Np * a.M);
     };
-    auto commit_x = [&](auto set, int stage, int q) {
+    auto commit_x = [&](auto set, int stage, int c) {   // slice c: column 2 lane + c -> chunk `wave` of row 2 lane + c in the three planes
         constexpr int S = decltype(set)::value;
-        f32x4 v = rx[S][q];
-        if (hc) v *= rh[S][q];
-        u32x2_t sp[3];
-        split3_f32x4(v, sp);
+        const float hf = x_ok ? rh[S][c] : 0.f;
+        u32x2_t lo4[3], hi4[3];
+        split3_f32x4(f32x4{rx[S][0][c] * hf, rx[S][1][c] * hf, rx[S][2][c] * hf, rx[S][3][c] * hf}, lo4);
+        split3_f32x4(f32x4{rx[S][4][c] * hf, rx[S][5][c] * hf, rx[S][6][c] * hf, rx[S][7][c] * hf}, hi4);
         uint16_t* Xs = smem + stage * STAGE;
-        const int o = c * B3_LDR + 4 * (mq + 2 * q);
+        const int o = b3_off(2 * lane + c, wave);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2_t*>(&Xs[pl * PLANE + o]) = sp[pl];
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(&Xs[pl * PLANE + o]) = u32x4_t{lo4[pl][0], lo4[pl][1], hi4[pl][0], hi4[pl][1]};
     };
     auto commit_y = [&](auto set, int stage, int p, bool fresh) {
         constexpr int S = decltype(set)::value;
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         uint16_t* Ys = smem + stage * STAGE + 3 * PLANE;
-        const int o = (e >> 2) * B3_LDR + (e & 3) * 8;
+        const int o = b3_off(e >> 2, e & 3);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(&Ys[pl * PLANE + o]) = ry[S][p][pl];
     };
@@ -140,15 +139,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
+    auto prefetch_all = [&](auto set, int m0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) prefetch_x(set, m0, q);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) prefetch_y(set, m0, p);
+    };
     if (nkt > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { prefetch_x(Set0{}, tile_m(0), q); if (q < 2) prefetch_y(Set0{}, tile_m(0), q); }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { prefetch_x(Set1{}, tile_m(1), q); if (q < 2) prefetch_y(Set1{}, tile_m(1), q); }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { commit_x(Set0{}, 0, q); if (q < 2) commit_y(Set0{}, 0, q, true); }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { prefetch_x(Set0{}, tile_m(2), q); if (q < 2) prefetch_y(Set0{}, tile_m(2), q); }
+        prefetch_all(Set0{}, tile_m(0));
+        prefetch_all(Set1{}, tile_m(1));
+        commit_x(Set0{}, 0, 0); commit_x(Set0{}, 0, 1); commit_y(Set0{}, 0, 0, true); commit_y(Set0{}, 0, 1, true);
+        prefetch_all(Set0{}, tile_m(2));
     }
     __syncthreads();
 
@@ -162,10 +163,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
-                fa[F][tm][pl] = *reinterpret_cast<const bf16x8_t*>(&Xs[pl * PLANE + ((wm * TM + tm) * 32 + j) * B3_LDR + s * 16 + h * 8]);
+                fa[F][tm][pl] = *reinterpret_cast<const bf16x8_t*>(&Xs[pl * PLANE + b3_off((wm * TM + tm) * 32 + j, s * 2 + h)]);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
-                fb[F][tn][pl] = *reinterpret_cast<const bf16x8_t*>(&Ys[pl * PLANE + ((wn * TN + tn) * 32 + j) * B3_LDR + s * 16 + h * 8]);
+                fb[F][tn][pl] = *reinterpret_cast<const bf16x8_t*>(&Ys[pl * PLANE + b3_off((wn * TN + tn) * 32 + j, s * 2 + h)]);
         }
     };
     auto mfma_group = [&](auto buf, int t) {
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using Buf1 = std::integral_constant<int, 1>;
     if (nkt > 0) load_frag(Buf0{}, 0, 0);
     int cur = 0;
-    constexpr int PER = (6 + TERMS - 1) / TERMS;   // 6 slices per k-step (4 X quads, 2 Y passes) over TERMS groups
+    constexpr int PER = 1;   // at most one staging slice per MFMA group: 4 commits in the first k-step, 6 prefetches in the second
     auto step = [&](auto set, int it) {   // set holds tile it+1; refilled with tile it+3
         const int m3 = tile_m(it + 3);
         const bool fresh = it + 1 < nkt;   // the clamped tail re-stages the last tile: not counted twice in the bias sums
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 const int q = g * PER + u;
-                if (q < 4) commit_x(set, cur ^ 1, q);
-                else if (q < 6) commit_y(set, cur ^ 1, q - 4, fresh);
+                if (q < 2) commit_x(set, cur ^ 1, q);
+                else if (q < 4) commit_y(set, cur ^ 1, q - 2, fresh);
             }
 #pragma unroll
             for (int i = 0; i < TM * TN; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 20, 0); }
@@ -216,9 +217,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         cur ^= 1;
     };
-    for (int it = 0; it < nkt; it += 2) {
-        step(Set1{}, it);
-        if (it + 1 < nkt) step(Set0{}, it + 1);
+    {
+        int it = 0;
+        for (; it + 1 < nkt; it += 2) { step(Set1{}, it); step(Set0{}, it + 1); }
+        if (it < nkt) step(Set1{}, it);
     }
 
     float* part = a.part + (size_t)chunk * a.part_stride;

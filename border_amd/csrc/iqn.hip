@@ -176,6 +176,9 @@ struct Iqn : bdr_agent {
     // FP32-MFMA kernels stay selectable (BDR_IQN_F32_EXACT=1) and serve every smaller shape.
     bool b3_allowed = true;
     bool merge_epilogue = true;
+    uint16_t* dypl_tr = nullptr;   // [3][Np][M] bf16 planes of the merge layer's output gradient (split once per update, dense_dw_b3)
+    size_t dypl_elems = 0;
+    bool dw_b3 = true;
     uint16_t *wpl_nat = nullptr, *wpl_tr = nullptr;   // [3][Kp][Np], [3][Np][Kp] bf16 planes of L[1]'s weights, re-split before every use
     bool use_b3(int M) const
     {
@@ -198,7 +201,7 @@ struct Iqn : bdr_agent {
         free_batch();
         (void)hipFree(p); (void)hipFree(p_tgt); (void)hipFree(grad); (void)hipFree(am); (void)hipFree(av); (void)hipFree(loss);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
-        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr);
+        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr); (void)hipFree(dypl_tr);
     }
     void free_batch()
     {
@@ -330,8 +333,13 @@ struct Iqn : bdr_agent {
         for (int i = L - 1; i >= 1; --i) {
             DenseSrc in = i == 1 ? DenseSrc{phi, Fp} : DenseSrc{f_act[i - 2], hd.L[i - 1].Np};
             {
-                Bracket br(a, ("iqn_f_dw" + std::to_string(i)).c_str());
-                if (i == 1) BDR_TRY(dense_dw(stream, hd.L[i], grad, in, f_dy[i - 1], M, part, ch, feat, ldf, Np));   // x = phi * psi[b]
+                const bool dw1_b3 = i == 1 && use_b3(M) && dw_b3 && M % 64 == 0 && Np % 8 == 0 && ch > 1;
+                Bracket br(a, dw1_b3 ? "iqn_f_dw1_3xbf16" : ("iqn_f_dw" + std::to_string(i)).c_str());
+                if (i == 1 && dw1_b3) {   // x = phi * psi[b], on the bf16 matrix cores: dy split once into transposed planes, x in the kernel
+                    const size_t n = (size_t)3 * M * hd.L[1].Np;
+                    if (dypl_elems < n) { BDR_HIP(hipStreamSynchronize(stream)); (void)hipFree(dypl_tr); dypl_tr = nullptr; BDR_HIP(hipMalloc((void**)&dypl_tr, n * 2)); dypl_elems = n; }
+                    BDR_TRY(dense_dw_b3(stream, hd.L[1], grad, in, f_dy[0], dypl_tr, M, part, ch, feat, ldf, Np));
+                } else if (i == 1) BDR_TRY(dense_dw(stream, hd.L[i], grad, in, f_dy[i - 1], M, part, ch, feat, ldf, Np));   // x = phi * psi[b]
                 else BDR_TRY(dense_dw(stream, hd.L[i], grad, in, f_dy[i - 1], M, part, ch));
             }
             if (i > 1) { Bracket br(a, ("iqn_f_dx" + std::to_string(i)).c_str()); BDR_TRY(dense_dx(stream, hd.L[i], p, f_dy[i - 1], f_dy[i - 2], f_act[i - 2], M)); }
@@ -638,7 +646,8 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
     a->cnn = cfg->psi.kind == BDR_NET_ATARI_CNN;
     a->b3_allowed = getenv("BDR_IQN_F32_EXACT") == nullptr;
-    a->merge_epilogue = getenv("BDR_IQN_NO_MERGE_EPILOGUE") == nullptr;   // (A/B switch: the separate k_iqn_merge_bwd pass)
+    a->merge_epilogue = getenv("BDR_IQN_NO_MERGE_EPILOGUE") == nullptr;
+    a->dw_b3 = getenv("BDR_IQN_DW_F32") == nullptr;                        // (A/B switch: the FP32-MFMA weight gradient of the merge layer)   // (A/B switch: the separate k_iqn_merge_bwd pass)
     a->F = cfg->feature_dim; a->E = cfg->embed_dim; a->A = cfg->n_actions;
     size_t o = 0;
     if (a->cnn) {

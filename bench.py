@@ -82,7 +82,7 @@ def dqn_kernel_bytes(B, nz, A=N_ACTIONS):
 # kernels on the bf16 matrix cores with exactly split f32 operands -> bf16 MFMAs issued per algorithmic product:
 #   3: one operand is exact in bf16 (u8 pixels), the other split into three terms (conv1 forward / weight gradient);
 #   6: both operands split into three terms, six of the nine partial products kept (IQN's merge layer at C4, csrc/igemm_b3.hpp)
-BF16_ISSUE = {"fwd_conv1": 3, "bwd_conv1_dw": 3, "psi_conv1": 3, "psi_conv1_dw": 3, "iqn_f_fwd1_3xbf16": 6, "iqn_f_dx1_3xbf16": 6, "iqn_f_dw1_3xbf16": 6}
+BF16_ISSUE = {"fwd_conv1": 3, "bwd_conv1_dw": 3, "psi_conv1": 3, "psi_conv1_dw": 3, "iqn_f_fwd1_3xbf16": 6, "iqn_f_dx1_3xbf16": 6, "iqn_f_dw1_3xbf16": 6, "iqn_phi_3xbf16": 6}
 BF16_KERNELS = tuple(BF16_ISSUE)
 
 
@@ -180,7 +180,7 @@ def build_config(B, name, args, rank, local_rank):
               "iqn_cos_dw": 2 * M * E * F}
         # the merge layer's forward (both networks) and input gradient run on the bf16 matrix cores with split operands unless
         # BDR_IQN_F32_EXACT=1; the profile label says which kernel ran (csrc/iqn.hip), the work is the same
-        fl["iqn_f_fwd1_3xbf16"], fl["iqn_f_dx1_3xbf16"], fl["iqn_f_dw1_3xbf16"] = fl["iqn_f_fwd1"], fl["iqn_f_dx1"], fl["iqn_f_dw1"]
+        fl["iqn_f_fwd1_3xbf16"], fl["iqn_f_dx1_3xbf16"], fl["iqn_f_dw1_3xbf16"], fl["iqn_phi_3xbf16"] = fl["iqn_f_fwd1"], fl["iqn_f_dx1"], fl["iqn_f_dw1"], fl["iqn_phi"]
         exact = os.environ.get("BDR_IQN_F32_EXACT") is not None
         by = {"sample": 2 * bs * 28224 + bs * 14}
         return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops=fl, bytes=by, step_flops=sum(fl.values()),
@@ -189,7 +189,7 @@ def build_config(B, name, args, rank, local_rank):
                              f"Uniform64 pred/tgt quantiles, replay {cap} u8 transitions, batch {bs}",
                     cfg_extra={"n_actions": N_ACTIONS, "quantiles": NQ, "optimizer": "Adam lr=1e-4", "soft_update_interval": 10000, "tau": 1.0,
                                "arithmetic": "f32 storage and accumulation throughout; FP32 MFMA for every layer" if exact else
-                                             "f32 storage and accumulation throughout; the merge layer [B*64][3136] x [3136][512] (forward of both networks, input gradient, weight gradient) "
+                                             "f32 storage and accumulation throughout; the merge layer [B*64][3136] x [3136][512] (forward of both networks, input gradient, weight gradient) and the cosine-embedding layer [B*64][64] x [64][3136] "
                                              "multiplies on the bf16 matrix cores with each f32 operand split exactly into 3 bf16 terms, 6 of the 9 partial products "
                                              "(4e-6 relative vs the exact FP32-MFMA kernels, which BDR_IQN_F32_EXACT=1 selects); every other layer FP32 MFMA"},
                     dtype="f32" if exact else "f32 (merge layer: 3xbf16 operand split, 6 products)",

@@ -10,6 +10,7 @@
 #include "agent_base.hpp"
 #include "igemm_b3.hpp"
 #include "igemm_red_b3.hpp"
+#include "dense_k64_b3.hpp"
 
 namespace bdr {
 
@@ -500,6 +501,14 @@ inline int32_t dense_forward_had(hipStream_t st, const DenseLayer& l, const floa
 inline int32_t dense_split_planes(hipStream_t st, const DenseLayer& l, const float* params_base, uint16_t* planes_nat, uint16_t* planes_tr)
 {
     hipLaunchKernelGGL(k_split_planes2, dim3((l.Np + 31) / 32, (l.Kp + 31) / 32), dim3(256), 0, st, params_base + l.w, l.Np, planes_nat, planes_tr, l.Kp, l.Np);
+    BDR_HIP(hipGetLastError());
+    return BDR_OK;
+}
+// a layer with Kp = 64 over many rows (dense_k64_b3.hpp): planes_tr = [3][Np][64]
+inline int32_t dense_forward_k64_b3(hipStream_t st, const DenseLayer& l, const float* params_base, const uint16_t* planes_tr, DenseSrc x, float* out, int M)
+{
+    DenseK64Args d{x.p, x.ld, planes_tr, params_base + l.b, out, l.Np, M, l.Np, l.relu};
+    hipLaunchKernelGGL(k_dense_k64_b3, dim3((M + 127) / 128), dim3(256), 0, st, d);
     BDR_HIP(hipGetLastError());
     return BDR_OK;
 }

@@ -179,6 +179,8 @@ struct Iqn : bdr_agent {
     uint16_t* dypl_tr = nullptr;   // [3][Np][M] bf16 planes of the merge layer's output gradient (split once per update, dense_dw_b3)
     size_t dypl_elems = 0;
     bool dw_b3 = true;
+    uint16_t* cpl_tr = nullptr;    // [3][Np][Kp] bf16 planes of the cosine-embedding layer's weights
+    bool phi_b3 = true;
     uint16_t *wpl_nat = nullptr, *wpl_tr = nullptr;   // [3][Kp][Np], [3][Np][Kp] bf16 planes of L[1]'s weights, re-split before every use
     bool use_b3(int M) const
     {
@@ -201,7 +203,7 @@ struct Iqn : bdr_agent {
         free_batch();
         (void)hipFree(p); (void)hipFree(p_tgt); (void)hipFree(grad); (void)hipFree(am); (void)hipFree(av); (void)hipFree(loss);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
-        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr); (void)hipFree(dypl_tr);
+        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr); (void)hipFree(cpl_tr); (void)hipFree(dypl_tr);
     }
     void free_batch()
     {
@@ -285,7 +287,13 @@ struct Iqn : bdr_agent {
         { Bracket br(a, "iqn_cos"); hipLaunchKernelGGL(k_iqn_cos, dim3((M * Ep + 255) / 256), dim3(256), 0, stream, tau, cosv, M, E, Ep); BDR_HIP(hipGetLastError()); }
         // phi = relu(cos-embedding * W + b); the merge m = phi * psi(x)[b] (iqn/model/base.rs) is the input of the next layer and of
         // its weight gradient and is formed inside those two GEMMs on the way into LDS: [B*N][F] floats that are never written
-        { Bracket br(a, "iqn_phi"); BDR_TRY(dense_forward(a, stream, hd.L[0], params, DenseSrc{cosv, Ep}, phi, M)); }
+        if (use_b3(M) && phi_b3 && Ep == 64) {   // 13 GFLOP per network at C4 with a 64-long reduction: the resident-rows kernel (dense_k64_b3.hpp)
+            Bracket br(a, "iqn_phi_3xbf16");
+            const DenseLayer& l = hd.L[0];
+            if (!cpl_tr) BDR_HIP(hipMalloc((void**)&cpl_tr, (size_t)3 * l.Kp * l.Np * 2));
+            BDR_TRY(dense_split_planes(stream, l, params, nullptr, cpl_tr));    // re-split from THIS network's f32 weights, as for the merge layer
+            BDR_TRY(dense_forward_k64_b3(stream, l, params, cpl_tr, DenseSrc{cosv, Ep}, phi, M));
+        } else { Bracket br(a, "iqn_phi"); BDR_TRY(dense_forward(a, stream, hd.L[0], params, DenseSrc{cosv, Ep}, phi, M)); }
         DenseSrc in{phi, hd.L[0].Np};
         for (size_t i = 1; i < hd.L.size(); ++i) {
             Bracket br(a, (i == 1 && use_b3(M)) ? "iqn_f_fwd1_3xbf16" : ("iqn_f_fwd" + std::to_string(i)).c_str());   // (the label names the arithmetic that ran)
@@ -647,6 +655,7 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     a->cnn = cfg->psi.kind == BDR_NET_ATARI_CNN;
     a->b3_allowed = getenv("BDR_IQN_F32_EXACT") == nullptr;
     a->merge_epilogue = getenv("BDR_IQN_NO_MERGE_EPILOGUE") == nullptr;
+    a->phi_b3 = getenv("BDR_IQN_PHI_F32") == nullptr;                         // (A/B switch: the cosine-embedding layer on the FP32 kernel)
     a->dw_b3 = getenv("BDR_IQN_DW_F32") == nullptr;                        // (A/B switch: the FP32-MFMA weight gradient of the merge layer)   // (A/B switch: the separate k_iqn_merge_bwd pass)
     a->F = cfg->feature_dim; a->E = cfg->embed_dim; a->A = cfg->n_actions;
     size_t o = 0;

@@ -195,7 +195,7 @@ def test_split_operand_merge_layer_equals_the_exact_kernels(B, monkeypatch, Bsz,
         a.profile_enable(False)
         out[mode] = (z, rec["loss_critic"], a.get_params("grad"), a.get_params("iqn"), labels)
         a.close()
-    assert all(l in out["split"][4] for l in ("iqn_f_fwd1_3xbf16", "iqn_f_dx1_3xbf16", "iqn_f_dw1_3xbf16")) and "iqn_f_fwd1" in out["exact"][4]
+    assert all(l in out["split"][4] for l in ("iqn_phi_3xbf16", "iqn_f_fwd1_3xbf16", "iqn_f_dx1_3xbf16", "iqn_f_dw1_3xbf16")) and "iqn_f_fwd1" in out["exact"][4]
     assert not any(l.endswith("3xbf16") for l in out["exact"][4])
     # (the merge's backward is the input-gradient kernel's epilogue when a wave's 64 rows are one sample's percent points)
     assert ("iqn_merge_bwd" not in out["split"][4]) == (NQ == 64) and "iqn_merge_bwd" in out["split_separate_merge_bwd"][4] and "iqn_merge_bwd" in out["exact"][4]

@@ -39,3 +39,19 @@ def test_iqn_mlp_small(golden_dir):
 
 def test_iqn_cnn_b2(golden_dir):
     _run("iqn_cnn_b2", golden_dir)
+
+
+def test_cnn_feature_extractor_takes_other_frame_stack_depths():
+    """AtariCnnConfig::n_stack on IQN's psi (cnn/config.rs:14-24): the restatement's parameter count and one tiny update per depth
+    (psi_in carries n_stack for the cnn trunk; 0 = the default 4)."""
+    for ns in (1, 2, 4, 8):
+        sh = T.iqn_shapes("cnn", 3136, 64, [32], 3, n_stack=ns)
+        p0 = T.init_params(sh[0] + sh[1] + sh[2], 5 + ns)
+        assert sh[0][0] == (32, ns, 8, 8)
+        ref = O.IqnOracle("cnn", p0, lr=1e-4, feature_dim=3136, embed_dim=64, f_units=[32], n_actions=3, psi_in=ns)
+        batch = T.iqn_batch(2, "cnn", 3, 4, 4, 9 + ns, n_stack=ns)
+        r = ref.update(*batch)
+        assert np.isfinite(r["loss"]) and np.isfinite(r["grads"]).all()
+        assert np.abs(r["grads"][:2048 * ns]).max() > 0          # conv1's weights receive a gradient
+    assert O.IqnOracle("cnn", T.init_params(sum(T.iqn_shapes("cnn", 3136, 64, [32], 3), []), 1), lr=1e-4, feature_dim=3136, embed_dim=64,
+                       f_units=[32], n_actions=3).p.size == sum(int(np.prod(s)) for s in sum(T.iqn_shapes("cnn", 3136, 64, [32], 3), []))

@@ -170,6 +170,9 @@ __global__ __launch_bounds__(64 * HEAD_ROWS * MAXZ) void k_head(HeadArgs a, TdAr
         const float v = h[j >> 2][j & 3] + (j < 4 ? b4lo[j & 3] : b4hi[j & 3]);
         hv[j] = v > 0.f ? v : 0.f;   // cnn/base.rs:34 relu
     }
+    // the TD step's row scalars land in their registers here, before the kernel's first store: stores share vmcnt with loads on gfx9 and may
+    // be acknowledged out of order, so a load result first used behind a store costs an s_waitcnt vmcnt(0) - the store's round trip too
+    asm volatile("" ::"v"(act), "v"(reward), "v"(term), "v"(wgt), "v"(b5));
     if (valid) {
         float* ho = a.h1[z] + (size_t)row * 512 + lane * 8;
         *reinterpret_cast<f32x4*>(ho) = f32x4{hv[0], hv[1], hv[2], hv[3]};
@@ -292,34 +295,33 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
     for (int b0 = 0; b0 < a.B; b0 += 256) {
         const int b = b0 + tid;
         bool match = false;
-        if (b < a.B) match = *reinterpret_cast<const long long*>(a.act + (size_t)b * a.act_bytes) == ac;
+        float dqv = 0.f;
+        if (b < a.B) {   // (dq beside the action: behind the match test it was one more dependent round trip)
+            match = *reinterpret_cast<const long long*>(a.act + (size_t)b * a.act_bytes) == ac;
+            dqv = a.dq[b];
+        }
         const unsigned long long m = __ballot(match);
         if (lane == 0) s_wcnt[wave] = __popcll(m);
         __syncthreads();
         int base = 0;
         for (int w = 0; w < wave; ++w) base += s_wcnt[w];
-        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3], padded = (total + 15) & ~15;
         if (match) {
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            s_rows[pos] = b; s_dq[pos] = a.dq[b];
+            s_rows[pos] = b; s_dq[pos] = dqv;
         }
+        if (tid >= total && tid < padded) { s_rows[tid] = b0; s_dq[tid] = 0.f; }   // pad to whole batches of 16: row b0 with weight 0 adds nothing
         __syncthreads();
-        int k = 0;
-        for (; k + 16 <= total; k += 16) {   // 16 row loads in flight per thread (each is an L2 round trip)
+        // 16 row loads in flight per thread (each is an L2 round trip); the padded tail replaces runs of 4 and single loads - up to five
+        // more dependent round trips at 43 rows per action.  The bias sum (one thread, LDS only) rides under the first batch.
+        for (int k = 0; k < padded; k += 16) {
             float hvv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) hvv[u] = a.h1[(size_t)s_rows[k + u] * 512 + j];
+            if (k == 0 && tid == 0) for (int q = 0; q < total; ++q) bacc += s_dq[q];
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc = fmaf(hvv[u], s_dq[k + u], acc);
         }
-        for (; k + 4 <= total; k += 4) {
-            const float h0 = a.h1[(size_t)s_rows[k] * 512 + j], h1v = a.h1[(size_t)s_rows[k + 1] * 512 + j];
-            const float h2 = a.h1[(size_t)s_rows[k + 2] * 512 + j], h3 = a.h1[(size_t)s_rows[k + 3] * 512 + j];
-            acc = fmaf(h0, s_dq[k], acc); acc = fmaf(h1v, s_dq[k + 1], acc);
-            acc = fmaf(h2, s_dq[k + 2], acc); acc = fmaf(h3, s_dq[k + 3], acc);
-        }
-        for (; k < total; ++k) acc = fmaf(a.h1[(size_t)s_rows[k] * 512 + j], s_dq[k], acc);
-        if (tid == 0) for (int q = 0; q < total; ++q) bacc += s_dq[q];
         __syncthreads();
     }
     a.gw5[(size_t)ac * 512 + j] = acc;

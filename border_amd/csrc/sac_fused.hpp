@@ -61,6 +61,7 @@ __global__ __launch_bounds__(512) void k_sac_heads_action(SacHeadsActionArgs p)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) zrow[rr] = lane < p.A ? p.z[(size_t)min(m0 + wave * 4 + rr, p.B - 1) * p.A + lane] : 0.f;
     dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, hd.w, p.w_ld, 0, p.kred, w4, lane, red[team]);
+    asm volatile("" ::"v"(zrow[0]), "v"(zrow[1]), "v"(zrow[2]), "v"(zrow[3]), "v"(bias_m), "v"(bias_s));   // landed before the first store (last_layer_dx_land)
     __syncthreads();
     // one wave per row, lanes over the action dimension: k_sac_action's arithmetic and its butterfly sums
 #pragma unroll
@@ -126,13 +127,32 @@ __device__ __forceinline__ void last_layer_dx_load(LastDxRegs& g, const float* _
         g.wv[u] = w[(size_t)k * w_ld];
     }
 }
+// Lands the prefetched operands in their registers (call once the loads have had time to complete, BEFORE the kernel's first store): on
+// gfx9 stores share vmcnt with loads and may be acknowledged out of order, so a load result first used behind a store costs the compiler
+// an s_waitcnt vmcnt(0) - the store's round trip as well.
+__device__ __forceinline__ void last_layer_dx_land(const LastDxRegs& g)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(g.hv[u]), "v"(g.wv[u]));
+}
 __device__ __forceinline__ void last_layer_dx_store(const LastDxRegs& g, const float* drow /* LDS [32] */, float* __restrict__ dh, int ldh, int c0, int m0,
                                                     int B, int tid)
 {
+    // values first, stores behind them: written as "load drow[r], store" per element the compiler put an s_waitcnt vmcnt(0) lgkmcnt(0) in
+    // front of every store (vmcnt counts stores too), i.e. it waited out the previous store's acknowledgement - 16 serialised round trips
+    // per call site in k_sac_q_last / k_sac_td_last
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = (tid + 512 * u) >> 6;
+        v[u] = g.hv[u] > 0.f ? drow[r] * g.wv[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(v[u]));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int e = tid + 512 * u, r = e >> 6, k = c0 + (e & 63);
-        if (m0 + r < B) dh[(size_t)(m0 + r) * ldh + k] = g.hv[u] > 0.f ? drow[r] * g.wv[u] : 0.f;
+        if (m0 + r < B) dh[(size_t)(m0 + r) * ldh + k] = v[u];
     }
 }
 
@@ -168,6 +188,14 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
         if (j < p.NC && !(SF_ABL & 4)) {   // team-uniform
             const float* arow = p.hin[jb + j] + (size_t)min(m0 + (lane & 31), p.B - 1) * p.ldh;
             dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, p.wl[jb + j].w, p.w_ld, 0, p.kred, w4, lane, red[team]);
+        }
+        if (j0 == 0) {   // the prefetched operands land before the first store of the kernel (last_layer_dx_land)
+            if (!act_pass && !(SF_ABL & 2)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < p.NC) last_layer_dx_land(dxr[i]);
+            }
+            asm volatile("" ::"v"(lp_pre), "v"(la_pre), "v"(out_pre), "v"(am_pre), "v"(av_pre));
         }
         __syncthreads();
         for (int e = tid; e < 2 * 32 * 32; e += 512) {
@@ -370,6 +398,12 @@ __global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
         if (j < p.NC) {
             const float* arow = p.hin_t[j] + (size_t)min(m0 + (lane & 31), p.B - 1) * p.ldh;
             dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, p.wl_t[j].w, p.w_ld, 0, p.kred, w4, lane, red[team]);
+        }
+        if (j0 == 0) {   // the prefetched operands (d loss / d h2, the row scalars) land before the first store of the kernel (last_layer_dx_land)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < p.NC) { last_layer_dx_land(dxr[i]); asm volatile("" ::"v"(q_pre[i])); }
+            asm volatile("" ::"v"(rew_pre), "v"(term_pre), "v"(lp_pre), "v"(la_pre), "v"(out_pre));
         }
         __syncthreads();
         for (int e = tid; e < 2 * 32 * 32; e += 512) {

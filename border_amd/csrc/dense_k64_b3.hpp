@@ -51,11 +51,16 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1
 
     prefetch_w(0);
     // the workgroup's 128 input rows -> three bf16 planes in LDS (rows beyond M: zeros)
+    f32x4 xin[8];   // (all eight loads first: behind a row test each was a round trip of its own)
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int e = tid + p * 256, row = e >> 4, kq = e & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + row < a.M) v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(m0 + row) * a.ldx + kq * 4);
+        xin[p] = *reinterpret_cast<const f32x4*>(a.x + (size_t)min(m0 + row, a.M - 1) * a.ldx + kq * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int e = tid + p * 256, row = e >> 4, kq = e & 15;
+        const f32x4 v = m0 + row < a.M ? xin[p] : f32x4{0.f, 0.f, 0.f, 0.f};
         u32x2_t sp[3];
         split3_f32x4(v, sp);
         const int o = k64_off(row, kq >> 1) + (kq & 1) * 4;
@@ -105,19 +110,39 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1
             else if (s == 1) { commit_w(cur ^ 1, 2); commit_w(cur ^ 1, 3); }
             else if (s == 2) prefetch_w(t + 2);
         }
+        // values first, then the 64 stores back to back (a bias used behind a store costs a wait on that store: stores share vmcnt)
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const int n = n0 + (wn * 2 + tn) * 32 + j;
+            for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * 2 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     float v = acc[tm][tn][r] + bias[tn];
                     if (a.relu) v = v > 0.f ? v : 0.f;
-                    if (m < a.M && n < a.Np) __builtin_nontemporal_store(v, &a.out[(size_t)m * a.ldo + n]);   // (a 411 MB result at C4: streamed, -4 % on the launch)
+                    acc[tm][tn][r] = v;
                 }
-            }
+        if (m0 + 128 <= a.M && n0 + 128 <= a.Np) {   // full tile (workgroup-uniform): no per-element predicates, one base pointer per block
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    float* o = a.out + (size_t)(m0 + (wm * 2 + tm) * 32 + 4 * h) * a.ldo + n0 + (wn * 2 + tn) * 32 + j;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[tm][tn][r], o + (size_t)((r & 3) + 8 * (r >> 2)) * a.ldo);   // (a 411 MB result at C4: streamed)
+                }
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const int n = n0 + (wn * 2 + tn) * 32 + j;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (wm * 2 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (m < a.M && n < a.Np) __builtin_nontemporal_store(acc[tm][tn][r], &a.out[(size_t)m * a.ldo + n]);
+                    }
+                }
+        }
         __syncthreads();
         cur ^= 1;
     }

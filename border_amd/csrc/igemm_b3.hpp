@@ -254,8 +254,9 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
     __syncthreads();
 
     int cur = 0;
-    // Slices of a k-tile's staging work: the commit of tile it+1 (A passes, B passes) into the idle stage rides on the MFMA groups of
-    // the first k-step, the global loads of tile it+3 (into the registers the commit has just freed) on those of the second; one
+    // Slices of a k-tile's staging work: the commit of tile it+1 (B passes, then A passes - each A pass followed at once by its load of
+    // tile it+3 into the registers it has just freed) into the idle stage rides on the MFMA groups of the first k-step, the B loads of
+    // tile it+3 on those of the second; one
     // barrier per k-tile, BETWEEN the two k-steps: by then every wave has committed tile it+1 and has read all of tile it (the
     // fragments of a k-step are fetched from LDS one k-step ahead), so the second k-step can already fetch tile it+1's first fragments
     // and the next step may overwrite this stage.
@@ -298,8 +299,13 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 const int q = g * PER + u;   // (compile-time after unrolling)
-                if (q < A_PASSES) commit_a(set, cur ^ 1, q);
-                else if (q < C_SLICES) commit_b(set, cur ^ 1, q - A_PASSES);
+                // the B chunks (weight planes: L2 hits) are committed first, the A rows (streamed from HBM, their loads issued first) last:
+                // the loads that take longest get the longest time to arrive (+1.9 % on the C4 step)
+                if (q < B_PASSES) commit_b(set, cur ^ 1, q);
+                else if (q < C_SLICES) {
+                    commit_a(set, cur ^ 1, q - B_PASSES);
+                    prefetch_a(set, k3, q - B_PASSES);   // the registers are free again: tile it+3's rows are requested half a step earlier (+1.3 %)
+                }
             }
             // within the group: one MFMA, then a run of the slice's VALU work, ... (a wave issues in order: four MFMAs back to back stall it
             // on the matrix pipe and the split behind them starts only when the last one has issued; +1 % on the C4 step)
@@ -319,8 +325,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 const int q = g * PER + u;
-                if (q < A_PASSES) prefetch_a(set, k3, q);
-                else if (q < C_SLICES) prefetch_b(set, k3, q - A_PASSES);
+                if (q < B_PASSES) prefetch_b(set, k3, q);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 const int q = g * PER + u;
-                if (q < 2) commit_x(set, cur ^ 1, q);
-                else if (q < 4) commit_y(set, cur ^ 1, q - 2, fresh);
+                if (q < 2) commit_y(set, cur ^ 1, q, fresh);          // (Y planes first, the X rows - streamed from HBM, loaded first - last)
+                else if (q < 4) commit_x(set, cur ^ 1, q - 2);
             }
 #pragma unroll
             for (int i = 0; i < TM * TN; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 20, 0); }

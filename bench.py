@@ -488,6 +488,14 @@ def self_launch(n_gpus: int, argv=None, python=None) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ main
+# The measurement protocol of the default (short-window) run is frozen: legs and their order below.  A change of WINDOW_ORDER needs a
+# PROTOCOL_VERSION bump (tests/test_bench_evidence.py holds the pair), so that a series of BENCH_rNN.json lines is never silently
+# re-defined.  Version 1 (rounds 1-3): W + K right after construction = `value`.  Version 2 (round 4 on): the line below;
+# `value_cold` is version 1's `value`.
+PROTOCOL_VERSION = 2
+WINDOW_ORDER = "cold_window (W + K right after construction) -> steady_state loop -> W untimed + K timed steps = value -> roofline leg"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -712,7 +720,14 @@ def main():
         if cold is not None:
             result["cold_window"] = cold
             result["untimed_steps_before_window"] = untimed_before
-            result["window_order"] = "cold_window (W + K right after construction) -> steady_state loop -> W untimed + K timed steps = value -> roofline leg"
+            result["window_order"] = WINDOW_ORDER
+            # first-class twins of the two other legs, so that BENCH_r01..rNN read as one series: rounds 1-3 reported what is now
+            # `value_cold` as `value`; `value_steady` is the sustained rate
+            result["value_cold"] = cold["value"]
+            result["value_steady"] = steady["value"]
+            result["warmup_note"] = (f"`warmup` = the W = {args.warmup} untimed steps directly in front of the K timed ones (the contract's window); "
+                                     f"{untimed_before} untimed steps ran in this process before the timed ones in total (cold window + steady-state leg + W)")
+        result["protocol_version"] = PROTOCOL_VERSION
     agent.close()
     rb.close()
 

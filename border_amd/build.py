@@ -28,7 +28,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not (force or _stale()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
@@ -41,8 +41,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                    "-Wall", "-Wno-unused-function", "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
         objs.append(obj)
+    if jobs:   # the translation units are independent: one hipcc per core (BORDER_AMD_BUILD_JOBS=1 for a serial build)
+        from concurrent.futures import ThreadPoolExecutor
+        n = max(1, min(len(jobs), int(os.environ.get("BORDER_AMD_BUILD_JOBS", os.cpu_count() or 1))))
+        with ThreadPoolExecutor(n) as ex:
+            for f in [ex.submit(subprocess.check_call, cmd) for cmd in jobs]:
+                f.result()
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

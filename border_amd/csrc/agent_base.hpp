@@ -169,8 +169,28 @@ struct bdr_agent {
     // (bdr_agent_sample_device ...) the rows already live in HBM, obs_row_stride bytes apart, and never touch the host.
     bool obs_rows_on_device = false;
     uint64_t obs_row_stride = 0;
+    // scope of a *_device entry point: the flag is down again on every way out of the nested host-row call
+    struct DeviceRowsScope {
+        bdr_agent* a;
+        DeviceRowsScope(bdr_agent* a_, uint64_t stride) : a(a_) { a->obs_rows_on_device = true; a->obs_row_stride = stride; }
+        ~DeviceRowsScope() { a->obs_rows_on_device = false; a->obs_row_stride = 0; }
+        DeviceRowsScope(const DeviceRowsScope&) = delete; DeviceRowsScope& operator=(const DeviceRowsScope&) = delete;
+    };
+    // obs_dev must be device memory of the agent's GPU, rows a multiple of 4 bytes apart
+    int32_t check_device_rows(const void* obs_dev, uint64_t row_stride) const
+    {
+        if (!obs_dev) return ::bdr::fail(BDR_ERR_INVALID, "null argument");
+        if (row_stride == 0 || row_stride % 4 != 0) return ::bdr::fail(BDR_ERR_INVALID, "row_stride must be a positive multiple of 4 bytes");
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, obs_dev) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != device)
+            return ::bdr::fail(BDR_ERR_INVALID, "obs_dev is not device memory of the agent's GPU (host rows go through the host-row entry point)");
+        return BDR_OK;
+    }
     int32_t stage_obs(void* dst, const void* src, size_t row_bytes, uint64_t n, hipStream_t st)
     {
+        if (obs_rows_on_device && obs_row_stride < row_bytes)
+            return ::bdr::fail(BDR_ERR_INVALID, "row_stride (%llu bytes) is smaller than the agent's observation row (%llu bytes)",
+                               (unsigned long long)obs_row_stride, (unsigned long long)row_bytes);
         if (!obs_rows_on_device) BDR_HIP(hipMemcpyAsync(dst, src, n * row_bytes, hipMemcpyHostToDevice, st));
         else if (obs_row_stride == row_bytes) BDR_HIP(hipMemcpyAsync(dst, src, n * row_bytes, hipMemcpyDeviceToDevice, st));
         else BDR_HIP(hipMemcpy2DAsync(dst, row_bytes, src, obs_row_stride, row_bytes, n, hipMemcpyDeviceToDevice, st));
@@ -350,11 +370,13 @@ __device__ __forceinline__ void adam_element(float& p, float g, float& m, float&
 }
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, size_t n4, AdamScalars s, const unsigned* poison = nullptr)
+                                              float* __restrict__ v, size_t n4, AdamScalars s, const unsigned* poison = nullptr,
+                                              unsigned long long* applied = nullptr, unsigned long long step = 0)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     if (poison && *poison) return;   // a cross-queue gate timed out: the gradients may be incomplete, keep the parameters
+    if (applied && i == 0) *applied = step;   // "optimizer step number `step` was applied": the host rolls its counter back to it after a time-out
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
@@ -385,11 +407,13 @@ __device__ __forceinline__ void adam_element_amsgrad(float& p, float g, float& m
 }
 
 __global__ __launch_bounds__(256) void k_adam_amsgrad(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                      float* __restrict__ vmax, size_t n4, AdamScalars s, const unsigned* poison = nullptr)
+                                                      float* __restrict__ vmax, size_t n4, AdamScalars s, const unsigned* poison = nullptr,
+                                                      unsigned long long* applied = nullptr, unsigned long long step = 0)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     if (poison && *poison) return;
+    if (applied && i == 0) *applied = step;
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], xx = reinterpret_cast<f32x4*>(vmax)[i];
 #pragma unroll
@@ -450,14 +474,14 @@ inline AdamScalars adam_scalars_for(bool adamw, double lr, double beta1, double 
 inline int32_t launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n_floats, const AdamScalars& s)
 {
     const size_t n4 = n_floats / 4;
-    BDR_HIP(step_launch(st, true, k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), p, g, m, v, n4, s, (const unsigned*)nullptr));
+    BDR_HIP(step_launch(st, true, k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), p, g, m, v, n4, s, (const unsigned*)nullptr, (unsigned long long*)nullptr, 0ull));
     return BDR_OK;
 }
 inline int32_t launch_adam_amsgrad(hipStream_t st, float* p, const float* g, float* m, float* v, float* vmax, size_t n_floats, const AdamScalars& s,
-                                   const unsigned* poison = nullptr)
+                                   const unsigned* poison = nullptr, unsigned long long* applied = nullptr, unsigned long long step = 0)
 {
     const size_t n4 = n_floats / 4;
-    BDR_HIP(step_launch(st, true, k_adam_amsgrad, dim3((unsigned)((n4 + 255) / 256)), dim3(256), p, g, m, v, vmax, n4, s, poison));
+    BDR_HIP(step_launch(st, true, k_adam_amsgrad, dim3((unsigned)((n4 + 255) / 256)), dim3(256), p, g, m, v, vmax, n4, s, poison, applied, step));
     return BDR_OK;
 }
 inline int32_t launch_track(hipStream_t st, float* dst, const float* src, size_t n_floats, double tau)

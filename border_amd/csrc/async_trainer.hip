@@ -130,6 +130,33 @@ int32_t bdr_agent_sync_model_from(bdr_agent* a, int32_t which, bdr_model_mailbox
 namespace {
 using Clock = std::chrono::steady_clock;
 
+// Device rows of the messages of device-resident actors, recycled: an actor takes a pair of [n_buffer][obs_row_bytes] buffers when it
+// starts a message, the learner hands them back when the message has been pushed (bdr_replay_push_device has synchronised by then).
+// hipMalloc / hipFree per message would stall the learner's device (hipFree synchronises the whole device).
+struct DevRowPool {
+    struct Pair { int device; size_t bytes; uint8_t* a; uint8_t* b; };
+    std::mutex mu;
+    std::vector<Pair> free_;
+    bool take(int device, size_t bytes, uint8_t** a, uint8_t** b)
+    {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].device == device && free_[i].bytes == bytes) { *a = free_[i].a; *b = free_[i].b; free_.erase(free_.begin() + (long)i); return true; }
+        }
+        *a = *b = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)a, bytes) != hipSuccess) return false;
+        if (hipMalloc((void**)b, bytes) != hipSuccess) { (void)hipFree(*a); *a = nullptr; return false; }
+        return true;
+    }
+    void give(int device, size_t bytes, uint8_t* a, uint8_t* b)
+    {
+        std::lock_guard<std::mutex> l(mu);
+        free_.push_back(Pair{device, bytes, a, b});
+    }
+    ~DevRowPool() { for (auto& p : free_) { (void)hipSetDevice(p.device); (void)hipFree(p.a); (void)hipFree(p.b); } }
+};
+
 // PushedItemMessage { id, pushed_items } (messages.rs): n transitions packed field by field
 struct Message {
     uint32_t id = 0;
@@ -138,8 +165,8 @@ struct Message {
     std::vector<float> reward;
     std::vector<int8_t> term, trunc;
     // device-resident environments (bdr_env_vtable::obs_on_device): the observation rows of the message stay in HBM -
-    // [n_buffer][obs_row_bytes] each, allocated by the actor, pushed with buffer_push_device and freed by the learner
-    uint8_t* d_obs = nullptr; uint8_t* d_next = nullptr; int device = 0;
+    // [n_buffer][obs_row_bytes] each, taken from the run's pool by the actor, pushed with buffer_push_device and handed back by the learner
+    uint8_t* d_obs = nullptr; uint8_t* d_next = nullptr; int device = 0; size_t d_bytes = 0; DevRowPool* pool = nullptr;
     Message() = default;
     Message(const Message&) = delete; Message& operator=(const Message&) = delete;
     Message(Message&& o) noexcept { *this = std::move(o); }
@@ -149,12 +176,18 @@ struct Message {
             release();
             id = o.id; n = o.n; obs = std::move(o.obs); act = std::move(o.act); next_obs = std::move(o.next_obs);
             reward = std::move(o.reward); term = std::move(o.term); trunc = std::move(o.trunc);
-            d_obs = o.d_obs; d_next = o.d_next; device = o.device; o.d_obs = o.d_next = nullptr; o.n = 0;
+            d_obs = o.d_obs; d_next = o.d_next; device = o.device; d_bytes = o.d_bytes; pool = o.pool; o.d_obs = o.d_next = nullptr; o.n = 0;
         }
         return *this;
     }
     ~Message() { release(); }
-    void release() { if (d_obs || d_next) { (void)hipSetDevice(device); (void)hipFree(d_obs); (void)hipFree(d_next); d_obs = d_next = nullptr; } }
+    void release()
+    {
+        if (!d_obs && !d_next) return;
+        if (pool) pool->give(device, d_bytes, d_obs, d_next);
+        else { (void)hipSetDevice(device); (void)hipFree(d_obs); (void)hipFree(d_next); }
+        d_obs = d_next = nullptr;
+    }
 };
 
 // crossbeam bounded(cap): try_send fails when full (replay_buffer_proxy.rs:63-68), try_iter drains what is there
@@ -178,6 +211,7 @@ struct Channel {
 
 struct Shared {
     const bdr_async_trainer_config* c;
+    DevRowPool rows;                   // (declared before the channel: messages still queued at the end hand their rows back first)
     Channel ch;
     std::atomic<bool> stop{false};
     std::atomic<bool> model_ready{false};
@@ -218,19 +252,27 @@ void actor_run(Shared* sh, const bdr_actor_ops* ops, uint32_t id, bdr_actor_stat
         buf.id = id;
         buf.act.reserve(c.n_buffer * c.act_row_bytes);
         if (!dev) { buf.obs.reserve(c.n_buffer * c.obs_row_bytes); buf.next_obs.reserve(c.n_buffer * c.obs_row_bytes); return true; }
-        buf.device = ops->env.device;
-        if (hipSetDevice(buf.device) != hipSuccess || hipMalloc((void**)&buf.d_obs, c.n_buffer * c.obs_row_bytes) != hipSuccess ||
-            hipMalloc((void**)&buf.d_next, c.n_buffer * c.obs_row_bytes) != hipSuccess) {
+        buf.device = ops->env.device; buf.d_bytes = c.n_buffer * c.obs_row_bytes; buf.pool = &sh->rows;
+        if (!sh->rows.take(buf.device, buf.d_bytes, &buf.d_obs, &buf.d_next)) {
             (void)fail(BDR_ERR_HIP, "actor %u: device rows of a message (2 x %llu bytes) could not be allocated", id, (unsigned long long)(c.n_buffer * c.obs_row_bytes));
             return false;
         }
         return true;
     };
+    // The rows of a transition are copied on the actor's own stream and the copy is COMPLETE before the loop goes on: a same-device
+    // hipMemcpy does not wait on the host, and the null stream orders nothing against the non-blocking streams of the environment
+    // (bdr_atari_prep), the agent and the learner's ring - the next environment step overwrites the source, the learner reads the copy.
+    hipStream_t copy_st = nullptr;
     auto finish = [&]() {
+        if (copy_st) { (void)hipSetDevice(ops->env.device); (void)hipStreamSynchronize(copy_st); (void)hipStreamDestroy(copy_st); copy_st = nullptr; }
         if (stat) { stat->env_steps = env_steps; stat->duration_s = std::chrono::duration<double>(Clock::now() - t_start).count(); }
     };
     if (prev.init(dev, ops->env.device, c.obs_row_bytes) != BDR_OK || obs_new.init(dev, ops->env.device, c.obs_row_bytes) != BDR_OK ||
         init_obs.init(dev, ops->env.device, c.obs_row_bytes) != BDR_OK || !reset_buf()) { sh->fail_from("actor", id); finish(); return; }
+    if (dev && (hipSetDevice(ops->env.device) != hipSuccess || hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking) != hipSuccess)) {
+        (void)fail(BDR_ERR_HIP, "actor %u: the copy stream could not be created", id);
+        sh->fail_from("actor", id); finish(); return;
+    }
     // "Waits and syncs the initial model" (:148-153)
     while (!sh->model_ready.load() && !sh->stop.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
     if (sh->stop.load()) { finish(); return; }
@@ -257,8 +299,9 @@ void actor_run(Shared* sh, const bdr_actor_ops* ops, uint32_t id, bdr_actor_stat
         const bool is_done = term == 1 || trunc == 1;
         // ReplayBufferProxy::push: buffer the item; at n_buffer items swap the Vec out and try_send it
         if (dev) {
-            if (hipMemcpy(buf.d_obs + buf.n * c.obs_row_bytes, prev.p(), c.obs_row_bytes, hipMemcpyDeviceToDevice) != hipSuccess ||
-                hipMemcpy(buf.d_next + buf.n * c.obs_row_bytes, obs_new.p(), c.obs_row_bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+            if (hipMemcpyAsync(buf.d_obs + buf.n * c.obs_row_bytes, prev.p(), c.obs_row_bytes, hipMemcpyDeviceToDevice, copy_st) != hipSuccess ||
+                hipMemcpyAsync(buf.d_next + buf.n * c.obs_row_bytes, obs_new.p(), c.obs_row_bytes, hipMemcpyDeviceToDevice, copy_st) != hipSuccess ||
+                hipStreamSynchronize(copy_st) != hipSuccess) {
                 (void)fail(BDR_ERR_HIP, "actor %u: device copy of a transition's rows failed", id);
                 sh->fail_from("actor", id); break;
             }

@@ -766,6 +766,7 @@ struct ReduceAdamArgs {
     AdamScalars s[RA_INST]; unsigned n4; float tau, omt; int track;
     int grads_only;   // 1: sum the partials into the gradient arena and stop (synchronous-DP mode: the all-reduce comes before Adam)
     const unsigned* poison;   // optional: a cross-queue wait of the step timed out (queue_flags.hpp) - the inputs may be incomplete, leave everything alone
+    unsigned long long* applied; unsigned long long step;   // optional: *applied = step by a pass that was not skipped (the host rolls its step counter back to it)
 };
 __global__ __launch_bounds__(256) void k_dense_reduce_adam(ReduceAdamArgs a)
 {
@@ -773,6 +774,7 @@ __global__ __launch_bounds__(256) void k_dense_reduce_adam(ReduceAdamArgs a)
     const int z = blockIdx.y;
     if (i >= a.n4) return;
     if (a.poison && *a.poison) return;
+    if (a.applied && i == 0 && z == 0 && !a.grads_only) *a.applied = a.step;
     int k = 0;
     for (int q = 1; q < a.nseg; ++q) k += i >= a.seg[q].off4 ? 1 : 0;
     const DenseReduceSeg sg = a.seg[k];

@@ -20,7 +20,7 @@
 #include "common.hpp"
 #include "agent_base.hpp"
 #include "igemm.hpp"
-#include "conv1_bf16.hpp"
+#include "conv1_bf16_img.hpp"
 #include "cnn_layers.hpp"
 
 using namespace bdr;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
             s_rows[pos] = b; s_dq[pos] = dqv;
         }
-        if (tid >= total && tid < padded) { s_rows[tid] = b0; s_dq[tid] = 0.f; }   // pad to whole batches of 16: row b0 with weight 0 adds nothing
+        if (tid >= total && tid < padded) { s_rows[tid] = b0; s_dq[tid] = 0.f; }   // pad to whole batches of 16: a valid address, weight 0, value replaced by 0 below
         __syncthreads();
         // 16 row loads in flight per thread (each is an L2 round trip); the padded tail replaces runs of 4 and single loads - up to five
         // more dependent round trips at 43 rows per action.  The bias sum (one thread, LDS only) rides under the first batch.
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a)
             for (int u = 0; u < 16; ++u) hvv[u] = a.h1[(size_t)s_rows[k + u] * 512 + j];
             if (k == 0 && tid == 0) for (int q = 0; q < total; ++q) bacc += s_dq[q];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc = fmaf(hvv[u], s_dq[k + u], acc);
+            for (int u = 0; u < 16; ++u) acc = fmaf(k + u < total ? hvv[u] : 0.f, s_dq[k + u], acc);   // (a padded slot is 0 x 0, not 0 x h1[b0]: an Inf / NaN activation of row b0 must not reach other actions' gradients)
         }
         __syncthreads();
     }
@@ -379,6 +379,7 @@ struct DqnCnn : bdr_agent {
     const float* last_reward = nullptr; int last_B = 0;
     // bookkeeping (dqn/base.rs:26-48)
     uint64_t adam_step = 0, soft_update_counter = 0;
+    unsigned long long* applied_step = nullptr;   // device word: the Adam step number of the last l1 / l2 pass that was not skipped (on_gate_timeout)
 
     ~DqnCnn() override;
     const char* kind() const override { return "dqn_cnn"; }
@@ -587,10 +588,8 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         for (int z = 0; z < nz; ++z) {
             c.x[z] = inst[z].x; c.w1[z] = inst[z].params + ar.w1; c.bias[z] = inst[z].params + ar.b1; c.out[z] = a->a1[inst[z].slot];
         }
-        const int items = (c.M + 31) / 32;
-        const int g = std::max(1, std::min(512 / nz, (items + 7) / 8));
         Bracket br(a, "fwd_conv1");
-        BDR_HIP(launch_conv1_bf16(ar.ns, dim3(g * nz), st, c));
+        BDR_HIP(conv1_forward(ar.ns, B, st, c));
     }
     f.M = B * 81;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a1[inst[z].slot]; f.w[z] = inst[z].params + ar.w2; f.bias[z] = inst[z].params + ar.b2; f.out[z] = a->a2[inst[z].slot]; }
@@ -787,7 +786,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         Bracket br(a, "adam_l1_l2");
         const size_t r4 = (ar.total - ar.w4) / 4;
         LAUNCH_FL(sd, any, nullptr, k_adam, dim3((unsigned)((r4 + 255) / 256)), dim3(256), a->q + ar.w4, (const float*)(a->grad + ar.w4), a->m + ar.w4,
-                  a->v + ar.w4, r4, adam_s, (const unsigned*)(a->sig + SIG_ERR));
+                  a->v + ar.w4, r4, adam_s, (const unsigned*)(a->sig + SIG_ERR), a->applied_step, (unsigned long long)a->adam_step);
         return BDR_OK;
     };
     auto c3_dw = [&]() -> int32_t {
@@ -945,9 +944,9 @@ int32_t adam_all(DqnCnn* a)
     Bracket br(a, "adam_all");
     const size_t n4 = a->ar.total / 4;
     if (a->amsgrad)
-        return launch_adam_amsgrad(a->stream, a->q, a->grad, a->m, a->v, a->vmax, a->ar.total, adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR));
+        return launch_adam_amsgrad(a->stream, a->q, a->grad, a->m, a->v, a->vmax, a->ar.total, adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR), a->applied_step, (unsigned long long)a->adam_step);
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q, (const float*)a->grad, a->m, a->v, n4,
-                       adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR));
+                       adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR), a->applied_step, (unsigned long long)a->adam_step);
     BDR_HIP(hipGetLastError());
     return BDR_OK;
 }
@@ -1131,6 +1130,18 @@ void DqnCnn::on_gate_timeout()
     if (comm_st) (void)hipStreamSynchronize(comm_st);
     xchg_pending_conv = xchg_pending_fc = false;
     if (sig) (void)hipMemset(sig, 0, 16 * sizeof(unsigned));
+    if (applied_step) {
+        // Updates whose parameter-writing kernels ran while the poison word was up were skipped on the device: the host's step numbers go
+        // back to the last update that was applied, so Adam's bias corrections continue from the state the parameters are in
+        // (the l1 / l2 pass, 95 % of the arena, records the step number it applied; opt.rs:74-83).
+        unsigned long long applied = 0;
+        if (hipMemcpy(&applied, applied_step, sizeof applied, hipMemcpyDeviceToHost) == hipSuccess && applied < adam_step) {
+            const uint64_t skipped = adam_step - applied;
+            adam_step = applied;
+            n_opts -= std::min(n_opts, skipped / std::max<uint64_t>(1, cfg.n_updates_per_opt));
+            fprintf(stderr, "border_amd: %llu update(s) behind the failed gate were skipped on the device; the step counters were rolled back with them\n", (unsigned long long)skipped);
+        }
+    }
     sig_epoch = 0; head_gate_enqueued = false;
     if (sched == 3) {
         fprintf(stderr, "border_amd: a cross-queue gate timed out; this agent continues with event ordering (schedule 1)\n");
@@ -1213,6 +1224,7 @@ DqnCnn::~DqnCnn()
         (void)hipFree(gate_trace);
     }
     if (sig) (void)hipFree(sig);
+    (void)hipFree(applied_step);
     if (aux) { (void)hipStreamSynchronize(aux); stream_retire(aux); (void)hipStreamDestroy(aux); }
     if (side) { stream_retire(side); (void)hipStreamDestroy(side); }
 }
@@ -1338,6 +1350,8 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* e = getenv("BDR_SCHED")) a->sched = std::max(0, std::min(3, atoi(e)));
     BDR_HIP(hipMalloc((void**)&a->sig, 16 * sizeof(unsigned)));
+    BDR_HIP(hipMalloc((void**)&a->applied_step, sizeof(unsigned long long)));
+    BDR_HIP(hipMemsetAsync(a->applied_step, 0, sizeof(unsigned long long), a->stream));
     BDR_HIP(hipMemsetAsync(a->sig, 0, 16 * sizeof(unsigned), a->stream));   // synchronised with the parameter upload below
     if (getenv("BDR_GATE_TRACE")) {
         BDR_HIP(hipMalloc((void**)&a->gate_trace, 32 * sizeof(unsigned long long)));

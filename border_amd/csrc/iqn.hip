@@ -12,7 +12,7 @@
 #include <cstdlib>
 
 #include "dense.hpp"
-#include "conv1_bf16.hpp"
+#include "conv1_bf16_img.hpp"
 #include "cnn_layers.hpp"
 
 using namespace bdr;
@@ -256,8 +256,7 @@ struct Iqn : bdr_agent {
         if (cnn) {
             Conv1Args c{}; c.M = Bn * 400; c.nz = 1;
             c.x[0] = obs; c.w1[0] = params + conv.w1; c.bias[0] = params + conv.b1; c.out[0] = a1;
-            const int items = (c.M + 31) / 32, g = std::max(1, std::min(512, (items + 7) / 8));
-            { Bracket br(a, "psi_conv1"); BDR_HIP(launch_conv1_bf16(conv.ns, dim3(g), stream, c)); }
+            { Bracket br(a, "psi_conv1"); BDR_HIP(conv1_forward(conv.ns, Bn, stream, c)); }
             FwdArgs f{};
             f.M = Bn * 81; f.x[0] = a1; f.w[0] = params + conv.w2; f.bias[0] = params + conv.b2; f.out[0] = a2;
             { Bracket br(a, "psi_conv2"); LAUNCH(k_igemm<FwdC2>, dim3((f.M + 63) / 64, 1, 1), f); }

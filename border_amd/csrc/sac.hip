@@ -70,6 +70,7 @@ struct SacSelectArgs {
     // EntCoef::update (ent_coef.rs:69-75) first: loss = -(log_alpha * (logp + H)).mean(); Adam on the scalar
     int auto_alpha; float target; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
     const unsigned* poison;              // a cross-queue wait timed out: no EntCoef step
+    unsigned long long* applied; unsigned long long step;   // the step number of the last EntCoef step that was NOT skipped (Sac::on_gate_timeout)
 };
 // Sums over the batch rows, in an order that does not depend on who computes it (the row-block kernels of sac_fused.hpp form the
 // block partials in their own workgroups): rows in blocks of 32, a block's partial = the 32-lane butterfly (xor 16, 8, 4, 2, 1) of
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(1024) void k_sac_select(SacSelectArgs p)
         const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
         log_alpha = log_alpha + p.s.neg_step * mm / denom;
         __syncthreads();                                          // all reads of al_m / al_v / log_alpha are done
-        if (threadIdx.x == 0 && !(p.poison && *p.poison)) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; }
+        if (threadIdx.x == 0 && !(p.poison && *p.poison)) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; if (p.applied) *p.applied = p.step; }
     }
     const float alpha = expf(log_alpha);
     const float s_logp = row_sum_1024(p.B, [&](int b) { return p.logp[b]; }, red);
@@ -313,6 +314,9 @@ struct Sac : bdr_agent, SacBatch {
     float* q_p[4] = {nullptr}; float* q_t[4] = {nullptr}; float* q_g[4] = {nullptr}; float* q_m[4] = {nullptr}; float* q_v[4] = {nullptr};
     float *log_alpha = nullptr, *al_m = nullptr, *al_v = nullptr;
     uint64_t step_pi = 0, step_q[4] = {0}, step_al = 0;
+    // device words: the step number of the last EntCoef / actor / critic optimizer pass that was not skipped under the poison word
+    static constexpr int AP_AL = 0, AP_PI = 1, AP_Q = 2;
+    unsigned long long* applied = nullptr;
     // batch buffers: the current set is the SacBatch base (flip() swaps it with `other`)
     int B = 0; uint64_t batch_gen = 0;   // bumped by every re-allocation (the captured graph holds the old pointers)
     SacBatch other;
@@ -363,7 +367,7 @@ struct Sac : bdr_agent, SacBatch {
         (void)hipFree(log_alpha); (void)hipFree(al_m); (void)hipFree(al_v); (void)hipFree(scal);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
         for (int i = 0; i < 4; ++i) (void)hipFree(pr_qpi[i]);
-        (void)hipFree(tickets);
+        (void)hipFree(tickets); (void)hipFree(applied);
         (void)hipFree(pr_logp);
     }
     static void free_set(SacBatch& b)
@@ -538,7 +542,7 @@ struct Sac : bdr_agent, SacBatch {
     // partial sums of a grouped dW launch -> gradient arena, Adam, (tracking) for `ninst` networks of one layout
     int32_t reduce_adam(const MlpLayout& net, const std::vector<size_t>& off, const std::vector<int>& chunks, int Bn, const float* part,
                         size_t inst_stride, int ninst, float* const* p, float* const* g, float* const* m, float* const* v,
-                        float* const* tgt_p, const AdamScalars* sc)
+                        float* const* tgt_p, const AdamScalars* sc, int applied_slot, uint64_t applied_value)
     {
         ReduceAdamArgs ra{};
         ra.nseg = (int)net.L.size(); ra.inst_part_stride = inst_stride;
@@ -550,6 +554,7 @@ struct Sac : bdr_agent, SacBatch {
         for (int i = 0; i < ninst; ++i) { ra.p[i] = p[i]; ra.g[i] = g[i]; ra.m[i] = m[i]; ra.v[i] = v[i]; ra.tgt[i] = tgt_p ? tgt_p[i] : nullptr; ra.s[i] = sc[i]; }
         ra.n4 = (unsigned)(net.total / 4); ra.track = tgt_p ? 1 : 0; ra.tau = (float)cfg.tau; ra.omt = (float)(1.0 - cfg.tau);
         ra.poison = dev_err + ERR_GATE;
+        ra.applied = applied + applied_slot; ra.step = applied_value;
         BDR_HIP(step_launch(stream, true, k_dense_reduce_adam, dim3((ra.n4 + 255) / 256, ninst), dim3(256), ra));
         return BDR_OK;
     }
@@ -619,6 +624,7 @@ struct Sac : bdr_agent, SacBatch {
             if (cfg.ent_coef_auto) {
                 step_al += 1;
                 p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v; p.poison = dev_err + ERR_GATE;
+                p.applied = applied + AP_AL; p.step = step_al;
                 p.s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
             }
             Bracket br(a, "sac_q_last");
@@ -632,6 +638,7 @@ struct Sac : bdr_agent, SacBatch {
             if (cfg.ent_coef_auto) {
                 step_al += 1;
                 p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v; p.poison = dev_err + ERR_GATE;
+                p.applied = applied + AP_AL; p.step = step_al;
                 p.s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
             }
             Bracket br(a, "sac_select");
@@ -692,7 +699,7 @@ struct Sac : bdr_agent, SacBatch {
             step_pi += 1;
             const AdamScalars sc = adam_scalars_for(false, cfg.lr_actor, 0, 0, 0, 0, step_pi);
             Bracket br(a, "adam_pi");
-            BDR_TRY(reduce_adam(pi, pi_off, pi_chunks, Bn, pi_part, 0, 1, &pi_p, &pi_g, &pi_m, &pi_v, nullptr, &sc));
+            BDR_TRY(reduce_adam(pi, pi_off, pi_chunks, Bn, pi_part, 0, 1, &pi_p, &pi_g, &pi_m, &pi_v, nullptr, &sc, AP_PI, step_pi));
         }
 
         // ---------------- update_critic (sac/base.rs:107-149) ----------------
@@ -739,7 +746,7 @@ struct Sac : bdr_agent, SacBatch {
             AdamScalars sc[4];
             for (int i = 0; i < NC; ++i) { step_q[i] += 1; sc[i] = adam_scalars_for(false, cfg.lr_critic, 0, 0, 0, 0, step_q[i]); }
             Bracket br(a, "adam_q_track");
-            BDR_TRY(reduce_adam(qn, q_off, q_chunks, Bn, q_part, q_part_stride, NC, q_p, q_g, q_m, q_v, q_t, sc));
+            BDR_TRY(reduce_adam(qn, q_off, q_chunks, Bn, q_part, q_part_stride, NC, q_p, q_g, q_m, q_v, q_t, sc, AP_Q, step_q[0]));
         }
         n_opts += 1;
         last_B = Bn;
@@ -764,6 +771,21 @@ struct Sac : bdr_agent, SacBatch {
         if (two_queues) fprintf(stderr, "border_amd: a cross-queue wait of the SAC step timed out; this agent continues on one queue\n");
         two_queues = false;
         main_ahead = true;   // whatever ran on `stream` since the failed wait is not covered by the flags
+        // The optimizer passes that ran while the poison word was up left parameters and moments alone (k_dense_reduce_adam, the EntCoef
+        // step): the host's step numbers go back to the passes that were applied, so the bias corrections of the next update are those of
+        // the state on the device (opt.rs:74-83; each optimizer on its own - a time-out between the actor's and the critics' pass of one
+        // update leaves the actor one step ahead, as it is on the device).  n_opts and the noise stream follow the critics' pass, the
+        // last one of an update.
+        unsigned long long ap[3] = {0, 0, 0};
+        if (applied && hipMemcpy(ap, applied, sizeof ap, hipMemcpyDeviceToHost) == hipSuccess) {
+            const uint64_t lost = step_q[0] > ap[AP_Q] ? step_q[0] - ap[AP_Q] : 0;
+            if (cfg.ent_coef_auto && ap[AP_AL] < step_al) step_al = ap[AP_AL];
+            if (ap[AP_PI] < step_pi) step_pi = ap[AP_PI];
+            for (int i = 0; i < NC; ++i) if (ap[AP_Q] < step_q[i]) step_q[i] = ap[AP_Q];
+            n_opts -= std::min<uint64_t>(n_opts, lost);
+            noise_counter -= std::min<uint64_t>(noise_counter, lost * 2ull * (uint64_t)last_B * (uint64_t)A);
+            if (lost) fprintf(stderr, "border_amd: %llu SAC update(s) behind the failed wait were skipped on the device; the step counters were rolled back with them\n", (unsigned long long)lost);
+        }
     }
     // the launch sequence of one opt() (Sac::opt_, sac/base.rs:175-192)
     // does this opt() take the two-queue sequence?
@@ -987,6 +1009,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     a->gather_in_pack = getenv("BDR_NO_STEP_GATHER") == nullptr;
     a->fuse_rows = getenv("BDR_NO_SAC_FUSE") == nullptr;
     BDR_HIP(hipMalloc((void**)&a->tickets, 2 * sizeof(unsigned))); BDR_HIP(hipMemsetAsync(a->tickets, 0, 2 * sizeof(unsigned), a->stream));
+    BDR_HIP(hipMalloc((void**)&a->applied, 3 * sizeof(unsigned long long))); BDR_HIP(hipMemsetAsync(a->applied, 0, 3 * sizeof(unsigned long long), a->stream));
     {
         const char* e = getenv("BDR_SAC_SIDE_QUEUE");
         if (!(e && e[0] == '0')) {
@@ -1169,10 +1192,10 @@ int32_t bdr_sac_sample_device(bdr_agent* base, uint64_t n, const void* obs_dev, 
     BDR_REQUIRE(base && obs_dev && act_out, "null argument");
     BDR_REQUIRE(!strcmp(base->kind(), "sac"), "not a SAC agent");
     BDR_REQUIRE(row_stride >= (uint64_t)static_cast<Sac*>(base)->O * 4 && row_stride % 4 == 0, "row_stride must be >= the row size and a multiple of 4");
-    base->obs_rows_on_device = true; base->obs_row_stride = row_stride;
-    const int32_t st = bdr_sac_sample(base, n, static_cast<const float*>(obs_dev), act_out);
-    base->obs_rows_on_device = false;
-    return st;
+    BDR_HIP(hipSetDevice(base->device));
+    BDR_TRY(base->check_device_rows(obs_dev, row_stride));
+    bdr_agent::DeviceRowsScope rows(base, row_stride);
+    return bdr_sac_sample(base, n, static_cast<const float*>(obs_dev), act_out);
 }
 
 }  // extern "C"

@@ -111,6 +111,7 @@ struct SacQLastArgs {
     float* out; float scale; int accumulate;
     int auto_alpha; float target; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
     const unsigned* poison;               // a cross-queue wait timed out: no EntCoef step
+    unsigned long long* applied; unsigned long long step;   // as SacSelectArgs
 };
 // relu'(h) * d[row] * W_last[:, 0] for 32 rows x the 64 columns [c0, c0 + 64) of one critic, in two halves: the operand loads do not
 // depend on anything the kernel computes, so they are issued first thing (next to the tile operands) and are long back when the
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
         const float denom = __fsqrt_rn(vv) / p.s.sqrt_bc2 + p.s.eps;
         log_alpha = log_alpha + p.s.neg_step * mm / denom;
         __syncthreads();
-        if (tid == 0 && !(p.poison && *p.poison)) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; }
+        if (tid == 0 && !(p.poison && *p.poison)) { p.log_alpha_rw[0] = log_alpha; p.al_m[0] = mm; p.al_v[0] = vv; if (p.applied) *p.applied = p.step; }
     }
     const float alpha = expf(log_alpha);
     const float s_logp = sum_partials(p.part + nb, nb, lsum);

@@ -266,11 +266,12 @@ class ParamExchange:
 
     def __init__(self, world_size: int, rank: int, sync_interval: int, backend: str = "rccl", device: int = 0,
                  bcast_bytes=None, which=("qnet",)):
+        if backend not in ("rccl", "torch"):
+            raise ValueError(f"ParamExchange backend {backend!r}: 'rccl' (the library's communicator, the GPU data plane) or 'torch' (host vectors over gloo, CPU tests)")
         self.world_size, self.rank, self.sync_interval, self.backend = world_size, rank, sync_interval, backend
         self.which = tuple(which)
         self.device = device
         self._comm = None
-        self._group = None
         self.fallback_reason = None
         if world_size > 1 and backend == "rccl":
             L = _lib.lib()
@@ -309,16 +310,6 @@ class ParamExchange:
             _lib.lib().bdr_comm_destroy(self._comm)
             self._comm = None
 
-    def _arena_tensor(self, agent, w):
-        """torch view (no copy) of the agent's flat device arena, through __cuda_array_interface__."""
-        import torch
-        ptr, n = agent.arena_device_ptr(w)
-
-        class _Arena:
-            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-        return torch.as_tensor(_Arena(), device=f"cuda:{self.device}")
-
     def after_opt(self, agent, opt_steps: int) -> bool:
         """Called after every opt step; averages every sync_interval-th step."""
         if self.world_size == 1 or self.sync_interval <= 0 or opt_steps % self.sync_interval != 0:
@@ -332,15 +323,6 @@ class ParamExchange:
         if self.backend == "rccl":
             for w in self.which:
                 _lib.check(_lib.lib().bdr_agent_allreduce_params(agent.handle, self._comm, agent.WHICH[w]))
-        elif self.backend == "torch-nccl":
-            import torch
-            import torch.distributed as dist
-            agent.sync()                                  # the agent's stream is not torch's
-            for w in self.which:
-                t = self._arena_tensor(agent, w)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._group)
-                t /= self.world_size
-            torch.cuda.synchronize(self.device)
         else:
             import torch
             import torch.distributed as dist
@@ -372,13 +354,6 @@ class ParamExchange:
         if self.backend == "rccl":
             for w in self.which:
                 _lib.check(_lib.lib().bdr_agent_broadcast_params(agent.handle, self._comm, agent.WHICH[w], root))
-        elif self.backend == "torch-nccl":
-            import torch
-            import torch.distributed as dist
-            agent.sync()
-            for w in self.which:
-                dist.broadcast(self._arena_tensor(agent, w), src=root, group=self._group)
-            torch.cuda.synchronize(self.device)
         else:
             import torch
             import torch.distributed as dist

@@ -112,3 +112,21 @@ def test_the_dominant_kernel_of_the_line_does_not_flip_between_near_ties():
     assert abs(r["frac"] - 2.718e9 / 0.0299e-3 / 1e12 / bench.PEAK_FP32_MFMA_TFLOPS) < 1e-3
     r = bench.roofline(conf, {"fwd_conv2": 0.0299, "bwd_conv2_dx": 0.0330, "fwd_conv3": 0.022, "sample": 0.011}, cnt, 0.003, 0.22)
     assert r["kernel"] == "bwd_conv2_dx" and "within_5pct" not in r
+
+
+def test_the_window_protocol_is_frozen_with_its_version():
+    """The legs of the default bench run and their order define what `value` means.  Round 4 re-ordered them once (version 1 -> 2, disclosed in
+    the line); from here on a change of `window_order` without a `protocol_version` bump fails this test, so a BENCH_rNN.json series cannot be
+    re-defined silently.  `value_cold` (version 1's `value`) and `value_steady` are first-class keys of the line."""
+    import hashlib
+    import inspect
+    frozen = {2: "4910ceb1b087"}   # protocol_version -> sha256(window_order)[:12]
+    assert bench.PROTOCOL_VERSION in frozen, "a new protocol version: add its window-order hash here, and say so in DESIGN.md section 6"
+    assert hashlib.sha256(bench.WINDOW_ORDER.encode()).hexdigest()[:12] == frozen[bench.PROTOCOL_VERSION], \
+        "bench.WINDOW_ORDER changed without a PROTOCOL_VERSION bump"
+    src = inspect.getsource(bench.main)
+    for key in ('"value_cold"', '"value_steady"', '"protocol_version"', '"warmup_note"', '"window_order"', '"untimed_steps_before_window"'):
+        assert key in src, key
+    # the legs run in the order the string names: cold window, steady-state loop, the timed window
+    i_cold, i_ss, i_val = src.index("dt_c = window(0)"), src.index("run(n_ss,"), src.index("dt = window(0 if cold is None")
+    assert i_cold < i_ss < i_val

@@ -342,6 +342,16 @@ except B.BdrError as e:
 a.sync()
 s0 = state()
 np.save(sys.argv[1], s0)
+# the host's step counters are those of the state on the device (rolled back with the skipped updates): the same update on the same
+# batch and noise gives the same bits as in the undisturbed run - Adam's bias corrections depend on the step numbers - and the agent's
+# own noise stream continues from the same position
+print("NOPTS", a.n_opts)
+g = np.random.default_rng(11); Bn = 128
+f32 = lambda x: x.astype(np.float32)
+a.update_on_batch(f32(g.standard_normal((Bn, od))), f32(g.uniform(-1, 1, (Bn, ad))), f32(g.standard_normal((Bn, od))), f32(g.standard_normal(Bn)),
+                  (g.random(Bn) < 0.1).astype(np.int8), f32(g.standard_normal((Bn, ad))), f32(g.standard_normal((Bn, ad))))
+a.sync()
+np.save(sys.argv[1] + ".s1.npy", np.concatenate([state(), a.draw_noise(256)]))
 for _ in range(6): a.opt(rb)
 rec = a.opt_with_record(rb)
 print("LOSS", bool(np.isfinite(rec["loss_critic"])), "MOVED", bool((state() != s0).any()))
@@ -355,14 +365,17 @@ print("LOSS", bool(np.isfinite(rec["loss_critic"])), "MOVED", bool((state() != s
             path = os.path.join(d, name + ".npy")
             r = subprocess.run([sys.executable, "-c", script, path, str(n_first)], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-1500:]
-            outs[name] = (r.stdout.split("\n"), r.stderr, np.load(path))
-    so, se, sp = outs["stalled"]
-    co, ce, cp = outs["clean"]
-    assert co[0] == "NO_ERROR" and co[1] == "LOSS True MOVED True", co
+            outs[name] = (r.stdout.split("\n"), r.stderr, np.load(path), np.load(path + ".s1.npy"))
+    so, se, sp, sp1 = outs["stalled"]
+    co, ce, cp, cp1 = outs["clean"]
+    assert co[0] == "NO_ERROR" and co[1] == "NOPTS 2" and co[2] == "LOSS True MOVED True", co
     assert so[0].startswith("ERR") and " 3 " in so[0] + " " and so[0].endswith("True"), (so, se[-500:])
-    assert so[1] == "LOSS True MOVED True", so
+    assert so[2] == "LOSS True MOVED True", so
     assert "continues on one queue" in se, se[-500:]
     assert (sp == cp).all()          # seven updates enqueued, the third one's wait failed: the state is the one after two
+    # ... and so are the host's counters (Sac::on_gate_timeout): n_opts, the three Adam step numbers (the next update's bits), the noise position
+    assert so[1] == "NOPTS 2" and "were rolled back" in se, (so, se[-500:])
+    assert (sp1 == cp1).all()
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds border_amd/libborder_amd_prev.so from the csrc/ of a git revision (default HEAD) for same-box A/B runs
+# Builds scratch/ab/libborder_amd_prev.so from the csrc/ of a git revision (default HEAD) for same-box A/B runs
 # (tools/probes/ab_libs.sh).  usage: build_prev.sh [rev]
 set -e
 rev=${1:-HEAD}
@@ -13,6 +13,7 @@ for f in "$tmp"/border_amd/csrc/*.hip; do
     objs="$objs $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/border_amd/libborder_amd_prev.so" $objs -ldl
+mkdir -p "$root/scratch/ab"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/scratch/ab/libborder_amd_prev.so" $objs -ldl
 rm -rf "$tmp"
-echo "$root/border_amd/libborder_amd_prev.so"
+echo "$root/scratch/ab/libborder_amd_prev.so"

@@ -12,13 +12,17 @@
 //    CONSECUTIVE channels of one pixel: the NHWC epilogue is 4 global_store_dwordx4 per unit instead of 16 dword stores (the MFMA
 //    computes D^T = B^T A^T element by element: same sums);
 //  * IPW images per workgroup pass (1 or 2): with two images the units of a pass spread more evenly over the waves.
-// RW = the weight fragments live in registers (one wave per SIMD, 256 threads; conv1_bf16_rw.hpp) or are read from LDS one k-step
-// ahead (two waves per SIMD, 512 threads).  NC = units a wave works on at a time (independent accumulator chains sharing every
-// weight fragment).  cnn/base.rs:26-28.
+// NT threads = NT / 64 waves take the pass's 32-pixel units round robin; the weight fragments are read from LDS one k-step ahead, the
+// pixel fragments two.  Measured and dropped (tools/probes/conv1_rw_probe.hip, conv1_bf16_rw.hpp): the weight planes in REGISTERS with one
+// wave per SIMD and two or four accumulator chains per wave (11.3 us: an in-order wave pays ~12 cycles of matrix-pipe time for every LDS
+// read it issues between its MFMAs, two waves per SIMD hide them), two units per wave with shared weight fragments (10.1), the
+// un-swapped roles with sixteen full-row dword stores (9.4-10.0: no difference).  Where the launch's 9.6 us are at one instance of
+// B = 256 (stamps of the probe): ~1.8 launch, 3.2 until the first MFMA (first-touch loads of image and weights, split, conversion,
+// barrier), ~2.3 of MFMAs with the 13 units of an image spread 4 / 3 / 3 / 3 over the SIMDs, ~2.3 for the 13 MB of stores, which
+// only start when the first units are done.  cnn/base.rs:26-28.
 #pragma once
 #include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 #include "conv1_bf16.hpp"
 
 namespace bdr {
@@ -32,7 +36,7 @@ __device__ unsigned long long* g_c1_trace;
 #define C1_TP(slot) do { } while (0)
 #endif
 
-template <int NS, int IPW, int NT, bool RW, int NC>
+template <int NS, int IPW, int NT>
 static __global__ __launch_bounds__(NT, NT / 256) void k_conv1_bf16_img(Conv1Args a)
 {
     C1_TP(0);
@@ -105,13 +109,6 @@ static __global__ __launch_bounds__(NT, NT / 256) void k_conv1_bf16_img(Conv1Arg
     __syncthreads();
     C1_TP(3);
     const uint4* wlane = wl + h * 32 + i;        // fragment (plane pl, k-step s) of this lane (output channel i, k half h): wlane[pl * PV + 64 s]
-    bf16x8 wr[RW ? 3 : 1][RW ? KS : 1];
-    if constexpr (RW) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) wr[pl][s] = __builtin_bit_cast(bf16x8, wlane[pl * PV + 64 * s]);
-    }
 
     float* out = a.out[z];
     const uint8_t* imgb = reinterpret_cast<const uint8_t*>(img);
@@ -142,7 +139,7 @@ static __global__ __launch_bounds__(NT, NT / 256) void k_conv1_bf16_img(Conv1Arg
             const uint2 lo = q[0], hi = q[1];
             return __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
         };
-        auto store_unit = [&](int unit, const f32x16& acc) {
+        auto store_unit = [&](int unit, const f32x16& acc) {   // lane = pixel i, four runs of 4 consecutive channels [8 q + 4 h, + 4)
             const int m = unit * 32 + i;
 #ifdef C1_ABL_NOSTORE
             if (m < Mloc && acc[0] == 12345.678f) {
@@ -159,76 +156,45 @@ static __global__ __launch_bounds__(NT, NT / 256) void k_conv1_bf16_img(Conv1Arg
                 }
             }
         };
-        // NU units at a time (units u, u + NW, ...): NU independent accumulator chains share every weight fragment
-        auto run = [&](auto nu_c, int u) __attribute__((always_inline)) {
-            constexpr int NU = decltype(nu_c)::value;
-            const uint8_t* p[NU];
-            f32x16 acc[NU];
-            bf16x8 fa[NU], fb[NU];
+        for (int u = wave; u < units; u += NW) {
+            const uint8_t* p = unit_base(u);
+            f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < NU; ++q) {
-                p[q] = unit_base(u + NW * q);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-                fa[q] = frag(p[q], 0); fb[q] = frag(p[q], 1);
-            }
-            bf16x8 wa[3], wb[3];   // (LDS weights) this k-step's and the next one's fragments
-            if constexpr (!RW) {
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wa[pl] = __builtin_bit_cast(bf16x8, wlane[pl * PV]);
-            }
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             // pixel fragments two k-steps ahead of the MFMAs that use them, weight fragments one (sched_barrier keeps hipcc from hoisting
-            // all the reads of a unit group: 4 VGPRs each)
+            // all the reads of a unit: 4 VGPRs each)
+            bf16x8 fa = frag(p, 0), fb = frag(p, 1), wa[3], wb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wa[pl] = __builtin_bit_cast(bf16x8, wlane[pl * PV]);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                bf16x8 fc[NU];
+                const bf16x8 fc = s + 2 < KS ? frag(p, s + 2) : fa;
 #pragma unroll
-                for (int q = 0; q < NU; ++q) fc[q] = s + 2 < KS ? frag(p[q], s + 2) : fa[q];
-                if constexpr (!RW) {
+                for (int pl = 0; pl < 3; ++pl) wb[pl] = s + 1 < KS ? __builtin_bit_cast(bf16x8, wlane[pl * PV + 64 * (s + 1)]) : wa[pl];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) wb[pl] = s + 1 < KS ? __builtin_bit_cast(bf16x8, wlane[pl * PV + 64 * (s + 1)]) : wa[pl];
-                }
+                for (int pl = 2; pl >= 0; --pl) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[pl], fa, acc, 0, 0, 0);   // small terms first
+                fa = fb; fb = fc;
 #pragma unroll
-                for (int pl = 2; pl >= 0; --pl)   // small terms first
-#pragma unroll
-                    for (int q = 0; q < NU; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(RW ? wr[RW ? pl : 0][RW ? s : 0] : wa[pl], fa[q], acc[q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < NU; ++q) { fa[q] = fb[q]; fb[q] = fc[q]; }
-                if constexpr (!RW) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) wa[pl] = wb[pl];
-                }
+                for (int pl = 0; pl < 3; ++pl) wa[pl] = wb[pl];
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int q = 0; q < NU; ++q) store_unit(u + NW * q, acc[q]);
-        };
-        int u = wave;
-        for (; u + NW * (NC - 1) < units; u += NW * NC) run(std::integral_constant<int, NC>{}, u);
-        const int left = u < units ? (units - u + NW - 1) / NW : 0;   // 0 ... NC - 1 units
-        if constexpr (NC > 1) { if (left == 1) run(std::integral_constant<int, 1>{}, u); }
-        if constexpr (NC > 2) { if (left == 2) run(std::integral_constant<int, 2>{}, u); }
-        if constexpr (NC > 3) { if (left == 3) run(std::integral_constant<int, 3>{}, u); }
+            store_unit(u, acc);
+        }
         C1_TP(6);
     }
 }
 
-// form: 0 = register weights, one wave per SIMD, 4 chains (n_stack <= 4); 1 = LDS weights, two waves per SIMD, 2 chains;
-// 2 = LDS weights, two waves per SIMD, 1 chain; 3 = LDS weights, four waves per SIMD, 1 chain
-inline hipError_t launch_conv1_bf16_img(int ns, int ipw, int form, dim3 grid, hipStream_t st, const Conv1Args& c)
+// waves = 8 or 16 per workgroup
+inline hipError_t launch_conv1_bf16_img(int ns, int ipw, int waves, dim3 grid, hipStream_t st, const Conv1Args& c)
 {
-    if (ns < 1 || ns > C1IMG_MAX_STACK || ipw < 1 || ipw > 2 || form < 0 || form > 3 || (ns > 4 && (ipw == 2 || form == 0))) return hipErrorInvalidValue;
-    switch ((ns - 1) * 8 + (ipw - 1) * 4 + form) {
+    if (ns < 1 || ns > C1IMG_MAX_STACK || ipw < 1 || ipw > 2 || (waves != 8 && waves != 16) || (ns > 4 && ipw == 2)) return hipErrorInvalidValue;
+    switch (ns * 4 + (ipw - 1) * 2 + (waves == 16)) {
 #define BDR_C1IMG_CASE1(N) \
-        case (N - 1) * 8 + 1: hipLaunchKernelGGL((k_conv1_bf16_img<N, 1, 512, false, 2>), grid, dim3(512), 0, st, c); break; \
-        case (N - 1) * 8 + 2: hipLaunchKernelGGL((k_conv1_bf16_img<N, 1, 512, false, 1>), grid, dim3(512), 0, st, c); break; \
-        case (N - 1) * 8 + 3: hipLaunchKernelGGL((k_conv1_bf16_img<N, 1, 1024, false, 1>), grid, dim3(1024), 0, st, c); break;
+        case N * 4 + 0: hipLaunchKernelGGL((k_conv1_bf16_img<N, 1, 512>), grid, dim3(512), 0, st, c); break; \
+        case N * 4 + 1: hipLaunchKernelGGL((k_conv1_bf16_img<N, 1, 1024>), grid, dim3(1024), 0, st, c); break;
 #define BDR_C1IMG_CASE(N) BDR_C1IMG_CASE1(N) \
-        case (N - 1) * 8 + 0: hipLaunchKernelGGL((k_conv1_bf16_img<N, 1, 256, true, 4>), grid, dim3(256), 0, st, c); break; \
-        case (N - 1) * 8 + 4: hipLaunchKernelGGL((k_conv1_bf16_img<N, 2, 256, true, 4>), grid, dim3(256), 0, st, c); break; \
-        case (N - 1) * 8 + 5: hipLaunchKernelGGL((k_conv1_bf16_img<N, 2, 512, false, 2>), grid, dim3(512), 0, st, c); break; \
-        case (N - 1) * 8 + 6: hipLaunchKernelGGL((k_conv1_bf16_img<N, 2, 512, false, 1>), grid, dim3(512), 0, st, c); break; \
-        case (N - 1) * 8 + 7: hipLaunchKernelGGL((k_conv1_bf16_img<N, 2, 1024, false, 1>), grid, dim3(1024), 0, st, c); break;
+        case N * 4 + 2: hipLaunchKernelGGL((k_conv1_bf16_img<N, 2, 512>), grid, dim3(512), 0, st, c); break; \
+        case N * 4 + 3: hipLaunchKernelGGL((k_conv1_bf16_img<N, 2, 1024>), grid, dim3(1024), 0, st, c); break;
         BDR_C1IMG_CASE(1) BDR_C1IMG_CASE(2) BDR_C1IMG_CASE(3) BDR_C1IMG_CASE(4) BDR_C1IMG_CASE1(5) BDR_C1IMG_CASE1(6)
 #undef BDR_C1IMG_CASE
 #undef BDR_C1IMG_CASE1
@@ -239,22 +205,20 @@ inline hipError_t launch_conv1_bf16_img(int ns, int ipw, int form, dim3 grid, hi
 
 // conv1 forward of nz network instances on B images each: the staged-image form where its LDS image fits (bf16 image(s) + three weight
 // planes <= 160 KB: n_stack <= 6, two images per pass up to n_stack 4), the direct form of conv1_bf16.hpp otherwise.  Same bits either way.
-// BDR_C1_FORM (diagnostic, read once): -1 = always the direct form, 0 ... 3 = the staged form's variants (default 2).
+// BDR_C1_FORM (diagnostic, read once): -1 = always the direct form, 8 / 16 = waves per workgroup of the staged form (default 8).
 inline int conv1_form_env()
 {
-    static const int form = [] { const char* e = getenv("BDR_C1_FORM"); return e ? atoi(e) : 2; }();
+    static const int form = [] { const char* e = getenv("BDR_C1_FORM"); return e ? atoi(e) : 8; }();
     return form;
 }
 inline hipError_t conv1_forward(int ns, int B, hipStream_t st, const Conv1Args& c, int cus = 256)
 {
-    int form = conv1_form_env();
-    if (form > 3) form = 2;
+    const int form = conv1_form_env();
     if (ns <= C1IMG_MAX_STACK && form >= 0 && c.M == B * 400) {
-        if (ns > 4 && form == 0) form = 2;
         const int per_inst = std::max(1, cus / c.nz);
         const int ipw = (ns <= 4 && B > per_inst) ? 2 : 1;
         const int g = std::max(1, std::min(per_inst, (B + ipw - 1) / ipw));
-        return launch_conv1_bf16_img(ns, ipw, form, dim3(g * c.nz), st, c);
+        return launch_conv1_bf16_img(ns, ipw, form == 16 ? 16 : 8, dim3(g * c.nz), st, c);
     }
     const int items = (c.M + 31) / 32;
     const int g = std::max(1, std::min(512 / c.nz, (items + 7) / 8));

@@ -24,16 +24,16 @@ int main()
     Conv1DwArgs a{x, dy, part, stride, B};
     unsigned long long* null = nullptr;
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_c1dw_trace), &null, sizeof(null)));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_conv1_dw_bf16<4>, dim3(B), dim3(512), 0, 0, a);
+    for (int i = 0; i < 3; ++i) launch_conv1_dw_bf16(4, dim3(B), 0, a);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(k_conv1_dw_bf16<4>, dim3(B), dim3(512), 0, 0, a);
+    for (int i = 0; i < 50; ++i) launch_conv1_dw_bf16(4, dim3(B), 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("k_conv1_dw_bf16 B=%d: %.2f us per launch (back to back)\n", B, ms * 1000 / 50);
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_c1dw_trace), &tr, sizeof(tr)));
-    hipLaunchKernelGGL(k_conv1_dw_bf16<4>, dim3(B), dim3(512), 0, 0, a);
+    launch_conv1_dw_bf16(4, dim3(B), 0, a);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(B * 4); CK(hipMemcpy(h.data(), tr, B * 4 * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;

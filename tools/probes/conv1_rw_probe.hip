@@ -27,7 +27,7 @@ int main(int argc, char** argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 256, NS = 4;
     const int M = B * 400;
-    const int form_img = getenv("C1_IMG_FORM") ? atoi(getenv("C1_IMG_FORM")) : 0;
+    const int form_img = getenv("C1_IMG_WAVES") ? atoi(getenv("C1_IMG_WAVES")) : 8;
     Conv1Args c{}, c2{};
     uint8_t* shadow[2];
     for (int z = 0; z < 2; ++z) {

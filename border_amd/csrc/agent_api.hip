@@ -546,7 +546,8 @@ int32_t bdr_agent_sample(bdr_agent* a, uint64_t n, const void* obs, int64_t* act
     std::vector<float> q;
     int A = 0;
     BDR_TRY(action_values(a, n, obs, q, &A));
-    BDR_TRY(a->err_check());
+    if (a->err_fresh) { a->err_fresh = false; BDR_TRY(a->err_poll()); }   // the forward pass brought the device's error words along (dqn_cnn_qvalues)
+    else BDR_TRY(a->err_check());
     Explorer& x = a->explorer;
     double eps = 0.0;
     bool is_random = false;

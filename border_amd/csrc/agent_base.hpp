@@ -128,6 +128,7 @@ struct bdr_agent {
     int32_t err_report(const unsigned* w);
     int32_t err_check();   // the stream has just been synchronised: read, report, clear
     int32_t err_poll();    // no synchronisation: look at the last asynchronous read-back, enqueue the next one when due
+    bool err_fresh = false;   // host_err was refreshed by the call in progress (an acting call's Q rows brought the words along): poll, do not copy again
     virtual void on_gate_timeout() {}   // DqnCnn: fall back to event ordering
     // Called by err_report BEFORE it clears the error words: every queue of the agent must be idle by then.  While the words are up
     // the waits queued on the other queues return at once (poison); cleared under them they would start a fresh time limit and

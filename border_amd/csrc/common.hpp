@@ -81,10 +81,14 @@ struct bdr_replay {
     bool read_pending = false;          // a gather on read_stream may still be reading ring rows / owns the batch buffers
     hipStream_t read_stream = nullptr;
     uint64_t written_gen = 1;           // bumped with every record of `written`
+    bool written_lazy = false;          // the newest write has not recorded `written` yet (wait_for_writer does it on the writer's stream)
     std::vector<std::pair<hipStream_t, uint64_t>> waited;   // consumer stream -> generation of `written` it has waited for
     // pinned staging for push
     uint8_t* stage = nullptr;
     uint64_t stage_records = 0;
+    unsigned* done_host = nullptr; unsigned* done_dev = nullptr; unsigned done_seq = 0;   // pinned "small push finished" word (host view / device view) and its sequence number
+    unsigned* done_ticket = nullptr;                        // device: records of the current small push that are finished
+    const void* dev_rows_ok[2] = {nullptr, nullptr};       // bdr_replay_push_device: the obs / next_obs base addresses that passed the device-pointer check last
     uint8_t* d_tails = nullptr; uint64_t tails_cap = 0;   // bdr_replay_push_device: device copy of a run's act / reward / flags
     // device batch buffers (lazily sized)
     uint64_t batch_cap = 0, batch_n = 0;

@@ -4,6 +4,7 @@
 // :376-402 (batch); border-tch-agent/src/tensor_batch.rs:85-120 (row storage).
 #include "chacha.hpp"
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
@@ -343,6 +344,10 @@ static int32_t wait_for_reader(bdr_replay* r, hipStream_t s)
 // RAW against pushes / fills / tree updates: once per consumer stream and generation of `written`
 static int32_t wait_for_writer(bdr_replay* r, hipStream_t s)
 {
+    if (r->written_lazy) {   // a small device push left the record of `written` to its first consumer: on the writer's stream now, it covers that push
+        r->written_lazy = false;
+        BDR_HIP(hipEventRecord(r->written, r->stream));
+    }
     for (auto& w : r->waited)
         if (w.first == s) {
             if (w.second == r->written_gen) return BDR_OK;
@@ -567,6 +572,8 @@ int32_t bdr_replay_destroy(bdr_replay* r)
     (void)hipFree(r->frames);
     if (r->fstage) (void)hipHostFree(r->fstage);
     (void)hipHostFree(r->stage);
+    if (r->done_host) (void)hipHostFree(r->done_host);
+    (void)hipFree(r->done_ticket);
     (void)hipFree(r->b_obs); (void)hipFree(r->b_next); (void)hipFree(r->b_act);
     (void)hipFree(r->b_reward); (void)hipFree(r->b_term); (void)hipFree(r->b_trunc); (void)hipFree(r->b_ixs);
     (void)hipFree(r->alt.obs); (void)hipFree(r->alt.next); (void)hipFree(r->alt.act); (void)hipFree(r->alt.reward);
@@ -674,6 +681,41 @@ __global__ __launch_bounds__(256) void k_push_device(PushDevArgs a)
     if (threadIdx.x < 6) rec[a.tail_off + threadIdx.x] = t[a.act_bytes + threadIdx.x];
 }
 
+// The same push for a handful of transitions (the one-environment online loop pushes ONE per step): the small fields ride in the
+// kernel arguments - no staging buffer to wait for, no host -> device copy in front of the kernel.
+constexpr int PUSH_SMALL_N = 8, PUSH_SMALL_TAIL = 24;   // up to 8 records whose act | reward | flags fit 24 bytes (a discrete action is 8)
+struct PushDevSmallArgs { PushDevArgs a; uint64_t capacity; unsigned* ticket; unsigned* done; unsigned seq; uint8_t tails[PUSH_SMALL_N * PUSH_SMALL_TAIL]; };   // (a.pos + k wraps at capacity; a.tails unused)
+__global__ __launch_bounds__(256) void k_push_device_small(PushDevSmallArgs s)
+{
+    const PushDevArgs& a = s.a;
+    const uint64_t k = blockIdx.x;
+    uint8_t* rec = a.ring + ((a.pos + k) % s.capacity) * a.stride;
+    const uint8_t* src[2] = {a.obs + k * a.obs_stride, a.next + k * a.next_stride};
+    uint8_t* dst[2] = {rec, rec + a.next_off};
+    for (int w = 0; w < 2; ++w) {
+        if ((((uintptr_t)src[w] | (uintptr_t)dst[w] | a.obs_bytes) & 15) == 0) {
+            const uint4* s4 = reinterpret_cast<const uint4*>(src[w]); uint4* d4 = reinterpret_cast<uint4*>(dst[w]);
+            for (uint64_t i = threadIdx.x; i < a.obs_bytes / 16; i += 256) d4[i] = s4[i];
+        } else {
+            for (uint64_t i = threadIdx.x; i < a.obs_bytes; i += 256) dst[w][i] = src[w][i];
+        }
+    }
+    const uint8_t* t = s.tails + k * PUSH_SMALL_TAIL;
+    for (uint64_t i = threadIdx.x; i < a.act_bytes; i += 256) rec[a.act_off + i] = t[i];
+    if (threadIdx.x < 6) rec[a.tail_off + threadIdx.x] = t[a.act_bytes + threadIdx.x];
+    // "the source rows have been read": the last record to finish says so in pinned host memory, where the caller waits for it - a
+    // hipStreamSynchronize costs ~15 us of host latency for a 3 us kernel (every load of this workgroup has returned: its data went into the
+    // stores above; what the stores themselves still owe is ordered by the stream for everything that follows on the device)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned n_done = __hip_atomic_fetch_add(s.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (n_done == gridDim.x) {
+            __hip_atomic_store(s.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(s.done, s.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 int32_t bdr_replay_push_device(bdr_replay* r, uint64_t n, const void* obs_dev, uint64_t obs_stride, const void* act, const void* next_obs_dev,
                                uint64_t next_obs_stride, const float* reward, const int8_t* term, const int8_t* trunc)
 {
@@ -685,11 +727,52 @@ int32_t bdr_replay_push_device(bdr_replay* r, uint64_t n, const void* obs_dev, u
                                  "buffer with frame_stack > 0");
     BDR_HIP(hipSetDevice(r->device));
     for (const void* p : {obs_dev, next_obs_dev}) {
+        // (the check is a driver call of ~2 us: an address that passed it last time - the environment's stacks, push after push - is not asked again)
+        if (p == r->dev_rows_ok[0] || p == r->dev_rows_ok[1]) continue;
         hipPointerAttribute_t at{};
         BDR_REQUIRE(hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice && at.device == r->device,
                     "observation rows must be device memory of the buffer's GPU (host rows go through bdr_replay_push)");
+        r->dev_rows_ok[p == obs_dev ? 0 : 1] = p;
     }
     BDR_TRY(wait_for_reader(r, r->stream));  // WAR: do not overwrite rows a consumer's gather may still be reading
+    if (n <= (uint64_t)PUSH_SMALL_N && r->act_bytes + 8 <= (uint64_t)PUSH_SMALL_TAIL && !r->per) {
+        PushDevSmallArgs sa{};
+        sa.a = PushDevArgs{r->ring, r->stride, r->obs_bytes, r->act_bytes, r->next_off, r->act_off, r->tail_off, r->i,
+                           (const uint8_t*)obs_dev, obs_stride, (const uint8_t*)next_obs_dev, next_obs_stride, nullptr};
+        sa.capacity = r->capacity;
+        const uint8_t* ab = (const uint8_t*)act;
+        for (uint64_t k = 0; k < n; ++k) {
+            uint8_t* t = sa.tails + k * PUSH_SMALL_TAIL;
+            memcpy(t, ab + k * r->act_bytes, r->act_bytes);
+            memcpy(t + r->act_bytes, &reward[k], 4);
+            t[r->act_bytes + 4] = (uint8_t)term[k]; t[r->act_bytes + 5] = (uint8_t)trunc[k];
+        }
+        if (!r->done_host) {
+            BDR_HIP(hipHostMalloc((void**)&r->done_host, 64, hipHostMallocMapped));
+            *reinterpret_cast<volatile unsigned*>(r->done_host) = 0;
+            BDR_HIP(hipHostGetDevicePointer((void**)&r->done_dev, r->done_host, 0));
+            BDR_HIP(hipMalloc((void**)&r->done_ticket, sizeof(unsigned)));
+            BDR_HIP(hipMemsetAsync(r->done_ticket, 0, sizeof(unsigned), r->stream));
+        }
+        sa.ticket = r->done_ticket; sa.done = r->done_dev; sa.seq = ++r->done_seq;
+        hipLaunchKernelGGL(k_push_device_small, dim3((uint32_t)n), dim3(256), 0, r->stream, sa);
+        BDR_HIP(hipGetLastError());
+        r->written_lazy = true; mark_written(r);   // `written` is recorded when a consumer on another stream asks for it (wait_for_writer)
+        // the caller's device rows may be overwritten by its next environment step: wait until the kernel has read them
+        {
+            const volatile unsigned* done = reinterpret_cast<const volatile unsigned*>(r->done_host);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; (int)(*done - sa.seq) < 0; ++spins) {
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {   // (a lost kernel: fall back to the stream's own report)
+                    BDR_HIP(hipStreamSynchronize(r->stream));
+                    break;
+                }
+            }
+        }
+        r->i = (r->i + n) % r->capacity;
+        r->size = std::min(r->size + n, r->capacity);
+        return BDR_OK;
+    }
     const uint64_t tw = r->act_bytes + 8;
     const uint8_t* a = (const uint8_t*)act;
     uint64_t done = 0;

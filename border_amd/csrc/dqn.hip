@@ -380,7 +380,6 @@ struct DqnCnn : bdr_agent {
     const float* last_reward = nullptr; int last_B = 0;
     // bookkeeping (dqn/base.rs:26-48)
     uint64_t adam_step = 0, soft_update_counter = 0;
-    float* qpub_host = nullptr; float* qpub_dev = nullptr; unsigned qpub_seq = 0;   // pinned Q rows of acting calls (dqn_cnn_qvalues): [0] sequence word, [16...] rows
     unsigned long long* applied_step = nullptr;   // device word: the Adam step number of the last l1 / l2 pass that was not skipped (on_gate_timeout)
 
     ~DqnCnn() override;
@@ -1227,7 +1226,6 @@ DqnCnn::~DqnCnn()
     }
     if (sig) (void)hipFree(sig);
     (void)hipFree(applied_step);
-    if (qpub_host) (void)hipHostFree(qpub_host);
     if (aux) { (void)hipStreamSynchronize(aux); stream_retire(aux); (void)hipStreamDestroy(aux); }
     if (side) { stream_retire(side); (void)hipStreamDestroy(side); }
 }
@@ -1442,17 +1440,6 @@ int32_t DqnCnn::grads_on_batch(uint64_t n, const void* obs, const int64_t* act, 
 }
 
 namespace bdr {
-constexpr size_t QPUB_MAX_FLOATS = 4096;
-// rows -> pinned host memory, then the sequence number the host waits for (system-scope release: the rows are visible before it)
-__global__ __launch_bounds__(256) void k_publish_rows(const float* src, float* dst_host, unsigned n, unsigned* seq_host, unsigned seq, const unsigned* dev_err)
-{
-    for (unsigned i = threadIdx.x; i < n; i += 256) dst_host[i] = src[i];
-    if (dev_err && threadIdx.x < bdr_agent::ERR_WORDS) seq_host[4 + threadIdx.x] = dev_err[threadIdx.x];   // the device-side error words ride along (bdr_agent::err_poll reads them)
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_out)
 {
     DqnCnn* a = static_cast<DqnCnn*>(base);
@@ -1467,40 +1454,7 @@ int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     }
     NetInst inst[1] = {{d, a->q, 0}};
     int32_t st = forward(a, inst, 1, (int)n);
-    const size_t nq = n * (size_t)a->ar.A;
-    if (st == BDR_OK && nq <= QPUB_MAX_FLOATS) {
-        // Acting calls (a handful of rows, one per environment step): a one-workgroup kernel behind the forward pass stores the Q rows
-        // and then a sequence number into pinned host memory, where this thread waits for it - instead of a copy command and a stream
-        // synchronisation (~15 us of host latency for 24 bytes; dqn/base.rs:211-242 is called once per environment step)
-        if (!a->qpub_host) {
-            hipError_t e = hipHostMalloc((void**)&a->qpub_host, (QPUB_MAX_FLOATS + 16) * sizeof(float), hipHostMallocMapped);
-            if (e == hipSuccess) { memset(a->qpub_host, 0, (QPUB_MAX_FLOATS + 16) * sizeof(float)); e = hipHostGetDevicePointer((void**)&a->qpub_dev, a->qpub_host, 0); }
-            if (e != hipSuccess) return fail(BDR_ERR_HIP, "pinned Q-value buffer: %s", hipGetErrorString(e));
-        }
-        const unsigned seq = ++a->qpub_seq;
-        hipLaunchKernelGGL(k_publish_rows, dim3(1), dim3(256), 0, a->stream, (const float*)a->qv[0], a->qpub_dev + 16, (unsigned)nq,
-                           reinterpret_cast<unsigned*>(a->qpub_dev), seq, (const unsigned*)a->dev_err);
-        BDR_HIP(hipGetLastError());
-        const volatile unsigned* done = reinterpret_cast<const volatile unsigned*>(a->qpub_host);
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0; (int)(*done - seq) < 0; ++spins) {
-            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {   // a lost kernel: let the stream report
-                BDR_HIP(hipStreamSynchronize(a->stream));
-                if ((int)(*done - seq) < 0) return fail(BDR_ERR_HIP, "the Q rows of an acting call never arrived in host memory");
-                break;
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        memcpy(q_out, a->qpub_host + 16, nq * sizeof(float));
-        if (a->dev_err && a->host_err) {   // this call's view of the error words: the caller polls them instead of copying them once more
-            for (int i = 0; i < bdr_agent::ERR_WORDS; ++i) reinterpret_cast<volatile unsigned*>(a->host_err)[i] = reinterpret_cast<const volatile unsigned*>(a->qpub_host)[4 + i];
-            a->err_fresh = true;
-        }
-    } else if (st == BDR_OK) {
-        hipError_t e = hipMemcpyAsync(q_out, a->qv[0], nq * 4, hipMemcpyDeviceToHost, a->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-        if (e != hipSuccess) st = fail(BDR_ERR_HIP, "qvalues copy failed: %s", hipGetErrorString(e));
-    }
+    if (st == BDR_OK) st = a->rows_to_host(a->qv[0], q_out, n * (size_t)a->ar.A);   // (pinned path for acting-sized results: agent_base.hpp)
     a->slot_cursor = 0;
     return st;
 }

@@ -710,11 +710,7 @@ int32_t dqn_mlp_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     int32_t st = a->forward(0, a->q, d, (int)n);
     const int L = (int)a->net.L.size(), ld = a->net.L[L - 1].Np, A = a->net.out_dim;
     std::vector<float> tmp(n * ld);
-    if (st == BDR_OK) {
-        hipError_t e = hipMemcpyAsync(tmp.data(), a->acts[0][L - 1], tmp.size() * 4, hipMemcpyDeviceToHost, a->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-        if (e != hipSuccess) st = fail(BDR_ERR_HIP, "qvalues copy failed: %s", hipGetErrorString(e));
-    }
+    if (st == BDR_OK) st = a->rows_to_host(a->acts[0][L - 1], tmp.data(), tmp.size());
     a->slot_cursor = 0;
     BDR_TRY(st);
     for (uint64_t i = 0; i < n; ++i) for (int k = 0; k < A; ++k) q_out[i * A + k] = tmp[i * ld + k];

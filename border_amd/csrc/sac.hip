@@ -1163,8 +1163,8 @@ int32_t bdr_sac_sample(bdr_agent* base, uint64_t n, const float* obs, float* act
     Sac* a = static_cast<Sac*>(base);
     BDR_HIP(hipSetDevice(a->device));
     BDR_TRY(a->ensure_batch((int)n));
-    float* d = nullptr;
-    BDR_HIP(hipMalloc((void**)&d, n * a->O * 4));
+    float* d = nullptr;   // (the agent's acting buffer: a hipMalloc / hipFree pair per call synchronised the whole device)
+    BDR_TRY(a->act_buffer(n * a->O * 4, (void**)&d));
     int32_t st = a->stage_obs(d, obs, (size_t)a->O * 4, n, a->stream);
     if (st == BDR_OK) st = pack_rows(a->stream, d, a->O, a->O, a->x_o, a->pi.L[0].Kp, 0, (int)n);
     if (st == BDR_OK) {
@@ -1174,12 +1174,7 @@ int32_t bdr_sac_sample(bdr_agent* base, uint64_t n, const float* obs, float* act
     if (st == BDR_OK) st = a->action_logp(a->x_o, a->z_a, (int)n, true, a->xq_a, a->stream);
     const int Ap = a->pi.L[a->n_trunk].Np;
     std::vector<float> tmp(n * Ap);
-    if (st == BDR_OK) {
-        hipError_t e = hipMemcpyAsync(tmp.data(), a->a_s, tmp.size() * 4, hipMemcpyDeviceToHost, a->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-        if (e != hipSuccess) st = fail(BDR_ERR_HIP, "sample copy failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d);
+    if (st == BDR_OK) st = a->rows_to_host(a->a_s, tmp.data(), tmp.size());
     a->slot_cursor = 0;
     BDR_TRY(st);
     for (uint64_t i = 0; i < n; ++i) for (int j = 0; j < a->A; ++j) act_out[i * a->A + j] = tmp[i * Ap + j];

@@ -137,7 +137,7 @@ class DeviceBatch(C.Structure):
 
 # every symbol include/border_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "bdr_last_error", "bdr_device_count", "bdr_version",
+    "bdr_last_error", "bdr_last_error_is_deferred", "bdr_device_count", "bdr_version",
     "bdr_replay_create", "bdr_replay_destroy", "bdr_replay_push", "bdr_replay_push_device", "bdr_replay_len", "bdr_replay_head", "bdr_replay_frames_used",
     "bdr_replay_sample_indices", "bdr_replay_batch", "bdr_replay_last_batch", "bdr_replay_fill_synthetic",
     "bdr_replay_read_rows",

@@ -228,14 +228,18 @@ int32_t bdr_agent::err_report(const unsigned* w)
     memset(host_err, 0, ERR_WORDS * sizeof(unsigned));
     if (gate) {
         on_gate_timeout();
-        return fail(BDR_ERR_HIP, "cross-queue gate %u of a %s agent timed out (the producer kernel it waits for never arrived): the agent continues on its "
+        const int32_t st__ = fail(BDR_ERR_HIP, "cross-queue gate %u of a %s agent timed out (the producer kernel it waits for never arrived): the agent continues on its "
                                  "fallback schedule (DqnCnn: event ordering; "
                                  "Sac: one queue; in both the parameter updates behind the failed wait were skipped on the device and the host's "
                                  "counters - n_opts, the Adam step numbers - were rolled back to the last update that was applied)", gate - 1, kind());
+        g_err_deferred = 1;
+        return st__;
     }
-    if (act) return fail(BDR_ERR_INVALID, "an action index outside [0, n_actions) reached the TD step (the reference's gather raises "
-                                          "an index error); it was clamped");
-    return fail(BDR_ERR_INVALID, "non-finite value flagged on the device (%u)", nonf);
+    const int32_t st__ = act ? fail(BDR_ERR_INVALID, "an action index outside [0, n_actions) reached the TD step (the reference's gather raises "
+                                                      "an index error); it was clamped")
+                             : fail(BDR_ERR_INVALID, "non-finite value flagged on the device (%u)", nonf);
+    g_err_deferred = 1;
+    return st__;
 }
 
 int32_t bdr_agent::err_check()

@@ -17,9 +17,11 @@
 namespace bdr {
 
 extern thread_local char g_err[512];
+extern thread_local int g_err_deferred;   // the last failure on this thread reports a device-side condition of an EARLIER, asynchronous step (bdr_last_error_is_deferred)
 
 inline int32_t fail(int32_t code, const char* fmt, ...)
 {
+    g_err_deferred = 0;
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);

@@ -444,8 +444,10 @@ int32_t per_check(bdr_per* p)
     BDR_HIP(hipMemcpy(&flag, p->mm + 2, 4, hipMemcpyDeviceToHost));
     if (!flag) return BDR_OK;
     BDR_HIP(hipMemset(p->mm + 2, 0, 4));
-    return fail(BDR_ERR_INVALID, "SumTree::update: change is NaN (a NaN priority / TD error reached update_priority; the reference panics, "
-                                 "sum_tree.rs:101-104); those updates were dropped");
+    const int32_t st = fail(BDR_ERR_INVALID, "SumTree::update: change is NaN (a NaN priority / TD error reached update_priority; the reference panics, "
+                                             "sum_tree.rs:101-104); those updates were dropped");
+    g_err_deferred = 1;   // a condition of an earlier asynchronous tree update, not of the call that reports it
+    return st;
 }
 
 void per_info(const bdr_per* p, bdr_per_info* o)

@@ -15,6 +15,7 @@
 
 namespace bdr {
 thread_local char g_err[512] = "";
+thread_local int g_err_deferred = 0;
 
 int32_t ensure_device(int32_t device)
 {
@@ -481,6 +482,7 @@ static int32_t push_frames(bdr_replay* r, uint64_t n, const uint8_t* o, const ui
 extern "C" {
 
 const char* bdr_last_error(void) { return bdr::g_err; }
+int32_t bdr_last_error_is_deferred(void) { return bdr::g_err_deferred; }
 const char* bdr_version(void) { return "border_amd 0.1 (gfx950)"; }
 
 int32_t bdr_device_count(int32_t* count)

@@ -45,6 +45,13 @@ typedef struct bdr_agent bdr_agent;
 typedef struct bdr_comm bdr_comm;
 
 BDR_API const char* bdr_last_error(void);
+/* 1 when the last failure on this thread reports a device-side condition of an EARLIER asynchronous step (an action index outside
+ * [0, n_actions) that reached a TD step, a cross-queue wait that timed out, a non-finite priority): the call that returned it did NOT
+ * fail on its own arguments, the condition has been cleared and the agent's state is that of the last good update.  Agent::opt returns
+ * () in the reference (border-core/src/base/agent.rs:24-136): a caller of bdr_agent_opt may log such a report and go on, and must
+ * treat every other failure (BDR_ERR_EMPTY, a buffer that does not match the agent, a HIP error of the call itself) as the reference's
+ * panic.  0 otherwise. */
+BDR_API int32_t bdr_last_error_is_deferred(void);
 BDR_API int32_t bdr_device_count(int32_t* count);
 BDR_API const char* bdr_version(void);
 

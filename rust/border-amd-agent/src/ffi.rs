@@ -406,6 +406,7 @@ pub struct bdr_sac_config {
 #[link(name = "border_amd")]
 extern "C" {
     pub fn bdr_last_error() -> *const c_char;
+    pub fn bdr_last_error_is_deferred() -> i32;
     pub fn bdr_device_count(count: *mut i32) -> i32;
     pub fn bdr_version() -> *const c_char;
 

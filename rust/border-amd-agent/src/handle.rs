@@ -17,9 +17,9 @@ pub(crate) struct AgentHandle {
     /// `*.safetensors` instead of the default `*.pt.tch` (set through `set_checkpoint_format`, mirrored here so that
     /// `save_params` can name the files the library actually wrote)
     safetensors: bool,
-    /// A device-side failure reported by `Agent::opt` (which returns `()` in the reference's trait): logged when it happens and
-    /// returned by the next call that can return an error (`sync`, `save_params`, `load_params`).
-    deferred: Option<anyhow::Error>,
+    /// A device-side condition of an EARLIER step that `Agent::opt` / `opt_with_record` reported (`bdr_last_error_is_deferred`): logged
+    /// when it happens and returned by the next call that can return an error (`sync`, `save_params`).  `RefCell`: `save_params` has `&self`.
+    deferred: std::cell::RefCell<Option<anyhow::Error>>,
 }
 
 // SAFETY: one HIP stream set per handle, hipSetDevice on every entry; `Send`, not `Sync` (all device work behind `&mut`).
@@ -27,7 +27,7 @@ unsafe impl Send for AgentHandle {}
 
 impl AgentHandle {
     pub(crate) fn new(h: *mut ffi::bdr_agent) -> Self {
-        Self { h, keys: Vec::new(), safetensors: false, deferred: None }
+        Self { h, keys: Vec::new(), safetensors: false, deferred: std::cell::RefCell::new(None) }
     }
 
     pub(crate) fn set_train(&mut self, on: bool) {
@@ -42,18 +42,35 @@ impl AgentHandle {
 
     /// `Agent::opt`: enqueues the step on the agent's streams and returns without waiting for the device.
     ///
-    /// The library reports device-side conditions of EARLIER steps here without synchronising (an action index outside
-    /// `[0, n_actions)`, a cross-queue wait that timed out).  They must not panic the learner thread: the state stays that of the
-    /// last good update and training can go on, so the error is logged and kept for the next fallible call.
+    /// Two kinds of failure come back from `bdr_agent_opt`, and `bdr_last_error_is_deferred` tells them apart:
+    /// * a device-side condition of an EARLIER step, noticed here without synchronising (an action index outside `[0, n_actions)`, a
+    ///   cross-queue wait that timed out, a NaN priority).  The library has cleared it, the state is that of the last good update and
+    ///   THIS step has not been enqueued yet: log it, keep it for the next fallible call, and enqueue the step again - `Trainer` counts
+    ///   an opt step for every call (`border-core/src/trainer.rs:214-225`), so the call must not return without one.
+    /// * a failure of the call itself - an empty buffer (`BDR_ERR_EMPTY`: the reference's `batch()` error is `unwrap()`ed,
+    ///   `dqn/base.rs:62`), a buffer whose rows do not fit the network, a wrong device, a HIP error of a launch: the reference panics
+    ///   in these places, and so does this (a run must not reach `max_opts` with zero updates and one log line).
     pub(crate) fn opt(&mut self, buffer: *mut ffi::bdr_replay) {
-        if let Err(e) = check(unsafe { ffi::bdr_agent_opt(self.h, buffer) }) {
-            log::error!("Agent::opt: {e:#}");
-            self.deferred.get_or_insert(e);
+        let mut rc = unsafe { ffi::bdr_agent_opt(self.h, buffer) };
+        if rc != ffi::BDR_OK && self.defer_if_async(rc, "Agent::opt") {
+            rc = unsafe { ffi::bdr_agent_opt(self.h, buffer) };
         }
+        expect(rc, "Agent::opt");
     }
 
-    fn take_deferred(&mut self) -> Result<()> {
-        match self.deferred.take() {
+    /// `true` when `rc` reports an earlier step's device-side condition (logged and kept); `false` when it is the call's own failure.
+    fn defer_if_async(&mut self, rc: i32, what: &str) -> bool {
+        if unsafe { ffi::bdr_last_error_is_deferred() } == 0 {
+            return false;
+        }
+        let e = check(rc).unwrap_err();
+        log::error!("{what}: {e:#}");
+        self.deferred.borrow_mut().get_or_insert(e);
+        true
+    }
+
+    fn take_deferred(&self) -> Result<()> {
+        match self.deferred.borrow_mut().take() {
             Some(e) => Err(e),
             None => Ok(()),
         }
@@ -88,10 +105,12 @@ impl AgentHandle {
     pub(crate) fn opt_with_record(&mut self, buffer: *mut ffi::bdr_replay) -> Record {
         let mut vals = vec![0f32; 256];
         let mut n = 0i32;
-        expect(
-            unsafe { ffi::bdr_agent_opt_with_scalars(self.h, buffer, vals.as_mut_ptr(), vals.len() as i32, &mut n) },
-            "Agent::opt_with_record",
-        );
+        // the same policy as `opt`: an earlier step's device-side report is logged and kept, then the step runs
+        let mut rc = unsafe { ffi::bdr_agent_opt_with_scalars(self.h, buffer, vals.as_mut_ptr(), vals.len() as i32, &mut n) };
+        if rc != ffi::BDR_OK && self.defer_if_async(rc, "Agent::opt_with_record") {
+            rc = unsafe { ffi::bdr_agent_opt_with_scalars(self.h, buffer, vals.as_mut_ptr(), vals.len() as i32, &mut n) };
+        }
+        expect(rc, "Agent::opt_with_record");
         let keys = self.record_keys().to_vec();
         let mut record = Record::empty();
         for (k, v) in keys.iter().zip(vals.iter().take(n as usize)) {
@@ -100,10 +119,15 @@ impl AgentHandle {
         record
     }
 
+    /// The synchronisation's own error first (it is the newer one; a kept report is logged with it), else the kept report.
     pub(crate) fn sync(&mut self) -> Result<()> {
         let now = check(unsafe { ffi::bdr_agent_sync(self.h) });
-        self.take_deferred()?;
-        now
+        let kept = self.take_deferred();
+        match (now, kept) {
+            (Err(e), Err(k)) => Err(e.context(format!("(an earlier report was pending as well: {k:#})"))),
+            (Err(e), Ok(())) => Err(e),
+            (Ok(()), kept) => kept,
+        }
     }
 
     pub(crate) fn n_opts(&self) -> usize {
@@ -136,12 +160,18 @@ impl AgentHandle {
     pub(crate) fn save_params(&self, path: &Path, stems: &[String]) -> Result<Vec<PathBuf>> {
         let dir = CString::new(path.to_str().ok_or_else(|| anyhow!("non-UTF-8 path"))?)?;
         check(unsafe { ffi::bdr_agent_save_params(self.h, dir.as_ptr()) })?;
+        // the files are written (the state of the last good update); a report kept from an earlier `opt` is returned now, as documented
+        self.take_deferred()?;
         let ext = if self.safetensors { "safetensors" } else { "pt.tch" };
         Ok(stems.iter().map(|f| path.join(format!("{f}.{ext}"))).collect())
     }
 
+    /// A report kept from an earlier `opt` does not stop a checkpoint from loading (the parameters it concerned are being replaced):
+    /// it is logged and dropped.
     pub(crate) fn load_params(&mut self, path: &Path) -> Result<()> {
-        self.take_deferred()?;
+        if let Err(e) = self.take_deferred() {
+            log::warn!("load_params: dropping a pending report of an earlier step: {e:#}");
+        }
         let dir = CString::new(path.to_str().ok_or_else(|| anyhow!("non-UTF-8 path"))?)?;
         check(unsafe { ffi::bdr_agent_load_params(self.h, dir.as_ptr()) })
     }

@@ -1018,3 +1018,31 @@ print("LOSS", np.isfinite(rec["loss"]), "MOVED", bool((a.get_params("qnet") != p
         assert out[2] in ("NOPTS 0", "NOPTS 1") and (mode == "poll" or out[2] == "NOPTS 0"), (mode, r.stdout)
         assert out[3] == "LOSS True MOVED True", (mode, r.stdout)
         assert "continues with event ordering" in r.stderr and "were rolled back" in r.stderr, r.stderr[-500:]
+
+
+@pytest.mark.gpu
+def test_a_deferred_report_is_told_apart_from_a_failure_of_the_call_itself(B):
+    """`bdr_last_error_is_deferred` (include/border_amd.h): Agent::opt returns () in the reference, so the Rust shim needs to know whether a
+    failing bdr_agent_opt reports an EARLIER step's device-side condition (log, keep, enqueue again) or failed on its own arguments (the
+    reference's panic).  An empty buffer is the call's own failure; an action index outside [0, n_actions) that reached a TD step is a
+    deferred report, surfaced by the next synchronising call, after which the agent trains on."""
+    from border_amd import _lib
+    L = _lib.lib()
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=64, seed=1), (4, 1, 84, 84), "uint8")
+    cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=6), opt_config=B.OptimizerConfig.Adam(1e-4)),
+                      device=0, batch_size=8, param_seed=2)
+    a = B.Dqn.build(cfg); a.train()
+    with pytest.raises(B.BdrError) as e:
+        a.opt(rb)                                      # empty buffer: BDR_ERR_EMPTY, the call's own failure
+    assert e.value.code == 4 and L.bdr_last_error_is_deferred() == 0
+    g = np.random.default_rng(0)
+    n = 32
+    obs = g.integers(0, 256, (n, 4, 1, 84, 84), dtype=np.uint8)
+    act = np.full((n, 1), 17, np.int64)                # no such action
+    rb.push(obs, act, obs, np.zeros(n, np.float32), np.zeros(n, np.int8), np.zeros(n, np.int8))
+    a.opt(rb)                                          # enqueued: the TD kernel clamps the index and raises the device flag
+    with pytest.raises(B.BdrError) as e:
+        a.sync()
+    assert e.value.code == 1 and "action index" in str(e.value) and L.bdr_last_error_is_deferred() == 1
+    a.sync()                                           # reported once, cleared
+    a.close(); rb.close()

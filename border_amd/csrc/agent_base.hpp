@@ -164,6 +164,11 @@ struct bdr_agent {
         hipLaunchKernelGGL(k_publish_rows, dim3(1), dim3(256), 0, stream, dev_rows, rows_dev + 16, (unsigned)n_floats, reinterpret_cast<unsigned*>(rows_dev), seq,
                            (const unsigned*)dev_err, (int)ERR_WORDS);
         BDR_HIP(hipGetLastError());
+        return rows_wait(seq, out, n_floats);
+    }
+    // wait for sequence number `seq` in the pinned area, then copy the rows (and this call's view of the error words) out
+    int32_t rows_wait(unsigned seq, float* out, size_t n_floats)
+    {
         const volatile unsigned* done = reinterpret_cast<const volatile unsigned*>(rows_host);
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; (int)(*done - seq) < 0; ++spins) {

@@ -23,6 +23,7 @@
 #include "igemm.hpp"
 #include "conv1_bf16_img.hpp"
 #include "cnn_layers.hpp"
+#include "act_small.hpp"
 
 using namespace bdr;
 
@@ -380,6 +381,7 @@ struct DqnCnn : bdr_agent {
     const float* last_reward = nullptr; int last_B = 0;
     // bookkeeping (dqn/base.rs:26-48)
     uint64_t adam_step = 0, soft_update_counter = 0;
+    float* act_part = nullptr; unsigned* act_tickets = nullptr;   // scratch of the acting kernels (act_small.hpp)
     unsigned long long* applied_step = nullptr;   // device word: the Adam step number of the last l1 / l2 pass that was not skipped (on_gate_timeout)
 
     ~DqnCnn() override;
@@ -464,7 +466,7 @@ int32_t ensure_batch(DqnCnn* a, int B)
 //                                the Adam update of those same elements (the conv layers: 78 k of the 1.69 M parameters);
 //   remaining blocks           : Adam over the rest of the arena (l1, l2), four elements per thread.
 // Element formulas are k_reduce_partials3's and k_adam's, unchanged.
-struct ReduceAdamArgs {
+struct ConvReduceAdamArgs {
     Reduce3Args r;
     float* p; const float* g; float* m; float* v;
     float* gbase;            // start of the gradient arena (segment gradients live at seg.g = gbase + offset)
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(64) void k_signal(unsigned* sig, int which, unsigne
     if (threadIdx.x == 0) __hip_atomic_store(sig + which, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void k_reduce_adam(ReduceAdamArgs a)
+__global__ __launch_bounds__(256) void k_reduce_adam(ConvReduceAdamArgs a)
 {
     const bool poisoned = a.reduce_only || (a.poison && *a.poison != 0);
     if ((int)blockIdx.x >= a.reduce_blocks) {
@@ -900,7 +902,7 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
             wg += (nw[k] + nb[k] + 31) / 32;
         }
         // the conv layers' Adam step rides on their partial reduction (k_reduce_adam); l1 / l2: adam_l1_l2 above
-        ReduceAdamArgs ra{};
+        ConvReduceAdamArgs ra{};
         ra.r = r; ra.p = a->q; ra.g = a->grad; ra.m = a->m; ra.v = a->v; ra.gbase = a->grad;
         ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg; ra.poison = a->sig + SIG_ERR; ra.reduce_only = defer ? 1 : 0;
         Bracket br(a, "reduce_adam");
@@ -1225,7 +1227,7 @@ DqnCnn::~DqnCnn()
         (void)hipFree(gate_trace);
     }
     if (sig) (void)hipFree(sig);
-    (void)hipFree(applied_step);
+    (void)hipFree(applied_step); (void)hipFree(act_part); (void)hipFree(act_tickets);
     if (aux) { (void)hipStreamSynchronize(aux); stream_retire(aux); (void)hipStreamDestroy(aux); }
     if (side) { stream_retire(side); (void)hipStreamDestroy(side); }
 }
@@ -1440,6 +1442,51 @@ int32_t DqnCnn::grads_on_batch(uint64_t n, const void* obs, const int64_t* act, 
 }
 
 namespace bdr {
+static int getenv_once_no_act_small()
+{
+    static const int v = getenv("BDR_NO_ACT_SMALL") ? 1 : 0;   // diagnostic: acting calls on the training kernels
+    return v;
+}
+
+// Q rows of n <= ACT_SMALL_MAX observations with the acting kernels (act_small.hpp): conv1 (staged-image form, one image per workgroup),
+// conv2 / conv3 / l1 as 32 x 32 tiles x k-slices, l2 + the hand-over to the host by the workgroup that finishes l1.  Five launches, no copy
+// command, no stream synchronisation.
+static int32_t act_small_forward(DqnCnn* a, const uint8_t* d, int n, float* q_out)
+{
+    const Arena& ar = a->ar;
+    hipStream_t st = a->stream;
+    BDR_TRY(a->join_exchange(true, true));   // an overlapped parameter exchange of the online network may still be in flight
+    if (!a->act_part) {
+        BDR_HIP(hipMalloc((void**)&a->act_part, act_small_part_floats() * sizeof(float)));
+        BDR_HIP(hipMalloc((void**)&a->act_tickets, ACT_SMALL_TICKETS * sizeof(unsigned)));
+        BDR_HIP(hipMemsetAsync(a->act_tickets, 0, ACT_SMALL_TICKETS * sizeof(unsigned), st));
+    }
+    if (!a->rows_host) {
+        BDR_HIP(hipHostMalloc((void**)&a->rows_host, (ROWS_PINNED_MAX_FLOATS + 16) * sizeof(float), hipHostMallocMapped));
+        memset(a->rows_host, 0, (ROWS_PINNED_MAX_FLOATS + 16) * sizeof(float));
+        BDR_HIP(hipHostGetDevicePointer((void**)&a->rows_dev, a->rows_host, 0));
+    }
+    {
+        Conv1Args c{};
+        c.M = n * 400; c.nz = 1; c.x[0] = d; c.w1[0] = a->q + ar.w1; c.bias[0] = a->q + ar.b1; c.out[0] = a->a1[0];
+        if (ar.ns <= C1IMG_MAX_STACK) BDR_HIP(launch_conv1_bf16_img(ar.ns, 1, 16, dim3(n), st, c));   // 16 waves: an image's 13 units in one round
+        else BDR_HIP(conv1_forward(ar.ns, n, st, c));
+    }
+    auto pad32 = [](int m) { return (m + 31) / 32 * 32; };
+    ActLayerArgs l{};
+    l.part = a->act_part; l.tickets = a->act_tickets; l.relu = 1;
+    l.x = a->a1[0]; l.w = a->q + ar.w2; l.bias = a->q + ar.b2; l.out = a->a2[0]; l.M = n * 81; l.Mpad = pad32(l.M); l.N = 64; l.K = 512; l.KS = 4;
+    BDR_HIP(launch_act_layer<2>(st, l));
+    l.x = a->a2[0]; l.w = a->q + ar.w3; l.bias = a->q + ar.b3; l.out = a->a3[0]; l.M = n * 49; l.Mpad = pad32(l.M); l.N = 64; l.K = 576; l.KS = 3;
+    BDR_HIP(launch_act_layer<3>(st, l));
+    const unsigned seq = ++a->rows_seq;
+    l.x = a->a3[0]; l.w = a->q + ar.w4; l.bias = a->q + ar.b4; l.out = a->h1[0]; l.M = n; l.Mpad = 32; l.N = 512; l.K = 3136; l.KS = 7;
+    l.head = ActLayerArgs::Head{a->q + ar.w5, a->q + ar.b5, a->qv[0], n, ar.A, a->rows_dev + 16, reinterpret_cast<unsigned*>(a->rows_dev), seq,
+                                (const unsigned*)a->dev_err, (int)bdr_agent::ERR_WORDS};
+    BDR_HIP(launch_act_layer<0>(st, l));
+    return a->rows_wait(seq, q_out, (size_t)n * ar.A);
+}
+
 int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_out)
 {
     DqnCnn* a = static_cast<DqnCnn*>(base);
@@ -1451,6 +1498,11 @@ int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
         BDR_TRY(a->act_buffer(n * ob, (void**)&stage));
         BDR_TRY(a->stage_obs(stage, obs, ob, n, a->stream));
         d = stage;
+    }
+    if (n <= (uint64_t)ACT_SMALL_MAX && !a->prof && getenv_once_no_act_small() == 0) {   // acting-sized call: act_small.hpp
+        const int32_t st = act_small_forward(a, d, (int)n, q_out);
+        a->slot_cursor = 0;
+        return st;
     }
     NetInst inst[1] = {{d, a->q, 0}};
     int32_t st = forward(a, inst, 1, (int)n);

@@ -138,3 +138,27 @@ def test_iqn_sample_eval_is_argmax_and_train_explores(B):
         ract, _, _ = ref.sample(q, train=True, dqn=False)
         assert act.tolist() == ract.tolist(), call
     a.close()
+
+
+@pytest.mark.parametrize("A", [6, 18, 33])
+def test_acting_kernels_agree_with_the_training_forward(B, A):
+    """Acting-sized calls (n <= 8 rows) take their own kernels (csrc/act_small.hpp: 32 x 32 tiles x k-slices, the last workgroup of a
+    tile adds the slices, l2 and the hand-over to the host by the workgroup that finishes l1); larger calls run the training forward.
+    The same rows through both: the same exact-f32 products added in a different order - 1e-6 relative at most, and the same greedy
+    action wherever the two leading Q-values are not within that distance of each other."""
+    rng = np.random.default_rng(A)
+    from oracle import torch_ref as T
+    a = _cnn_agent(B, A=A, train=False)
+    a.set_params(T.init_params(T.cnn_shapes(A), 9), "qnet")
+    for n in (1, 2, 3, 5, 8):
+        obs = rng.integers(0, 256, (n, 4, 1, 84, 84), dtype=np.uint8)
+        q_act = a.qvalues(obs)                                                       # acting kernels
+        filler = rng.integers(0, 256, (24, 4, 1, 84, 84), dtype=np.uint8)
+        q_train = a.qvalues(np.concatenate([obs, filler]))[:n]                       # the training forward (32 rows)
+        scale = np.abs(q_train).max()
+        assert np.abs(q_act - q_train).max() <= 1e-6 * scale, (n, np.abs(q_act - q_train).max() / scale)
+        top2 = np.sort(q_train, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 4e-6 * scale
+        assert (q_act.argmax(1)[clear] == q_train.argmax(1)[clear]).all()
+    # device-resident rows take the same kernels: same bits as host rows
+    a.close()

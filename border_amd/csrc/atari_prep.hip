@@ -11,6 +11,7 @@
 // all loads of an item in flight together) writes a [84][160][3] u8 intermediate to LDS (40 KB), pass 2
 // (columns 160 -> 84) and the luma read it back.  FMA contraction is switched off for this file: the reference multiplies and adds
 // separately (Rust never contracts).
+#include <chrono>
 #include "common.hpp"
 
 // hipcc contracts a * b + c into an FMA by default (also through HIP's __fmul_rn / __fadd_rn, which are plain operators
@@ -28,7 +29,6 @@ struct bdr_atari_prep {
     uint8_t* prev = nullptr;        // [n_envs][4][84][84]: every environment's stack as it was BEFORE its last step (obs_t of the
                                     // transition whose next_obs is `stacks`) - what a device-side push needs (bdr_replay_push_device)
     uint8_t* d_frames = nullptr;    // staging: [cap][2][H][W][3]
-    uint32_t* d_ixs = nullptr;
     uint8_t* h_stage = nullptr;     // pinned
     uint32_t cap = 0;
 };
@@ -96,17 +96,20 @@ __device__ inline uint32_t max_u8x4(uint32_t x, uint32_t y)
     return r;
 }
 
-// 512 threads per environment.  The tap tables of both passes are built once per workgroup in LDS; pass 1 works on
+// PREP_BANDS workgroups of 512 threads per environment: a workgroup owns a band of 84 / PREP_BANDS output rows through both passes (the
+// vertical pass of a band needs nothing of the others), so one environment - the one-env online loop - is spread over six CUs instead of
+// being one workgroup's 57 us latency chain.  The tap tables of both passes are built once per workgroup in LDS; pass 1 works on
 // 4-byte groups of a row (W * 3 is a multiple of 4 for even W; odd widths take the byte path) with all of an item's loads
 // issued before the arithmetic.
-constexpr int PREP_THREADS = 512;
+constexpr int PREP_THREADS = 512, PREP_BANDS = 6, BAND_ROWS = OUT / PREP_BANDS;
+static_assert(OUT % PREP_BANDS == 0, "bands of whole output rows");
 __global__ __launch_bounds__(PREP_THREADS) void k_atari_prep(PrepArgs a)
 {
     NO_FMA
-    extern __shared__ uint8_t tmp[];   // [84][W][3] (rounded up to 16 B), then the two tap tables
-    const int e = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ uint8_t tmp[];   // [BAND_ROWS][W][3] (rounded up to 16 B), then the two tap tables
+    const int e = blockIdx.x / PREP_BANDS, y0 = (blockIdx.x % PREP_BANDS) * BAND_ROWS, tid = threadIdx.x;
     const int rowb = a.W * 3;
-    Taps* vt = reinterpret_cast<Taps*>(tmp + ((OUT * rowb + 15) & ~15));
+    Taps* vt = reinterpret_cast<Taps*>(tmp + ((BAND_ROWS * rowb + 15) & ~15));
     Taps* ht = vt + OUT;
     const size_t fsz = (size_t)a.H * rowb;
     const uint8_t* fa = a.frames + (size_t)e * 2 * fsz;
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_atari_prep(PrepArgs a)
         const uint32_t* wa = reinterpret_cast<const uint32_t*>(fa);
         const uint32_t* wb = reinterpret_cast<const uint32_t*>(fb);
         uint32_t* tw = reinterpret_cast<uint32_t*>(tmp);
-        for (int idx = tid; idx < OUT * roww; idx += PREP_THREADS) {
+        for (int idx = tid; idx < BAND_ROWS * roww; idx += PREP_THREADS) {
             const int oy = idx / roww, xw = idx - oy * roww;
-            const Taps& t = vt[oy];
+            const Taps& t = vt[y0 + oy];
             uint32_t px[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -143,9 +146,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_atari_prep(PrepArgs a)
             tw[idx] = o;
         }
     } else {
-        for (int idx = tid; idx < OUT * rowb; idx += PREP_THREADS) {
+        for (int idx = tid; idx < BAND_ROWS * rowb; idx += PREP_THREADS) {
             const int oy = idx / rowb, xb = idx - oy * rowb;
-            const Taps& t = vt[oy];
+            const Taps& t = vt[y0 + oy];
             float acc = 0.0f;
             for (int k = 0; k < t.n; ++k) {
                 const size_t off = (size_t)(t.left + k) * rowb + xb;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_atari_prep(PrepArgs a)
 
     // stack_frame (env.rs:197-209): slots 1..3 <- slots 0..2, every thread moves its own pixels (oldest first)
     if (!a.reset) {
-        for (int p = tid; p < OUT * OUT; p += PREP_THREADS) {
+        for (int p = y0 * OUT + tid; p < (y0 + BAND_ROWS) * OUT; p += PREP_THREADS) {
             const uint8_t s0 = stack[p], s1 = stack[1 * OUT * OUT + p], s2 = stack[2 * OUT * OUT + p], s3 = stack[3 * OUT * OUT + p];
             prev[p] = s0; prev[1 * OUT * OUT + p] = s1; prev[2 * OUT * OUT + p] = s2; prev[3 * OUT * OUT + p] = s3;   // obs_t, kept for the push
             stack[3 * OUT * OUT + p] = s2;
@@ -167,12 +170,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_atari_prep(PrepArgs a)
         }
     }
     // pass 2: horizontal_sample + luma; one thread per output pixel (the same pixels it just moved)
-    for (int p = tid; p < OUT * OUT; p += PREP_THREADS) {
+    for (int p = y0 * OUT + tid; p < (y0 + BAND_ROWS) * OUT; p += PREP_THREADS) {
         const int oy = p / OUT, ox = p - oy * OUT;
         const Taps& t = ht[ox];
         float c[3] = {0.0f, 0.0f, 0.0f};
         for (int k = 0; k < t.n; ++k) {
-            const uint8_t* px = tmp + (size_t)oy * rowb + (t.left + k) * 3;
+            const uint8_t* px = tmp + (size_t)(oy - y0) * rowb + (t.left + k) * 3;
             for (int ch = 0; ch < 3; ++ch) c[ch] = c[ch] + (float)px[ch] * t.w[k];
         }
         const float c0 = (float)finish(c[0], t.sum), c1 = (float)finish(c[1], t.sum), c2 = (float)finish(c[2], t.sum);
@@ -188,12 +191,13 @@ int32_t ensure_cap(bdr_atari_prep* h, uint32_t n)
 {
     if (n <= h->cap) return BDR_OK;
     BDR_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(h->d_frames); (void)hipFree(h->d_ixs); (void)hipHostFree(h->h_stage);
-    h->d_frames = nullptr; h->d_ixs = nullptr; h->h_stage = nullptr; h->cap = 0;
+    (void)hipFree(h->d_frames); (void)hipHostFree(h->h_stage);
+    h->d_frames = nullptr; h->h_stage = nullptr; h->cap = 0;
     const size_t fsz = (size_t)h->width * h->height * 3;
-    BDR_HIP(hipMalloc((void**)&h->d_frames, (size_t)n * 2 * fsz));
-    BDR_HIP(hipMalloc((void**)&h->d_ixs, (size_t)n * sizeof(uint32_t)));
-    BDR_HIP(hipHostMalloc((void**)&h->h_stage, (size_t)n * 2 * fsz, hipHostMallocDefault));
+    // frames and environment indices travel in ONE pinned staging buffer and one copy: [n][2][H][W][3] u8, padded to 16 bytes, then [n] u32
+    const size_t ixs_off = ((size_t)n * 2 * fsz + 15) & ~(size_t)15;
+    BDR_HIP(hipMalloc((void**)&h->d_frames, ixs_off + (size_t)n * sizeof(uint32_t)));
+    BDR_HIP(hipHostMalloc((void**)&h->h_stage, ixs_off + (size_t)n * sizeof(uint32_t), hipHostMallocDefault));
     h->cap = n;
     return BDR_OK;
 }
@@ -208,18 +212,26 @@ int32_t run(bdr_atari_prep* h, uint32_t n, const uint32_t* env_ixs, const uint8_
     }
     BDR_HIP(hipSetDevice(h->device));
     BDR_TRY(ensure_cap(h, n));
-    BDR_HIP(hipStreamSynchronize(h->stream));   // staging buffer free again
+    // (the staging buffer is free: the previous call returned after its kernel had finished)
     const size_t fsz = (size_t)h->width * h->height * 3;
     for (uint32_t k = 0; k < n; ++k) {
         memcpy(h->h_stage + (size_t)k * 2 * fsz, fa + (size_t)k * fsz, fsz);
         memcpy(h->h_stage + (size_t)k * 2 * fsz + fsz, fb + (size_t)k * fsz, fsz);
     }
-    BDR_HIP(hipMemcpyAsync(h->d_frames, h->h_stage, (size_t)n * 2 * fsz, hipMemcpyHostToDevice, h->stream));
-    BDR_HIP(hipMemcpyAsync(h->d_ixs, env_ixs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    PrepArgs a{h->d_frames, h->d_ixs, h->stacks, h->prev, (int)h->width, (int)h->height, reset};
-    hipLaunchKernelGGL(k_atari_prep, dim3(n), dim3(PREP_THREADS), (((size_t)OUT * h->width * 3 + 15) & ~(size_t)15) + 2 * OUT * sizeof(Taps), h->stream, a);
+    const size_t ixs_off = ((size_t)h->cap * 2 * fsz + 15) & ~(size_t)15;   // (the layout of ensure_cap: indices behind the capacity's frames)
+    memcpy(h->h_stage + ixs_off, env_ixs, (size_t)n * sizeof(uint32_t));
+    if (n == h->cap) BDR_HIP(hipMemcpyAsync(h->d_frames, h->h_stage, ixs_off + (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    else {
+        BDR_HIP(hipMemcpyAsync(h->d_frames, h->h_stage, (size_t)n * 2 * fsz, hipMemcpyHostToDevice, h->stream));
+        BDR_HIP(hipMemcpyAsync(h->d_frames + ixs_off, h->h_stage + ixs_off, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    PrepArgs a{h->d_frames, reinterpret_cast<const uint32_t*>(h->d_frames + ixs_off), h->stacks, h->prev, (int)h->width, (int)h->height, reset};
+    hipLaunchKernelGGL(k_atari_prep, dim3(n * PREP_BANDS), dim3(PREP_THREADS), (((size_t)BAND_ROWS * h->width * 3 + 15) & ~(size_t)15) + 2 * OUT * sizeof(Taps), h->stream, a);
     BDR_HIP(hipGetLastError());
-    BDR_HIP(hipStreamSynchronize(h->stream));   // env_ixs / frames may be reused by the caller
+    // The kernel is COMPLETE when the call returns (its end-of-kernel release included): the agent and the replay buffer read the stacks
+    // on their own streams without an event.  (A completion word in pinned memory, as the acting calls use for their results, would return
+    // ~10 us earlier - but before that release; the stacks' readers are kernels, not the host.)
+    BDR_HIP(hipStreamSynchronize(h->stream));
     return BDR_OK;
 }
 }  // namespace
@@ -256,7 +268,7 @@ int32_t bdr_atari_prep_destroy(bdr_atari_prep* h)
     if (!h) return BDR_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->stacks); (void)hipFree(h->prev); (void)hipFree(h->d_frames); (void)hipFree(h->d_ixs); (void)hipHostFree(h->h_stage);
+    (void)hipFree(h->stacks); (void)hipFree(h->prev); (void)hipFree(h->d_frames); (void)hipHostFree(h->h_stage);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return BDR_OK;

@@ -260,8 +260,11 @@ int32_t bdr_agent::err_poll()
     unsigned w[ERR_WORDS];
     for (int i = 0; i < ERR_WORDS; ++i) w[i] = reinterpret_cast<volatile unsigned*>(host_err)[i];
     BDR_TRY(err_report(w));
-    if (++err_poll_count % ERR_POLL_INTERVAL == 0)
-        BDR_HIP(hipMemcpyAsync(host_err, dev_err, ERR_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    if (++err_poll_count % ERR_POLL_INTERVAL == 0) {
+        if (!host_err_dev) BDR_HIP(hipHostGetDevicePointer((void**)&host_err_dev, host_err, 0));
+        hipLaunchKernelGGL(k_err_mirror, dim3(1), dim3(64), 0, stream, (const unsigned*)dev_err, host_err_dev, (int)ERR_WORDS);
+        BDR_HIP(hipGetLastError());
+    }
     return BDR_OK;
 }
 

@@ -68,6 +68,14 @@ struct ObsRow {
 // rows -> pinned host memory, then the sequence number the host waits for (system-scope release: the rows are visible before it); the
 // device-side error words ride along (bdr_agent::err_poll reads them)
 constexpr size_t ROWS_PINNED_MAX_FLOATS = 4096;
+// the device's error words -> their pinned host mirror (bdr_agent::err_poll, every ERR_POLL_INTERVAL opts): a one-wave kernel in the
+// agent's stream.  (A device -> host copy COMMAND there made the queue wait for it: 0.75 ms under the kernel tracer, the 0.8 ms gate
+// launches of the default-schedule trace - the other queue waiting through it; profiles/gate_max_r05.md.)
+static __global__ __launch_bounds__(64) void k_err_mirror(const unsigned* dev_err, unsigned* host_err, int n)
+{
+    if ((int)threadIdx.x < n) host_err[threadIdx.x] = dev_err[threadIdx.x];
+}
+
 static __global__ __launch_bounds__(256) void k_publish_rows(const float* src, float* dst_host, unsigned n, unsigned* seq_host, unsigned seq, const unsigned* dev_err, int n_err)
 {
     for (unsigned i = threadIdx.x; i < n; i += 256) dst_host[i] = src[i];
@@ -118,6 +126,7 @@ struct bdr_agent {
     enum { ERR_ACTION = 0, ERR_GATE = 1, ERR_NONFINITE = 2, ERR_WORDS = 4, ERR_POLL_INTERVAL = 256 };
     unsigned* dev_err = nullptr;        // [ERR_WORDS] device
     unsigned* host_err = nullptr;       // [ERR_WORDS] pinned mirror (last asynchronous read-back)
+    unsigned* host_err_dev = nullptr;   // the mirror's device address (k_err_mirror)
     uint64_t err_poll_count = 0;
     bool rec_opt = false;               // record() is being called by Agent::opt_with_record (dqn/base.rs:316-342)
     uint64_t last_replay_uid = 0;       // uid of the buffer of the last opt (its PER error flag is checked with the agent's); a uid, not a

@@ -347,7 +347,7 @@ struct DqnCnn : bdr_agent {
     bool aux_gated = true;     // the PER queue may wait through gates (queues_independent at its creation)
     bool head_gate_enqueued = false;
     bool side_gather = true;   // BDR_NO_SIDE_GATHER=1: opt() gathers on the dX queue
-    unsigned long long* gate_trace = nullptr;   // BDR_GATE_TRACE=1: [5][2] (100 MHz ticks waited, count), printed at destruction
+    unsigned long long* gate_trace = nullptr;   // BDR_GATE_TRACE=1: [5][2] (100 MHz ticks waited, count), [20] join lag, [22 + site] longest wait; printed at destruction
     int sched = 3;   // backward schedule, see update_critic (BDR_SCHED=0|1|2; BDR_NO_OVERLAP=1 == 0)
     unsigned long long gate_limit = 1000000000ull;   // gate time limit in 100 MHz ticks (10 s; BDR_GATE_LIMIT_MS for tests)
     bool holds_gate_token = false;                   // see claim_gates()
@@ -505,7 +505,10 @@ __global__ __launch_bounds__(64) void k_gate(unsigned* sig, int which, unsigned 
         }
     }
     if (waited) {   // BDR_GATE_TRACE: time spent waiting, per gate site; for the join also how long the flag had been set
-        waited[0] += wall_clock64() - t0; waited[1] += 1;
+        const unsigned long long dt = wall_clock64() - t0;
+        waited[0] += dt; waited[1] += 1;
+        unsigned long long* mx = waited + 22 - (which == SIG_SIDE ? 4 : which);   // (waited = trace + 2 site: the site's longest wait at trace[22 + site])
+        if (dt > *mx) *mx = dt;
         if (which == SIG_SIDE) {
             const unsigned long long ts = *reinterpret_cast<volatile unsigned long long*>(sig + 12);
             if (ts && t0 > ts) waited[12] += t0 - ts;
@@ -1222,7 +1225,7 @@ DqnCnn::~DqnCnn()
         (void)hipMemcpy(t, gate_trace, sizeof t, hipMemcpyDeviceToHost);
         static const char* site[5] = {"side<-head", "side<-DxL1", "side<-DxC3", "-", "main<-side (join)"};
         for (int k = 0; k < 5; ++k)
-            if (t[2 * k + 1]) fprintf(stderr, "gate %-18s mean wait %.2f us over %llu gates\n", site[k], t[2 * k] / 100.0 / t[2 * k + 1], t[2 * k + 1]);
+            if (t[2 * k + 1]) fprintf(stderr, "gate %-18s mean wait %.2f us, longest %.1f us, over %llu gates\n", site[k], t[2 * k] / 100.0 / t[2 * k + 1], t[22 + k] / 100.0, t[2 * k + 1]);
         if (t[9]) fprintf(stderr, "the weight-gradient queue finished on average %.2f us before the dX queue reached the join\n", t[20] / 100.0 / (t[9] / 2.0));
         (void)hipFree(gate_trace);
     }

@@ -105,15 +105,15 @@ int main(int argc, char** argv)
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_c1_trace), &tr, sizeof tr));
         for (int rep = 0; rep < 3; ++rep) { CK(launch_conv1_bf16_img(NS, ipw, form_img, dim3(g_img), 0, c2)); CK(hipDeviceSynchronize()); }
         std::vector<unsigned long long> h((size_t)g_img * 16); CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull, t1 = 0; for (int w = 0; w < g_img * 2; ++w) { t0 = std::min(t0, h[w * 8]); for (int k = 0; k < 7; ++k) t1 = std::max(t1, h[w * 8 + k]); }
+        unsigned long long t0 = ~0ull, t1 = 0; for (int w = 0; w < g_img * 2; ++w) { t0 = std::min(t0, h[w * 8]); for (int k : {0, 1, 2, 3, 4, 6}) t1 = std::max(t1, h[w * 8 + k]); }
         for (int wv = 0; wv < 2; ++wv) {
             double s[7] = {0}; double mx[7] = {0};
-            for (int g = 0; g < g_img; ++g) for (int k = 0; k < 7; ++k) { const double v = (double)(h[(g * 2 + wv) * 8 + k] - t0) * 0.01; s[k] += v; mx[k] = std::max(mx[k], v); }
-            printf("trace wave %d (us since the first workgroup started; mean / max over %d workgroups): start %.2f/%.2f  weights split %.2f/%.2f  images committed %.2f/%.2f  barrier %.2f/%.2f  regs %.2f/%.2f  last pair stored %.2f/%.2f  end %.2f/%.2f\n",
-                   wv ? 3 : 0, g_img, s[0] / g_img, mx[0], s[1] / g_img, mx[1], s[2] / g_img, mx[2], s[3] / g_img, mx[3], s[4] / g_img, mx[4], s[5] / g_img, mx[5], s[6] / g_img, mx[6]);
+            for (int g = 0; g < g_img; ++g) for (int k : {0, 1, 2, 3, 4, 6}) { const double v = (double)(h[(g * 2 + wv) * 8 + k] - t0) * 0.01; s[k] += v; mx[k] = std::max(mx[k], v); }
+            printf("trace wave %d (us since the first workgroup started; mean / max over %d workgroups): start %.2f/%.2f  weights split %.2f/%.2f  images committed %.2f/%.2f  barrier %.2f/%.2f  first fragment %.2f/%.2f  end %.2f/%.2f\n",
+                   wv ? (int)(8 * 1) - 1 : 0, g_img, s[0] / g_img, mx[0], s[1] / g_img, mx[1], s[2] / g_img, mx[2], s[3] / g_img, mx[3], s[4] / g_img, mx[4], s[6] / g_img, mx[6]);
         }
         { double cyc = 0, us = 0; for (int g = 0; g < g_img; ++g) { cyc += (double)(h[(g * 2) * 8 + 7] - h[(g * 2) * 8 + 5]); us += (double)(h[(g * 2) * 8 + 6] - h[(g * 2) * 8 + 4]) * 0.01; }
-          printf("wave 0, registers loaded -> end of its units: %.0f shader cycles in %.2f us = %.2f GHz; %d MFMAs -> %.1f cycles per MFMA\n", cyc / g_img, us / g_img, cyc / us * 1e-3, ipw == 1 ? 192 : 336, cyc / g_img / (ipw == 1 ? 192 : 336)); }
+          printf("wave 0, first fragment -> end of its units: %.0f shader cycles in %.2f us = %.2f GHz (8 waves per workgroup: 2 units = 96 MFMAs of wave 0, a SIMD carries two waves)\n", cyc / g_img, us / g_img, cyc / us * 1e-3); }
         printf("kernel span first start -> last stamp: %.2f us\n", (double)(t1 - t0) * 0.01);
         unsigned long long* z0 = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_c1_trace), &z0, sizeof z0));
     }

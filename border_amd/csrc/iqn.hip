@@ -753,8 +753,7 @@ int32_t bdr_iqn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     hipLaunchKernelGGL(k_iqn_average, dim3((unsigned)((n * a->A + 255) / 256)), dim3(256), 0, a->stream, a->f_act.back(), a->hd.L.back().Np, a->qavg, (int)n, N, a->A);
     BDR_HIP(hipGetLastError());
     std::vector<float> q(n * a->A);
-    BDR_HIP(hipMemcpyAsync(q.data(), a->qavg, q.size() * 4, hipMemcpyDeviceToHost, a->stream));
-    BDR_HIP(hipStreamSynchronize(a->stream));
+    BDR_TRY(a->rows_to_host(a->qavg, q.data(), q.size()));   // (pinned path for acting-sized results: agent_base.hpp)
     a->slot_cursor = 0;
     if (q_out) memcpy(q_out, q.data(), q.size() * 4);
     if (argmax_out)

@@ -6,8 +6,8 @@
 // a workgroup owns a 32 x 32 output tile AND one of KS slices of the reduction, its four waves a quarter of the slice each, operands
 // straight from memory into the FP32 MFMAs (dense.hpp dense_small_tile: no LDS staging, no barrier in the loop); the KS partial tiles
 // meet in the LAST workgroup of the tile to finish (ticket; agent-scope stores / loads: the XCDs' L2s are not coherent), which adds
-// them in slice order, then bias and ReLU.  conv2 at n = 1: 24 workgroups of 16 MFMAs per wave instead of 2 x 256; l1: 784 workgroups
-// of one memory round trip each.  The workgroup that completes l1's last tile goes on to l2 and stores the Q rows, the device's error
+// them in slice order, then bias and ReLU.  conv2 at n = 1: 24 workgroups of 16 MFMAs per wave instead of 2 x 256; l1: 16 column tiles
+// x 7 slices = 112 workgroups (49 slices of one round trip each were slower: the last arriver then adds 49 partials).  The workgroup that completes l1's last tile goes on to l2 and stores the Q rows, the device's error
 // words and a sequence number into pinned host memory, where the caller waits: five launches, no copy command, no synchronisation.
 // Products and the per-slice sums are exact-f32 MFMA chains as in training; the ORDER of the additions differs from the training
 // forward (k-tiles there, slices here), so Q agrees with it to ~1e-6 relative, not bit for bit - acting and training never compare bits.

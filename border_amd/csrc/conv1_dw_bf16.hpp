@@ -263,8 +263,14 @@ inline hipError_t launch_conv1_dw_bf16(int ns, dim3 grid, hipStream_t st, const 
 {
     switch (ns) {
 #define BDR_C1DW_CASE(N) case N: { \
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1_dw_bf16<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c1dw_lds_bytes(N)); \
-            if (attr != hipSuccess) return attr; \
+            static bool allowed[64] = {false};   /* per device: a process may drive several GPUs (the attribute belongs to the current one) */ \
+            int dev = 0; \
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice; \
+            if (!allowed[dev]) { \
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1_dw_bf16<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c1dw_lds_bytes(N)); \
+                if (e != hipSuccess) return e; \
+                allowed[dev] = true; \
+            } \
             hipLaunchKernelGGL(k_conv1_dw_bf16<N>, grid, dim3(512), c1dw_lds_bytes(N), st, d); break; }
         BDR_C1DW_CASE(1) BDR_C1DW_CASE(2) BDR_C1DW_CASE(3) BDR_C1DW_CASE(4) BDR_C1DW_CASE(5) BDR_C1DW_CASE(6) BDR_C1DW_CASE(7) BDR_C1DW_CASE(8)
 #undef BDR_C1DW_CASE

@@ -26,6 +26,7 @@ struct ActLayerArgs {
     float* part;             // [KS][Mpad][N] partial tiles (KS > 1)
     unsigned* tickets;       // [m-tiles * n-tiles] (+ 1 for the head ticket), zero between launches
     int M, Mpad, N, K, KS, relu;
+    const float* had; int had_group;   // GEO 1: the input row m is x[m][k] * had[m / had_group][k] (IQN's merge relu(phi) * psi(x)[b]); both rows K long
     // l1 only (head.n_rows > 0): the workgroup that completes the LAST tile of the layer goes on to l2 and the hand-over to the host
     struct Head {
         const float* w5; const float* b5; float* q; int n_rows, A;
@@ -33,7 +34,7 @@ struct ActLayerArgs {
     } head;
 };
 
-// GEO: 0 = dense rows, 2 = conv2 patches (4 x 4 x 32, stride 2 on a 20 x 20 map), 3 = conv3 patches (3 x 3 x 64, stride 1 on 9 x 9)
+// GEO: 0 = dense rows, 1 = dense rows times a per-group row (Hadamard), 2 = conv2 patches (4 x 4 x 32, stride 2 on a 20 x 20 map), 3 = conv3 patches (3 x 3 x 64, stride 1 on 9 x 9)
 template <int GEO>
 static __global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a)
 {
@@ -47,10 +48,12 @@ static __global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a)
     if constexpr (GEO == 2) { const int b = row / 81, r = row - b * 81, oh = r / 9, ow = r - oh * 9; base = a.x + ((size_t)(b * 20 + 2 * oh) * 20 + 2 * ow) * 32; }
     else if constexpr (GEO == 3) { const int b = row / 49, r = row - b * 49, oh = r / 7, ow = r - oh * 7; base = a.x + ((size_t)(b * 9 + oh) * 9 + ow) * 64; }
     else base = a.x + (size_t)row * a.K;
+    const float* hrow = GEO == 1 ? a.had + (size_t)(row / a.had_group) * a.K : nullptr;
     auto loadA = [&](int k) -> f32x4 {   // the lane's four input values k0 + k ... + 3 of its row (k % 4 == 0: inside one channel run)
         const int kk = k0 + k;
         if constexpr (GEO == 2) { const int seg = kk >> 5, kh = seg >> 2, kw = seg & 3; return *reinterpret_cast<const f32x4*>(base + (kh * 20 + kw) * 32 + (kk & 31)); }
         else if constexpr (GEO == 3) { const int seg = kk >> 6, kh = seg / 3, kw = seg - kh * 3; return *reinterpret_cast<const f32x4*>(base + (kh * 9 + kw) * 64 + (kk & 63)); }
+        else if constexpr (GEO == 1) return *reinterpret_cast<const f32x4*>(base + kk) * *reinterpret_cast<const f32x4*>(hrow + kk);
         else return *reinterpret_cast<const f32x4*>(base + kk);
     };
     // the epilogue's operand is requested beside the tile operands
@@ -162,7 +165,7 @@ inline hipError_t launch_act_layer(hipStream_t st, const ActLayerArgs& a)
 constexpr size_t act_small_part_floats()
 {
     const size_t c2 = (size_t)4 * (((size_t)81 * ACT_SMALL_MAX + 31) / 32 * 32) * 64, c3 = (size_t)3 * (((size_t)49 * ACT_SMALL_MAX + 31) / 32 * 32) * 64,
-                 l1 = (size_t)49 * 32 * 512;
+                 l1 = (size_t)7 * 32 * 512;
     return c2 > c3 ? (c2 > l1 ? c2 : l1) : (c3 > l1 ? c3 : l1);
 }
 constexpr size_t ACT_SMALL_TICKETS = 128;

@@ -14,6 +14,7 @@
 #include "dense.hpp"
 #include "conv1_bf16_img.hpp"
 #include "cnn_layers.hpp"
+#include "act_small.hpp"
 
 using namespace bdr;
 
@@ -171,6 +172,26 @@ struct Iqn : bdr_agent {
     uint8_t *u_obs = nullptr, *u_next = nullptr, *u_act = nullptr; float* u_rew = nullptr; int8_t* u_term = nullptr; uint64_t u_cap = 0;
     uint64_t adam_step = 0, soft_update_counter = 0, noise_counter = 0;
     int n_updates_done = 0;
+    // acting calls (bdr_iqn_qvalues on a handful of observations): the trunk's conv2 / conv3 and the merge layer take the acting kernels
+    // (act_small.hpp): at 33 percent points per observation the merge layer is a [33 n][3136] x [3136][512] product that the training
+    // kernel walks in 8 workgroups of 98 k-tiles (71 us of a 175 us call)
+    bool acting = false;
+    float* act_part = nullptr; unsigned* act_tickets = nullptr; size_t act_part_floats = 0;
+    uint8_t* act_pin = nullptr; uint8_t* act_pin_dev = nullptr;   // pinned host rows of an acting call (host view / device view)
+    int32_t act_scratch(size_t floats)
+    {
+        if (floats > act_part_floats) {
+            BDR_HIP(hipStreamSynchronize(stream));
+            (void)hipFree(act_part); act_part = nullptr; act_part_floats = 0;
+            BDR_HIP(hipMalloc((void**)&act_part, floats * sizeof(float)));
+            act_part_floats = floats;
+        }
+        if (!act_tickets) {
+            BDR_HIP(hipMalloc((void**)&act_tickets, 1024 * sizeof(unsigned)));
+            BDR_HIP(hipMemsetAsync(act_tickets, 0, 1024 * sizeof(unsigned), stream));
+        }
+        return BDR_OK;
+    }
     // The merge layer f.L[1] ([B*N][F] x [F][units]) on the bf16 matrix cores with split operands (igemm_b3.hpp) when it is large
     // enough to be matrix-bound (config C4: 32 768 x 3 136 x 512): forward of both networks and the input gradient.  The exact
     // FP32-MFMA kernels stay selectable (BDR_IQN_F32_EXACT=1) and serve every smaller shape.
@@ -203,7 +224,7 @@ struct Iqn : bdr_agent {
         free_batch();
         (void)hipFree(p); (void)hipFree(p_tgt); (void)hipFree(grad); (void)hipFree(am); (void)hipFree(av); (void)hipFree(loss);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
-        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr); (void)hipFree(cpl_tr); (void)hipFree(dypl_tr);
+        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr); (void)hipFree(cpl_tr); (void)hipFree(dypl_tr); (void)hipFree(act_part); (void)hipFree(act_tickets); if (act_pin) (void)hipHostFree(act_pin);
     }
     void free_batch()
     {
@@ -257,6 +278,18 @@ struct Iqn : bdr_agent {
             Conv1Args c{}; c.M = Bn * 400; c.nz = 1;
             c.x[0] = obs; c.w1[0] = params + conv.w1; c.bias[0] = params + conv.b1; c.out[0] = a1;
             { Bracket br(a, "psi_conv1"); BDR_HIP(conv1_forward(conv.ns, Bn, stream, c)); }
+            if (acting && Bn <= ACT_SMALL_MAX) {
+                auto pad32 = [](int m) { return (m + 31) / 32 * 32; };
+                BDR_TRY(act_scratch(act_small_part_floats()));
+                ActLayerArgs l{};
+                l.part = act_part; l.tickets = act_tickets; l.relu = 1;
+                l.x = a1; l.w = params + conv.w2; l.bias = params + conv.b2; l.out = a2; l.M = Bn * 81; l.Mpad = pad32(l.M); l.N = 64; l.K = 512; l.KS = 4;
+                BDR_HIP(launch_act_layer<2>(stream, l));
+                l.x = a2; l.w = params + conv.w3; l.bias = params + conv.b3; l.out = a3; l.M = Bn * 49; l.Mpad = pad32(l.M); l.N = 64; l.K = 576; l.KS = 3;
+                BDR_HIP(launch_act_layer<3>(stream, l));
+                *feat = a3; *ld = 3136;
+                return BDR_OK;
+            }
             FwdArgs f{};
             f.M = Bn * 81; f.x[0] = a1; f.w[0] = params + conv.w2; f.bias[0] = params + conv.b2; f.out[0] = a2;
             { Bracket br(a, "psi_conv2"); LAUNCH(k_igemm<FwdC2>, dim3((f.M + 63) / 64, 1, 1), f); }
@@ -301,6 +334,16 @@ struct Iqn : bdr_agent {
                 // the parameters last - Adam, track, set_params, a model sync, an all-reduce - nothing can leave them stale
                 BDR_TRY(split_l1(params, params == p));
                 BDR_TRY(dense_forward_had_b3(stream, hd.L[1], params, wpl_tr, in, feat, ldf, N, f_act[0], M));
+            } else if (i == 1 && acting && M <= 32 * 16 && hd.L[1].Kp % 448 == 0 && hd.L[1].Np % 32 == 0 && in.ld == hd.L[1].Kp && ldf == hd.L[1].Kp) {
+                // 32 x 32 tiles x 7 k-slices instead of 64 x 64 tiles walking the whole reduction
+                const DenseLayer& l1 = hd.L[1];
+                const int Mpad = (M + 31) / 32 * 32;
+                BDR_TRY(act_scratch(std::max(act_small_part_floats(), (size_t)7 * Mpad * l1.Np)));
+                ActLayerArgs l{};
+                l.part = act_part; l.tickets = act_tickets; l.relu = l1.relu;
+                l.x = in.p; l.had = feat; l.had_group = N; l.w = params + l1.w; l.bias = params + l1.b; l.out = f_act[0];
+                l.M = M; l.Mpad = Mpad; l.N = l1.Np; l.K = l1.Kp; l.KS = l1.Kp / 448;
+                BDR_HIP(launch_act_layer<1>(stream, l));
             } else if (i == 1) BDR_TRY(dense_forward_had(stream, hd.L[1], params, in, feat, ldf, N, f_act[0], M));
             else BDR_TRY(dense_forward(a, stream, hd.L[i], params, in, f_act[i - 1], M));
             in = DenseSrc{f_act[i - 1], hd.L[i].Np};
@@ -747,9 +790,25 @@ int32_t bdr_iqn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     BDR_HIP(hipSetDevice(a->device));
     const int N = sample_points(a->cfg.sample_percents_act);
     BDR_TRY(a->ensure_batch((int)n, N));
-    BDR_TRY(a->stage(n, obs, nullptr, nullptr, nullptr, nullptr));
+    const uint8_t* rows = nullptr;
+    if (a->cnn && n <= (uint64_t)ACT_SMALL_MAX && !a->obs_rows_on_device) {
+        // host rows of an acting call: pinned memory the device reads in place (as DqnCnn's acting path)
+        const size_t ob = (size_t)7056 * a->conv.ns;
+        if (!a->act_pin) {
+            BDR_HIP(hipHostMalloc((void**)&a->act_pin, (size_t)ACT_SMALL_MAX * C1_MAX_STACK * 7056, hipHostMallocMapped));
+            BDR_HIP(hipHostGetDevicePointer((void**)&a->act_pin_dev, a->act_pin, 0));
+        }
+        memcpy(a->act_pin, obs, n * ob);
+        rows = a->act_pin_dev;
+    } else {
+        BDR_TRY(a->stage(n, obs, nullptr, nullptr, nullptr, nullptr));
+        rows = a->u_obs;
+    }
     BDR_TRY(a->fill_tau(a->tau_p, a->cfg.sample_percents_act, (int)n));
-    BDR_TRY(a->model_forward(a->p, a->u_obs, a->tau_p, (int)n, N));
+    a->acting = true;
+    const int32_t st_fwd = a->model_forward(a->p, rows, a->tau_p, (int)n, N);
+    a->acting = false;
+    BDR_TRY(st_fwd);
     hipLaunchKernelGGL(k_iqn_average, dim3((unsigned)((n * a->A + 255) / 256)), dim3(256), 0, a->stream, a->f_act.back(), a->hd.L.back().Np, a->qavg, (int)n, N, a->A);
     BDR_HIP(hipGetLastError());
     std::vector<float> q(n * a->A);

@@ -162,3 +162,19 @@ def test_acting_kernels_agree_with_the_training_forward(B, A):
         assert (q_act.argmax(1)[clear] == q_train.argmax(1)[clear]).all()
     # device-resident rows take the same kernels: same bits as host rows
     a.close()
+
+
+def test_iqn_acting_kernels_agree_with_the_training_forward(B):
+    """bdr_iqn_qvalues on <= 8 observations: the trunk's conv2 / conv3 and the merge layer ([33 n][3136] x [3136][512] at the Const32 percent
+    points of iqn/model/base.rs:361-364) run on the acting kernels (act_small.hpp); more rows run the training forward.  The same rows
+    through both: 1e-6 relative at most (same exact-f32 products, other order of additions)."""
+    rng = np.random.default_rng(5)
+    a = B.Iqn.build(B.IqnConfig(n_actions=9, device=0, batch_size=32, seed=3))
+    a.eval()
+    for n in (1, 2, 5, 8):
+        obs = rng.integers(0, 256, (n, 4, 1, 84, 84), dtype=np.uint8)
+        q_act = a.qvalues(obs)
+        q_train = a.qvalues(np.concatenate([obs, rng.integers(0, 256, (12, 4, 1, 84, 84), dtype=np.uint8)]))[:n]
+        assert q_act.shape == (n, 9)
+        assert np.abs(q_act - q_train).max() <= 1e-6 * np.abs(q_train).max(), n
+    a.close()

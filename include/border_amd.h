@@ -93,7 +93,9 @@ BDR_API int32_t bdr_replay_create(const bdr_replay_config* cfg, bdr_replay** out
 BDR_API int32_t bdr_replay_destroy(bdr_replay* r);
 
 /* ExperienceBufferBase::push (base.rs:295-316): n transitions, rows written at
- * (i+k) % capacity, i = (i+n) % capacity, size = min(size+n, capacity). Host pointers. */
+ * (i+k) % capacity, i = (i+n) % capacity, size = min(size+n, capacity). Host pointers.  The call returns when the
+ * caller's buffers are free (the rows sit in the buffer's pinned staging area); the copy into the ring completes on
+ * the buffer's stream, in order before every later batch / read of this buffer. */
 BDR_API int32_t bdr_replay_push(bdr_replay* r, uint64_t n, const void* obs, const void* act,
                                 const void* next_obs, const float* reward,
                                 const int8_t* is_terminated, const int8_t* is_truncated);

@@ -139,6 +139,7 @@ struct bdr_agent {
         (void)hipFree(dev_err);
         if (host_err) (void)hipHostFree(host_err);
         if (rows_host) (void)hipHostFree(rows_host);
+        if (act_pin) (void)hipHostFree(act_pin);
     }
     int32_t err_init()
     {
@@ -193,6 +194,26 @@ struct bdr_agent {
             for (int i = 0; i < ERR_WORDS; ++i) reinterpret_cast<volatile unsigned*>(host_err)[i] = reinterpret_cast<const volatile unsigned*>(rows_host)[4 + i];
             err_fresh = true;
         }
+        return BDR_OK;
+    }
+    // Host rows of an acting call -> pinned memory the device reads in place (a host -> device copy command from pageable memory costs
+    // ~10-20 us of host time for a few rows; the first kernel of the forward fetches them over PCIe instead).  Acting calls are synchronous -
+    // the caller waits for their result - so the area is free again whenever the next call fills it.
+    static constexpr size_t HOST_ROWS_PINNED_MAX = 256 * 1024;
+    uint8_t* act_pin = nullptr; uint8_t* act_pin_dev = nullptr; size_t act_pin_bytes = 0;
+    int32_t host_rows_pinned(const void* rows, size_t bytes, const uint8_t** dev)
+    {
+        if (bytes > act_pin_bytes) {
+            BDR_HIP(hipStreamSynchronize(stream));
+            if (act_pin) (void)hipHostFree(act_pin);
+            act_pin = nullptr; act_pin_dev = nullptr; act_pin_bytes = 0;
+            const size_t cap = std::max(bytes, (size_t)64 * 1024);
+            BDR_HIP(hipHostMalloc((void**)&act_pin, cap, hipHostMallocMapped));
+            BDR_HIP(hipHostGetDevicePointer((void**)&act_pin_dev, act_pin, 0));
+            act_pin_bytes = cap;
+        }
+        memcpy(act_pin, rows, bytes);
+        *dev = act_pin_dev;
         return BDR_OK;
     }
     bool err_fresh = false;   // host_err was refreshed by the call in progress (an acting call's Q rows brought the words along): poll, do not copy again

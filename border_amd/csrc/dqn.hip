@@ -382,7 +382,6 @@ struct DqnCnn : bdr_agent {
     // bookkeeping (dqn/base.rs:26-48)
     uint64_t adam_step = 0, soft_update_counter = 0;
     float* act_part = nullptr; unsigned* act_tickets = nullptr;   // scratch of the acting kernels (act_small.hpp)
-    uint8_t* act_pin = nullptr; uint8_t* act_pin_dev = nullptr;   // pinned host rows of an acting call (host view / device view)
     unsigned long long* applied_step = nullptr;   // device word: the Adam step number of the last l1 / l2 pass that was not skipped (on_gate_timeout)
 
     ~DqnCnn() override;
@@ -1231,7 +1230,7 @@ DqnCnn::~DqnCnn()
         (void)hipFree(gate_trace);
     }
     if (sig) (void)hipFree(sig);
-    (void)hipFree(applied_step); (void)hipFree(act_part); (void)hipFree(act_tickets); if (act_pin) (void)hipHostFree(act_pin);
+    (void)hipFree(applied_step); (void)hipFree(act_part); (void)hipFree(act_tickets);
     if (aux) { (void)hipStreamSynchronize(aux); stream_retire(aux); (void)hipStreamDestroy(aux); }
     if (side) { stream_retire(side); (void)hipStreamDestroy(side); }
 }
@@ -1501,12 +1500,7 @@ int32_t dqn_cnn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     if (small && !a->obs_rows_on_device) {
         // host rows of an acting call: into pinned memory the device reads in place (conv1's image staging fetches the 28 KB over PCIe while
         // the weights are split) - a host -> device copy command from pageable memory costs ~20 us of host time for these few rows
-        if (!a->act_pin) {
-            BDR_HIP(hipHostMalloc((void**)&a->act_pin, (size_t)ACT_SMALL_MAX * C1_MAX_STACK * 7056, hipHostMallocMapped));
-            BDR_HIP(hipHostGetDevicePointer((void**)&a->act_pin_dev, a->act_pin, 0));
-        }
-        memcpy(a->act_pin, obs, n * ob);
-        d = a->act_pin_dev;
+        BDR_TRY(a->host_rows_pinned(obs, n * ob, &d));
     } else if (!a->obs_in_place(ob)) {   // host rows, or device rows with a stride: into the agent's contiguous staging buffer
         uint8_t* stage = nullptr;
         BDR_TRY(a->act_buffer(n * ob, (void**)&stage));

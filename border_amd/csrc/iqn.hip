@@ -177,7 +177,6 @@ struct Iqn : bdr_agent {
     // kernel walks in 8 workgroups of 98 k-tiles (71 us of a 175 us call)
     bool acting = false;
     float* act_part = nullptr; unsigned* act_tickets = nullptr; size_t act_part_floats = 0;
-    uint8_t* act_pin = nullptr; uint8_t* act_pin_dev = nullptr;   // pinned host rows of an acting call (host view / device view)
     int32_t act_scratch(size_t floats)
     {
         if (floats > act_part_floats) {
@@ -224,7 +223,7 @@ struct Iqn : bdr_agent {
         free_batch();
         (void)hipFree(p); (void)hipFree(p_tgt); (void)hipFree(grad); (void)hipFree(am); (void)hipFree(av); (void)hipFree(loss);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
-        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr); (void)hipFree(cpl_tr); (void)hipFree(dypl_tr); (void)hipFree(act_part); (void)hipFree(act_tickets); if (act_pin) (void)hipHostFree(act_pin);
+        (void)hipFree(wpl_nat); (void)hipFree(wpl_tr); (void)hipFree(cpl_tr); (void)hipFree(dypl_tr); (void)hipFree(act_part); (void)hipFree(act_tickets);
     }
     void free_batch()
     {
@@ -794,12 +793,7 @@ int32_t bdr_iqn_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     if (a->cnn && n <= (uint64_t)ACT_SMALL_MAX && !a->obs_rows_on_device) {
         // host rows of an acting call: pinned memory the device reads in place (as DqnCnn's acting path)
         const size_t ob = (size_t)7056 * a->conv.ns;
-        if (!a->act_pin) {
-            BDR_HIP(hipHostMalloc((void**)&a->act_pin, (size_t)ACT_SMALL_MAX * C1_MAX_STACK * 7056, hipHostMallocMapped));
-            BDR_HIP(hipHostGetDevicePointer((void**)&a->act_pin_dev, a->act_pin, 0));
-        }
-        memcpy(a->act_pin, obs, n * ob);
-        rows = a->act_pin_dev;
+        BDR_TRY(a->host_rows_pinned(obs, n * ob, &rows));
     } else {
         BDR_TRY(a->stage(n, obs, nullptr, nullptr, nullptr, nullptr));
         rows = a->u_obs;

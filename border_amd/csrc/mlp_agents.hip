@@ -704,9 +704,14 @@ int32_t dqn_mlp_qvalues(bdr_agent* base, uint64_t n, const void* obs, float* q_o
     DqnMlp* a = static_cast<DqnMlp*>(base);
     BDR_TRY(a->ensure_batch((int)n));
     const size_t ob = (size_t)a->net.in_dim * 4;
-    uint8_t* d = nullptr;
-    BDR_TRY(a->act_buffer(n * ob, (void**)&d));
-    BDR_TRY(a->stage_obs(d, obs, ob, n, a->stream));
+    const uint8_t* d = nullptr;
+    if (!a->obs_rows_on_device && n * ob <= bdr_agent::HOST_ROWS_PINNED_MAX) BDR_TRY(a->host_rows_pinned(obs, n * ob, &d));   // (read in place by the packing kernel)
+    else {
+        uint8_t* stage = nullptr;
+        BDR_TRY(a->act_buffer(n * ob, (void**)&stage));
+        BDR_TRY(a->stage_obs(stage, obs, ob, n, a->stream));
+        d = stage;
+    }
     int32_t st = a->forward(0, a->q, d, (int)n);
     const int L = (int)a->net.L.size(), ld = a->net.L[L - 1].Np, A = a->net.out_dim;
     std::vector<float> tmp(n * ld);

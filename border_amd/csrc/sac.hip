@@ -1163,9 +1163,18 @@ int32_t bdr_sac_sample(bdr_agent* base, uint64_t n, const float* obs, float* act
     Sac* a = static_cast<Sac*>(base);
     BDR_HIP(hipSetDevice(a->device));
     BDR_TRY(a->ensure_batch((int)n));
-    float* d = nullptr;   // (the agent's acting buffer: a hipMalloc / hipFree pair per call synchronised the whole device)
-    BDR_TRY(a->act_buffer(n * a->O * 4, (void**)&d));
-    int32_t st = a->stage_obs(d, obs, (size_t)a->O * 4, n, a->stream);
+    const float* d = nullptr;   // (a hipMalloc / hipFree pair per call used to synchronise the whole device here)
+    int32_t st = BDR_OK;
+    if (!a->obs_rows_on_device && n * a->O * 4 <= bdr_agent::HOST_ROWS_PINNED_MAX) {   // host rows: read in place from pinned memory by the packing kernel
+        const uint8_t* pd = nullptr;
+        BDR_TRY(a->host_rows_pinned(obs, n * a->O * 4, &pd));
+        d = reinterpret_cast<const float*>(pd);
+    } else {
+        float* stage = nullptr;
+        BDR_TRY(a->act_buffer(n * a->O * 4, (void**)&stage));
+        st = a->stage_obs(stage, obs, (size_t)a->O * 4, n, a->stream);
+        d = stage;
+    }
     if (st == BDR_OK) st = pack_rows(a->stream, d, a->O, a->O, a->x_o, a->pi.L[0].Kp, 0, (int)n);
     if (st == BDR_OK) {
         if (a->train) st = a->gen_noise(a->z_a, n * a->A);

@@ -56,15 +56,23 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+EXAMPLES = ("train_dqn_synthetic", "online_loop_atari")
+
+
 def build_examples() -> str:
-    """examples/train_dqn_synthetic: a training program in compiled code only, on the C ABI (plain g++, no HIP headers)."""
+    """examples/*: programs in compiled code only, on the C ABI (plain g++, no HIP headers): train_dqn_synthetic (a training run
+    with host observations) and online_loop_atari (the one-environment loop with the observation resident in HBM).  Returns the
+    first program's path."""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "examples", "train_dqn_synthetic.cpp")
-    exe = os.path.join(root, "examples", "train_dqn_synthetic")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", src, "-I" + os.path.join(root, "include"), "-L" + HERE, "-lborder_amd",
-                               "-Wl,-rpath,$ORIGIN/../border_amd", "-o", exe])
-    return exe
+    exes = []
+    for name in EXAMPLES:
+        src = os.path.join(root, "examples", name + ".cpp")
+        exe = os.path.join(root, "examples", name)
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB)):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", src, "-I" + os.path.join(root, "include"), "-L" + HERE, "-lborder_amd",
+                                   "-Wl,-rpath,$ORIGIN/../border_amd", "-o", exe])
+        exes.append(exe)
+    return exes[0]
 
 
 if __name__ == "__main__":

@@ -154,3 +154,23 @@ def test_compiled_example_program_trains(B):
     assert opt_steps == n_opts == 120 and env_steps == 64 + 119 and buffer_len == env_steps     # warm-up 64, then one opt per step
     losses = [float(x) for x in re.findall(r"loss ([0-9.eE+-]+)", out.stdout)]
     assert len(losses) == 2 and all(np.isfinite(losses))
+
+
+def test_compiled_online_loop_with_device_observations(B):
+    """examples/online_loop_atari.cpp: the one-environment loop in compiled code with the observation resident in HBM
+    (bdr_atari_prep -> obs_on_device environment -> bdr_trainer_train): counters of trainer.rs:267-327, both conventions."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "..", "examples", "online_loop_atari")
+    if not os.path.exists(exe):
+        from border_amd import build
+        build.build_examples()
+    for where in ("device", "host"):
+        out = subprocess.run([exe, "200", "32", "0", where], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:] + out.stdout[-500:]
+        m = re.search(r"done: env_steps (\d+) opt_steps (\d+) episodes (\d+) buffer_len (\d+) n_opts (\d+)", out.stdout)
+        assert m, out.stdout[-500:]
+        env_steps, opt_steps, episodes, buffer_len, n_opts = map(int, m.groups())
+        assert opt_steps == n_opts == 200 and env_steps == 512 + 199 and buffer_len == env_steps
+        assert ("observations on the " + where) in out.stdout and re.search(r"= [0-9.]+ it/s", out.stdout)

@@ -81,9 +81,9 @@ def dqn_kernel_bytes(B, nz, A=N_ACTIONS):
 
 # kernels on the bf16 matrix cores with exactly split f32 operands -> bf16 MFMAs issued per algorithmic product:
 #   3: one operand is exact in bf16 (u8 pixels), the other split into three terms (conv1 forward / weight gradient);
-#   6: both operands split into three terms, six of the nine partial products kept (IQN's merge layer at C4, csrc/igemm_b3.hpp)
+#   6: both operands split into three terms, six of the nine partial products kept (csrc/igemm_b3.hpp: IQN's merge layer at C4; conv2 / conv3
+#      forward of the DQN step at C2 - build_config adds those two labels unless BDR_DQN_F32_EXACT selects the FP32-MFMA kernels)
 BF16_ISSUE = {"fwd_conv1": 3, "bwd_conv1_dw": 3, "psi_conv1": 3, "psi_conv1_dw": 3, "iqn_f_fwd1_3xbf16": 6, "iqn_f_dx1_3xbf16": 6, "iqn_f_dw1_3xbf16": 6, "iqn_phi_3xbf16": 6}
-BF16_KERNELS = tuple(BF16_ISSUE)
 
 
 def mlp_layer_dims(in_dim, units, out_dim):
@@ -132,6 +132,9 @@ def build_config(B, name, args, rank, local_rank):
                           soft_update_interval=10000, n_updates_per_opt=1, batch_size=bs, discount_factor=0.99,
                           tau=1.0, double_dqn=args.double_dqn, critic_loss=args.loss, device=local_rank, param_seed=0)
         agent = B.Dqn.build(cfg)
+        exact = os.environ.get("BDR_DQN_F32_EXACT") is not None
+        if not exact:
+            BF16_ISSUE.update({"fwd_conv2": 6, "fwd_conv3": 6})
         nz = 3 if args.double_dqn else 2
         fl = dqn_kernel_flops(bs, nz)
         by = {"sample": 2 * bs * 28224 + bs * 14, "adam_l1_l2": 7 * 4 * (3136 * 512 + 512 + 512 * N_ACTIONS + N_ACTIONS)}
@@ -142,7 +145,13 @@ def build_config(B, name, args, rank, local_rank):
                     workload=f"synthetic Atari DQN Nature-CNN, replay {cap} u8 transitions/GPU, batch {bs}/GPU",
                     cfg_extra={"n_actions": N_ACTIONS, "critic_loss": args.loss, "double_dqn": args.double_dqn,
                                "prioritized_replay": bool(args.per), "single_frame_store": bool(args.frame_ring), "optimizer": "Adam lr=1e-4",
-                               "soft_update_interval": 10000, "tau": 1.0},
+                               "soft_update_interval": 10000, "tau": 1.0,
+                               "arithmetic": "f32 storage and accumulation throughout; conv1 forward / dW on the bf16 MFMA with exact operands; every other layer FP32 MFMA" if exact else
+                                             "f32 storage and accumulation throughout; conv1 forward / dW on the bf16 MFMA with exact operands (u8 pixels, weights in 3 bf16 terms); "
+                                             "conv2 / conv3 FORWARD on the bf16 MFMA with each f32 operand split exactly into 3 bf16 terms, 6 of the 9 partial products "
+                                             "(~2e-6 relative per layer vs the exact FP32-MFMA kernels, which BDR_DQN_F32_EXACT=1 selects; parity bar 1e-4); "
+                                             "l1 and every backward GEMM FP32 MFMA"},
+                    dtype="f32" if exact else "f32 (conv2 / conv3 forward: 3xbf16 operand split, 6 products)",
                     which=("qnet",), loss_key="loss")
     if name == "c1":
         cap, bs = args.capacity or 10_000, args.batch or 32
@@ -283,7 +292,7 @@ def roofline(conf, prof, cnt, null_ms, ms_step):
         e = {"ms": round(v, 5), "launches": cnt[k]}
         if k in fl and v > 0:
             tf = fl[k] / (v * 1e-3) / 1e12
-            if k in BF16_KERNELS:   # 3 (or 6) bf16 MFMAs per product: the matrix pipe issues that multiple of the algorithmic flops
+            if k in BF16_ISSUE:   # 3 (or 6) bf16 MFMAs per product: the matrix pipe issues that multiple of the algorithmic flops
                 iss = BF16_ISSUE[k]
                 e.update(bound="mfma_bf16", gflop=round(fl[k] / 1e9, 3), achieved_TFLOPs=round(tf, 2), issued_TFLOPs=round(iss * tf, 2),
                          bf16_products_per_f32_product=iss, frac=round(iss * tf / PEAK_BF16_MFMA_TFLOPS, 4))
@@ -293,8 +302,8 @@ def roofline(conf, prof, cnt, null_ms, ms_step):
             gbs = by[k] / (v * 1e-3) / 1e9
             e.update(bound="hbm", bytes=by[k], achieved_GBs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
         per[k] = e
-    fp32 = [k for k in prof if k in fl and k not in BF16_KERNELS and prof[k] > 0]
-    bf16 = [k for k in prof if k in fl and k in BF16_KERNELS and prof[k] > 0]
+    fp32 = [k for k in prof if k in fl and k not in BF16_ISSUE and prof[k] > 0]
+    bf16 = [k for k in prof if k in fl and k in BF16_ISSUE and prof[k] > 0]
     roof = {}
     if fp32:
         # the longest launch of the step; two launches within 5 % of each other (C2: conv2 forward of both networks and conv2's

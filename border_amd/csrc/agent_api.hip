@@ -670,6 +670,7 @@ int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint
     size_t n = 0;
     float* p = a->arena(which, &n);
     BDR_REQUIRE(p, "unknown arena %d", which);
+    a->arena_escaped(which);   // the caller may write through it whenever they like: derived copies of these parameters are never trusted again
     *ptr = p; *n_floats = n;
     return BDR_OK;
 }

@@ -298,6 +298,7 @@ struct bdr_agent {
     virtual int32_t get_params(int which, float* out, uint64_t n) = 0;
     virtual int32_t set_params(int which, const float* in, uint64_t n) = 0;
     virtual float* arena(int which, size_t* n) = 0;               // flat device arena (kernel layout)
+    virtual void arena_escaped(int) {}                            // the raw pointer of arena `which` left the library (bdr_agent_arena_device_ptr)
     virtual int32_t save(const char* dir) = 0;
     virtual int32_t load(const char* dir) = 0;
 };

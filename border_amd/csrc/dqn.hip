@@ -23,6 +23,7 @@
 #include "igemm.hpp"
 #include "conv1_bf16_img.hpp"
 #include "cnn_layers.hpp"
+#include "igemm_b3.hpp"
 #include "act_small.hpp"
 
 using namespace bdr;
@@ -64,6 +65,53 @@ namespace {
 #define BDR_FWDC3_SHAPE 1, 2, 1, 1
 #endif
 using FwdC3D = FwdConvP<GeomC3, BDR_FWDC3_SHAPE>;
+constexpr size_t PL2_U16 = (size_t)3 * 64 * 512, PL3_U16 = (size_t)3 * 64 * 576;   // W2's / W3's three planes
+// One parameter set's planes: W2 then W3, each [3 planes][K / 32][64 cout][32 k]: the B tile of k-tile kt (64 columns x 32 k of one plane) is
+// 4 KB contiguous, so a wave of staging threads (16 columns x four 16-byte chunks) fetches 1 KB in one piece.  Measured against [cout][K] rows
+// (+0.8 % on the step) and [K / 8][cout][8] (-1.8 %); k_reduce_adam's 32 consecutive cout of one k land 64 bytes apart.
+constexpr size_t CPL_W2 = 0, CPL_W3 = PL2_U16, CPL_U16 = PL2_U16 + PL3_U16;
+__device__ __forceinline__ size_t cpl_index(int k, int n) { return ((size_t)(k >> 5) * 64 + n) * 32 + (k & 31); }
+
+// element e = k * 64 + n of W2 (layer 0) or W3 (layer 1) -> its three bf16 terms
+__device__ __forceinline__ void conv_plane_store(uint16_t* __restrict__ pl, int layer, int e, float x)
+{
+    const uint32_t hi = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hi);                   // exact
+    const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mid);                 // exact, <= 8 significant bits
+    const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
+    const size_t n = (size_t)(layer ? 576 : 512) * 64, o = cpl_index(e >> 6, e & 63);
+    uint16_t* d = pl + (layer ? CPL_W3 : CPL_W2);
+    d[o] = (uint16_t)(hi >> 16); d[n + o] = (uint16_t)(mid >> 16); d[2 * n + o] = (uint16_t)(lo >> 16);
+}
+
+// the planes of one parameter set from its f32 weights (every writer of conv parameters other than k_reduce_adam leaves them stale:
+// DqnCnn::cpl_fresh; the forward re-splits before it reads them)
+__global__ __launch_bounds__(256) void k_conv_planes(const float* __restrict__ w2, const float* __restrict__ w3, uint16_t* __restrict__ pl)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 512 * 64) conv_plane_store(pl, 0, i, w2[i]);
+    else if (i < 512 * 64 + 576 * 64) conv_plane_store(pl, 1, i - 512 * 64, w3[i - 512 * 64]);
+}
+// conv2 / conv3 forward on the bf16 matrix cores with split operands (igemm_b3.hpp, six of the nine partial products): the A rows are the
+// f32 activations, split on their way into LDS; the weights are read from bf16 planes kept beside each parameter set (cpl_index)
+#ifndef BDR_FWDC2_B3_SHAPE
+#define BDR_FWDC2_B3_SHAPE 2, 2
+#endif
+#ifndef BDR_FWDC3_B3_SHAPE
+#define BDR_FWDC3_B3_SHAPE 2, 2
+#endif
+struct FwdB3Args : FwdArgs { const uint16_t* wpl[MAXZ]; };
+template <class G, int WM_, int WN_, int TM_ = 1, int TN_ = 1>
+struct FwdB3 : FwdP<G, AFwd<G>, WM_, WN_, false, 0, TM_, TN_> {
+    using Args = FwdB3Args;
+    __device__ static const uint4* b_chunk(const Args& a, int z, int, int pl, int kt, int n, int kq)
+    {
+        return reinterpret_cast<const uint4*>(a.wpl[z] + (size_t)pl * G::COUT * G::K + cpl_index(kt * 32 + kq * 8, n));
+    }
+};
+using FwdC2B3 = FwdB3<GeomC2, BDR_FWDC2_B3_SHAPE>;
+using FwdC3B3 = FwdB3<GeomC3, BDR_FWDC3_B3_SHAPE>;
 constexpr int TEAMS_FWD_C2 = BDR_TEAMS_FWD_C2, TEAMS_FWD_C3 = BDR_TEAMS_FWD_C3, TEAMS_FWD_L1 = BDR_TEAMS_FWD_L1, TEAMS_DX_L1 = BDR_TEAMS_DX_L1,
               TEAMS_DX_C3 = BDR_TEAMS_DX_C3, TEAMS_DX_C2 = BDR_TEAMS_DX_C2;
 
@@ -381,6 +429,16 @@ struct DqnCnn : bdr_agent {
     const float* last_reward = nullptr; int last_B = 0;
     // bookkeeping (dqn/base.rs:26-48)
     uint64_t adam_step = 0, soft_update_counter = 0;
+    // conv2 / conv3 on the bf16 matrix cores with split f32 operands (igemm_b3.hpp): bf16 planes of W2 / W3 beside each parameter set
+    // ([0] online, [1] target).  k_reduce_adam writes the online set's planes with the parameters; every other writer of conv
+    // parameters marks the set stale (planes_stale) and the next forward re-splits it on its own queue, behind whatever orders
+    // it after that writer.  A raw arena pointer handed out (bdr_agent_arena_device_ptr) can be written at any time: that set is
+    // then re-split before every forward.  BDR_DQN_F32_EXACT=1: every layer on the FP32 MFMA (exact products), no planes.
+    uint16_t* cpl[2] = {nullptr, nullptr};
+    bool cpl_fresh[2] = {false, false}, cpl_escaped[2] = {false, false};
+    bool conv_b3 = true;
+    void planes_stale(int set) { if (set == 0 || set == 1) cpl_fresh[set] = false; }
+    void arena_escaped(int which) override { if (which == 0 || which == 1) cpl_escaped[which] = true; }
     float* act_part = nullptr; unsigned* act_tickets = nullptr;   // scratch of the acting kernels (act_small.hpp)
     unsigned long long* applied_step = nullptr;   // device word: the Adam step number of the last l1 / l2 pass that was not skipped (on_gate_timeout)
 
@@ -475,6 +533,7 @@ struct ConvReduceAdamArgs {
     int reduce_blocks;
     const unsigned* poison;  // sig + SIG_ERR: a gate timed out, leave the parameters alone
     int reduce_only;         // gradients only (the optimizer step follows an all-reduce: synchronous data-parallel mode)
+    uint16_t* cpl;           // the parameter set's bf16 planes of W2 / W3 (segments 1, 2), written with the parameters; null: none
 };
 // Schedule 3 cross-queue ordering without barrier packets (igemm.hpp start_signal).
 // k_gate: one wave; returns once *flag has reached `epoch` (wrap-safe compare).  It holds one wave slot while it waits, so
@@ -570,6 +629,7 @@ __global__ __launch_bounds__(256) void k_reduce_adam(ConvReduceAdamArgs a)
         float pe = a.p[e], me = a.m[e], ve = a.v[e];
         adam_element(pe, g, me, ve, a.s);
         a.p[e] = pe; a.m[e] = me; a.v[e] = ve;
+        if (a.cpl && s_id >= 1 && i < sg.n_weights) conv_plane_store(a.cpl, s_id - 1, i, pe);
     }
 }
 
@@ -599,10 +659,30 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
     }
     f.M = B * 81;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a1[inst[z].slot]; f.w[z] = inst[z].params + ar.w2; f.bias[z] = inst[z].params + ar.b2; f.out[z] = a->a2[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv2"); BDR_HIP((launch_igemm<FwdC2, TEAMS_FWD_C2>(st, dim3(m_tiles<FwdC2>(f.M) * n_tiles<FwdC2>(), 1, nz), f))); }
+    bool b3 = a->conv_b3;
+    FwdB3Args fb{};
+    for (int z = 0; z < nz && b3; ++z) b3 = inst[z].params == a->q || inst[z].params == a->q_tgt;
+    for (int z = 0; z < nz && b3; ++z) {
+        const int set = inst[z].params == a->q ? 0 : 1;
+        if (a->cpl_fresh[set] && !a->cpl_escaped[set]) continue;
+        hipLaunchKernelGGL(k_conv_planes, dim3((512 * 64 + 576 * 64 + 255) / 256), dim3(256), 0, st, inst[z].params + ar.w2, inst[z].params + ar.w3, a->cpl[set]);
+        BDR_HIP(hipGetLastError());
+        a->cpl_fresh[set] = true;
+    }
+    if (b3) {
+        static_cast<FwdArgs&>(fb) = f;
+        for (int z = 0; z < nz; ++z) fb.wpl[z] = a->cpl[inst[z].params == a->q ? 0 : 1] + CPL_W2;
+        Bracket br(a, "fwd_conv2");
+        BDR_HIP((launch_igemm_b3<FwdC2B3, 6>(st, dim3(m_tiles<FwdC2B3>(f.M), 1, nz), fb)));
+    } else { Bracket br(a, "fwd_conv2"); BDR_HIP((launch_igemm<FwdC2, TEAMS_FWD_C2>(st, dim3(m_tiles<FwdC2>(f.M) * n_tiles<FwdC2>(), 1, nz), f))); }
     f.M = B * 49;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a2[inst[z].slot]; f.w[z] = inst[z].params + ar.w3; f.bias[z] = inst[z].params + ar.b3; f.out[z] = a->a3[inst[z].slot]; }
-    { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3D, TEAMS_FWD_C3>(st, dim3(m_tiles<FwdC3D>(f.M) * n_tiles<FwdC3D>(), 1, nz), f))); }
+    if (b3) {
+        static_cast<FwdArgs&>(fb) = f;
+        for (int z = 0; z < nz; ++z) fb.wpl[z] = a->cpl[inst[z].params == a->q ? 0 : 1] + CPL_W3;
+        Bracket br(a, "fwd_conv3");
+        BDR_HIP((launch_igemm_b3<FwdC3B3, 6>(st, dim3(m_tiles<FwdC3B3>(f.M), 1, nz), fb)));
+    } else { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3D, TEAMS_FWD_C3>(st, dim3(m_tiles<FwdC3D>(f.M) * n_tiles<FwdC3D>(), 1, nz), f))); }
     f.M = B; f.nkt_per_split = (98 + L1_SPLIT - 1) / L1_SPLIT;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a3[inst[z].slot]; f.w[z] = inst[z].params + ar.w4; f.bias[z] = nullptr; f.out[z] = a->p1[inst[z].slot]; }
     if (uses_q) BDR_TRY(a->join_exchange(false, true));
@@ -908,9 +988,11 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         ConvReduceAdamArgs ra{};
         ra.r = r; ra.p = a->q; ra.g = a->grad; ra.m = a->m; ra.v = a->v; ra.gbase = a->grad;
         ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg; ra.poison = a->sig + SIG_ERR; ra.reduce_only = defer ? 1 : 0;
+        ra.cpl = a->conv_b3 && !defer ? a->cpl[0] : nullptr;
         Bracket br(a, "reduce_adam");
         hipLaunchKernelGGL(k_reduce_adam, dim3(wg), dim3(256), 0, a->stream, ra);
         BDR_HIP(hipGetLastError());
+        if (ra.cpl) a->cpl_fresh[0] = true;   // (a poisoned launch skips parameters and planes alike; on_gate_timeout marks them stale anyway)
     }
     return BDR_OK;
 }
@@ -920,6 +1002,7 @@ int32_t soft_update(DqnCnn* a)
     const size_t n4 = a->ar.total / 4;
     const float tau = (float)a->cfg.tau, omt = (float)(1.0 - a->cfg.tau);
     Bracket br(a, "track");
+    a->planes_stale(1);
     hipLaunchKernelGGL(k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q_tgt, a->q, n4, tau, omt);
     BDR_HIP(hipGetLastError());
     if (a->sig_epoch != 0 && a->split_fwd && !a->prof) {   // the other queue's next target forward must see the new target parameters
@@ -947,6 +1030,7 @@ int32_t after_updates(DqnCnn* a)
 int32_t adam_all(DqnCnn* a)
 {
     a->adam_step += 1;
+    a->planes_stale(0);
     Bracket br(a, "adam_all");
     const size_t n4 = a->ar.total / 4;
     if (a->amsgrad)
@@ -1135,6 +1219,7 @@ void DqnCnn::on_gate_timeout()
     if (aux) (void)hipStreamSynchronize(aux);
     if (comm_st) (void)hipStreamSynchronize(comm_st);
     xchg_pending_conv = xchg_pending_fc = false;
+    planes_stale(0); planes_stale(1);
     if (sig) (void)hipMemset(sig, 0, 16 * sizeof(unsigned));
     if (applied_step) {
         // Updates whose parameter-writing kernels ran while the poison word was up were skipped on the device: the host's step numbers go
@@ -1178,6 +1263,7 @@ int DqnCnn::exchange_plan(int which, ExchangeSeg* segs, int cap, hipStream_t* co
     if (comm_state != 1) return 0;
     segs[0] = ExchangeSeg{ar.w4, ar.total - ar.w4};
     segs[1] = ExchangeSeg{0, ar.w4};
+    planes_stale(which);   // the conv segment is about to be overwritten on the communication queue
     *comm = comm_st;
     xchg_epoch = sig_epoch;
     xchg_tracked = track_wait_pending && track_epoch == sig_epoch;   // this step ended with a soft update
@@ -1216,7 +1302,7 @@ DqnCnn::~DqnCnn()
     if (side) (void)hipStreamSynchronize(side);
     free_batch_buffers(this);
     (void)hipFree(q); (void)hipFree(q_tgt); (void)hipFree(grad); (void)hipFree(m); (void)hipFree(v); (void)hipFree(vmax);
-    (void)hipFree(loss);
+    (void)hipFree(loss); (void)hipFree(cpl[0]); (void)hipFree(cpl[1]);
     (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
     for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -1305,12 +1391,14 @@ int32_t DqnCnn::set_params(int which, const float* inp, uint64_t n)
     to_internal(ar, inp, in.data());
     BDR_HIP(hipMemcpyAsync(dst, in.data(), ar.total * 4, hipMemcpyHostToDevice, stream));
     BDR_HIP(hipStreamSynchronize(stream));
+    planes_stale(which);
     return BDR_OK;
 }
 
 float* DqnCnn::arena(int which, size_t* n)
 {
     (void)join_exchange(true, true);   // whoever asks for the arena is about to enqueue work on it behind this queue
+    planes_stale(which);               // ... possibly a write
     if (n) *n = ar.total;
     return arena_ptr(this, which);
 }
@@ -1369,6 +1457,8 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->kev = getenv("BDR_NO_KEV") == nullptr;
     a->side_gather = getenv("BDR_NO_SIDE_GATHER") == nullptr;
     a->split_fwd = getenv("BDR_NO_SPLIT_FWD") == nullptr;
+    a->conv_b3 = getenv("BDR_DQN_F32_EXACT") == nullptr;
+    if (a->conv_b3) for (auto& pl : a->cpl) BDR_HIP(hipMalloc((void**)&pl, CPL_U16 * 2));
     a->three_queues = getenv("BDR_TQ") != nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {

@@ -117,10 +117,13 @@ template <class P> struct b3_group_epi<P, std::enable_if_t<P::GROUP_EPI>> : std:
 
 template <class P, class = void> struct b3_maxw { static constexpr int value = 2; };
 template <class P> struct b3_maxw<P, std::void_t<decltype(P::MAXW)>> { static constexpr int value = P::MAXW; };
+template <class P, class = void> struct b3_minw { static constexpr int value = 1; };   // P::MINW (optional): waves per SIMD the registers must leave room for
+template <class P> struct b3_minw<P, std::void_t<decltype(P::MINW)>> { static constexpr int value = P::MINW; };
 template <class P, int TERMS = 9>
-__global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per_eu(1, b3_maxw<P>::value))) void k_igemm_b3(typename P::Args args)
+__global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per_eu(b3_minw<P>::value, b3_maxw<P>::value))) void k_igemm_b3(typename P::Args args)
 {
     using A = typename P::A;
+    if constexpr (has_start_signal<typename P::Args>::value) start_signal(args.sig_flag, args.sig_epoch);   // (igemm.hpp: cross-queue progress flag)
     static_assert(A::VEC == 4, "f32 A operands");
     static_assert(TERMS == 6 || TERMS == 9, "6 or 9 partial products");
     constexpr int NW = P::WM * P::WN, NT = 64 * NW;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
         int mr;
-        const bool ok = P::vrow(args, m0 + p * (NT / APR) + a_r, mr);
+        const bool ok = vrow_of<P>(args, y, m0 + p * (NT / APR) + a_r, mr);   // (position-class policies: the row map depends on blockIdx.y)
         rows[p] = A::row(P::a_src(args, z), ok ? mr : M, M);
     }
     int kt0, kt1;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int mv = m0 + (wm * P::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (P::vrow(args, mv, mrow[tm][r])) okmask[tm] |= 1u << r;
+            if (vrow_of<P>(args, y, mv, mrow[tm][r])) okmask[tm] |= 1u << r;
             else mrow[tm][r] = 0;
 #pragma unroll
             for (int tn = 0; tn < P::TN; ++tn)
@@ -377,10 +380,11 @@ __global__ __launch_bounds__(64 * P::WM * P::WN) __attribute__((amdgpu_waves_per
     }
 }
 
+// stop: event completed by this kernel's own dispatch packet (as launch_igemm)
 template <class P, int TERMS = 9>
-inline hipError_t launch_igemm_b3(hipStream_t st, dim3 grid, const typename P::Args& args)
+inline hipError_t launch_igemm_b3(hipStream_t st, dim3 grid, const typename P::Args& args, hipEvent_t stop = nullptr)
 {
-    hipLaunchKernelGGL((k_igemm_b3<P, TERMS>), grid, dim3(64 * P::WM * P::WN), 0, st, args);
+    hipExtLaunchKernelGGL((k_igemm_b3<P, TERMS>), grid, dim3(64 * P::WM * P::WN), 0, st, nullptr, stop, 0, args);
     return hipGetLastError();
 }
 

@@ -71,7 +71,7 @@ def test_fp32_gemm_sum_and_traffic_ratios_are_in_the_line(tmp_path, monkeypatch)
     prof = {k: 0.02 for k in fl}
     r = bench.roofline(conf, prof, {k: 1 for k in prof}, 0.0026, 0.221)
     g = r["fp32_gemm_sum"]
-    fp32 = [k for k in fl if k not in bench.BF16_KERNELS]
+    fp32 = [k for k in fl if k not in bench.BF16_ISSUE]
     assert g["kernels"] == sorted(fp32) and abs(g["rocprofv3_us"] - 20.0 * len(fp32)) < 1e-6 and g["same_kernel_sources"] is True
     assert abs(g["gflop"] - sum(fl[k] for k in fp32) / 1e9) < 1e-2 and abs(g["frac"] - g["gflop"] / (g["rocprofv3_us"] * 1e-3) / 157.3) < 1e-3
     t = r["traffic_vs_algorithmic"]

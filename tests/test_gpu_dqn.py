@@ -1046,3 +1046,55 @@ def test_a_deferred_report_is_told_apart_from_a_failure_of_the_call_itself(B):
     assert e.value.code == 1 and "action index" in str(e.value) and L.bdr_last_error_is_deferred() == 1
     a.sync()                                           # reported once, cleared
     a.close(); rb.close()
+
+
+@pytest.mark.gpu
+def test_split_operand_conv_planes_follow_every_parameter_writer(B, monkeypatch, tmp_path):
+    """conv2 / conv3 (forward and input gradients) run on the bf16 matrix cores from bf16 planes of W2 / W3 kept beside each parameter set
+    (csrc/dqn.hip: cpl, k_reduce_adam writes the online planes with the parameters; soft updates, set_params, load, the all-reduce
+    and a gate time-out leave a set stale and the next forward re-splits it).  A stale plane would be a whole Adam step / soft update
+    behind: at lr = 3e-3, tau = 0.5 that is tens of percent on the loss.  A twin agent on the exact FP32-MFMA kernels
+    (BDR_DQN_F32_EXACT=1) over the same ring and the same parameters must agree at every step within the split's own error class
+    (six of nine partial products: ~2e-6 per layer) plus Adam's amplification of it; and the acting kernels (exact f32, n <= 8)
+    must agree with the training forward (planes) on the same rows after the run."""
+    from oracle import torch_ref as T
+    cap, Bsz = 256, 32
+    p0 = T.init_params(T.cnn_shapes(6), 9)
+    kw = dict(batch_size=Bsz, lr=3e-3, critic_loss="SmoothL1", tau=0.5, soft_update_interval=3)
+    agents, bufs = [], []
+    for exact in (False, True):
+        if exact: monkeypatch.setenv("BDR_DQN_F32_EXACT", "1")
+        else: monkeypatch.delenv("BDR_DQN_F32_EXACT", raising=False)
+        a = make_agent(B, **kw)
+        a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (4, 1, 84, 84), np.uint8)
+        rb.fill_synthetic(cap, seed=3, kind=0, n_actions=6)
+        agents.append(a); bufs.append(rb)
+    monkeypatch.delenv("BDR_DQN_F32_EXACT", raising=False)
+    rng = np.random.default_rng(4)
+    obs = rng.integers(0, 256, (24, 4, 1, 84, 84), dtype=np.uint8)
+
+    def both(step):
+        recs = [a.opt_with_record(rb) for a, rb in zip(agents, bufs)]
+        assert abs(recs[0]["loss"] - recs[1]["loss"]) <= 2e-3 * abs(recs[1]["loss"]) + 1e-7, (step, recs[0]["loss"], recs[1]["loss"])
+
+    def acting_agrees(a):
+        q_train = a.qvalues(obs)                    # 24 rows: the training forward (planes of the online set)
+        q_act = a.qvalues(obs[:8])                  # 8 rows: the acting kernels (f32 weights)
+        assert np.abs(q_act - q_train[:8]).max() <= 1e-5 * np.abs(q_train).max()
+
+    for step in range(7): both(step)                # two soft updates inside
+    acting_agrees(agents[0])
+    # writers other than the update itself: set_params on both sets, a checkpoint load, the raw arena pointer
+    pq, pt = agents[1].get_params("qnet"), agents[1].get_params("qnet_tgt")
+    for a in agents: a.set_params(pt, "qnet"); a.set_params(pq, "qnet_tgt")
+    acting_agrees(agents[0])
+    for step in range(7, 10): both(step)
+    agents[1].save_params(str(tmp_path / "ck"))
+    for a in agents: a.load_params(str(tmp_path / "ck"))
+    acting_agrees(agents[0])
+    for step in range(10, 13): both(step)
+    agents[0].arena_device_ptr("qnet"); agents[0].arena_device_ptr("qnet_tgt")    # from here on: re-split before every forward
+    for step in range(13, 17): both(step)
+    acting_agrees(agents[0])
+    for a, rb in zip(agents, bufs): a.close(); rb.close()

@@ -144,8 +144,9 @@ def test_iqn_sample_eval_is_argmax_and_train_explores(B):
 def test_acting_kernels_agree_with_the_training_forward(B, A):
     """Acting-sized calls (n <= 8 rows) take their own kernels (csrc/act_small.hpp: 32 x 32 tiles x k-slices, the last workgroup of a
     tile adds the slices, l2 and the hand-over to the host by the workgroup that finishes l1); larger calls run the training forward.
-    The same rows through both: the same exact-f32 products added in a different order - 1e-6 relative at most, and the same greedy
-    action wherever the two leading Q-values are not within that distance of each other."""
+    The same rows through both: the acting kernels multiply in exact f32, the training forward's conv2 / conv3 on the bf16 matrix cores keep
+    six of the nine partial products of their split operands (~2e-6 per layer; BDR_DQN_F32_EXACT=1: exact, 1e-6 between the two) -
+    5e-6 relative at most, and the same greedy action wherever the two leading Q-values are not within that distance of each other."""
     rng = np.random.default_rng(A)
     from oracle import torch_ref as T
     a = _cnn_agent(B, A=A, train=False)
@@ -156,9 +157,9 @@ def test_acting_kernels_agree_with_the_training_forward(B, A):
         filler = rng.integers(0, 256, (24, 4, 1, 84, 84), dtype=np.uint8)
         q_train = a.qvalues(np.concatenate([obs, filler]))[:n]                       # the training forward (32 rows)
         scale = np.abs(q_train).max()
-        assert np.abs(q_act - q_train).max() <= 1e-6 * scale, (n, np.abs(q_act - q_train).max() / scale)
+        assert np.abs(q_act - q_train).max() <= 5e-6 * scale, (n, np.abs(q_act - q_train).max() / scale)
         top2 = np.sort(q_train, axis=1)[:, -2:]
-        clear = (top2[:, 1] - top2[:, 0]) > 4e-6 * scale
+        clear = (top2[:, 1] - top2[:, 0]) > 2e-5 * scale
         assert (q_act.argmax(1)[clear] == q_train.argmax(1)[clear]).all()
     # device-resident rows take the same kernels: same bits as host rows
     a.close()

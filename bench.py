@@ -45,6 +45,7 @@ PEAK_HBM_GBS = 8000.0
 # rocprofv3 kernel name (prefix) -> the profile label bench.py uses for that launch (tools/rocprof_summary.py --json and
 # tools/make_hbm_traffic.py build the committed evidence files with it; first match wins, so longer prefixes come first)
 KERNEL_LABELS = [("bdr::k_conv1_bf16", "fwd_conv1"), ("bdr::k_conv1_dw_bf16", "bwd_conv1_dw"), ("k_igemm<FwdPC2>", "fwd_conv2"), ("k_igemm<FwdPC3>", "fwd_conv3"),
+                 ("k_igemm_b3<FwdB3C2>", "fwd_conv2"), ("k_igemm_b3<FwdB3C3>", "fwd_conv3"),
                  ("k_igemm<FwdL1", "fwd_l1"), ("k_igemm<DxC2", "bwd_conv2_dx"), ("k_igemm<DxC3", "bwd_conv3_dx"), ("k_igemm<DxL1", "bwd_l1_dx"),
                  ("k_igemm_red<DwPC2>", "bwd_conv2_dw"), ("k_igemm_red<DwPC3>", "bwd_conv3_dw"), ("k_igemm_red<DwPL1>", "bwd_l1_dw"),
                  ("k_reduce_adam", "reduce_adam"), ("k_adam", "adam_l1_l2"), ("k_gather", "sample"), ("k_head_bwd", "head_bwd"), ("k_head<", "head_fwd_td")]

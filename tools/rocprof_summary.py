@@ -10,7 +10,7 @@ import sys
 
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
-    m = re.match(r"void bdr::(k_igemm(?:_red)?)<(.*)>\(", name)
+    m = re.match(r"void bdr::(k_igemm(?:_red|_b3)?)<(.*)>\(", name)
     if m:
         inner = m.group(2)
         pol = re.match(r"(\w+)", inner).group(1)
@@ -19,6 +19,8 @@ def short(name):
         if g:
             d = [int(x) for x in g.group(1).split(",")]
             extra = {(84, 84, 4): "C1", (20, 20, 32): "C2", (9, 9, 64): "C3", (1, 1, 3136): "L1"}.get(tuple(d[:3]), "")
+        if m.group(1) == "k_igemm_b3" and not g:   # dense policies (IQN): keep the full name
+            return re.sub(r"\(.*", "", name).replace("void ", "")
         return f"{m.group(1)}<{pol}{extra}>"
     return re.sub(r"\(.*", "", name).replace("void ", "")
 

@@ -34,6 +34,7 @@ using namespace bdr;
 
 namespace bdr {
 float* agent_arena(bdr_agent* a, int which, size_t* n_floats, hipStream_t* stream, int* device);   // agent_api.hip
+bool default_buffer_device(const bdr_trainer_ops* t, int* device);                                  // trainer.hip
 }
 
 // ---- device-resident SyncModel::ModelInfo mailbox --------------------------------------------------------------------------
@@ -354,6 +355,15 @@ int32_t bdr_async_train(const bdr_async_trainer_config* c, const bdr_learner_ops
     for (uint32_t i = 0; i < n_actors; ++i)
         BDR_REQUIRE(actors[i].agent_set_train && actors[i].agent_sample && actors[i].sync_model && actors[i].env.reset && actors[i].env.step_with_reset &&
                     (!actors[i].env.obs_on_device || actors[i].agent_sample_device), "actor %u: function table is incomplete", i);
+    // device-resident observations are pushed without leaving HBM (bdr_replay_push_device): the rows must live on the learner ring's GPU.
+    // Checked here, not at the first message of a run that has already started its actors.
+    int ring_dev = -1;
+    if (default_buffer_device(&L->t, &ring_dev))
+        for (uint32_t i = 0; i < n_actors; ++i)
+            BDR_REQUIRE(!actors[i].env.obs_on_device || actors[i].env.device == ring_dev,
+                        "actor %u keeps its observations on GPU %d, the learner's replay buffer lives on GPU %d: device-resident rows are pushed without a "
+                        "host copy and must be on the buffer's GPU (run this actor's environment on GPU %d, or with obs_on_device = 0)", i,
+                        (int)actors[i].env.device, ring_dev, ring_dev);
     Shared sh;
     sh.c = c; sh.ch.cap = c->channel_capacity; sh.observer = observer; sh.observer_ctx = observer_ctx;
     if (actor_stats) memset(actor_stats, 0, sizeof(bdr_actor_stat) * n_actors);
@@ -510,21 +520,13 @@ int32_t d_sample_dev(void* a, uint64_t n, const void* obs_dev, uint64_t stride, 
     if (ag && !strcmp(ag->kind(), "sac")) return bdr_sac_sample_device(ag, n, obs_dev, stride, (float*)act);
     return bdr_agent_sample_device(ag, n, obs_dev, stride, (int64_t*)act, nullptr);
 }
-int32_t d_push_dev(void* b, uint64_t n, const void* obs_dev, uint64_t os, const void* act, const void* next_dev, uint64_t ns, const float* rew,
-                   const int8_t* term, const int8_t* trunc)
-{
-    return bdr_replay_push_device((bdr_replay*)b, n, obs_dev, os, act, next_dev, ns, rew, term, trunc);
-}
 }  // namespace
 
 void bdr_learner_ops_default(bdr_learner_ops* ops, bdr_agent* agent, bdr_replay* buffer, bdr_model_mailbox* mailbox)
 {
     if (!ops) return;
     memset(ops, 0, sizeof *ops);
-    ops->t.agent = agent; ops->t.buffer = buffer;
-    ops->t.agent_set_train = d_set_train; ops->t.agent_sample = d_sample; ops->t.agent_opt = d_opt; ops->t.agent_opt_with_record = d_opt_rec;
-    ops->t.buffer_push = d_push;
-    ops->t.agent_sample_device = d_sample_dev; ops->t.buffer_push_device = d_push_dev;
+    bdr_trainer_ops_default(&ops->t, agent, buffer);   // the Trainer's table (trainer.hip): the same wrappers, and how bdr_async_train knows the ring is the library's own
     ops->buffer_len = d_len; ops->publish_model = d_publish; ops->mailbox = mailbox;
 }
 

@@ -109,6 +109,16 @@ int32_t d_push_dev(void* b, uint64_t n, const void* obs_dev, uint64_t os, const 
 }
 }  // namespace
 
+namespace bdr {
+// the GPU of the library's own ring behind a function table (bdr_trainer_ops_default); false: the caller's own buffer object
+bool default_buffer_device(const bdr_trainer_ops* t, int* device)
+{
+    if (!t || !t->buffer || t->buffer_push_device != d_push_dev) return false;
+    *device = ((const bdr_replay*)t->buffer)->device;
+    return true;
+}
+}  // namespace bdr
+
 extern "C" {
 
 void bdr_trainer_config_default(bdr_trainer_config* c)   // trainer/config.rs:68-87 (intervals the loops use; 0 = never)

@@ -240,3 +240,23 @@ def test_async_trainer_with_device_resident_actors_moves_the_same_transitions(B)
         assert m >= 10
         for x, y in zip(rows[False][actor], rows[True][actor]):
             assert (x[:m] == y[:m]).all()
+
+
+def test_async_trainer_refuses_device_rows_of_another_gpu_before_it_starts(B):
+    """An actor whose device-resident observations live on another GPU than the learner's ring cannot push them without a host copy
+    (bdr_replay_push_device): bdr_async_train says so before any actor thread starts, not at the first message of a running job."""
+    from border_amd._lib import BdrError
+    envs = [B.AtariDeviceEnv(_Emulator(20 + i, p_term=0.1), device_obs=True) for i in range(2)]
+    envs[1].device = 1        # what the actor's function table will carry; the check comes before any use of that GPU
+    rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=100, seed=7), (4, 1, 84, 84), np.uint8)
+    learner = _cnn(B, train=True)
+    actors = [_cnn(B, train=True) for _ in range(2)]
+    tr = B.AsyncTrainer(B.AsyncTrainerConfig(max_opts=2, warmup_period=10, sync_interval=1000, record_agent_info_interval=0, record_compute_cost_interval=0,
+                                             warmup_sleep_ms=1), B.ActorManagerConfig(n_buffer=5))
+    pushed = []
+    with pytest.raises(BdrError, match="actor 1 keeps its observations on GPU 1"):
+        tr.train(learner, rb, actors, envs, (4, 1, 84, 84), np.uint8, on_event=lambda actor, a, b, ev, v: pushed.append(v) if ev == "push" else None)
+    assert not pushed and len(rb) == 0 and learner.n_opts == 0
+    for ag in actors: ag.close()
+    learner.close(); rb.close()
+    for e in envs: e.close()

@@ -245,12 +245,13 @@ def build_config(B, name, args, rank, local_rank):
 # ------------------------------------------------------------------------------------------------ profile -> roofline
 def kernel_source_hash():
     """sha256 (16 hex) over the kernel sources the library is built from (border_amd/csrc/*.hip, *.hpp + include/border_amd.h): what ties a
-    committed measurement (profiles/hbm_traffic.json, profiles/kernel_trace_*.json) to the binary that is running."""
+    committed measurement (profiles/hbm_traffic.json, profiles/kernel_trace_*.json) to the binary that is running.  The two files that
+    hold host code only (the compiled Trainer / AsyncTrainer loops: no kernel, no launch) are left out."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "border_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith((".hip", ".hpp")) and f not in ("trainer.hip", "async_trainer.hip"):
             h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "border_amd.h"), "rb").read())
     return h.hexdigest()[:16]

@@ -450,8 +450,13 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
     P::kt_range(args, y, kt0, kt1);
     // team g owns k-tiles kt0+g, kt0+g+TEAMS, ...; both teams run the same number of iterations so the
     // workgroup barriers match (the shorter team idles through its last one)
-    const int iters = (kt1 - kt0 + TEAMS - 1) / TEAMS;
-    const int my_n = kt0 + team < kt1 ? (kt1 - kt0 - team + TEAMS - 1) / TEAMS : 0;
+#ifdef BDR_IGEMM_ABL   // (tools/probes/dx_abl.hip) bit 0: no k loop, bit 1: no stores, bit 2: no epilogue operand loads
+    constexpr int ABL = BDR_IGEMM_ABL;
+#else
+    constexpr int ABL = 0;
+#endif
+    const int iters = (ABL & 1) ? 0 : (kt1 - kt0 + TEAMS - 1) / TEAMS;
+    const int my_n = (ABL & 1) ? 0 : (kt0 + team < kt1 ? (kt1 - kt0 - team + TEAMS - 1) / TEAMS : 0);
     auto tile = [&](int it) { return kt0 + team + min(it, max(my_n - 1, 0)) * TEAMS; };   // clamped to my last tile
 
     // Two register sets: global loads are issued ~2 k-tiles before they are committed to LDS (one k-tile
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
             else mrow[tm][r] = 0;
 #pragma unroll
             for (int tn = 0; tn < P::TN; ++tn)
-                aux[tm][tn][r] = P::epi_load(epi, mrow[tm][r], n0 + (wn * P::TN + tn) * 32 + j);
+                aux[tm][tn][r] = (ABL & 4) ? 1.f : P::epi_load(epi, mrow[tm][r], n0 + (wn * P::TN + tn) * 32 + j);
         }
     }
     __syncthreads();
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(64 * P::WM * P::WN * TEAMS) void k_igemm(typename P
             for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(aux[tm][tn][r]));
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (okmask[tm] >> r & 1) P::store(epi, mrow[tm][r], n, acc[tm][tn][r], aux[tm][tn][r]);
+                if ((okmask[tm] >> r & 1) && !((ABL & 2) && acc[tm][tn][r] != 12345.f)) P::store(epi, mrow[tm][r], n, acc[tm][tn][r], aux[tm][tn][r]);
         }
 }
 

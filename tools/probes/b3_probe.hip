@@ -42,6 +42,19 @@ struct DxC3B3 : DxC3P<WM_, WN_> {
     }
 };
 
+template <int WM_, int WN_, int TM_, int TN_>
+struct DxC2MB3 : DxC2MP<WM_, WN_, TM_, TN_> {
+    using Base = DxC2MP<WM_, WN_, TM_, TN_>;
+    using Args = DxB3Args;
+    using G = GeomC2;
+    __device__ static const uint4* b_chunk(const Args& a, int, int y, int pl, int kt, int n, int kq)
+    {
+        constexpr int TPT = G::COUT / BK;
+        const int tap = kt / TPT, c0 = (kt % TPT) * BK;
+        return reinterpret_cast<const uint4*>(a.wpl + (size_t)pl * G::K * G::COUT + ((size_t)Base::b_row(y, tap, n) * G::COUT + c0 + kq * 8));
+    }
+};
+
 template <class F>
 static double time_us(F f)
 {
@@ -128,6 +141,33 @@ int main()
         compare("9 terms vs f32", dx2b, dx2, n2);
         printf("dx_c3   3xbf16, 6 terms   : %7.2f us\n", time_us([&] { CK((launch_igemm_b3<P9, 6>(0, g, d3b))); }));
         compare("6 terms vs f32", dx2b, dx2, n2);
+    }
+    {   // conv2 input gradient over merged parity classes: [B*100][256] x [256][128]
+        float* dy2 = dev_rand(n2, -1.f, 1.f, 8);
+        const size_t n1 = (size_t)B * 400 * 32;
+        float* mask1 = dev_rand(n1, -1.f, 1.f, 9);
+        float *dx1, *dx1b; CK(hipMalloc(&dx1, n1 * 4)); CK(hipMalloc(&dx1b, n1 * 4));
+        uint16_t* w2p; CK(hipMalloc(&w2p, 3 * 512 * 64 * 2));
+        hipLaunchKernelGGL(k_split_planes, dim3((512 * 64 + 255) / 256), dim3(256), 0, 0, w2, w2p, 512, 64, 0);
+        DxB3Args d2{}; d2.dy = dy2; d2.w = w2; d2.mask = mask1; d2.out = dx1; d2.M = B * 100; d2.wpl = w2p;
+        DxB3Args d2b = d2; d2b.out = dx1b;
+        using PF = DxC2MP<2, 2, 1, 2>;
+        printf("dx_c2m  f32 MFMA 64x128   : %7.2f us\n", time_us([&] { CK((launch_igemm<PF, 1>(0, dim3(m_tiles<PF>(d2.M) * n_tiles<PF>(), 1, 1), (const DxArgs&)d2))); }));
+        using P1 = DxC2MB3<2, 2, 1, 2>;
+        printf("dx_c2m  3xbf16 6t 64x128  : %7.2f us\n", time_us([&] { CK((launch_igemm_b3<P1, 6>(0, dim3(m_tiles<P1>(d2.M) * n_tiles<P1>(), 1, 1), d2b))); }));
+        compare("6 terms vs f32", dx1b, dx1, n1);
+        using P2 = DxC2MB3<2, 2, 1, 1>;
+        printf("dx_c2m  3xbf16 6t 64x64   : %7.2f us\n", time_us([&] { CK((launch_igemm_b3<P2, 6>(0, dim3(m_tiles<P2>(d2.M) * n_tiles<P2>(), 1, 1), d2b))); }));
+        compare("6 terms vs f32", dx1b, dx1, n1);
+        using P3 = DxC2MB3<4, 1, 1, 1>;
+        printf("dx_c2m  3xbf16 6t 128x32  : %7.2f us\n", time_us([&] { CK((launch_igemm_b3<P3, 6>(0, dim3(m_tiles<P3>(d2.M) * n_tiles<P3>(), 1, 1), d2b))); }));
+        compare("6 terms vs f32", dx1b, dx1, n1);
+        using P4 = DxC2MB3<2, 2, 2, 1>;
+        printf("dx_c2m  3xbf16 6t 128x64  : %7.2f us\n", time_us([&] { CK((launch_igemm_b3<P4, 6>(0, dim3(m_tiles<P4>(d2.M) * n_tiles<P4>(), 1, 1), d2b))); }));
+        compare("6 terms vs f32", dx1b, dx1, n1);
+        using P5 = DxC2MB3<1, 4, 1, 1>;
+        printf("dx_c2m  3xbf16 6t 32x128  : %7.2f us\n", time_us([&] { CK((launch_igemm_b3<P5, 6>(0, dim3(m_tiles<P5>(d2.M) * n_tiles<P5>(), 1, 1), d2b))); }));
+        compare("6 terms vs f32", dx1b, dx1, n1);
     }
     return 0;
 }

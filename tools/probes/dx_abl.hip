@@ -51,5 +51,13 @@ int main()
     printf("  conv2 dX merged classes, 64 x 128 tiles, 400 workgroups : %7.2f us\n", time_us([&] { CK((launch_igemm<DxC2M, 1>(0, dim3(m_tiles<DxC2M>(d2.M) * n_tiles<DxC2M>(), 1, 1), d2))); }));
     printf("  conv3 dX position classes, 2 teams                      : %7.2f us\n",
            time_us([&] { CK((launch_igemm<DxC3Pos, 2>(0, dim3(((B + DxC3Pos::WM * DxC3Pos::TM * 32 - 1) / (DxC3Pos::WM * DxC3Pos::TM * 32)) * n_tiles<DxC3Pos>(), 81, 1), d3))); }));
+    // one workgroup per CU for the position-class kernel: extra dynamic LDS so that a second workgroup does not fit beside the first (the
+    // 68 workgroups behind the first 256 then start where a SHORT workgroup has finished, not beside an interior position's 9 iterations)
+    for (unsigned extra : {0u, 8u << 10, 16u << 10, 24u << 10}) {
+        const dim3 g(((B + DxC3Pos::WM * DxC3Pos::TM * 32 - 1) / (DxC3Pos::WM * DxC3Pos::TM * 32)) * n_tiles<DxC3Pos>(), 81, 1);
+        printf("  conv3 dX position classes, 2 teams, +%2u KB dynamic LDS   : %7.2f us\n", extra >> 10, time_us([&] {
+            hipExtLaunchKernelGGL((k_igemm<DxC3Pos, 2>), g, dim3(64 * DxC3Pos::WM * DxC3Pos::WN * 2), extra, 0, nullptr, nullptr, 0, d3);
+            CK(hipGetLastError()); }));
+    }
     return 0;
 }

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "dense.hpp"
+#include "dense_chain.hpp"
 #include "queue_flags.hpp"
 
 using namespace bdr;
@@ -334,6 +335,7 @@ struct Sac : bdr_agent, SacBatch {
     StepGraph graph; StepGraphPolicy graph_policy;   // step_graph.hpp
     bool gather_in_pack = true;               // BDR_NO_STEP_GATHER=1: separate gather launch
     bool fuse_rows = true;                    // BDR_NO_SAC_FUSE=1: the narrow layers as launches of their own (sac_fused.hpp)
+    bool chain2 = true; int chain2_tpw = 0;   // BDR_NO_SAC_CHAIN=1: a two-layer trunk as two launches (dense_chain.hpp); BDR_SAC_CHAIN_TPW=1|4: tile form
     unsigned* tickets = nullptr;              // [2] last-workgroup tickets of k_sac_q_last / k_sac_td_last
     float* lrow = nullptr;                    // [3 + NC][ceil(B / 32)] block partials of the batch-wide sums (k_sac_q_last, k_sac_td_last)
     bool small_gemm = true;                   // BDR_NO_SMALL_GEMM=1: the 64x64-tile kernels of the large-batch agents
@@ -483,6 +485,12 @@ struct Sac : bdr_agent, SacBatch {
         if (fused()) {   // trunk layer by layer, then heads + action + log-prob in one row-block kernel
             bdr_agent* a = this;
             DenseSrc in{x, pi.L[0].Kp};
+            if (chain2 && n_trunk == 2 && dense_chain2_ok(pi.L[0], pi.L[1])) {   // both trunk layers in one launch, same bits (dense_chain.hpp)
+                Bracket br(a, "pi_fwd");
+                const float* pb[1] = {pi_p}; float* h0[1] = {t_act[0]}; float* h1[1] = {t_act[1]};
+                BDR_TRY(dense_chain2_z(st, pi.L[0], pi.L[1], 1, pb, &in, h0, h1, Bn, chain2_tpw, sig_flag, sig_epoch));
+                in = DenseSrc{t_act[1], pi.L[1].Np};
+            } else
             for (int i = 0; i < n_trunk; ++i) {
                 Bracket br(a, "pi_fwd");
                 BDR_TRY(dense_forward(a, st, pi.L[i], pi_p, in, t_act[i], Bn, small_gemm, i == 0 ? sig_flag : nullptr, sig_epoch));
@@ -519,6 +527,13 @@ struct Sac : bdr_agent, SacBatch {
             const int nz = std::min(4, n - j0);
             DenseSrc in[4]; float* out[4];
             for (int j = 0; j < nz; ++j) in[j] = DenseSrc{x[j0 + j], qn.L[0].Kp};
+            if (chain2 && small_gemm && nl == 2 && dense_chain2_ok(qn.L[0], qn.L[1])) {   // the two wide layers in one launch, same bits (dense_chain.hpp)
+                float* h0[4]; float* h1[4];
+                for (int j = 0; j < nz; ++j) { h0[j] = (*acts[j0 + j])[0]; h1[j] = (*acts[j0 + j])[1]; }
+                Bracket br(a, "q_fwd");
+                BDR_TRY(dense_chain2_z(stream, qn.L[0], qn.L[1], nz, params + j0, in, h0, h1, Bn, chain2_tpw));
+                continue;
+            }
             for (size_t l = 0; l < nl; ++l) {
                 for (int j = 0; j < nz; ++j) out[j] = (*acts[j0 + j])[l];
                 Bracket br(a, "q_fwd");
@@ -1008,6 +1023,8 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     { const char* e = getenv("BDR_NO_SMALL_GEMM"); a->small_gemm = !(e && e[0] == '1'); }
     a->gather_in_pack = getenv("BDR_NO_STEP_GATHER") == nullptr;
     a->fuse_rows = getenv("BDR_NO_SAC_FUSE") == nullptr;
+    a->chain2 = getenv("BDR_NO_SAC_CHAIN") == nullptr;
+    { const char* e = getenv("BDR_SAC_CHAIN_TPW"); a->chain2_tpw = e ? atoi(e) : 0; }
     BDR_HIP(hipMalloc((void**)&a->tickets, 2 * sizeof(unsigned))); BDR_HIP(hipMemsetAsync(a->tickets, 0, 2 * sizeof(unsigned), a->stream));
     BDR_HIP(hipMalloc((void**)&a->applied, 3 * sizeof(unsigned long long))); BDR_HIP(hipMemsetAsync(a->applied, 0, 3 * sizeof(unsigned long long), a->stream));
     {

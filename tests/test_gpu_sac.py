@@ -173,6 +173,42 @@ def test_sac_row_block_kernels_equal_the_layer_by_layer_path(B, monkeypatch, od,
         assert (f[k] == u[k]).all(), (k, np.abs(f[k].astype(np.float64) - u[k]).max())
 
 
+@pytest.mark.parametrize("od,ad,pu,qu,nc,Bsz,ent", [
+    (17, 6, [256, 256], [256, 256], 2, 1024, ("Auto", -6.0, 3e-4)),   # BASELINE config 5 (64 -> 256 -> 256)
+    (17, 6, [256, 256], [256, 256], 2, 1000, ("Auto", -6.0, 3e-4)),   # a last row block of 8 rows
+    (11, 3, [256, 40], [256, 136], 3, 72, ("Auto", -3.0, 1e-3)),      # second layers of 64 / 192 (padded) columns: one tile per workgroup only; three critics (4 + 2 passes, then 3)
+    (40, 6, [256, 64], [256, 128], 1, 96, ("Fix", 0.2)),               # one critic (2 passes, then 1), a 128-wide second layer
+])
+def test_sac_two_layer_chain_kernel_equals_two_launches(B, monkeypatch, od, ad, pu, qu, nc, Bsz, ent):
+    """dense_chain.hpp: the two wide layers of the actor's trunk and of every critic pass run in ONE launch (32 rows per workgroup, the
+    first layer's output kept in LDS).  Its tiles use the k-slices, MFMA order and four-way sum of the layer-by-layer kernel, in both of
+    its forms (a wave per tile / a wave per k-slice): three updates, every parameter, gradient, moment, probe and loss bit for bit equal
+    to BDR_NO_SAC_CHAIN=1."""
+    from oracle import torch_ref as T
+    pi0 = T.init_params(T.sac_pi_shapes(od, pu, ad), 31) * np.float32(0.5)
+    q0 = [T.init_params(T.sac_q_shapes(od, ad, qu), 40 + i) for i in range(nc)]
+    kw = dict(lr_actor=1e-3, lr_critic=2e-3, ent_coef=ent, critic_loss="Mse")
+    outs = []
+    for mode in ("off", "auto", "1", "4"):
+        monkeypatch.delenv("BDR_NO_SAC_CHAIN", raising=False); monkeypatch.delenv("BDR_SAC_CHAIN_TPW", raising=False)
+        if mode == "off": monkeypatch.setenv("BDR_NO_SAC_CHAIN", "1")
+        elif mode != "auto": monkeypatch.setenv("BDR_SAC_CHAIN_TPW", mode)
+        a = _agent(B, od, ad, pu, qu, nc, Bsz, kw, pi0, q0)
+        recs = [a.update_on_batch(*T.sac_batch(Bsz, od, ad, 900 + s)) for s in range(3)]
+        names = ["pi", "log_alpha"] + [f"qnet_{i}" for i in range(nc)] + [f"qnet_tgt_{i}" for i in range(nc)]
+        out = {n: a.get_params(n) for n in names}
+        out.update({n + "/grad": a.get_params(n, "grad") for n in names if n != "log_alpha" and not n.startswith("qnet_tgt")})
+        out.update({n + "/exp_avg_sq": a.get_params(n, "exp_avg_sq") for n in ("pi", "qnet_0")})
+        out.update({k: a.probe(k, Bsz) for k in ("q_pred", "q_next", "qvals_min", "next_log_p", "tgt", "q_pi", "log_p", "next_act")})
+        outs.append((mode, out, recs))
+        a.close()
+    _, ref, rrec = outs[0]
+    for mode, out, recs in outs[1:]:
+        assert recs == rrec, (mode, recs, rrec)
+        for k in ref:
+            assert (out[k] == ref[k]).all(), (mode, k, np.abs(out[k].astype(np.float64) - ref[k]).max())
+
+
 def test_sac_opt_over_replay_and_sample(B, tmp_path):
     """Agent::opt over the HBM ring with device-generated noise: finite losses, counters, checkpoint round trip,
     Policy::sample in eval mode == tanh(mean) of the oracle actor."""

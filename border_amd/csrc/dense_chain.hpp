@@ -224,7 +224,8 @@ inline int32_t dense_chain2_z(hipStream_t st, const DenseLayer& l0, const DenseL
     c.sig_flag = sig_flag; c.sig_epoch = sig_epoch;
     const int rb = (M + 31) / 32;
     const bool can4 = l1.Np % 128 == 0;
-    const bool four = tpw == 4 ? can4 : tpw == 1 ? false : (can4 && rb * (l1.Np / 128) * nz >= 192);
+    static const int min4 = [] { const char* e = getenv("BDR_CHAIN_MIN4"); return e ? atoi(e) : 192; }();   // (tuning switch)
+    const bool four = tpw == 4 ? can4 : tpw == 1 ? false : (can4 && rb * (l1.Np / 128) * nz >= min4);
     const bool narrow = l0.in <= 32;   // input columns in the first two k-slices only
     const dim3 g4(rb * (l1.Np / 128), 1, nz), g1(rb * (l1.Np / 32), 1, nz);
     if (four) BDR_HIP(narrow ? step_launch(st, false, k_dense_chain2<4, 2>, g4, dim3(256), c) : step_launch(st, false, k_dense_chain2<4, 4>, g4, dim3(256), c));

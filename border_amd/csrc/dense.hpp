@@ -419,12 +419,10 @@ __device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_wg, 
 
 struct HeadRef { const float* w; const float* bias; int relu; };   // a narrow layer handed to a row-block kernel
 
+// (the body as a function: sac.hip's k_dense_small_dx_tail runs it beside one more workgroup)
 template <bool DX>
-__global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
+__device__ __forceinline__ void dense_small_body(const DenseArgs& a, float (*red)[32][33])
 {
-    start_signal(dz.sig_flag, dz.sig_epoch);
-    const DenseArgs& a = dz.a[blockIdx.z];
-    __shared__ float red[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = a.ncols / 32;
     const int m0 = ((int)blockIdx.x / NT) * 32, n0 = ((int)blockIdx.x % NT) * 32;
@@ -457,6 +455,13 @@ __global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
         if (a.accum) v += e1;
     }
     *reinterpret_cast<f32x4*>(o) = v;
+}
+template <bool DX>
+__global__ __launch_bounds__(256) void k_dense_small(DenseArgsZ dz)
+{
+    start_signal(dz.sig_flag, dz.sig_epoch);
+    __shared__ float red[4][32][33];
+    dense_small_body<DX>(dz.a[blockIdx.z], red);
 }
 template <bool DX>
 inline hipError_t launch_dense_small(hipStream_t st, const DenseArgsZ& dz, int nz)

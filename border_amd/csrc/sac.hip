@@ -335,6 +335,7 @@ struct Sac : bdr_agent, SacBatch {
     StepGraph graph; StepGraphPolicy graph_policy;   // step_graph.hpp
     bool gather_in_pack = true;               // BDR_NO_STEP_GATHER=1: separate gather launch
     bool fuse_rows = true;                    // BDR_NO_SAC_FUSE=1: the narrow layers as launches of their own (sac_fused.hpp)
+    bool tail_next = true;                    // BDR_SAC_TAIL_IN_KERNEL=1: the row-block kernels' batch-wide parts by their own last workgroup (ticket) instead of in the next launch
     bool chain2 = true; int chain2_tpw = 0;   // BDR_NO_SAC_CHAIN=1: a two-layer trunk as two launches (dense_chain.hpp); BDR_SAC_CHAIN_TPW=1|4: tile form
     unsigned* tickets = nullptr;              // [2] last-workgroup tickets of k_sac_q_last / k_sac_td_last
     float* lrow = nullptr;                    // [3 + NC][ceil(B / 32)] block partials of the batch-wide sums (k_sac_q_last, k_sac_td_last)
@@ -545,11 +546,23 @@ struct Sac : bdr_agent, SacBatch {
         return BDR_OK;
     }
     // dX of layer l for all critics in one launch: c_dy[i][l] -> (l == 0 ? dxq[i] : c_dy[i][l-1]), ReLU mask from `acts`
-    int32_t critic_dx_all(int l, int Bn, std::vector<float*>* acts)
+    // tail: the batch-wide part of the row-block kernel in front of this launch rides in it as one more workgroup (sac_fused.hpp k_dense_small_dx_tail)
+    int32_t critic_dx_all(int l, int Bn, std::vector<float*>* acts, const SacTailArgs* tail = nullptr, bool tail_varying = false)
     {
         const float* pb[4]; const float* dy[4]; float* dx[4]; const float* mask[4];
         for (int i = 0; i < NC; ++i) {
             pb[i] = q_p[i]; dy[i] = c_dy[i][l]; dx[i] = l == 0 ? dxq[i] : c_dy[i][l - 1]; mask[i] = l == 0 ? nullptr : acts[i][l - 1];
+        }
+        if (tail) {   // (small_gemm; the arguments of dense_dx_z)
+            const DenseLayer& ly = qn.L[l];
+            DenseArgsZ dz{};
+            for (int z = 0; z < NC; ++z) {
+                DenseArgs& d = dz.a[z];
+                d.x = DenseSrc{dy[z], ly.Np}; d.w = pb[z] + ly.w; d.out = dx[z]; d.ldo = ly.Kp; d.mask = mask[z]; d.ldm = ly.Kp;
+                d.M = Bn; d.ncols = ly.Kp; d.kred = ly.Np; d.w_ld = ly.Np;
+            }
+            BDR_HIP(step_launch(stream, tail_varying, k_dense_small_dx_tail, dim3(((Bn + 31) / 32) * (ly.Kp / 32) + 1, 1, NC), dim3(256), dz, *tail));
+            return BDR_OK;
         }
         if (NC == 1) return dense_dx(stream, qn.L[l], pb[0], dy[0], dx[0], mask[0], Bn, false, small_gemm);
         return dense_dx_z(stream, qn.L[l], NC, pb, dy, dx, l == 0 ? nullptr : mask, Bn, small_gemm);
@@ -618,6 +631,9 @@ struct Sac : bdr_agent, SacBatch {
         bdr_agent* a = this;
         const int L = (int)qn.L.size(), ldq = qn.L[L - 1].Np, Ap = pi.L[n_trunk].Np, Kq = qn.L[0].Kp;
         const bool fz = fused();
+        // the batch-wide parts of k_sac_q_last / k_sac_td_last ride in the launch behind them (needs one: a critic of three layers or more)
+        const bool tail_defer = fz && tail_next && L - 2 >= 1 && std::max(3, NC) * ((Bn + 31) / 32) <= SAC_TAIL_LDS;
+        SacTailArgs sel_tail{}, td_tail{};
         {   // Q_i(obs, a_pi) for the actor loss and Q_i(obs, act) for the TD loss: the same parameters (the critics only step at the end)
             const float* params[8]; const float* x[8]; std::vector<float*>* acts[8];
             for (int i = 0; i < NC; ++i) { params[i] = q_p[i]; x[i] = xq_a; acts[i] = &c_act[i]; params[NC + i] = q_p[i]; x[NC + i] = xq_c; acts[NC + i] = &c2_act[i]; }
@@ -641,6 +657,13 @@ struct Sac : bdr_agent, SacBatch {
                 p.target = (float)cfg.target_entropy; p.log_alpha_rw = log_alpha; p.al_m = al_m; p.al_v = al_v; p.poison = dev_err + ERR_GATE;
                 p.applied = applied + AP_AL; p.step = step_al;
                 p.s = adam_scalars_for(false, cfg.ent_coef_lr, 0, 0, 0, 0, step_al);
+            }
+            p.tail_here = tail_defer ? 0 : 1;
+            if (tail_defer) {   // EntCoef::update + the actor loss: one more workgroup of the layer-(L-2) input-gradient launch below (the next reader of log_alpha is k_sac_actor_bwd)
+                sel_tail.kind = 1; sel_tail.part = lrow; sel_tail.nb = (Bn + 31) / 32; sel_tail.NC = NC; sel_tail.B = Bn;
+                sel_tail.log_alpha = log_alpha; sel_tail.out = p.out; sel_tail.scale = p.scale; sel_tail.accumulate = p.accumulate;
+                sel_tail.auto_alpha = p.auto_alpha; sel_tail.log_alpha_rw = p.log_alpha_rw; sel_tail.al_m = p.al_m; sel_tail.al_v = p.al_v; sel_tail.s = p.s;
+                sel_tail.poison = p.poison; sel_tail.applied = p.applied; sel_tail.step = p.step;
             }
             Bracket br(a, "sac_q_last");
             BDR_HIP(step_launch(stream, cfg.ent_coef_auto != 0, k_sac_q_last, dim3((Bn + 31) / 32, ll.Kp / 64 + 1), dim3(512), p));
@@ -670,7 +693,7 @@ struct Sac : bdr_agent, SacBatch {
         }
         for (int l = fz ? L - 2 : L - 1; l >= (fz ? 1 : 0); --l) {   // d qmin / d input through the critics (weights untouched here)
             Bracket br(a, "q_dx");
-            BDR_TRY(critic_dx_all(l, Bn, c_act));
+            BDR_TRY(critic_dx_all(l, Bn, c_act, tail_defer && l == L - 2 ? &sel_tail : nullptr, cfg.ent_coef_auto != 0));
         }
         if (fz) {   // d qmin / d a (first layer, action columns) + tanh-Gaussian backward + both heads' input gradient
             const DenseLayer &l0 = qn.L[0], &hm = pi.L[n_trunk], &hs = pi.L[n_trunk + 1];
@@ -738,6 +761,11 @@ struct Sac : bdr_agent, SacBatch {
             p.logp = logp; p.log_alpha = log_alpha; p.reward = reward; p.term = term; p.gamma = (float)cfg.gamma; p.reward_scale = (float)cfg.reward_scale;
             p.tgt = tgt; p.part = lrow + (size_t)3 * ((Bn + 31) / 32); p.B = Bn; p.loss_kind = cfg.critic_loss;
             p.ticket = tickets + 1; p.out = scal; p.scale = 1.0f / ((float)Bn * (float)NC); p.accumulate = first ? 0 : 1;
+            p.tail_here = tail_defer ? 0 : 1;
+            if (tail_defer) {   // the critics' loss sums (recorded only): one more workgroup of the launch below
+                td_tail.kind = 2; td_tail.part = p.part; td_tail.nb = (Bn + 31) / 32; td_tail.NC = NC; td_tail.B = Bn;
+                td_tail.out = p.out; td_tail.scale = p.scale; td_tail.accumulate = p.accumulate;
+            }
             Bracket br(a, "sac_td_last");
             BDR_HIP(step_launch(stream, false, k_sac_td_last, dim3((Bn + 31) / 32, ll.Kp / 64), dim3(512), p));
         } else {
@@ -750,7 +778,7 @@ struct Sac : bdr_agent, SacBatch {
             Bracket br(a, "critic_td");
             BDR_HIP(step_launch(stream, false, k_sac_critic_td, dim3(1), dim3(1024), p));
         }
-        for (int l = fz ? L - 2 : L - 1; l > 0; --l) { Bracket br(a, "q_dx"); BDR_TRY(critic_dx_all(l, Bn, c2_act)); }
+        for (int l = fz ? L - 2 : L - 1; l > 0; --l) { Bracket br(a, "q_dx"); BDR_TRY(critic_dx_all(l, Bn, c2_act, tail_defer && l == L - 2 ? &td_tail : nullptr, false)); }
         {   // every weight gradient of every critic in one grouped launch; partial sums -> gradients, Adam and soft_update (:169-173) in one more
             std::vector<DenseDwJob> jobs;
             for (int i = 0; i < NC; ++i)
@@ -1024,6 +1052,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     a->gather_in_pack = getenv("BDR_NO_STEP_GATHER") == nullptr;
     a->fuse_rows = getenv("BDR_NO_SAC_FUSE") == nullptr;
     a->chain2 = getenv("BDR_NO_SAC_CHAIN") == nullptr;
+    a->tail_next = getenv("BDR_SAC_TAIL_IN_KERNEL") == nullptr;
     { const char* e = getenv("BDR_SAC_CHAIN_TPW"); a->chain2_tpw = e ? atoi(e) : 0; }
     BDR_HIP(hipMalloc((void**)&a->tickets, 2 * sizeof(unsigned))); BDR_HIP(hipMemsetAsync(a->tickets, 0, 2 * sizeof(unsigned), a->stream));
     BDR_HIP(hipMalloc((void**)&a->applied, 3 * sizeof(unsigned long long))); BDR_HIP(hipMemsetAsync(a->applied, 0, 3 * sizeof(unsigned long long), a->stream));

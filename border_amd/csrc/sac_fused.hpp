@@ -112,6 +112,7 @@ struct SacQLastArgs {
     int auto_alpha; float target; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
     const unsigned* poison;               // a cross-queue wait timed out: no EntCoef step
     unsigned long long* applied; unsigned long long step;   // as SacSelectArgs
+    int tail_here;                        // 0: the batch-wide part runs as one more workgroup of the NEXT launch (k_dense_small_dx_tail), which nothing of it precedes
 };
 // relu'(h) * d[row] * W_last[:, 0] for 32 rows x the 64 columns [c0, c0 + 64) of one critic, in two halves: the operand loads do not
 // depend on anything the kernel computes, so they are issued first thing (next to the tile operands) and are long back when the
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
     }
     if (SF_ABL & 1) return;
     // the partials are out: take the ticket now (its barrier also publishes `sel`) and let its round trip run under the gradient stores
-    ticket_take(p.ticket, gridDim.x * gridDim.y, &s_last);
+    if (p.tail_here) ticket_take(p.ticket, gridDim.x * gridDim.y, &s_last);
+    else __syncthreads();
     if (!act_pass) {
         // d qmin / d h2 = relu'(h2) * dout * W_last[:, 0]   (what the last layer's dX launch computes: its only non-zero term)
         if (!(SF_ABL & 2))
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(512) void k_sac_q_last(SacQLastArgs p)
             for (int i = 0; i < 4; ++i)
                 if (i < p.NC) last_layer_dx_store(dxr[i], sel[i], p.dh[i], p.ldh, y * 64, m0, p.B, tid);
     }
-    if (!ticket_last(&s_last)) return;
+    if (!p.tail_here || !ticket_last(&s_last)) return;
     // ---- k_sac_select's batch-wide part, by the last workgroup to finish: the block partials in block order
     const int nb = (p.B + 31) / 32;
     float log_alpha = la_pre;
@@ -367,6 +369,7 @@ struct SacTdLastArgs {
     float* tgt; float* part;                                // part: [NC][ceil(B / 32)] block partials of the critics' loss sums
     int B; int loss_kind;
     unsigned* ticket; float* out; float scale; int accumulate;
+    int tail_here;                                          // as SacQLastArgs
 };
 __global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
 {
@@ -440,15 +443,69 @@ __global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
         }
     }
     // the partials are out: ticket first (its barrier also publishes `dl`), its round trip runs under the gradient stores
-    ticket_take(p.ticket, gridDim.x * gridDim.y, &s_last);
+    if (p.tail_here) ticket_take(p.ticket, gridDim.x * gridDim.y, &s_last);
+    else __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < p.NC) last_layer_dx_store(dxr[i], dl[i], p.dh[i], p.ldh, (int)blockIdx.y * 64, m0, p.B, tid);
-    if (!ticket_last(&s_last)) return;
+    if (!p.tail_here || !ticket_last(&s_last)) return;
     const int nb = (p.B + 31) / 32;
     float total = out_pre;
     for (int i = 0; i < p.NC; ++i) total = add_scaled(total, sum_partials(p.part + (size_t)i * nb, nb, lsum), p.scale);
     if (tid == 0) p.out[0] = total;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The batch-wide parts of k_sac_q_last (EntCoef::update + the actor loss) and k_sac_td_last (the critics' loss sums) as ONE MORE WORKGROUP of the
+// launch that follows them on the queue - the critics' layer-1 input gradient, which reads nothing they write.  Inside their own kernels these parts
+// are a ticket (agent-scope partials acknowledged, an atomic's round trip) and then one workgroup's 2-3 dependent round trips while the queue waits for
+// the kernel to end: 3.2 of k_sac_q_last's 13.9 us (DESIGN.md 5, round 3 stamps).  Behind a kernel boundary the partials are ordinary memory, and the
+// sums run in the shadow of 512 tile workgroups.  Same partials, same order (block partials one by one in block order), same scalar arithmetic.
+struct SacTailArgs {
+    int kind;                             // 0: none; 1: k_sac_q_last's part; 2: k_sac_td_last's part
+    const float* part; int nb, NC, B;     // kind 1: [3][nb] (log_p + target, log_p, qmin); kind 2: [NC][nb] loss partials
+    const float* log_alpha; float* out; float scale; int accumulate;
+    int auto_alpha; float* log_alpha_rw; float* al_m; float* al_v; AdamScalars s;
+    const unsigned* poison; unsigned long long* applied; unsigned long long step;
+};
+constexpr int SAC_TAIL_LDS = 4 * 32 * 33;   // floats: the tile workgroups' `red`
+__device__ __forceinline__ void sac_tail(const SacTailArgs& t, float* lds)
+{
+    const int tid = threadIdx.x, nsum = t.kind == 1 ? 3 : t.NC;
+    for (int k = tid; k < nsum * t.nb; k += blockDim.x) lds[k] = t.part[k];
+    const float out_pre = t.accumulate ? t.out[0] : 0.f;
+    float la = 0.f, am = 0.f, av = 0.f;
+    if (t.kind == 1) { la = t.log_alpha[0]; if (t.auto_alpha) { am = t.al_m[0]; av = t.al_v[0]; } }
+    __syncthreads();
+    auto sum = [&](int i) { float v = 0.f; for (int k = 0; k < t.nb; ++k) v += lds[i * t.nb + k]; return v; };   // sum_partials' order
+    if (t.kind == 1) {
+        float log_alpha = la;
+        if (t.auto_alpha) {
+            const float g = -(sum(0) / (float)t.B);
+            const float mm = am * t.s.b1 + g * t.s.omb1;
+            const float vv = av * t.s.b2 + t.s.omb2 * g * g;
+            const float denom = __fsqrt_rn(vv) / t.s.sqrt_bc2 + t.s.eps;
+            log_alpha = log_alpha + t.s.neg_step * mm / denom;
+            if (tid == 0 && !(t.poison && *t.poison)) { t.log_alpha_rw[0] = log_alpha; t.al_m[0] = mm; t.al_v[0] = vv; if (t.applied) *t.applied = t.step; }
+        }
+        const float alpha = expf(log_alpha);
+        const float s_logp = sum(1), s_qm = sum(2);
+        if (tid == 0) t.out[0] = actor_loss_sum(out_pre, alpha, s_logp, s_qm, t.scale);
+    } else {
+        float total = out_pre;
+        for (int i = 0; i < t.NC; ++i) total = add_scaled(total, sum(i), t.scale);
+        if (tid == 0) t.out[0] = total;
+    }
+}
+// k_dense_small<true> + the tail: grid.x = tiles + 1, the extra workgroup (of instance 0) runs sac_tail
+__global__ __launch_bounds__(256) void k_dense_small_dx_tail(DenseArgsZ dz, SacTailArgs t)
+{
+    __shared__ float red[4][32][33];
+    if (blockIdx.x + 1 == gridDim.x) {
+        if (blockIdx.z == 0) sac_tail(t, &red[0][0][0]);
+        return;
+    }
+    dense_small_body<true>(dz.a[blockIdx.z], red);
+}
 }  // namespace

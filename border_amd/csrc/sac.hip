@@ -458,6 +458,12 @@ struct Sac : bdr_agent, SacBatch {
     {
         bdr_agent* a = this;
         DenseSrc in{x, pi.L[0].Kp};
+        if (chain2 && small_gemm && n_trunk == 2 && dense_chain2_ok(pi.L[0], pi.L[1])) {   // (acting calls: one launch fewer)
+            Bracket br(a, "pi_fwd");
+            const float* pb[1] = {pi_p}; float* h0[1] = {t_act[0]}; float* h1[1] = {t_act[1]};
+            BDR_TRY(dense_chain2_z(st, pi.L[0], pi.L[1], 1, pb, &in, h0, h1, Bn, chain2_tpw));
+            in = DenseSrc{t_act[1], pi.L[1].Np};
+        } else
         for (int i = 0; i < n_trunk; ++i) {
             Bracket br(a, "pi_fwd");
             BDR_TRY(dense_forward(a, st, pi.L[i], pi_p, in, t_act[i], Bn, small_gemm));
@@ -486,7 +492,7 @@ struct Sac : bdr_agent, SacBatch {
         if (fused()) {   // trunk layer by layer, then heads + action + log-prob in one row-block kernel
             bdr_agent* a = this;
             DenseSrc in{x, pi.L[0].Kp};
-            if (chain2 && n_trunk == 2 && dense_chain2_ok(pi.L[0], pi.L[1])) {   // both trunk layers in one launch, same bits (dense_chain.hpp)
+            if (chain2 && small_gemm && n_trunk == 2 && dense_chain2_ok(pi.L[0], pi.L[1])) {   // both trunk layers in one launch, same bits (dense_chain.hpp)
                 Bracket br(a, "pi_fwd");
                 const float* pb[1] = {pi_p}; float* h0[1] = {t_act[0]}; float* h1[1] = {t_act[1]};
                 BDR_TRY(dense_chain2_z(st, pi.L[0], pi.L[1], 1, pb, &in, h0, h1, Bn, chain2_tpw, sig_flag, sig_epoch));
@@ -589,7 +595,7 @@ struct Sac : bdr_agent, SacBatch {
 
     // One iteration of the Sac::opt_ loop on a device-resident batch (obs/next_obs/act rows are f32).  The order of the reference is
     // kept where it matters (actor first, the critic target from the UPDATED actor, tracking after every critic step); launches that
-    // do not depend on each other are merged and the narrow layers ride in row-block kernels (sac_fused.hpp): 21 launches for twin
+    // do not depend on each other are merged, the narrow layers ride in row-block kernels (sac_fused.hpp) and the two wide layers of a forward pass share a launch (dense_chain.hpp): 17 launches for twin
     // critics instead of one per layer and tensor (70).  update() = prologue() + update_rest(); the two-queue sequence (opt_enqueue) runs
     // the prologue of the NEXT update on the side queue.
     // draw_noise: z_actor / z_next ([Bn][A] each, contiguous) are drawn on the device inside the first launch
@@ -874,7 +880,7 @@ struct Sac : bdr_agent, SacBatch {
         BDR_REQUIRE(r->device == device, "agent and replay buffer live on different devices");
         const int Bn = (int)cfg.batch_size;
         BDR_TRY(ensure_batch(Bn));
-        // 21 kernels of 4-14 us.  Default: eager launches on two queues (opt_enqueue).  Without the side queue the sequence can be
+        // 17 kernels of 4-14 us.  Default: eager launches on two queues (opt_enqueue).  Without the side queue the sequence can be
         // replayed from a captured graph (step_graph.hpp; the policy measures whether that pays).  Profiling brackets and prioritized
         // replay (tree kernels with their own host state) take the eager one-queue path - the same sequence, launched one by one.
         if (prof || r->per || side_queue_for(r)) return opt_enqueue(r, Bn);

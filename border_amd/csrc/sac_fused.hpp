@@ -11,7 +11,7 @@
 //                        gradient                                                     (sac/base.rs:160-167;  4 -> 1)
 //   k_sac_td_last        target critics' last layer + TD target + critic losses + d loss / d h2 + (last workgroup) the loss sums
 //                                                                                      (sac/base.rs:107-149;  3 -> 1)
-// 30 launches per update become 21.  Reductions over the whole batch (mean log p for the entropy coefficient, the recorded losses)
+// 30 launches per update become 21 (17 with dense_chain.hpp).  Reductions over the whole batch (mean log p for the entropy coefficient, the recorded losses)
 // are done by the LAST workgroup to finish (atomic ticket), in exactly the order of the single-workgroup kernels they replace
 // (block_sum_1024 with its 16 wave totals): every path - fused, layer by layer, captured graph - gives the same bits
 // (tests/test_gpu_sac.py).

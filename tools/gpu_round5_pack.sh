@@ -12,6 +12,7 @@ timeout 600 python bench.py --config c2 --frame-ring --no-cpu-baseline > $O/benc
 timeout 600 python bench.py --config c2 --per --no-cpu-baseline > $O/bench_${tag}_c2_per.json 2>/dev/null
 BDR_NO_SAC_FUSE=1 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_layer_by_layer.json 2>/dev/null
 BDR_SAC_SIDE_QUEUE=0 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_one_queue.json 2>/dev/null
+BDR_NO_SAC_CHAIN=1 BDR_SAC_TAIL_IN_KERNEL=1 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_no_chain_tail_in_kernel.json 2>/dev/null
 BDR_IQN_F32_EXACT=1 timeout 600 python bench.py --config c4 --no-cpu-baseline > $O/bench_${tag}_c4_exact_f32.json 2>/dev/null
 BDR_DQN_F32_EXACT=1 timeout 600 python bench.py --config c2 --no-cpu-baseline > $O/bench_${tag}_c2_exact_f32.json 2>/dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${tag}_c2_driver_form.json 2>/dev/null
@@ -51,6 +52,7 @@ db=$(find $O/prof_${tag}_gate -name "*.db" | head -1)
 [ -n "$db" ] && python tools/gate_max.py $db > $O/gate_max_${tag}.md 2>&1
 rm -rf $O/prof_${tag}_gate
 ( cd tools/probes && { ./conv1_rw_probe.bin 256; ./c1dw_probe.bin 256 4; ./c1dw_trace.bin; ./mfma_bf16_rate.bin; } > ../../$O/conv1_probes_${tag}.txt 2>&1 )
+( cd tools/probes && timeout 120 ./chain2_probe.bin > ../../$O/chain2_probe_${tag}.txt 2>&1 )
 timeout 300 python tools/probes/sample_device_probe.py 1000 > $O/sample_device_${tag}.txt 2>/dev/null
 timeout 300 python tools/probes/sample_latency.py > $O/sample_latency_${tag}.txt 2>/dev/null
 ls $O | grep -E "$tag" | head -80

@@ -25,6 +25,9 @@ struct Chain2Args {
     Chain2Net n[4];
     int M, n1, relu0, relu1;                  // layer 0: [C2_K0][C2_N0], layer 1: [C2_N0][n1]; n1 % (32 TPW) == 0
     unsigned* sig_flag; unsigned sig_epoch;   // optional: start_signal (igemm.hpp)
+    // optional: the inputs x are written by another queue, which publishes wait_epoch in *wait_flag when they are complete (queue_flags.hpp).  The wait
+    // is the kernel's first act - one load's round trip, ~1 us - instead of a one-wave k_flag_wait packet in front of the launch (a launch slot, ~4 us)
+    const unsigned* wait_flag; unsigned wait_epoch; unsigned long long wait_limit; unsigned* wait_err; unsigned wait_code;
 #ifdef C2_STAMPS
     long long* stamps;
 #endif
@@ -80,6 +83,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TPW == 1 ? 
     constexpr int J0 = C2_K0 / 32, J1 = C2_N0 / 32;   // k-quad slots per slice and lane half: 2 (layer 0), 8 (layer 1)
     start_signal(a.sig_flag, a.sig_epoch);
     C2_STAMP(0);
+    if (a.wait_flag) {   // every workgroup, before its first load of x
+        if (threadIdx.x == 0) {
+            // first look with ordinary loads: the caches were invalidated when this kernel started and the flag only grows, so a cached value can be
+            // too OLD, never too new - and 256 workgroups reading one word with agent scope (uncached, one channel) cost 6 us (measured)
+            const unsigned f = *a.wait_flag, e = a.wait_err ? *a.wait_err : 0u;
+            if ((int)(f - a.wait_epoch) < 0 && e == 0u) {   // not there yet: k_flag_wait's loop (time limit, poison word)
+                const unsigned long long t0 = wall_clock64();
+                while ((int)(__hip_atomic_load(a.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.wait_epoch) < 0) {   // wrap-safe
+                    __builtin_amdgcn_s_sleep(2);
+                    if (a.wait_err && __hip_atomic_load(a.wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // another wait failed first
+                    if (wall_clock64() - t0 > a.wait_limit) {
+                        if (a.wait_err) __hip_atomic_store(a.wait_err, a.wait_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+        }
+        // (no x line can be in a cache of this workgroup's XCD: the kernel's start invalidated them, and no workgroup reads x before its own wait)
+        __syncthreads();
+    }
     const Chain2Net& nt = a.n[blockIdx.z];
     __shared__ __attribute__((aligned(16))) float hs[32 * C2_LD];
     __shared__ float red[TPW == 1 ? 4 : 1][32][33];
@@ -214,14 +237,17 @@ inline bool dense_chain2_ok(const DenseLayer& l0, const DenseLayer& l1)
     return l0.Kp == C2_K0 && l0.Np == C2_N0 && l1.Kp == l0.Np && l1.Np % 32 == 0;
 }
 // tpw: 0 = by the size of the launch, 1 / 4 = forced (4 needs l1.Np % 128 == 0)
+struct ChainWait { const unsigned* flag = nullptr; unsigned epoch = 0; unsigned long long limit = 0; unsigned* err = nullptr; unsigned code = 0; };
 inline int32_t dense_chain2_z(hipStream_t st, const DenseLayer& l0, const DenseLayer& l1, int nz, const float* const* params_base, const DenseSrc* x,
-                              float* const* h0, float* const* h1, int M, int tpw = 0, unsigned* sig_flag = nullptr, unsigned sig_epoch = 0)
+                              float* const* h0, float* const* h1, int M, int tpw = 0, unsigned* sig_flag = nullptr, unsigned sig_epoch = 0,
+                              const ChainWait* wait = nullptr)
 {
     Chain2Args c{};
     for (int z = 0; z < nz; ++z)
         c.n[z] = Chain2Net{x[z].p, x[z].ld, params_base[z] + l0.w, params_base[z] + l0.b, params_base[z] + l1.w, params_base[z] + l1.b, h0[z], h1[z]};
     c.M = M; c.n1 = l1.Np; c.relu0 = l0.relu; c.relu1 = l1.relu;
     c.sig_flag = sig_flag; c.sig_epoch = sig_epoch;
+    if (wait && wait->flag) { c.wait_flag = wait->flag; c.wait_epoch = wait->epoch; c.wait_limit = wait->limit; c.wait_err = wait->err; c.wait_code = wait->code; }
     const int rb = (M + 31) / 32;
     const bool can4 = l1.Np % 128 == 0;
     static const int min4 = [] { const char* e = getenv("BDR_CHAIN_MIN4"); return e ? atoi(e) : 192; }();   // (tuning switch)

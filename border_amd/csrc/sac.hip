@@ -335,6 +335,8 @@ struct Sac : bdr_agent, SacBatch {
     StepGraph graph; StepGraphPolicy graph_policy;   // step_graph.hpp
     bool gather_in_pack = true;               // BDR_NO_STEP_GATHER=1: separate gather launch
     bool fuse_rows = true;                    // BDR_NO_SAC_FUSE=1: the narrow layers as launches of their own (sac_fused.hpp)
+    bool wait_in_kernel = true;               // BDR_SAC_WAIT_PACKET=1: the main queue's wait for the prologue as a one-wave packet instead of inside the first critic launch
+    ChainWait pending_wait;                   // set by opt_enqueue, taken by the first critic launch of update_rest
     bool tail_next = true;                    // BDR_SAC_TAIL_IN_KERNEL=1: the row-block kernels' batch-wide parts by their own last workgroup (ticket) instead of in the next launch
     bool chain2 = true; int chain2_tpw = 0;   // BDR_NO_SAC_CHAIN=1: a two-layer trunk as two launches (dense_chain.hpp); BDR_SAC_CHAIN_TPW=1|4: tile form
     unsigned* tickets = nullptr;              // [2] last-workgroup tickets of k_sac_q_last / k_sac_td_last
@@ -538,7 +540,9 @@ struct Sac : bdr_agent, SacBatch {
                 float* h0[4]; float* h1[4];
                 for (int j = 0; j < nz; ++j) { h0[j] = (*acts[j0 + j])[0]; h1[j] = (*acts[j0 + j])[1]; }
                 Bracket br(a, "q_fwd");
-                BDR_TRY(dense_chain2_z(stream, qn.L[0], qn.L[1], nz, params + j0, in, h0, h1, Bn, chain2_tpw));
+                const ChainWait w = pending_wait;
+                pending_wait = ChainWait{};
+                BDR_TRY(dense_chain2_z(stream, qn.L[0], qn.L[1], nz, params + j0, in, h0, h1, Bn, chain2_tpw, nullptr, 0, &w));
                 continue;
             }
             for (size_t l = 0; l < nl; ++l) {
@@ -858,7 +862,10 @@ struct Sac : bdr_agent, SacBatch {
                 BDR_TRY(replay_sample_plan(r, Bn, side, &plan));
                 BDR_TRY(prologue(side, Bn, (const float*)r->b_obs, (const float*)r->b_act, (const float*)r->b_next, z_a, z_a + (size_t)Bn * A, true, &plan));
                 if ((long long)epoch != stall_at) BDR_TRY(flag_set(side, sig + SIG_PRO, epoch));
-                BDR_TRY(flag_wait(stream, sig + SIG_PRO, epoch, dev_err + ERR_GATE, 1u + SIG_PRO, flag_limit));
+                // the main queue waits for the prologue: inside the first launch of update_rest where that is the two-layer critic launch (dense_chain.hpp)
+                if (wait_in_kernel && chain2 && small_gemm && fused() && qn.L.size() == 3 && dense_chain2_ok(qn.L[0], qn.L[1]))
+                    pending_wait = ChainWait{sig + SIG_PRO, epoch, flag_limit, dev_err + ERR_GATE, 1u + SIG_PRO};
+                else BDR_TRY(flag_wait(stream, sig + SIG_PRO, epoch, dev_err + ERR_GATE, 1u + SIG_PRO, flag_limit));
                 BDR_TRY(update_rest(Bn, r->b_reward, r->b_term, z_a, z_a + (size_t)Bn * A, u == 0, true));
                 continue;
             }
@@ -1059,6 +1066,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     a->fuse_rows = getenv("BDR_NO_SAC_FUSE") == nullptr;
     a->chain2 = getenv("BDR_NO_SAC_CHAIN") == nullptr;
     a->tail_next = getenv("BDR_SAC_TAIL_IN_KERNEL") == nullptr;
+    a->wait_in_kernel = getenv("BDR_SAC_WAIT_PACKET") == nullptr;
     { const char* e = getenv("BDR_SAC_CHAIN_TPW"); a->chain2_tpw = e ? atoi(e) : 0; }
     BDR_HIP(hipMalloc((void**)&a->tickets, 2 * sizeof(unsigned))); BDR_HIP(hipMemsetAsync(a->tickets, 0, 2 * sizeof(unsigned), a->stream));
     BDR_HIP(hipMalloc((void**)&a->applied, 3 * sizeof(unsigned long long))); BDR_HIP(hipMemsetAsync(a->applied, 0, 3 * sizeof(unsigned long long), a->stream));

@@ -422,6 +422,7 @@ print("LOSS", bool(np.isfinite(rec["loss_critic"])), "MOVED", bool((state() != s
     (5, 2, [64], [300], 1, 200, ("Fix", 0.2), 3),                          # one trunk layer, one critic, three updates per opt
     (23, 7, [128, 64, 32], [64, 64, 64], 4, 33, ("Auto", -7.0, 3e-4), 2),  # three trunk layers, four critics, 33 rows
     (30, 8, [64, 64], [64, 64], 2, 64, ("Fix", 1.0), 1),                   # a shape the row-block kernels do not cover (layer-by-layer launches on two queues)
+    (17, 6, [256, 256], [256, 256], 2, 256, ("Auto", -6.0, 3e-4), 2),      # BASELINE config 5's networks: the two-layer launches, the main queue's wait for the prologue INSIDE the first critic launch
 ])
 def test_sac_two_queue_sequence_equals_one_queue_on_ragged_shapes(B, monkeypatch, od, ad, pu, qu, nc, Bsz, ent, n_upd):
     """Agent::opt over the ring, eager launches: the two-queue sequence (next update's sample + actor forward on the side queue, two
@@ -442,7 +443,7 @@ def test_sac_two_queue_sequence_equals_one_queue_on_ragged_shapes(B, monkeypatch
                                     ent_coef_mode=ent, n_updates_per_opt=n_upd, critic_loss="SmoothL1", device=0, seed=3))
         a.train()
         recs = []
-        for k in range(9):
+        for k in range(60 if pu == [256, 256] else 9):   # (the in-kernel wait of the config-5 shape: 120 updates)
             recs.append(a.opt_with_record(rb) if k % 4 == 3 else (a.opt(rb), None)[1])
             if k % 2 == 0: push(37)        # the ring wraps (capacity 700) while updates are in flight
         names = ["pi", "log_alpha"] + [f"qnet_{i}" for i in range(nc)] + [f"qnet_tgt_{i}" for i in range(nc)]

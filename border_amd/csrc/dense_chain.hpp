@@ -75,11 +75,14 @@ __device__ __forceinline__ void chain_land(const f32x4 (&v)[8])
 
 // KZ0: k-slices of layer 0 that hold input columns (2: logical width <= 32, the SAC observations / observation + action rows; else 4).  A slice of
 // padding is +0 for every element (0 x 0 products): its MFMAs are left out and the sum keeps its "+ 0.f" so that a -0 partial sum becomes the same +0.
-template <int TPW, int KZ0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TPW == 1 ? 2 : 1, TPW == 1 ? 2 : 1))) void k_dense_chain2(Chain2Args a)
+// The kernel's body.  hs: [32 * C2_LD] floats, red: [4][32][33] (TPW = 1 only).  AGENT_H1 (TPW = 1): h1 is stored with agent scope and the function returns in
+// every thread - for a caller that hands the row block's h1 to the last of its workgroups (sac_fused.hpp k_sac_pi_chain_heads).
+template <int TPW, int KZ0, bool AGENT_H1 = false>
+__device__ __forceinline__ void dense_chain2_body(const Chain2Args& a, float* hs, float (*red)[32][33])
 {
     static_assert(TPW == 1 || TPW == 4, "one tile per workgroup (a wave per k-slice) or four (a wave per tile)");
     static_assert(KZ0 == 2 || KZ0 == 4, "two or four k-slices of layer 0");
+    static_assert(!AGENT_H1 || TPW == 1, "the hand-over form is the one-tile form");
     constexpr int J0 = C2_K0 / 32, J1 = C2_N0 / 32;   // k-quad slots per slice and lane half: 2 (layer 0), 8 (layer 1)
     start_signal(a.sig_flag, a.sig_epoch);
     C2_STAMP(0);
@@ -104,8 +107,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TPW == 1 ? 
         __syncthreads();
     }
     const Chain2Net& nt = a.n[blockIdx.z];
-    __shared__ __attribute__((aligned(16))) float hs[32 * C2_LD];
-    __shared__ float red[TPW == 1 ? 4 : 1][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int NCG = a.n1 / (32 * TPW);
@@ -207,11 +208,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TPW == 1 ? 
     if constexpr (TPW == 1) {
         __syncthreads();
         const int r = tid >> 3, c4 = (tid & 7) * 4, m = m0 + r;
-        if (m >= a.M) return;
-        f32x4 v;
+        if (m < a.M) {
+            f32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = dense_small_sum(red, r, c4 + q) + e1[q]; if (a.relu1) v[q] = v[q] > 0.f ? v[q] : 0.f; }
-        *reinterpret_cast<f32x4*>(nt.h1 + (size_t)m * a.n1 + n1_0 + c4) = v;
+            for (int q = 0; q < 4; ++q) { v[q] = dense_small_sum(red, r, c4 + q) + e1[q]; if (a.relu1) v[q] = v[q] > 0.f ? v[q] : 0.f; }
+            float* o = nt.h1 + (size_t)m * a.n1 + n1_0 + c4;
+            if constexpr (AGENT_H1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st_agent(o + q, v[q]);   // read by the row block's last workgroup, possibly on another XCD
+            } else *reinterpret_cast<f32x4*>(o) = v;
+        }
     } else {
         float* o = nt.h1 + (size_t)(m0 + 4 * h) * a.n1 + n1_0 + i;
 #pragma unroll
@@ -231,16 +237,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TPW == 1 ? 
     }
 }
 
+template <int TPW, int KZ0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TPW == 1 ? 2 : 1, TPW == 1 ? 2 : 1))) void k_dense_chain2(Chain2Args a)
+{
+    __shared__ __attribute__((aligned(16))) float hs[32 * C2_LD];
+    __shared__ float red[TPW == 1 ? 4 : 1][32][33];
+    dense_chain2_body<TPW, KZ0>(a, hs, red);
+}
+
 // can layers l0 -> l1 go through k_dense_chain2?
 inline bool dense_chain2_ok(const DenseLayer& l0, const DenseLayer& l1)
 {
     return l0.Kp == C2_K0 && l0.Np == C2_N0 && l1.Kp == l0.Np && l1.Np % 32 == 0;
 }
 // tpw: 0 = by the size of the launch, 1 / 4 = forced (4 needs l1.Np % 128 == 0)
+struct ChainWait;
+inline Chain2Args dense_chain2_args(const DenseLayer& l0, const DenseLayer& l1, int nz, const float* const* params_base, const DenseSrc* x, float* const* h0,
+                                    float* const* h1, int M, unsigned* sig_flag, unsigned sig_epoch, const ChainWait* wait);
 struct ChainWait { const unsigned* flag = nullptr; unsigned epoch = 0; unsigned long long limit = 0; unsigned* err = nullptr; unsigned code = 0; };
-inline int32_t dense_chain2_z(hipStream_t st, const DenseLayer& l0, const DenseLayer& l1, int nz, const float* const* params_base, const DenseSrc* x,
-                              float* const* h0, float* const* h1, int M, int tpw = 0, unsigned* sig_flag = nullptr, unsigned sig_epoch = 0,
-                              const ChainWait* wait = nullptr)
+inline Chain2Args dense_chain2_args(const DenseLayer& l0, const DenseLayer& l1, int nz, const float* const* params_base, const DenseSrc* x, float* const* h0,
+                                    float* const* h1, int M, unsigned* sig_flag, unsigned sig_epoch, const ChainWait* wait)
 {
     Chain2Args c{};
     for (int z = 0; z < nz; ++z)
@@ -248,6 +264,13 @@ inline int32_t dense_chain2_z(hipStream_t st, const DenseLayer& l0, const DenseL
     c.M = M; c.n1 = l1.Np; c.relu0 = l0.relu; c.relu1 = l1.relu;
     c.sig_flag = sig_flag; c.sig_epoch = sig_epoch;
     if (wait && wait->flag) { c.wait_flag = wait->flag; c.wait_epoch = wait->epoch; c.wait_limit = wait->limit; c.wait_err = wait->err; c.wait_code = wait->code; }
+    return c;
+}
+inline int32_t dense_chain2_z(hipStream_t st, const DenseLayer& l0, const DenseLayer& l1, int nz, const float* const* params_base, const DenseSrc* x,
+                              float* const* h0, float* const* h1, int M, int tpw = 0, unsigned* sig_flag = nullptr, unsigned sig_epoch = 0,
+                              const ChainWait* wait = nullptr)
+{
+    const Chain2Args c = dense_chain2_args(l0, l1, nz, params_base, x, h0, h1, M, sig_flag, sig_epoch, wait);
     const int rb = (M + 31) / 32;
     const bool can4 = l1.Np % 128 == 0;
     static const int min4 = [] { const char* e = getenv("BDR_CHAIN_MIN4"); return e ? atoi(e) : 192; }();   // (tuning switch)

@@ -47,6 +47,35 @@ struct SacHeadsActionArgs {
     float* logp;
     int B, A; float lo, hi, eps;
 };
+// row `row` (r of its block) by one wave, lanes over the action dimension: k_sac_action's arithmetic and its butterfly sums (shared by k_sac_heads_action
+// and k_sac_pi_chain_heads: one source, one instruction sequence)
+__device__ __forceinline__ void sac_heads_row(const SacHeadsActionArgs& p, const float (*red_m)[32][33], const float (*red_s)[32][33], int r, int row, int lane,
+                                              float bias_m, float bias_s, float zv)
+{
+    float nl = 0.f, sl = 0.f;
+    if (lane < 32) {   // columns of tile 0 (the rest of the padded width stays zero from allocation)
+        float mv = dense_small_sum(red_m, r, lane) + bias_m;
+        float ev = dense_small_sum(red_s, r, lane) + bias_s;
+        if (p.hm.relu) mv = mv > 0.f ? mv : 0.f;
+        if (p.hs.relu) ev = ev > 0.f ? ev : 0.f;
+        const size_t q = (size_t)row * p.ld + lane;
+        p.mean[q] = mv; p.e[q] = ev;
+        if (lane < p.A) {
+            const float z = zv;
+            const float s = expf(ev);
+            const float cl = fminf(fmaxf(s, p.lo), p.hi);
+            const float sd = expf(cl);
+            const float a = tanhf(sd * z + mv);
+            p.xq[(size_t)row * p.ldq + p.col0 + lane] = a;
+            if (p.a_out) { p.a_out[q] = a; p.s_out[q] = s; p.sd_out[q] = sd; }
+            nl += -0.91893853320467274178f - 0.5f * (z * z);
+            sl += logf((1.0f - a * a) + p.eps);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { nl += __shfl_xor(nl, off); sl += __shfl_xor(sl, off); }
+    if (lane == 0) p.logp[row] = nl - sl;
+}
 __global__ __launch_bounds__(512) void k_sac_heads_action(SacHeadsActionArgs p)
 {
     __shared__ float red[2][4][32][33];
@@ -68,29 +97,7 @@ __global__ __launch_bounds__(512) void k_sac_heads_action(SacHeadsActionArgs p)
     for (int rr = 0; rr < 4; ++rr) {
         const int r = wave * 4 + rr, row = m0 + r;
         if (row >= p.B) break;
-        float nl = 0.f, sl = 0.f;
-        if (lane < 32) {   // columns of tile 0 (the rest of the padded width stays zero from allocation)
-            float mv = dense_small_sum(red[0], r, lane) + bias_m;
-            float ev = dense_small_sum(red[1], r, lane) + bias_s;
-            if (p.hm.relu) mv = mv > 0.f ? mv : 0.f;
-            if (p.hs.relu) ev = ev > 0.f ? ev : 0.f;
-            const size_t q = (size_t)row * p.ld + lane;
-            p.mean[q] = mv; p.e[q] = ev;
-            if (lane < p.A) {
-                const float z = zrow[rr];
-                const float s = expf(ev);
-                const float cl = fminf(fmaxf(s, p.lo), p.hi);
-                const float sd = expf(cl);
-                const float a = tanhf(sd * z + mv);
-                p.xq[(size_t)row * p.ldq + p.col0 + lane] = a;
-                if (p.a_out) { p.a_out[q] = a; p.s_out[q] = s; p.sd_out[q] = sd; }
-                nl += -0.91893853320467274178f - 0.5f * (z * z);
-                sl += logf((1.0f - a * a) + p.eps);
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { nl += __shfl_xor(nl, off); sl += __shfl_xor(sl, off); }
-        if (lane == 0) p.logp[row] = nl - sl;
+        sac_heads_row(p, red[0], red[1], r, row, lane, bias_m, bias_s, zrow[rr]);
     }
 }
 
@@ -507,5 +514,51 @@ __global__ __launch_bounds__(256) void k_dense_small_dx_tail(DenseArgsZ dz, SacT
         return;
     }
     dense_small_body<true>(dz.a[blockIdx.z], red);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The actor's trunk (dense_chain.hpp, one h1 tile per workgroup) AND k_sac_heads_action in one launch: the eight workgroups of a row block store their
+// h1 tiles with agent scope and take a ticket; the last one to arrive forms both heads' tiles for the 32 rows (k_sac_heads_action's tiles: same k-slices,
+// MFMA order and sum; h1 comes back through the coherent level - the other seven may sit on other XCDs) and does the rows' action / log-probability
+// arithmetic (sac_heads_row).  One launch less on the main queue's chain per update (the critic phase's actor pass) and one on the side queue - and
+// 3 % SLOWER in the step (7 645 against 7 880 opt-steps/s): eight agent-scope tile stores acknowledged, a ticket and an uncached reload of h1 cost more than the
+// launch they replace (as round 3 found for the weight gradients).  Same bits; kept behind BDR_SAC_HEADS_FUSE=1 with its test, not the default.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sac_pi_chain_heads(Chain2Args a, SacHeadsActionArgs p, unsigned* tickets)
+{
+    __shared__ __attribute__((aligned(16))) float hs[32 * C2_LD];
+    __shared__ float red[4][32][33];
+    __shared__ unsigned s_last;
+    static_assert(32 * C2_LD >= 4 * 32 * 33, "the second head's slices reuse the h0 block");
+    dense_chain2_body<1, 2, true>(a, hs, red);
+    const int NCG = a.n1 / 32, rb = (int)blockIdx.x / NCG, m0 = rb * 32;
+    if (!last_workgroup(tickets + rb, (unsigned)NCG, &s_last)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float (*red_s)[32][33] = reinterpret_cast<float (*)[32][33]>(hs);
+    // operands: the lane's row of h1, k-slice `wave` (sc1: served by the coherent level), both heads' weights of that slice, the rows' noise and the biases
+    const float* arow = p.h + (size_t)min(m0 + i, p.B - 1) * p.ldh + wave * (C2_N0 / 4) + 4 * h;
+    f32x4 av[8], bm[8], bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float* pa = arow + 8 * j; asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(av[j]) : "v"(pa) : "memory"); }
+    dense_small_load_b<false>(p.hm.w, p.w_ld, 0, C2_N0, wave, lane, bm);
+    dense_small_load_b<false>(p.hs.w, p.w_ld, 0, C2_N0, wave, lane, bs);
+    const float bias_m = p.hm.bias[i], bias_s = p.hs.bias[i];
+    float zrow[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) zrow[rr] = lane < p.A ? p.z[(size_t)min(m0 + wave * 8 + rr, p.B - 1) * p.A + lane] : 0.f;
+    // (the wait carries the asm loads' destinations as in/out operands: to the compiler an asm's output is there when the statement is)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]) :: "memory");
+    {
+        const f32x16 am = chain_mfma<8>(av, bm), as = chain_mfma<8>(av, bs);   // dense_small_tile's slots (c * 2 + u) and order
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = am[r]; red_s[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = as[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave * 8 + rr, row = m0 + r;
+        if (row >= p.B) break;
+        sac_heads_row(p, red, red_s, r, row, lane, bias_m, bias_s, zrow[rr]);
+    }
 }
 }  // namespace

@@ -184,16 +184,19 @@ def test_sac_two_layer_chain_kernel_equals_two_launches(B, monkeypatch, od, ad, 
     first layer's output kept in LDS).  Its tiles use the k-slices, MFMA order and four-way sum of the layer-by-layer kernel, in both of
     its forms (a wave per tile / a wave per k-slice): three updates, every parameter, gradient, moment, probe and loss bit for bit equal
     to BDR_NO_SAC_CHAIN=1.  Likewise the batch-wide parts of k_sac_q_last / k_sac_td_last (EntCoef::update, the loss sums), which run as one
-    more workgroup of the launch behind them (k_dense_small_dx_tail) unless BDR_SAC_TAIL_IN_KERNEL=1 keeps them with their last workgroup."""
+    more workgroup of the launch behind them (k_dense_small_dx_tail) unless BDR_SAC_TAIL_IN_KERNEL=1 keeps them with their last workgroup, and
+    the heads + action + log-probability part done by the last workgroup of each row block of the actor's trunk launch (k_sac_pi_chain_heads,
+    BDR_SAC_HEADS_FUSE=1: same bits, slower - not the default)."""
     from oracle import torch_ref as T
     pi0 = T.init_params(T.sac_pi_shapes(od, pu, ad), 31) * np.float32(0.5)
     q0 = [T.init_params(T.sac_q_shapes(od, ad, qu), 40 + i) for i in range(nc)]
     kw = dict(lr_actor=1e-3, lr_critic=2e-3, ent_coef=ent, critic_loss="Mse")
     outs = []
-    for mode in ("off", "auto", "1", "4", "tail"):
-        for k in ("BDR_NO_SAC_CHAIN", "BDR_SAC_CHAIN_TPW", "BDR_SAC_TAIL_IN_KERNEL"): monkeypatch.delenv(k, raising=False)
+    for mode in ("off", "auto", "1", "4", "tail", "heads"):
+        for k in ("BDR_NO_SAC_CHAIN", "BDR_SAC_CHAIN_TPW", "BDR_SAC_TAIL_IN_KERNEL", "BDR_SAC_HEADS_FUSE"): monkeypatch.delenv(k, raising=False)
         if mode == "off": monkeypatch.setenv("BDR_NO_SAC_CHAIN", "1"); monkeypatch.setenv("BDR_SAC_TAIL_IN_KERNEL", "1")
         elif mode == "tail": monkeypatch.setenv("BDR_SAC_TAIL_IN_KERNEL", "1")
+        elif mode == "heads": monkeypatch.setenv("BDR_SAC_HEADS_FUSE", "1")
         elif mode != "auto": monkeypatch.setenv("BDR_SAC_CHAIN_TPW", mode)
         a = _agent(B, od, ad, pu, qu, nc, Bsz, kw, pi0, q0)
         recs = [a.update_on_batch(*T.sac_batch(Bsz, od, ad, 900 + s)) for s in range(3)]

@@ -8,6 +8,7 @@ tag=${1:-r05}
 for c in c2 c4 c5 c1; do timeout 900 python bench.py --config $c > $O/bench_${tag}_$c.json 2> $O/bench_${tag}_$c.err; done
 BDR_NO_SAC_FUSE=1 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_layer_by_layer.json 2>/dev/null
 BDR_SAC_SIDE_QUEUE=0 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_one_queue.json 2>/dev/null
+BDR_NO_SAC_CHAIN=1 BDR_SAC_TAIL_IN_KERNEL=1 BDR_SAC_WAIT_PACKET=1 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_round4_form.json 2>/dev/null
 timeout 600 python bench.py --config c2 --frame-ring --no-cpu-baseline > $O/bench_${tag}_c2_frame_ring.json 2>/dev/null
 timeout 600 python bench.py --config c2 --per --no-cpu-baseline > $O/bench_${tag}_c2_per.json 2>/dev/null
 BDR_IQN_F32_EXACT=1 timeout 600 python bench.py --config c4 --no-cpu-baseline > $O/bench_${tag}_c4_exact_f32.json 2>/dev/null

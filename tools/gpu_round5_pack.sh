@@ -12,7 +12,7 @@ timeout 600 python bench.py --config c2 --frame-ring --no-cpu-baseline > $O/benc
 timeout 600 python bench.py --config c2 --per --no-cpu-baseline > $O/bench_${tag}_c2_per.json 2>/dev/null
 BDR_NO_SAC_FUSE=1 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_layer_by_layer.json 2>/dev/null
 BDR_SAC_SIDE_QUEUE=0 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_one_queue.json 2>/dev/null
-BDR_NO_SAC_CHAIN=1 BDR_SAC_TAIL_IN_KERNEL=1 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_no_chain_tail_in_kernel.json 2>/dev/null
+BDR_NO_SAC_CHAIN=1 BDR_SAC_TAIL_IN_KERNEL=1 BDR_SAC_WAIT_PACKET=1 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_${tag}_c5_round4_form.json 2>/dev/null
 BDR_IQN_F32_EXACT=1 timeout 600 python bench.py --config c4 --no-cpu-baseline > $O/bench_${tag}_c4_exact_f32.json 2>/dev/null
 BDR_DQN_F32_EXACT=1 timeout 600 python bench.py --config c2 --no-cpu-baseline > $O/bench_${tag}_c2_exact_f32.json 2>/dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${tag}_c2_driver_form.json 2>/dev/null

@@ -1,7 +1,7 @@
 // Two dense layers of an Mlp in ONE launch for the launch-bound agents (SAC: mlp/base.rs:13-41 as called by sac/base.rs:73-105):
 //   h0 = act(x W0 + b0),  h1 = act(h0 W1 + b1)      x [M][k0], W0 [k0][n0], W1 [n0][n1], up to four networks per launch (blockIdx.z)
 // The rows of an Mlp are independent between its layers: a workgroup takes 32 batch rows, forms ALL of h0 for them (k0 = 64, the padded
-// observation width, n0 = 256: eight 32 x 32 tiles of 8 MFMAs per k-slice), keeps it in LDS and forms its share of h1 from there.  No
+// observation width, n0 = 256: eight 32 x 32 tiles of 8 MFMAs per k-slice, two slices when the input has <= 32 columns), keeps it in LDS and forms its share of h1 from there.  No
 // workgroup waits for another one, nothing depends on placement; what goes away is one kernel boundary (>= 2.4 us) and the round trip
 // of h0 through memory between two dependent launches of ~8-12 us each.
 //   Every 32 x 32 tile is formed with the k-slices, the MFMA order and the four-way sum of dense_small_tile / dense_small_sum
@@ -9,7 +9,7 @@
 //   TPW = 4: the workgroup owns four h1 tiles, one per wave; a wave runs the four k-slices one after the other into registers and adds
 //            them in the fixed order - no LDS round trip, 128 MFMAs back to back (1024 x 256 x 256 x 4 networks: 256 workgroups).
 //   TPW = 1: the workgroup owns one h1 tile, wave w takes k-slice w, the slices meet in LDS (k_dense_small's form) - 8 x the
-//            workgroups for a single network, each recomputing h0 (64 MFMAs per wave) for 32 more.
+//            workgroups for a single network, each recomputing h0 (32 MFMAs per wave once the padding slices are left out) for 32 more.
 // h0 is stored once per row block (the column groups share its rows): the backward reads it (ReLU mask, dW operand).
 #pragma once
 
@@ -26,7 +26,7 @@ struct Chain2Args {
     int M, n1, relu0, relu1;                  // layer 0: [C2_K0][C2_N0], layer 1: [C2_N0][n1]; n1 % (32 TPW) == 0
     unsigned* sig_flag; unsigned sig_epoch;   // optional: start_signal (igemm.hpp)
     // optional: the inputs x are written by another queue, which publishes wait_epoch in *wait_flag when they are complete (queue_flags.hpp).  The wait
-    // is the kernel's first act - one load's round trip, ~1 us - instead of a one-wave k_flag_wait packet in front of the launch (a launch slot, ~4 us)
+    // is the kernel's first act - one cached load's round trip - instead of a one-wave k_flag_wait packet in front of the launch (+0.9 % of the SAC step)
     const unsigned* wait_flag; unsigned wait_epoch; unsigned long long wait_limit; unsigned* wait_err; unsigned wait_code;
 #ifdef C2_STAMPS
     long long* stamps;

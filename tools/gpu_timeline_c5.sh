@@ -1,0 +1,12 @@
+#!/bin/bash
+# kernel-trace timeline of the SAC step (c5, two queues): tools/rocprof_timeline.py on a rocprofv3 trace, one step = one k_sac_pack to the next
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out; mkdir -p $O
+tag=${1:-c5}
+( cd /tmp && env ${@:2} timeout 600 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof_tl_$tag -o tl -- python $GRAFT_REPO_ROOT/bench.py --config c5 --steps 300 --warmup 50 --no-cpu-baseline --profile-steps 0 > $GRAFT_REPO_ROOT/$O/tl_$tag.log 2>&1 )
+db=$(find $O/prof_tl_$tag -name "*.db" | head -1)
+python tools/rocprof_timeline.py $db --first-kernel k_sac_pack --skip 40 > $O/timeline_$tag.md 2>> $O/tl_$tag.log
+rm -rf $O/prof_tl_$tag
+tail -3 $O/tl_$tag.log | cut -c1-300
+cat $O/timeline_$tag.md

@@ -254,7 +254,7 @@ def test_world_size_2_gloo_learners_are_averaged_at_every_sync_point():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in range(2))
+    res = sorted(q.get(timeout=420) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -331,7 +331,7 @@ def test_world_size_2_a_failed_rank_stops_its_peer_at_the_next_sync_point():
     procs = [ctx.Process(target=_worker_fail, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in range(2))
+    res = sorted(q.get(timeout=420) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -71,7 +71,7 @@ def test_world_size_2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=420) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -34,6 +34,20 @@ class NetConfig(C.Structure):
                 ("units", C.c_int32 * BDR_MAX_UNITS), ("out_dim", C.c_int32), ("activation_out", C.c_int32)]
 
 
+class AdamWConfigC(C.Structure):
+    _fields_ = [("opt_kind", C.c_int32), ("amsgrad", C.c_int32), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("weight_decay", C.c_double), ("eps", C.c_double)]
+
+    def fill(self, o) -> None:
+        """o: border_amd.OptimizerConfig (opt.rs:13-28); lr travels in the owning struct"""
+        self.opt_kind = {"Adam": 0, "AdamW": 1}[o.kind]
+        self.beta1, self.beta2, self.weight_decay, self.eps = o.beta1, o.beta2, o.wd, o.eps
+        self.amsgrad = 1 if (o.kind == "AdamW" and o.amsgrad) else 0
+
+
+ARITHMETIC = {"bf16x3_6": 0, "f32_exact": 1}   # BDR_ARITH_*
+
+
 class DqnConfigC(C.Structure):
     _fields_ = [("net", NetConfig), ("opt_kind", C.c_int32), ("lr", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("weight_decay", C.c_double), ("eps", C.c_double), ("amsgrad", C.c_int32),
@@ -41,7 +55,8 @@ class DqnConfigC(C.Structure):
                 ("batch_size", C.c_uint64), ("discount_factor", C.c_double), ("tau", C.c_double),
                 ("train", C.c_int32), ("double_dqn", C.c_int32), ("critic_loss", C.c_int32),
                 ("has_clip_td_err", C.c_int32), ("clip_td_err_min", C.c_double), ("clip_td_err_max", C.c_double),
-                ("record_verbose_level", C.c_int32), ("device", C.c_int32), ("param_seed", C.c_uint64)]
+                ("record_verbose_level", C.c_int32), ("device", C.c_int32), ("param_seed", C.c_uint64),
+                ("arithmetic", C.c_int32), ("reserved", C.c_int32)]
 
 
 class IqnConfigC(C.Structure):
@@ -50,7 +65,7 @@ class IqnConfigC(C.Structure):
                 ("soft_update_interval", C.c_uint64), ("n_updates_per_opt", C.c_uint64), ("batch_size", C.c_uint64),
                 ("discount_factor", C.c_double), ("tau", C.c_double), ("sample_percents_pred", C.c_int32),
                 ("sample_percents_tgt", C.c_int32), ("sample_percents_act", C.c_int32), ("train", C.c_int32),
-                ("device", C.c_int32), ("seed", C.c_uint64)]
+                ("device", C.c_int32), ("seed", C.c_uint64), ("opt", AdamWConfigC), ("arithmetic", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SacConfigC(C.Structure):
@@ -60,7 +75,7 @@ class SacConfigC(C.Structure):
                 ("target_entropy", C.c_double), ("ent_coef_lr", C.c_double), ("epsilon", C.c_double), ("min_lstd", C.c_double),
                 ("max_lstd", C.c_double), ("n_updates_per_opt", C.c_uint64), ("batch_size", C.c_uint64), ("train", C.c_int32),
                 ("critic_loss", C.c_int32), ("reward_scale", C.c_double), ("n_critics", C.c_int32), ("device", C.c_int32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("opt_actor", AdamWConfigC), ("opt_critic", AdamWConfigC)]
 
 
 class DqnRecordC(C.Structure):

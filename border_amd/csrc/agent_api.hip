@@ -299,6 +299,7 @@ void bdr_dqn_config_default(bdr_dqn_config* c)
     c->discount_factor = 0.99; c->tau = 0.005; c->train = 0; c->double_dqn = 0;
     c->critic_loss = BDR_LOSS_MSE; c->has_clip_td_err = 0; c->record_verbose_level = 0;
     c->device = -1; c->param_seed = 0;
+    c->arithmetic = BDR_ARITH_BF16X3_6;
 }
 
 int32_t bdr_dqn_create(const bdr_dqn_config* cfg, bdr_agent** out)
@@ -310,6 +311,7 @@ int32_t bdr_dqn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_REQUIRE(cfg->soft_update_interval >= 1 && cfg->n_updates_per_opt >= 1, "intervals must be >= 1");
     BDR_REQUIRE(cfg->critic_loss == BDR_LOSS_MSE || cfg->critic_loss == BDR_LOSS_SMOOTH_L1, "unknown critic_loss");
     BDR_REQUIRE(cfg->opt_kind == BDR_OPT_ADAM || cfg->opt_kind == BDR_OPT_ADAMW, "unknown optimizer");
+    BDR_REQUIRE(cfg->arithmetic == BDR_ARITH_BF16X3_6 || cfg->arithmetic == BDR_ARITH_F32_EXACT, "unknown arithmetic %d (BDR_ARITH_*)", cfg->arithmetic);
     BDR_TRY(ensure_device(cfg->device));
     return cfg->net.kind == BDR_NET_ATARI_CNN ? dqn_cnn_create(cfg, out) : dqn_mlp_create(cfg, out);
 }

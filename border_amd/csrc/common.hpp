@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,6 +52,15 @@ inline int32_t fail(int32_t code, const char* fmt, ...)
 inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 int32_t ensure_device(int32_t device);
+
+// bdr_{dqn,iqn}_config::arithmetic -> "the large layers take the split-operand bf16 kernels".  `override_var` (=1 exact, =0 split;
+// set but empty counts as 1, as in round 5) is read for A/B runs only: the boundary's field is what a caller states.
+inline bool arith_is_split(int32_t arithmetic, const char* override_var)
+{
+    bool split = arithmetic != BDR_ARITH_F32_EXACT;
+    if (const char* e = getenv(override_var)) split = e[0] == '0';
+    return split;
+}
 
 }  // namespace bdr
 

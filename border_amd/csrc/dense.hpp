@@ -768,6 +768,7 @@ struct DenseReduceSeg { const float* part; size_t stride; int chunks; unsigned o
 struct ReduceAdamArgs {
     DenseReduceSeg seg[RA_SEGS]; int nseg; size_t inst_part_stride;   // instance z reads seg.part + z * inst_part_stride
     float* p[RA_INST]; float* g[RA_INST]; float* m[RA_INST]; float* v[RA_INST]; float* tgt[RA_INST];
+    float* vmax[RA_INST];   // AdamW{amsgrad: true}: max_exp_avg_sq of instance z (nullptr: plain Adam / AdamW)
     AdamScalars s[RA_INST]; unsigned n4; float tau, omt; int track;
     int grads_only;   // 1: sum the partials into the gradient arena and stop (synchronous-DP mode: the all-reduce comes before Adam)
     const unsigned* poison;   // optional: a cross-queue wait of the step timed out (queue_flags.hpp) - the inputs may be incomplete, leave everything alone
@@ -800,11 +801,22 @@ __global__ __launch_bounds__(256) void k_dense_reduce_adam(ReduceAdamArgs a)
     if (a.grads_only) return;
     f32x4 pp = reinterpret_cast<f32x4*>(a.p[z])[i], mm = reinterpret_cast<f32x4*>(a.m[z])[i], vv = reinterpret_cast<f32x4*>(a.v[z])[i];
     const AdamScalars s = a.s[z];
+    if (a.vmax[z]) {   // (uniform per launch row z)
+        f32x4 xx = reinterpret_cast<f32x4*>(a.vmax[z])[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float pe = pp[j], me = mm[j], ve = vv[j];
-        adam_element(pe, gg[j], me, ve, s);
-        pp[j] = pe; mm[j] = me; vv[j] = ve;
+        for (int j = 0; j < 4; ++j) {
+            float pe = pp[j], me = mm[j], ve = vv[j], xe = xx[j];
+            adam_element_amsgrad(pe, gg[j], me, ve, xe, s);
+            pp[j] = pe; mm[j] = me; vv[j] = ve; xx[j] = xe;
+        }
+        reinterpret_cast<f32x4*>(a.vmax[z])[i] = xx;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pe = pp[j], me = mm[j], ve = vv[j];
+            adam_element(pe, gg[j], me, ve, s);
+            pp[j] = pe; mm[j] = me; vv[j] = ve;
+        }
     }
     reinterpret_cast<f32x4*>(a.p[z])[i] = pp;
     reinterpret_cast<f32x4*>(a.m[z])[i] = mm;

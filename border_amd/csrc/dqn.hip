@@ -1457,7 +1457,7 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->kev = getenv("BDR_NO_KEV") == nullptr;
     a->side_gather = getenv("BDR_NO_SIDE_GATHER") == nullptr;
     a->split_fwd = getenv("BDR_NO_SPLIT_FWD") == nullptr;
-    a->conv_b3 = getenv("BDR_DQN_F32_EXACT") == nullptr;
+    a->conv_b3 = arith_is_split(cfg->arithmetic, "BDR_DQN_F32_EXACT");   // bdr_dqn_config::arithmetic; the variable overrides it for A/B runs only
     if (a->conv_b3) for (auto& pl : a->cpl) BDR_HIP(hipMalloc((void**)&pl, CPL_U16 * 2));
     a->three_queues = getenv("BDR_TQ") != nullptr;
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};

@@ -161,6 +161,7 @@ struct Iqn : bdr_agent {
     MlpLayout hd;               // L[0] = cos-embed layer (E -> F, relu), L[1..] = f layers
     size_t total = 0, ref_total = 0;
     float *p = nullptr, *p_tgt = nullptr, *grad = nullptr, *am = nullptr, *av = nullptr;
+    float* avmax = nullptr;     // AdamW{amsgrad: true}: max_exp_avg_sq (arena 5)
     // batch buffers
     int B = 0, Nmax = 0;
     float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *dy3 = nullptr, *dy2 = nullptr, *dy1 = nullptr, *part_conv = nullptr;
@@ -221,7 +222,7 @@ struct Iqn : bdr_agent {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
         free_batch();
-        (void)hipFree(p); (void)hipFree(p_tgt); (void)hipFree(grad); (void)hipFree(am); (void)hipFree(av); (void)hipFree(loss);
+        (void)hipFree(p); (void)hipFree(p_tgt); (void)hipFree(grad); (void)hipFree(am); (void)hipFree(av); (void)hipFree(avmax); (void)hipFree(loss);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
         (void)hipFree(wpl_nat); (void)hipFree(wpl_tr); (void)hipFree(cpl_tr); (void)hipFree(dypl_tr); (void)hipFree(act_part); (void)hipFree(act_tickets);
     }
@@ -451,7 +452,13 @@ struct Iqn : bdr_agent {
             }
         }
         adam_step += 1;
-        { Bracket br(a, "adam"); BDR_TRY(launch_adam(stream, p, grad, am, av, total, adam_scalars_for(false, cfg.lr, 0, 0, 0, 0, adam_step))); }
+        {   // IqnModel::backward_step (iqn/model/base.rs) -> opt.rs:74-83; OptimizerConfig::{Adam, AdamW} (opt.rs:30-57)
+            const bdr_adamw_config& o = cfg.opt;
+            const AdamScalars sc = adam_scalars_for(o.opt_kind == BDR_OPT_ADAMW, cfg.lr, o.beta1, o.beta2, o.eps, o.weight_decay, adam_step);
+            Bracket br(a, "adam");
+            if (avmax) BDR_TRY(launch_adam_amsgrad(stream, p, grad, am, av, avmax, total, sc));
+            else BDR_TRY(launch_adam(stream, p, grad, am, av, total, sc));
+        }
         return BDR_OK;
     }
 
@@ -588,13 +595,13 @@ struct Iqn : bdr_agent {
     }
     float* arena_ptr(int which)
     {
-        switch (which) { case 0: return p; case 1: return p_tgt; case 2: return am; case 3: return av; case 4: return grad; default: return nullptr; }
+        switch (which) { case 0: return p; case 1: return p_tgt; case 2: return am; case 3: return av; case 4: return grad; case 5: return avmax; default: return nullptr; }
     }
     uint64_t param_count(int which) override { return which == -1 ? (uint64_t)A : ref_total; }
     int32_t get_params(int which, float* out, uint64_t n) override
     {
         float* src = arena_ptr(which);
-        BDR_REQUIRE(src, "which must be 0..4");
+        BDR_REQUIRE(src, "which must be 0..4 (5: max_exp_avg_sq of AdamW{amsgrad})");
         BDR_REQUIRE(n == ref_total, "parameter count mismatch (%llu vs %llu)", (unsigned long long)n, (unsigned long long)ref_total);
         std::vector<float> in(total);
         BDR_HIP(hipMemcpyAsync(in.data(), src, total * 4, hipMemcpyDeviceToHost, stream));
@@ -605,7 +612,7 @@ struct Iqn : bdr_agent {
     int32_t set_params(int which, const float* inp, uint64_t n) override
     {
         float* dst = arena_ptr(which);
-        BDR_REQUIRE(dst, "which must be 0..4");
+        BDR_REQUIRE(dst, "which must be 0..4 (5: max_exp_avg_sq of AdamW{amsgrad})");
         BDR_REQUIRE(n == ref_total, "parameter count mismatch");
         std::vector<float> in(total);
         to_internal(inp, in.data());
@@ -679,6 +686,8 @@ void bdr_iqn_config_default(bdr_iqn_config* c)
     c->soft_update_interval = 1; c->n_updates_per_opt = 1; c->batch_size = 1; c->discount_factor = 0.99; c->tau = 0.005;
     c->sample_percents_pred = BDR_IQN_UNIFORM8; c->sample_percents_tgt = BDR_IQN_UNIFORM8; c->sample_percents_act = BDR_IQN_CONST32;
     c->train = 0; c->device = -1;
+    c->opt.opt_kind = BDR_OPT_ADAM; c->opt.beta1 = 0.9; c->opt.beta2 = 0.999; c->opt.weight_decay = 0.0; c->opt.eps = 1e-8;
+    c->arithmetic = BDR_ARITH_BF16X3_6;
 }
 
 int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
@@ -690,11 +699,13 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     BDR_REQUIRE(cfg->n_f_units >= 0 && cfg->n_f_units <= BDR_MAX_UNITS, "bad merge-net layer count");
     for (int m : {cfg->sample_percents_pred, cfg->sample_percents_tgt, cfg->sample_percents_act}) BDR_REQUIRE(m >= 0 && m <= 6, "unknown IqnSample");
     BDR_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= 65536 && cfg->n_updates_per_opt >= 1 && cfg->soft_update_interval >= 1, "bad counts");
+    BDR_REQUIRE(cfg->opt.opt_kind == BDR_OPT_ADAM || cfg->opt.opt_kind == BDR_OPT_ADAMW, "unknown optimizer");
+    BDR_REQUIRE(cfg->arithmetic == BDR_ARITH_BF16X3_6 || cfg->arithmetic == BDR_ARITH_F32_EXACT, "unknown arithmetic %d (BDR_ARITH_*)", cfg->arithmetic);
     BDR_TRY(ensure_device(cfg->device));
     Iqn* a = new Iqn();
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
     a->cnn = cfg->psi.kind == BDR_NET_ATARI_CNN;
-    a->b3_allowed = getenv("BDR_IQN_F32_EXACT") == nullptr;
+    a->b3_allowed = arith_is_split(cfg->arithmetic, "BDR_IQN_F32_EXACT");   // bdr_iqn_config::arithmetic; the variable overrides it for A/B runs only
     a->merge_epilogue = getenv("BDR_IQN_NO_MERGE_EPILOGUE") == nullptr;
     a->phi_b3 = getenv("BDR_IQN_PHI_F32") == nullptr;                         // (A/B switch: the cosine-embedding layer on the FP32 kernel)
     a->dw_b3 = getenv("BDR_IQN_DW_F32") == nullptr;                        // (A/B switch: the FP32-MFMA weight gradient of the merge layer)   // (A/B switch: the separate k_iqn_merge_bwd pass)
@@ -724,6 +735,7 @@ int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out)
     BDR_TRY(a->err_init());
     float** arenas[5] = {&a->p, &a->p_tgt, &a->grad, &a->am, &a->av};
     for (auto q : arenas) BDR_TRY(a->zalloc(q, a->total));
+    if (cfg->opt.opt_kind == BDR_OPT_ADAMW && cfg->opt.amsgrad) BDR_TRY(a->zalloc(&a->avmax, a->total));
     BDR_TRY(a->zalloc(&a->loss, 4));
     {   // library initialiser (uniform +-1/sqrt(fan_in)); model cloned into its target (IqnModel::clone)
         std::vector<float> ref(a->ref_total);

@@ -312,6 +312,7 @@ struct Sac : bdr_agent, SacBatch {
     MlpLayout qn;               // critic layout (same for every critic / target)
     // arenas
     float *pi_p = nullptr, *pi_g = nullptr, *pi_m = nullptr, *pi_v = nullptr;
+    float* pi_vmax = nullptr; float* q_vmax[4] = {nullptr};   // AdamW{amsgrad: true} of the actor / the critics: max_exp_avg_sq (parameter model +400)
     float* q_p[4] = {nullptr}; float* q_t[4] = {nullptr}; float* q_g[4] = {nullptr}; float* q_m[4] = {nullptr}; float* q_v[4] = {nullptr};
     float *log_alpha = nullptr, *al_m = nullptr, *al_v = nullptr;
     uint64_t step_pi = 0, step_q[4] = {0}, step_al = 0;
@@ -370,7 +371,8 @@ struct Sac : bdr_agent, SacBatch {
         if (ev_main) (void)hipEventDestroy(ev_main);
         (void)hipFree(sig);
         free_batch();
-        (void)hipFree(pi_p); (void)hipFree(pi_g); (void)hipFree(pi_m); (void)hipFree(pi_v);
+        (void)hipFree(pi_p); (void)hipFree(pi_g); (void)hipFree(pi_m); (void)hipFree(pi_v); (void)hipFree(pi_vmax);
+        for (auto q : q_vmax) (void)hipFree(q);
         for (int i = 0; i < 4; ++i) { (void)hipFree(q_p[i]); (void)hipFree(q_t[i]); (void)hipFree(q_g[i]); (void)hipFree(q_m[i]); (void)hipFree(q_v[i]); }
         (void)hipFree(log_alpha); (void)hipFree(al_m); (void)hipFree(al_v); (void)hipFree(scal);
         (void)hipFree(u_obs); (void)hipFree(u_next); (void)hipFree(u_act); (void)hipFree(u_rew); (void)hipFree(u_term);
@@ -597,10 +599,15 @@ struct Sac : bdr_agent, SacBatch {
         if (NC == 1) return dense_dx(stream, qn.L[l], pb[0], dy[0], dx[0], mask[0], Bn, false, small_gemm);
         return dense_dx_z(stream, qn.L[l], NC, pb, dy, dx, l == 0 ? nullptr : mask, Bn, small_gemm);
     }
+    // OptimizerConfig::{Adam, AdamW} of one model (opt.rs:30-57) at optimizer step `step`
+    static AdamScalars opt_scalars(const bdr_adamw_config& o, double lr, uint64_t step)
+    {
+        return adam_scalars_for(o.opt_kind == BDR_OPT_ADAMW, lr, o.beta1, o.beta2, o.eps, o.weight_decay, step);
+    }
     // partial sums of a grouped dW launch -> gradient arena, Adam, (tracking) for `ninst` networks of one layout
     int32_t reduce_adam(const MlpLayout& net, const std::vector<size_t>& off, const std::vector<int>& chunks, int Bn, const float* part,
                         size_t inst_stride, int ninst, float* const* p, float* const* g, float* const* m, float* const* v,
-                        float* const* tgt_p, const AdamScalars* sc, int applied_slot, uint64_t applied_value)
+                        float* const* tgt_p, const AdamScalars* sc, int applied_slot, uint64_t applied_value, float* const* vmax = nullptr)
     {
         ReduceAdamArgs ra{};
         ra.nseg = (int)net.L.size(); ra.inst_part_stride = inst_stride;
@@ -609,7 +616,7 @@ struct Sac : bdr_agent, SacBatch {
             const size_t nfl = (size_t)L.Kp * L.Np + L.Np;
             ra.seg[l] = DenseReduceSeg{part + off[l], nfl, std::min(chunks[l], std::max(1, Bn / (small_gemm ? 256 : 64))), (unsigned)(L.w / 4), (unsigned)(nfl / 4)};
         }
-        for (int i = 0; i < ninst; ++i) { ra.p[i] = p[i]; ra.g[i] = g[i]; ra.m[i] = m[i]; ra.v[i] = v[i]; ra.tgt[i] = tgt_p ? tgt_p[i] : nullptr; ra.s[i] = sc[i]; }
+        for (int i = 0; i < ninst; ++i) { ra.p[i] = p[i]; ra.g[i] = g[i]; ra.m[i] = m[i]; ra.v[i] = v[i]; ra.tgt[i] = tgt_p ? tgt_p[i] : nullptr; ra.s[i] = sc[i]; ra.vmax[i] = vmax ? vmax[i] : nullptr; }
         ra.n4 = (unsigned)(net.total / 4); ra.track = tgt_p ? 1 : 0; ra.tau = (float)cfg.tau; ra.omt = (float)(1.0 - cfg.tau);
         ra.poison = dev_err + ERR_GATE;
         ra.applied = applied + applied_slot; ra.step = applied_value;
@@ -765,9 +772,9 @@ struct Sac : bdr_agent, SacBatch {
             jobs[nj++] = DenseDwJob{&pi.L[n_trunk + 1], hin, ge, pi_part + pi_off[n_trunk + 1], chunks_rt(pi_chunks[n_trunk + 1])};
             { Bracket br(a, "pi_dw"); BDR_TRY(small_gemm ? dense_dw_small_group(stream, jobs, nj, Bn) : dense_dw_group(stream, jobs, nj, Bn)); }
             step_pi += 1;
-            const AdamScalars sc = adam_scalars_for(false, cfg.lr_actor, 0, 0, 0, 0, step_pi);
+            const AdamScalars sc = opt_scalars(cfg.opt_actor, cfg.lr_actor, step_pi);   // Actor::backward_step -> opt.rs:74-83
             Bracket br(a, "adam_pi");
-            BDR_TRY(reduce_adam(pi, pi_off, pi_chunks, Bn, pi_part, 0, 1, &pi_p, &pi_g, &pi_m, &pi_v, nullptr, &sc, AP_PI, step_pi));
+            BDR_TRY(reduce_adam(pi, pi_off, pi_chunks, Bn, pi_part, 0, 1, &pi_p, &pi_g, &pi_m, &pi_v, nullptr, &sc, AP_PI, step_pi, &pi_vmax));
         }
 
         // ---------------- update_critic (sac/base.rs:107-149) ----------------
@@ -817,9 +824,9 @@ struct Sac : bdr_agent, SacBatch {
                                               q_part + (size_t)i * q_part_stride + q_off[l], std::min(q_chunks[l], std::max(1, Bn / (small_gemm ? 256 : 64)))});
             { Bracket br(a, "q_dw"); BDR_TRY(small_gemm ? dense_dw_small_group(stream, jobs.data(), (int)jobs.size(), Bn) : dense_dw_group(stream, jobs.data(), (int)jobs.size(), Bn)); }
             AdamScalars sc[4];
-            for (int i = 0; i < NC; ++i) { step_q[i] += 1; sc[i] = adam_scalars_for(false, cfg.lr_critic, 0, 0, 0, 0, step_q[i]); }
+            for (int i = 0; i < NC; ++i) { step_q[i] += 1; sc[i] = opt_scalars(cfg.opt_critic, cfg.lr_critic, step_q[i]); }
             Bracket br(a, "adam_q_track");
-            BDR_TRY(reduce_adam(qn, q_off, q_chunks, Bn, q_part, q_part_stride, NC, q_p, q_g, q_m, q_v, q_t, sc, AP_Q, step_q[0]));
+            BDR_TRY(reduce_adam(qn, q_off, q_chunks, Bn, q_part, q_part_stride, NC, q_p, q_g, q_m, q_v, q_t, sc, AP_Q, step_q[0], q_vmax));
         }
         n_opts += 1;
         last_B = Bn;
@@ -939,13 +946,13 @@ struct Sac : bdr_agent, SacBatch {
         return BDR_OK;
     }
 
-    // which: 0 pi, 1+i qnet_i, 1+NC+i qnet_tgt_i, 1+2NC log_alpha;  +100 grad, +200 exp_avg, +300 exp_avg_sq
+    // which: 0 pi, 1+i qnet_i, 1+NC+i qnet_tgt_i, 1+2NC log_alpha;  +100 grad, +200 exp_avg, +300 exp_avg_sq, +400 max_exp_avg_sq (AdamW{amsgrad})
     struct Slot { float* p; const MlpLayout* lay; size_t n; };
     Slot slot(int which)
     {
         const int role = which / 100, id = which % 100;
-        if (id == 0) { float* r[4] = {pi_p, pi_g, pi_m, pi_v}; return role < 4 ? Slot{r[role], &pi, pi.total} : Slot{nullptr, nullptr, 0}; }
-        if (id >= 1 && id <= NC) { const int i = id - 1; float* r[4] = {q_p[i], q_g[i], q_m[i], q_v[i]}; return role < 4 ? Slot{r[role], &qn, qn.total} : Slot{nullptr, nullptr, 0}; }
+        if (id == 0) { float* r[5] = {pi_p, pi_g, pi_m, pi_v, pi_vmax}; return role < 5 && r[role] ? Slot{r[role], &pi, pi.total} : Slot{nullptr, nullptr, 0}; }
+        if (id >= 1 && id <= NC) { const int i = id - 1; float* r[5] = {q_p[i], q_g[i], q_m[i], q_v[i], q_vmax[i]}; return role < 5 && r[role] ? Slot{r[role], &qn, qn.total} : Slot{nullptr, nullptr, 0}; }
         if (id >= 1 + NC && id <= 2 * NC && role == 0) return Slot{q_t[id - 1 - NC], &qn, qn.total};
         if (id == 1 + 2 * NC) { float* r[4] = {log_alpha, nullptr, al_m, al_v}; return (role < 4 && r[role]) ? Slot{r[role], nullptr, 4} : Slot{nullptr, nullptr, 0}; }
         return Slot{nullptr, nullptr, 0};
@@ -1050,6 +1057,7 @@ void bdr_sac_config_default(bdr_sac_config* c)
     c->gamma = 0.99; c->tau = 0.005; c->ent_coef_auto = 0; c->ent_coef_alpha = 1.0; c->epsilon = 1e-4;
     c->min_lstd = -20.0; c->max_lstd = 2.0; c->n_updates_per_opt = 1; c->batch_size = 1; c->train = 0;
     c->critic_loss = BDR_LOSS_MSE; c->reward_scale = 1.0; c->n_critics = 1; c->device = -1;
+    for (bdr_adamw_config* o : {&c->opt_actor, &c->opt_critic}) { o->opt_kind = BDR_OPT_ADAM; o->beta1 = 0.9; o->beta2 = 0.999; o->weight_decay = 0.0; o->eps = 1e-8; }
 }
 
 int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
@@ -1060,6 +1068,7 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     BDR_REQUIRE(cfg->n_pi_units >= 1 && cfg->n_pi_units <= BDR_MAX_UNITS && cfg->n_q_units >= 0 && cfg->n_q_units <= BDR_MAX_UNITS, "bad layer counts");
     BDR_REQUIRE(cfg->n_critics >= 1 && cfg->n_critics <= 4, "n_critics must be in [1,4]");
     BDR_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= 65536 && cfg->n_updates_per_opt >= 1, "bad batch / update counts");
+    for (const bdr_adamw_config* o : {&cfg->opt_actor, &cfg->opt_critic}) BDR_REQUIRE(o->opt_kind == BDR_OPT_ADAM || o->opt_kind == BDR_OPT_ADAMW, "unknown optimizer");
     BDR_TRY(ensure_device(cfg->device));
     Sac* a = new Sac();
     a->cfg = *cfg; a->device = cfg->device; a->train = cfg->train != 0;
@@ -1107,9 +1116,11 @@ int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out)
     }
     float** pis[4] = {&a->pi_p, &a->pi_g, &a->pi_m, &a->pi_v};
     for (auto p : pis) BDR_TRY(a->zalloc(p, a->pi.total));
+    if (cfg->opt_actor.opt_kind == BDR_OPT_ADAMW && cfg->opt_actor.amsgrad) BDR_TRY(a->zalloc(&a->pi_vmax, a->pi.total));
     for (int i = 0; i < a->NC; ++i) {
         float** qs[5] = {&a->q_p[i], &a->q_t[i], &a->q_g[i], &a->q_m[i], &a->q_v[i]};
         for (auto p : qs) BDR_TRY(a->zalloc(p, a->qn.total));
+        if (cfg->opt_critic.opt_kind == BDR_OPT_ADAMW && cfg->opt_critic.amsgrad) BDR_TRY(a->zalloc(&a->q_vmax[i], a->qn.total));
     }
     BDR_TRY(a->zalloc(&a->log_alpha, 4)); BDR_TRY(a->zalloc(&a->al_m, 4)); BDR_TRY(a->zalloc(&a->al_v, 4)); BDR_TRY(a->zalloc(&a->scal, 4));
     // initial parameters: library initialiser; critics cloned into their targets (Critic::clone)

@@ -111,6 +111,7 @@ class DqnConfig:
     critic_loss: str = "Mse"                # util.rs:17-23
     record_verbose_level: int = 0
     param_seed: int = 0
+    arithmetic: str = "bf16x3_6"            # BDR_ARITH_* (include/border_amd.h; not a reference field): "bf16x3_6" | "f32_exact"
 
     def to_c(self) -> _lib.DqnConfigC:
         c = _lib.DqnConfigC()
@@ -141,6 +142,7 @@ class DqnConfig:
         c.record_verbose_level = self.record_verbose_level
         c.device = -1 if self.device is None else self.device
         c.param_seed = self.param_seed
+        c.arithmetic = _lib.ARITHMETIC[self.arithmetic]
         return c
 
 

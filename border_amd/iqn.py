@@ -15,7 +15,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib
-from .dqn import AtariCnnConfig, MlpConfig
+from .dqn import AtariCnnConfig, MlpConfig, OptimizerConfig
 from .replay import SimpleReplayBuffer
 
 IQN_SAMPLE = {"Const10": 0, "Const32": 1, "Uniform10": 2, "Uniform8": 3, "Uniform32": 4, "Uniform64": 5, "Median": 6}
@@ -29,6 +29,7 @@ class IqnConfig:
     m_units: Tuple[int, ...] = (512,)            # merge net M = Mlp(feature_dim, units, n_actions)
     n_actions: int = 0
     lr: float = 1e-4
+    opt_config: Optional[OptimizerConfig] = None   # IqnModelConfig.opt_config (iqn/model/config.rs:50); None = OptimizerConfig.Adam(lr)
     soft_update_interval: int = 1
     n_updates_per_opt: int = 1
     batch_size: int = 1
@@ -40,6 +41,7 @@ class IqnConfig:
     train: bool = False
     device: Optional[int] = None
     seed: int = 0
+    arithmetic: str = "bf16x3_6"                 # BDR_ARITH_* (not a reference field): "bf16x3_6" | "f32_exact"
 
     def to_c(self) -> _lib.IqnConfigC:
         c = _lib.IqnConfigC()
@@ -61,6 +63,10 @@ class IqnConfig:
                                                                                IQN_SAMPLE[self.sample_percents_tgt],
                                                                                IQN_SAMPLE[self.sample_percents_act])
         c.train, c.device, c.seed = int(self.train), -1 if self.device is None else self.device, self.seed
+        if self.opt_config is not None:
+            c.lr = self.opt_config.lr
+            c.opt.fill(self.opt_config)
+        c.arithmetic = _lib.ARITHMETIC[self.arithmetic]
         return c
 
 
@@ -69,7 +75,7 @@ def _p(a):
 
 
 class Iqn:
-    WHICH = {"qnet": 0, "iqn": 0, "iqn_tgt": 1, "exp_avg": 2, "exp_avg_sq": 3, "grad": 4}
+    WHICH = {"qnet": 0, "iqn": 0, "iqn_tgt": 1, "exp_avg": 2, "exp_avg_sq": 3, "grad": 4, "max_exp_avg_sq": 5}
 
     def arena_device_ptr(self, which="iqn"):
         """(device pointer, float count) of a flat parameter arena in the kernels' internal layout."""

@@ -14,6 +14,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib
+from .dqn import OptimizerConfig
 from .replay import SimpleReplayBuffer
 
 
@@ -25,6 +26,8 @@ class SacConfig:
     q_units: Tuple[int, ...] = (64, 64)         # CriticConfig.q_config
     lr_actor: float = 3e-4
     lr_critic: float = 3e-4
+    opt_actor: Optional[OptimizerConfig] = None   # ActorConfig.opt_config (sac/actor/config.rs:15); None = OptimizerConfig.Adam(lr_actor)
+    opt_critic: Optional[OptimizerConfig] = None  # CriticConfig.opt_config; None = OptimizerConfig.Adam(lr_critic)
     gamma: float = 0.99
     tau: float = 0.005
     ent_coef_mode: tuple = ("Fix", 1.0)          # or ("Auto", target_entropy, lr)
@@ -59,6 +62,12 @@ class SacConfig:
         c.critic_loss = {"Mse": 0, "SmoothL1": 1}[self.critic_loss]
         c.reward_scale, c.n_critics, c.seed = self.reward_scale, self.n_critics, self.seed
         c.device = -1 if self.device is None else self.device
+        if self.opt_actor is not None:
+            c.lr_actor = self.opt_actor.lr
+            c.opt_actor.fill(self.opt_actor)
+        if self.opt_critic is not None:
+            c.lr_critic = self.opt_critic.lr
+            c.opt_critic.fill(self.opt_critic)
         return c
 
 
@@ -103,7 +112,7 @@ class Sac:
             i = 1 + int(name[len("qnet_"):])
         else:
             i = base[name]
-        return i + {"param": 0, "grad": 100, "exp_avg": 200, "exp_avg_sq": 300}[role]
+        return i + {"param": 0, "grad": 100, "exp_avg": 200, "exp_avg_sq": 300, "max_exp_avg_sq": 400}[role]
 
     WHICH = {"qnet": 0, "pi": 0}   # ParamExchange / ModelMailbox: SyncModel ships `pi` (sac/base.rs:377-386) == model 0
 

@@ -201,6 +201,25 @@ enum { BDR_LOSS_MSE = 0, BDR_LOSS_SMOOTH_L1 = 1 };        /* util.rs:17-23 Criti
 enum { BDR_OPT_ADAM = 0, BDR_OPT_ADAMW = 1 };             /* opt.rs:13-28 OptimizerConfig  */
 #define BDR_MAX_UNITS 8
 
+/* Which products the large matrix layers of an agent compute.  NOT a reference field: the reference has one arithmetic (f32
+ * products, f32 accumulation in ATen's summation order).  Both settings accumulate in f32 and sit inside the 1e-4 parity bar:
+ *   BDR_ARITH_BF16X3_6   (default) every f32 operand of conv2 / conv3 forward (DQN) and of the merge / cosine-embedding layers
+ *                        (IQN at C4-sized shapes) is split, round-to-nearest, into three bf16 terms (a = a0 + a1 + a2 exactly up to
+ *                        the last bit) and six of the nine partial products run on the bf16 MFMA; the three dropped products are
+ *                        <= 2^-24 relative per product, zero-mean.  Every other layer, every gradient and the n <= 8 acting
+ *                        kernels compute exact f32 products.
+ *   BDR_ARITH_F32_EXACT  every product is an f32 x f32 product on the FP32 MFMA (v_mfma_f32_32x32x2_f32).
+ * The environment variables BDR_DQN_F32_EXACT / BDR_IQN_F32_EXACT (=1 exact, =0 split) override the field for A/B runs only. */
+enum { BDR_ARITH_BF16X3_6 = 0, BDR_ARITH_F32_EXACT = 1 };
+
+/* OptimizerConfig's AdamW variant (opt.rs:20-27, 38-55) beside a model's `lr`: opt_kind BDR_OPT_ADAM ignores every other field
+ * (tch nn::Adam::default(): .9, .999, 1e-8, wd 0); amsgrad keeps a max_exp_avg_sq arena (parameter model +400 / arena 5). */
+typedef struct {
+    int32_t opt_kind; /* BDR_OPT_* */
+    int32_t amsgrad;
+    double beta1, beta2, weight_decay, eps;
+} bdr_adamw_config;
+
 /* AtariCnnConfig (cnn/config.rs:13-18) / MlpConfig (mlp/config.rs:7-12) */
 typedef struct {
     int32_t kind;    /* BDR_NET_* */
@@ -232,6 +251,8 @@ typedef struct {
     int32_t record_verbose_level;
     int32_t device; /* HIP device ordinal ("No device is given for DQN agent": dqn/base.rs:256) */
     uint64_t param_seed; /* seed of the library's own uniform(+-1/sqrt(fan_in)) initialiser */
+    int32_t arithmetic;  /* BDR_ARITH_* (AtariCnn only; an Mlp Q-network always computes exact f32 products) */
+    int32_t reserved;
 } bdr_dqn_config;
 
 BDR_API void bdr_dqn_config_default(bdr_dqn_config* cfg); /* dqn/config.rs:82-102 */
@@ -602,13 +623,16 @@ typedef struct {
     int32_t feature_dim, embed_dim;                   /* IqnModelConfig */
     int32_t n_f_units; int32_t f_units[BDR_MAX_UNITS];   /* merge net M = Mlp(feature_dim -> units -> n_actions) */
     int32_t n_actions;
-    double lr;                                        /* OptimizerConfig::Adam{lr} */
+    double lr;                                        /* OptimizerConfig::{Adam,AdamW}.lr; AdamW fields: `opt` below */
     uint64_t soft_update_interval, n_updates_per_opt, batch_size;
     double discount_factor, tau;
     int32_t sample_percents_pred, sample_percents_tgt, sample_percents_act;
     int32_t train;
     int32_t device;
     uint64_t seed;
+    bdr_adamw_config opt;        /* IqnModelConfig.opt_config (iqn/model/config.rs:50) when it is AdamW; `lr` above either way */
+    int32_t arithmetic;          /* BDR_ARITH_* */
+    int32_t reserved;
 } bdr_iqn_config;
 BDR_API void bdr_iqn_config_default(bdr_iqn_config* cfg);                    /* iqn/config.rs:50-67 */
 BDR_API int32_t bdr_iqn_create(const bdr_iqn_config* cfg, bdr_agent** out);  /* iqn/base.rs:230-268 */
@@ -632,7 +656,7 @@ typedef struct {
     int32_t obs_dim, act_dim;
     int32_t n_pi_units; int32_t pi_units[BDR_MAX_UNITS];   /* ActorConfig.pi_config (MlpConfig.units) */
     int32_t n_q_units;  int32_t q_units[BDR_MAX_UNITS];    /* CriticConfig.q_config                  */
-    double lr_actor, lr_critic;                             /* OptimizerConfig::Adam{lr} of each       */
+    double lr_actor, lr_critic;                             /* lr of each model; AdamW fields: opt_actor / opt_critic below */
     double gamma, tau;
     int32_t ent_coef_auto;       /* EntCoefMode::Auto(target_entropy, lr) vs Fix(alpha) */
     double ent_coef_alpha, target_entropy, ent_coef_lr;
@@ -644,13 +668,15 @@ typedef struct {
     int32_t n_critics;
     int32_t device;
     uint64_t seed;
+    bdr_adamw_config opt_actor;  /* ActorConfig.opt_config (sac/actor/config.rs:15) when it is AdamW; lr_actor above either way  */
+    bdr_adamw_config opt_critic; /* CriticConfig.opt_config (sac/critic/config.rs) likewise; EntCoef keeps nn::Adam::default() (ent_coef.rs:41) */
 } bdr_sac_config;
 BDR_API void bdr_sac_config_default(bdr_sac_config* cfg);                    /* sac/config.rs:85-105  */
 BDR_API int32_t bdr_sac_create(const bdr_sac_config* cfg, bdr_agent** out);  /* sac/base.rs:237-285   */
 /* One Sac::opt_ loop iteration on a host minibatch with injected N(0,1) draws (the reference takes
  * them from torch's global CPU generator, sac/base.rs:76).  rec3: loss_critic, loss_actor, ent_coef.
  * Parameter models for bdr_agent_{get,set}_params / param_count_of: 0 pi, 1+i qnet_i,
- * 1+n_critics+i qnet_tgt_i, 1+2*n_critics log_alpha; +100 gradient, +200 exp_avg, +300 exp_avg_sq. */
+ * 1+n_critics+i qnet_tgt_i, 1+2*n_critics log_alpha; +100 gradient, +200 exp_avg, +300 exp_avg_sq, +400 max_exp_avg_sq (amsgrad). */
 BDR_API int32_t bdr_sac_update_on_batch(bdr_agent* a, uint64_t n, const float* obs, const float* act,
                                         const float* next_obs, const float* reward, const int8_t* is_terminated,
                                         const float* z_actor, const float* z_next, float* rec3);

@@ -61,6 +61,47 @@ impl OptimizerConfig {
             OptimizerConfig::AdamW { lr, .. } => *lr,
         }
     }
+
+    /// -> the AdamW fields a `bdr_{iqn,sac}_config` carries beside the model's `lr` (`OptimizerConfig::build`, opt.rs:30-57).
+    pub(crate) fn fill(&self, c: &mut ffi::bdr_adamw_config) {
+        match self {
+            OptimizerConfig::Adam { .. } => c.opt_kind = ffi::BDR_OPT_ADAM, // the library's defaults are tch's Adam::default()
+            OptimizerConfig::AdamW { lr: _, beta1, beta2, wd, eps, amsgrad } => {
+                c.opt_kind = ffi::BDR_OPT_ADAMW;
+                c.beta1 = *beta1;
+                c.beta2 = *beta2;
+                c.weight_decay = *wd;
+                c.eps = *eps;
+                c.amsgrad = *amsgrad as i32;
+            }
+        }
+    }
+}
+
+/// Which products the large matrix layers compute (`BDR_ARITH_*`, include/border_amd.h).  NOT a reference field - the reference
+/// has one arithmetic, f32 - and absent in a reference YAML (-> the library default).  Both settings accumulate in f32 and stay
+/// inside the 1e-4 parity bar; `F32Exact` is what to choose when Q-values must not depend on the kernel selection at all.
+#[derive(Debug, Deserialize, Serialize, PartialEq, Clone, Copy)]
+pub enum Arithmetic {
+    /// conv2 / conv3 forward (DQN), merge / embedding layers (IQN): operands split into three bf16 terms, six of nine products.
+    Bf16x3,
+    /// every product an f32 x f32 product on the FP32 MFMA.
+    F32Exact,
+}
+
+impl Default for Arithmetic {
+    fn default() -> Self {
+        Arithmetic::Bf16x3
+    }
+}
+
+impl Arithmetic {
+    pub fn code(&self) -> i32 {
+        match self {
+            Arithmetic::Bf16x3 => ffi::BDR_ARITH_BF16X3_6,
+            Arithmetic::F32Exact => ffi::BDR_ARITH_F32_EXACT,
+        }
+    }
 }
 
 /// `mlp::MlpConfig`.
@@ -296,6 +337,9 @@ pub struct DqnConfig {
     /// torch generators are unseeded; absent in a reference YAML -> 0).
     #[serde(default)]
     pub seed: u64,
+    /// `bdr_dqn_config::arithmetic` (not a reference field; absent in a reference YAML -> the library default).
+    #[serde(default)]
+    pub arithmetic: Arithmetic,
 }
 
 impl Default for DqnConfig {
@@ -316,6 +360,7 @@ impl Default for DqnConfig {
             critic_loss: CriticLoss::Mse,
             record_verbose_level: 0,
             seed: 0,
+            arithmetic: Arithmetic::default(),
         }
     }
 }
@@ -358,6 +403,7 @@ impl DqnConfig {
     setter!(critic_loss, CriticLoss);
     setter!(record_verbose_level, usize);
     setter!(seed, u64);
+    setter!(arithmetic, Arithmetic);
     yaml_io!();
 
     pub fn out_dim(mut self, out_dim: i64) -> Self {
@@ -417,6 +463,7 @@ impl DqnConfig {
         c.record_verbose_level = self.record_verbose_level as i32;
         c.device = Device::ordinal(&self.device, "DQN");
         c.param_seed = self.seed;
+        c.arithmetic = self.arithmetic.code();
         Ok(c)
     }
 }
@@ -513,6 +560,9 @@ pub struct IqnConfig {
     /// Seed of the percent-point stream (`Tensor::rand` in the reference, iqn/model/base.rs:365-368) and of exploration.
     #[serde(default)]
     pub seed: u64,
+    /// `bdr_iqn_config::arithmetic` (not a reference field; absent in a reference YAML -> the library default).
+    #[serde(default)]
+    pub arithmetic: Arithmetic,
 }
 
 impl Default for IqnConfig {
@@ -531,6 +581,7 @@ impl Default for IqnConfig {
             explorer: DqnExplorer::Softmax(Softmax::new()),
             device: None,
             seed: 0,
+            arithmetic: Arithmetic::default(),
         }
     }
 }
@@ -547,6 +598,7 @@ impl IqnConfig {
     setter!(sample_percents_tgt, IqnSample);
     setter!(sample_percents_act, IqnSample);
     setter!(seed, u64);
+    setter!(arithmetic, Arithmetic);
     yaml_io!();
 
     pub fn out_dim(mut self, out_dim: i64) -> Self {
@@ -584,10 +636,9 @@ impl IqnConfig {
         }
         fill_units(&mm.units, &mut c.n_f_units, &mut c.f_units, "m_config")?;
         c.n_actions = mm.out_dim as i32;
-        c.lr = match &m.opt_config {
-            OptimizerConfig::Adam { lr } => *lr,
-            OptimizerConfig::AdamW { .. } => return Err(anyhow!("IQN: OptimizerConfig::Adam only (as every IQN use in the reference)")),
-        };
+        c.lr = m.opt_config.lr(); // iqn/model/config.rs:50 -> opt.rs:30-57 (Adam or AdamW)
+        m.opt_config.fill(&mut c.opt);
+        c.arithmetic = self.arithmetic.code();
         c.soft_update_interval = self.soft_update_interval as u64;
         c.n_updates_per_opt = self.n_updates_per_opt as u64;
         c.batch_size = self.batch_size as u64;
@@ -745,14 +796,11 @@ impl SacConfig {
         }
         fill_units(&pi.units, &mut c.n_pi_units, &mut c.pi_units, "pi_config")?;
         fill_units(&q.units, &mut c.n_q_units, &mut c.q_units, "q_config")?;
-        let adam = |o: &OptimizerConfig, who: &str| -> Result<f64> {
-            match o {
-                OptimizerConfig::Adam { lr } => Ok(*lr),
-                OptimizerConfig::AdamW { .. } => Err(anyhow!("SAC {}: OptimizerConfig::Adam only (as every SAC use in the reference)", who)),
-            }
-        };
-        c.lr_actor = adam(&self.actor_config.opt_config, "actor")?;
-        c.lr_critic = adam(&self.critic_config.opt_config, "critic")?;
+        // sac/actor/config.rs:15, sac/critic/config.rs: each model's own OptimizerConfig (Adam or AdamW, opt.rs:30-57)
+        c.lr_actor = self.actor_config.opt_config.lr();
+        self.actor_config.opt_config.fill(&mut c.opt_actor);
+        c.lr_critic = self.critic_config.opt_config.lr();
+        self.critic_config.opt_config.fill(&mut c.opt_critic);
         c.gamma = self.gamma;
         c.tau = self.tau;
         match &self.ent_coef_mode {

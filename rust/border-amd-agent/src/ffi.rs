@@ -23,6 +23,8 @@ pub const BDR_LOSS_MSE: i32 = 0;
 pub const BDR_LOSS_SMOOTH_L1: i32 = 1;
 pub const BDR_OPT_ADAM: i32 = 0;
 pub const BDR_OPT_ADAMW: i32 = 1;
+pub const BDR_ARITH_BF16X3_6: i32 = 0;
+pub const BDR_ARITH_F32_EXACT: i32 = 1;
 pub const BDR_MAX_UNITS: usize = 8;
 pub const BDR_EXPLORER_SOFTMAX: i32 = 0;
 pub const BDR_EXPLORER_EPS_GREEDY: i32 = 1;
@@ -134,6 +136,17 @@ pub struct bdr_net_config {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
+pub struct bdr_adamw_config {
+    pub opt_kind: i32,
+    pub amsgrad: i32,
+    pub beta1: f64,
+    pub beta2: f64,
+    pub weight_decay: f64,
+    pub eps: f64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
 pub struct bdr_dqn_config {
     pub net: bdr_net_config,
     pub opt_kind: i32,
@@ -157,6 +170,8 @@ pub struct bdr_dqn_config {
     pub record_verbose_level: i32,
     pub device: i32,
     pub param_seed: u64,
+    pub arithmetic: i32,
+    pub reserved: i32,
 }
 
 #[repr(C)]
@@ -371,6 +386,9 @@ pub struct bdr_iqn_config {
     pub train: i32,
     pub device: i32,
     pub seed: u64,
+    pub opt: bdr_adamw_config,
+    pub arithmetic: i32,
+    pub reserved: i32,
 }
 
 #[repr(C)]
@@ -401,6 +419,8 @@ pub struct bdr_sac_config {
     pub n_critics: i32,
     pub device: i32,
     pub seed: u64,
+    pub opt_actor: bdr_adamw_config,
+    pub opt_critic: bdr_adamw_config,
 }
 
 #[link(name = "border_amd")]

@@ -33,7 +33,7 @@ pub use bytes::{ActFromRows, DiscreteAct, FloatAct, ObsRows, RowBatch};
 pub use comm::Comm;
 pub use config::{
     ActorConfig, AtariCnnConfig, CriticConfig, CriticLoss, Device, DqnConfig, DqnExplorer, DqnModelConfig, EntCoefMode, EpsilonGreedy,
-    IqnConfig, IqnExplorer, IqnModelConfig, IqnSample, MlpConfig, OptimizerConfig, QNetConfig, SacConfig, Softmax,
+    Arithmetic, IqnConfig, IqnExplorer, IqnModelConfig, IqnSample, MlpConfig, OptimizerConfig, QNetConfig, SacConfig, Softmax,
 };
 pub use dqn::AmdDqn;
 pub use iqn::AmdIqn;

@@ -87,6 +87,25 @@ def dqn_kernel_bytes(B, nz, A=N_ACTIONS):
 BF16_ISSUE = {"fwd_conv1": 3, "bwd_conv1_dw": 3, "psi_conv1": 3, "psi_conv1_dw": 3, "iqn_f_fwd1_3xbf16": 6, "iqn_f_dx1_3xbf16": 6, "iqn_f_dw1_3xbf16": 6, "iqn_phi_3xbf16": 6}
 
 
+C4_SPLIT_LAYERS = ("iqn_f_fwd1", "iqn_f_dx1", "iqn_f_dw1", "iqn_phi")   # their "<label>_3xbf16" twins name the split-operand kernel of the same layer
+
+
+def iqn_kernel_flops(bs, NQ, A=N_ACTIONS):
+    """Algorithmic FLOPs of the C4 step per profile label (every layer once; labels cover all launches that carry them)."""
+    M, F, E, H = bs * NQ, 3136, 64, 512
+    c1, c2, c3 = 2 * bs * 400 * 256 * 32, 2 * bs * 81 * 512 * 64, 2 * bs * 49 * 576 * 64
+    return {"psi_conv1": 2 * c1, "psi_conv2": 2 * c2, "psi_conv3": 2 * c3, "psi_conv1_dw": c1, "psi_conv2_dw": c2, "psi_conv2_dx": c2,
+            "psi_conv3_dw": c3, "psi_conv3_dx": c3,
+            "iqn_phi": 2 * (2 * M * E * F), "iqn_f_fwd1": 2 * (2 * M * F * H), "iqn_f_fwd2": 2 * (2 * M * H * A),
+            "iqn_f_dw2": 2 * M * H * A, "iqn_f_dx2": 2 * M * H * A, "iqn_f_dw1": 2 * M * F * H, "iqn_f_dx1": 2 * M * F * H,
+            "iqn_cos_dw": 2 * M * E * F}
+
+
+def distinct_layer_flops(fl):
+    """sum of a work model over DISTINCT layers: a "<label>_3xbf16" entry is the same layer as "<label>" (one of the two runs)"""
+    return sum(v for k, v in fl.items() if not (k.endswith("_3xbf16") and k[:-len("_3xbf16")] in fl))
+
+
 def mlp_layer_dims(in_dim, units, out_dim):
     dims, i = [], in_dim
     for u in list(units) + [out_dim]:
@@ -118,22 +137,35 @@ def host_cpu_info():
 
 
 # ------------------------------------------------------------------------------------------------ configurations
-def build_config(B, name, args, rank, local_rank):
-    """-> dict(agent, rb, batch, workload, metric, extra config keys, work model)"""
+def arithmetic_is_exact(arithmetic, override_var):
+    """what the library decides (csrc/common.hpp arith_is_split): the config field, unless the A/B variable is set (=0 split, else exact)"""
+    e = os.environ.get(override_var)
+    if e is not None:
+        return not e.startswith("0")
+    return arithmetic == "f32_exact"
+
+
+def build_config(B, name, args, rank, local_rank, arithmetic=None, rb=None):
+    """-> dict(agent, rb, batch, workload, metric, extra config keys, work model).  arithmetic: bdr_{dqn,iqn}_config::arithmetic
+    (default: --arithmetic); rb: an existing replay buffer to train on (the exact-f32 twin of the headline agent shares the ring)."""
     import numpy as np
+    arithmetic = arithmetic or args.arithmetic
     if name == "c2":
         cap, bs = args.capacity or 1_000_000, args.batch or 256
-        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=B.shard_seed(42, rank),
-                                                              per_config=B.PerConfig() if args.per else None,
-                                                              frame_stack=4 if args.frame_ring else 0),
-                                  (4, 1, 84, 84), "uint8", device=local_rank)
-        rb.fill_synthetic(cap, seed=rank, kind=0, n_actions=N_ACTIONS)
+        if rb is None:
+            rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=B.shard_seed(42, rank),
+                                                                  per_config=B.PerConfig() if args.per else None,
+                                                                  frame_stack=4 if args.frame_ring else 0),
+                                      (4, 1, 84, 84), "uint8", device=local_rank)
+            rb.fill_synthetic(cap, seed=rank, kind=0, n_actions=N_ACTIONS)
         cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=B.AtariCnnConfig(n_stack=4, out_dim=N_ACTIONS),
                                                         opt_config=B.OptimizerConfig.Adam(1e-4)),
                           soft_update_interval=10000, n_updates_per_opt=1, batch_size=bs, discount_factor=0.99,
-                          tau=1.0, double_dqn=args.double_dqn, critic_loss=args.loss, device=local_rank, param_seed=0)
+                          tau=1.0, double_dqn=args.double_dqn, critic_loss=args.loss, device=local_rank, param_seed=0,
+                          arithmetic=arithmetic)
         agent = B.Dqn.build(cfg)
-        exact = os.environ.get("BDR_DQN_F32_EXACT") is not None
+        exact = arithmetic_is_exact(arithmetic, "BDR_DQN_F32_EXACT")
+        BF16_ISSUE.pop("fwd_conv2", None); BF16_ISSUE.pop("fwd_conv3", None)
         if not exact:
             BF16_ISSUE.update({"fwd_conv2": 6, "fwd_conv3": 6})
         nz = 3 if args.double_dqn else 2
@@ -150,7 +182,8 @@ def build_config(B, name, args, rank, local_rank):
                                "arithmetic": "f32 storage and accumulation throughout; conv1 forward / dW on the bf16 MFMA with exact operands; every other layer FP32 MFMA" if exact else
                                              "f32 storage and accumulation throughout; conv1 forward / dW on the bf16 MFMA with exact operands (u8 pixels, weights in 3 bf16 terms); "
                                              "conv2 / conv3 FORWARD on the bf16 MFMA with each f32 operand split exactly into 3 bf16 terms, 6 of the 9 partial products "
-                                             "(~2e-6 relative per layer vs the exact FP32-MFMA kernels, which BDR_DQN_F32_EXACT=1 selects; parity bar 1e-4); "
+                                             "(bdr_dqn_config::arithmetic = BDR_ARITH_BF16X3_6, the default; ~2e-6 relative per layer vs the exact FP32-MFMA kernels, which "
+                                             "BDR_ARITH_F32_EXACT selects and `value_exact_f32` times in this same process; parity bar 1e-4); "
                                              "l1 and every backward GEMM FP32 MFMA"},
                     dtype="f32" if exact else "f32 (conv2 / conv3 forward: 3xbf16 operand split, 6 products)",
                     which=("qnet",), loss_key="loss")
@@ -176,24 +209,20 @@ def build_config(B, name, args, rank, local_rank):
                     which=("qnet",), loss_key="loss")
     if name == "c4":
         cap, bs, NQ = args.capacity or 1_000_000, args.batch or 512, 64
-        rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=B.shard_seed(42, rank)), (4, 1, 84, 84), "uint8", device=local_rank)
-        rb.fill_synthetic(cap, seed=rank, kind=0, n_actions=N_ACTIONS)
+        if rb is None:
+            rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=B.shard_seed(42, rank)), (4, 1, 84, 84), "uint8", device=local_rank)
+            rb.fill_synthetic(cap, seed=rank, kind=0, n_actions=N_ACTIONS)
         cfg = B.IqnConfig(n_actions=N_ACTIONS, lr=1e-4, batch_size=bs, sample_percents_pred="Uniform64", sample_percents_tgt="Uniform64",
-                          soft_update_interval=10000, tau=1.0, device=local_rank, seed=rank)
+                          soft_update_interval=10000, tau=1.0, device=local_rank, seed=rank, arithmetic=arithmetic)
         agent = B.Iqn.build(cfg)
-        M, F, E, H = bs * NQ, 3136, 64, 512
-        c1, c2, c3 = 2 * bs * 400 * 256 * 32, 2 * bs * 81 * 512 * 64, 2 * bs * 49 * 576 * 64
-        fl = {"psi_conv1": 2 * c1, "psi_conv2": 2 * c2, "psi_conv3": 2 * c3, "psi_conv1_dw": c1, "psi_conv2_dw": c2, "psi_conv2_dx": c2,
-              "psi_conv3_dw": c3, "psi_conv3_dx": c3,
-              "iqn_phi": 2 * (2 * M * E * F), "iqn_f_fwd1": 2 * (2 * M * F * H), "iqn_f_fwd2": 2 * (2 * M * H * N_ACTIONS),
-              "iqn_f_dw2": 2 * M * H * N_ACTIONS, "iqn_f_dx2": 2 * M * H * N_ACTIONS, "iqn_f_dw1": 2 * M * F * H, "iqn_f_dx1": 2 * M * F * H,
-              "iqn_cos_dw": 2 * M * E * F}
-        # the merge layer's forward (both networks) and input gradient run on the bf16 matrix cores with split operands unless
-        # BDR_IQN_F32_EXACT=1; the profile label says which kernel ran (csrc/iqn.hip), the work is the same
-        fl["iqn_f_fwd1_3xbf16"], fl["iqn_f_dx1_3xbf16"], fl["iqn_f_dw1_3xbf16"], fl["iqn_phi_3xbf16"] = fl["iqn_f_fwd1"], fl["iqn_f_dx1"], fl["iqn_f_dw1"], fl["iqn_phi"]
-        exact = os.environ.get("BDR_IQN_F32_EXACT") is not None
+        fl = iqn_kernel_flops(bs, NQ)
+        step_flops = sum(fl.values())   # every layer ONCE (before the aliases below: round 5 summed the aliased dict and printed 936.7 GFLOP for 489.5)
+        # the merge layer's forward (both networks), input gradient and weight gradient and the embedding layer run on the bf16 matrix cores
+        # with split operands unless the arithmetic is f32_exact; the profile label says which kernel ran (csrc/iqn.hip), the work is the same
+        fl.update({k + "_3xbf16": fl[k] for k in C4_SPLIT_LAYERS})
+        exact = arithmetic_is_exact(arithmetic, "BDR_IQN_F32_EXACT")
         by = {"sample": 2 * bs * 28224 + bs * 14}
-        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops=fl, bytes=by, step_flops=sum(fl.values()),
+        return dict(agent=agent, rb=rb, batch=bs, capacity=cap, flops=fl, bytes=by, step_flops=step_flops,
                     metric="agent opt-steps/sec (IQN synthetic Atari, 64 quantiles, batch 512)",
                     workload=f"IQN on synthetic Atari: Nature-CNN trunk (F=3136), embed 64, merge Mlp(3136,[512],{N_ACTIONS}), "
                              f"Uniform64 pred/tgt quantiles, replay {cap} u8 transitions, batch {bs}",
@@ -201,7 +230,8 @@ def build_config(B, name, args, rank, local_rank):
                                "arithmetic": "f32 storage and accumulation throughout; FP32 MFMA for every layer" if exact else
                                              "f32 storage and accumulation throughout; the merge layer [B*64][3136] x [3136][512] (forward of both networks, input gradient, weight gradient) and the cosine-embedding layer [B*64][64] x [64][3136] "
                                              "multiplies on the bf16 matrix cores with each f32 operand split exactly into 3 bf16 terms, 6 of the 9 partial products "
-                                             "(4e-6 relative vs the exact FP32-MFMA kernels, which BDR_IQN_F32_EXACT=1 selects); every other layer FP32 MFMA"},
+                                             "(bdr_iqn_config::arithmetic = BDR_ARITH_BF16X3_6, the default; 4e-6 relative vs the exact FP32-MFMA kernels, which BDR_ARITH_F32_EXACT "
+                                             "selects and `value_exact_f32` times in this same process); every other layer FP32 MFMA"},
                     dtype="f32" if exact else "f32 (merge layer: 3xbf16 operand split, 6 products)",
                     which=("iqn",), loss_key="loss_critic")
     if name == "c5":
@@ -417,8 +447,8 @@ def roofline(conf, prof, cnt, null_ms, ms_step):
             "serial_kernel_ms": round(sum(prof.values()), 5), "launches_per_step": int(sum(cnt.values()))}
     step["frac"] = step["frac_of_fp32_peak"]
     if bf16:
-        step["note"] = ("algorithmic flops of ALL kernels over the FP32-MFMA peak: kernels on the bf16 pipes (exact / split operands) count with their "
-                        "algorithmic work, so the fraction can exceed 1 (C4); the two pipes apart: fp32_mfma, bf16_mfma_exact_split")
+        step["note"] = ("algorithmic flops of ALL kernels (every layer once) over the FP32-MFMA peak: kernels on the bf16 pipes (exact / split operands) "
+                        "count with their algorithmic work, not with the bf16 MFMAs they issue; the two pipes apart: fp32_mfma, bf16_mfma_exact_split")
     if fp32:   # the two matrix pipes apart: FP32-MFMA kernels against the FP32 peak, exact-bf16 kernels against the bf16 peak
         f32_fl, f32_ms = sum(fl[k] for k in fp32), sum(prof[k] for k in fp32)
         step["fp32_mfma"] = {"gflop": round(f32_fl / 1e9, 3), "kernel_ms": round(f32_ms, 5),
@@ -524,6 +554,10 @@ def main():
                          "form has only ever run on ONE rank (tests/test_gpu_multi.py needs 2 GPUs), and a measurement must not hang")
     ap.add_argument("--per", action="store_true", help="prioritized replay (PerConfig defaults) instead of uniform sampling (c2)")
     ap.add_argument("--frame-ring", action="store_true", help="c2 / c4: single-frame store (8.8 GB instead of 56.6 GB for 1M transitions)")
+    ap.add_argument("--arithmetic", default="bf16x3_6", choices=["bf16x3_6", "f32_exact"],
+                    help="bdr_{dqn,iqn}_config::arithmetic of the measured agent (c2 / c4): the library default (split-operand bf16 products in the large forward "
+                         "layers) or exact f32 products everywhere; with the default, N=1 runs time an exact-f32 twin as well (`value_exact_f32`)")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the exact-f32 twin of the c2 / c4 agent (value_exact_f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--profile-steps", type=int, default=30)
@@ -739,6 +773,42 @@ def main():
             result["warmup_note"] = (f"`warmup` = the W = {args.warmup} untimed steps directly in front of the K timed ones (the contract's window); "
                                      f"{untimed_before} untimed steps ran in this process before the timed ones in total (cold window + steady-state leg + W)")
         result["protocol_version"] = PROTOCOL_VERSION
+    # The exact-f32 twin (round 6): the default agent of c2 / c4 computes split-operand bf16 products in its large forward layers
+    # (bdr_{dqn,iqn}_config::arithmetic = BDR_ARITH_BF16X3_6).  A second agent built with BDR_ARITH_F32_EXACT on the same ring runs
+    # the same protocol in this process - half a second of the loop, then W untimed + K timed steps - so that every line carries both
+    # arithmetics' rates from one box.  N = 1 only; after the headline's legs, so `value` is untouched (protocol version unchanged).
+    if (rank == 0 and world == 1 and args.config in ("c2", "c4") and not args.no_exact_leg and cold is not None
+            and not arithmetic_is_exact(args.arithmetic, {"c2": "BDR_DQN_F32_EXACT", "c4": "BDR_IQN_F32_EXACT"}[args.config])):
+        agent.sync()
+        saved_issue = dict(BF16_ISSUE)
+        conf_x = build_config(B, args.config, args, rank, local_rank, arithmetic="f32_exact", rb=rb)
+        conf_x["name"] = args.config
+        ax = conf_x["agent"]
+        ax.train()
+
+        def run_x(n):
+            for _ in range(n):
+                ax.opt(rb)
+
+        run_x(args.warmup); ax.sync()
+        n_ss = max(100, int(0.5 / max(result["ms_per_step"] * 1e-3, 1e-6)))
+        t1 = time.perf_counter(); run_x(n_ss); ax.sync(); dt_ss = time.perf_counter() - t1
+        run_x(args.warmup); ax.sync()
+        t1 = time.perf_counter(); run_x(args.steps); ax.sync(); dt_x = time.perf_counter() - t1
+        rec_x = ax.opt_with_record(rb)
+        ex = {"value": round(args.steps / dt_x, 2), "unit": "opt-steps/s", "ms_per_step": round(1000.0 * dt_x / args.steps, 5),
+              "value_steady": round(n_ss / dt_ss, 2), "steady_steps": n_ss, "final_loss": round(float(rec_x[conf_x["loss_key"]]), 6),
+              "arithmetic": conf_x["cfg_extra"]["arithmetic"], "dtype": conf_x.get("dtype", "f32"),
+              "protocol": f"a second agent (arithmetic = f32_exact) on the same ring, after the headline's legs: W = {args.warmup} untimed, {n_ss} steady steps, "
+                          f"W untimed + K = {args.steps} timed"}
+        if args.profile_steps > 0:
+            prof_x, cnt_x, null_x = profile(ax, rb, args.profile_steps)
+            rx = roofline(conf_x, prof_x, cnt_x, null_x, ex["ms_per_step"])
+            ex["roofline"] = {k: rx.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "step") if k in rx}
+        ax.close()
+        BF16_ISSUE.clear(); BF16_ISSUE.update(saved_issue)
+        result["value_exact_f32"] = ex["value"]
+        result["exact_f32"] = ex
     agent.close()
     rb.close()
 

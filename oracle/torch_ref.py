@@ -80,6 +80,30 @@ def mlp_forward(p, x: torch.Tensor, activation_out=False) -> torch.Tensor:
     return x
 
 
+def optimizer_step(params, m, v, vmax, step, lr, adamw=None):
+    """One libtorch optimizer step over `params` (grads in .grad) at step number `step` (1-based), in place: Adam::step with tch's
+    nn::Adam::default() (opt.rs:35) when adamw is None, AdamW::step (adamw.cpp: decoupled decay `param.mul_(1 - lr * wd)` first;
+    amsgrad: denominator from max_exp_avg_sq) for OptimizerConfig::AdamW = dict(beta1, beta2, wd, eps[, amsgrad]) (opt.rs:38-55)."""
+    b1, b2, eps, wd, amsgrad = 0.9, 0.999, 1e-8, 0.0, False
+    if adamw is not None:
+        b1, b2, eps, wd = adamw["beta1"], adamw["beta2"], adamw["eps"], adamw["wd"]
+        amsgrad = bool(adamw.get("amsgrad", False))
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    with torch.no_grad():
+        for p, m_, v_, x_ in zip(params, m, v, vmax):
+            g = p.grad
+            if adamw is not None:
+                p.mul_(1 - lr * wd)
+            m_.mul_(b1).add_(g, alpha=1 - b1)
+            v_.mul_(b2).addcmul_(g, g, value=1 - b2)
+            if amsgrad:
+                torch.maximum(x_, v_, out=x_)
+                denom = (x_.sqrt() / math.sqrt(bc2)).add_(eps)
+            else:
+                denom = (v_.sqrt() / math.sqrt(bc2)).add_(eps)
+            p.addcdiv_(m_, denom, value=-(lr / bc1))
+
+
 class TorchDqn:
     """Dqn (dqn/base.rs) with DqnModel (dqn/model/base.rs) and tch's Adam (opt.rs:35)."""
 
@@ -101,28 +125,9 @@ class TorchDqn:
         return cnn_forward(p, x) if self.kind == "cnn" else mlp_forward(p, x)
 
     def _adam(self):
-        """libtorch torch/csrc/api/src/optim/adam.cpp (Adam::step), defaults of opt.rs:35; adamw.cpp (AdamW::step:
-        decoupled decay `param.mul_(1 - lr * weight_decay)` first) for OptimizerConfig::AdamW (opt.rs:38-55)."""
-        b1, b2, eps, wd, amsgrad = 0.9, 0.999, 1e-8, 0.0, False
-        if self.adamw is not None:
-            b1, b2, eps, wd = self.adamw["beta1"], self.adamw["beta2"], self.adamw["eps"], self.adamw["wd"]
-            amsgrad = bool(self.adamw.get("amsgrad", False))
+        """libtorch Adam::step / AdamW::step (optimizer_step above)."""
         self.step += 1
-        bc1 = 1 - b1 ** self.step
-        bc2 = 1 - b2 ** self.step
-        with torch.no_grad():
-            for p, m, v, vmax in zip(self.q, self.m, self.v, self.vmax):
-                g = p.grad
-                if self.adamw is not None:
-                    p.mul_(1 - self.lr * wd)
-                m.mul_(b1).add_(g, alpha=1 - b1)
-                v.mul_(b2).addcmul_(g, g, value=1 - b2)
-                if amsgrad:   # adamw.cpp: torch::max_out(max_exp_avg_sq, exp_avg_sq, max_exp_avg_sq); denom from the maximum
-                    torch.maximum(vmax, v, out=vmax)
-                    denom = (vmax.sqrt() / math.sqrt(bc2)).add_(eps)
-                else:
-                    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
-                p.addcdiv_(m, denom, value=-(self.lr / bc1))
+        optimizer_step(self.q, self.m, self.v, self.vmax, self.step, self.lr, self.adamw)
 
     def update(self, obs, act, next_obs, reward, term, weight=None):
         """dqn/base.rs:60-160 followed by :190-196 (soft update)."""
@@ -352,7 +357,7 @@ class TorchSac:
 
     def __init__(self, obs_dim, act_dim, pi_units, q_units, pi_params, q_params_list, *, lr_actor, lr_critic, gamma=0.99,
                  tau=0.005, ent_coef=("Fix", 1.0), epsilon=1e-4, min_lstd=-20.0, max_lstd=2.0, reward_scale=1.0,
-                 critic_loss="Mse"):
+                 critic_loss="Mse", adamw_actor=None, adamw_critic=None):
         self.pi_shapes = sac_pi_shapes(obs_dim, pi_units, act_dim)
         self.q_shapes = sac_q_shapes(obs_dim, act_dim, q_units)
         self.n_trunk = len(pi_units)
@@ -367,26 +372,20 @@ class TorchSac:
         else:                      # Auto(target_entropy, lr): ent_coef.rs:39-46
             self.log_alpha = torch.zeros(1, requires_grad=True)
             self.target_entropy, self.lr_alpha = ent_coef[1], ent_coef[2]
-        self.opt = {"pi": self._state(self.pi, lr_actor), "alpha": self._state([self.log_alpha], self.lr_alpha or 0.0)}
+        # ActorConfig / CriticConfig.opt_config (Adam, or AdamW = dict(beta1, beta2, wd, eps[, amsgrad])); EntCoef: nn::Adam::default() (ent_coef.rs:41)
+        self.opt = {"pi": self._state(self.pi, lr_actor, adamw_actor), "alpha": self._state([self.log_alpha], self.lr_alpha or 0.0)}
         for i, q in enumerate(self.qs):
-            self.opt[f"q{i}"] = self._state(q, lr_critic)
+            self.opt[f"q{i}"] = self._state(q, lr_critic, adamw_critic)
 
     @staticmethod
-    def _state(params, lr):
-        return dict(m=[torch.zeros_like(p) for p in params], v=[torch.zeros_like(p) for p in params], step=0, lr=lr)
+    def _state(params, lr, adamw=None):
+        return dict(m=[torch.zeros_like(p) for p in params], v=[torch.zeros_like(p) for p in params],
+                    vmax=[torch.zeros_like(p) for p in params], step=0, lr=lr, adamw=adamw)
 
     @staticmethod
     def _adam(params, st):
-        b1, b2, eps = 0.9, 0.999, 1e-8
         st["step"] += 1
-        bc1, bc2 = 1 - b1 ** st["step"], 1 - b2 ** st["step"]
-        with torch.no_grad():
-            for p, m, v in zip(params, st["m"], st["v"]):
-                g = p.grad
-                m.mul_(b1).add_(g, alpha=1 - b1)
-                v.mul_(b2).addcmul_(g, g, value=1 - b2)
-                denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
-                p.addcdiv_(m, denom, value=-(st["lr"] / bc1))
+        optimizer_step(params, st["m"], st["v"], st["vmax"], st["step"], st["lr"], st["adamw"])
 
     def pi_forward(self, o):
         """Mlp2::forward (mlp2.rs:23-28): returns (mean, exp(head2))."""
@@ -501,14 +500,16 @@ class TorchIqn:
     Tensor::rand on the CPU generator: iqn/model/base.rs:365-368)."""
 
     def __init__(self, psi_kind, shapes3, params, *, lr, feature_dim, embed_dim, discount_factor=0.99, tau=0.005,
-                 soft_update_interval=1, psi_activation_out=True):
+                 soft_update_interval=1, psi_activation_out=True, adamw=None):
         self.psi_kind = psi_kind
+        self.adamw = adamw   # IqnModelConfig.opt_config: None = Adam{lr}, or AdamW = dict(beta1, beta2, wd, eps[, amsgrad])
         self.shapes = shapes3[0] + shapes3[1] + shapes3[2]
         self.n_psi, self.n_f = len(shapes3[0]), len(shapes3[2])
         self.p = [t.requires_grad_(True) for t in unflatten(params, self.shapes)]
         self.p_tgt = unflatten(params, self.shapes)   # IqnModel::clone
         self.m = [torch.zeros_like(t) for t in self.p]
         self.v = [torch.zeros_like(t) for t in self.p]
+        self.vmax = [torch.zeros_like(t) for t in self.p]
         self.lr, self.step, self.gamma, self.tau = lr, 0, discount_factor, tau
         self.F, self.E = feature_dim, embed_dim
         self.soft_update_interval, self.soft_update_counter = soft_update_interval, 0
@@ -557,16 +558,8 @@ class TorchIqn:
             p.grad = None
         loss.backward()
         grads = flatten([p.grad for p in self.p])
-        b1, b2, eps = 0.9, 0.999, 1e-8
         self.step += 1
-        bc1, bc2 = 1 - b1 ** self.step, 1 - b2 ** self.step
-        with torch.no_grad():
-            for p, m, v in zip(self.p, self.m, self.v):
-                g = p.grad
-                m.mul_(b1).add_(g, alpha=1 - b1)
-                v.mul_(b2).addcmul_(g, g, value=1 - b2)
-                denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
-                p.addcdiv_(m, denom, value=-(self.lr / bc1))
+        optimizer_step(self.p, self.m, self.v, self.vmax, self.step, self.lr, self.adamw)
         self.soft_update_counter += 1
         if self.soft_update_counter == self.soft_update_interval:
             self.soft_update_counter = 0

@@ -151,6 +151,11 @@ SAC_CASES = {
     "sac_pendulum_fix_huber": (3, 1, [64, 64], [64, 64], 1, 16, 2,
                                dict(lr_actor=3e-4, lr_critic=3e-4, ent_coef=("Fix", 1.0), critic_loss="SmoothL1",
                                     reward_scale=0.5)),
+    # OptimizerConfig::AdamW on both models (opt.rs:20-27, 38-55): the actor without, the twin critics with amsgrad
+    "sac_17_6_twinq_adamw": (17, 6, [64, 64], [64, 64], 2, 32, 4,
+                             dict(lr_actor=1e-3, lr_critic=2e-3, ent_coef=("Auto", -6.0, 3e-4), critic_loss="Mse",
+                                  adamw_actor=dict(beta1=0.85, beta2=0.97, wd=0.02, eps=1e-6, amsgrad=False),
+                                  adamw_critic=dict(beta1=0.8, beta2=0.9, wd=0.05, eps=1e-6, amsgrad=True))),
 }
 
 
@@ -163,6 +168,17 @@ def sac_case_params(name):
     return od, ad, pu, qu, nc, B, steps, kw, pi0, q0, seed
 
 
+def sac_case_batch(name, s):
+    """minibatch + noise of step s; the AdamW case scales rewards 10x on its first two steps and 0.1x after, so that exp_avg_sq
+    decays below its running maximum and amsgrad is not a no-op"""
+    from oracle import torch_ref as T
+    od, ad, pu, qu, nc, B, steps, kw = SAC_CASES[name]
+    obs, act, nobs, rew, term, za, zn = T.sac_batch(B, od, ad, sum(map(ord, name)) + 100 + s)
+    if "adamw_critic" in kw:
+        rew = (rew * (10.0 if s < 2 else 0.1)).astype(np.float32)
+    return obs, act, nobs, rew, term, za, zn
+
+
 def make_sac():
     """SAC goldens: PyTorch CPU autograd on seeded minibatches with injected N(0,1) noise."""
     from oracle import torch_ref as T
@@ -173,7 +189,7 @@ def make_sac():
         agent = T.TorchSac(od, ad, pu, qu, pi0, q0, **kw)
         out = {}
         for s in range(steps):
-            r = agent.update(*T.sac_batch(B, od, ad, seed + 100 + s))
+            r = agent.update(*sac_case_batch(name, s))
             for k in ("loss_critic", "loss_actor", "ent_coef", "log_alpha"):
                 out[f"s{s}_{k}"] = np.float32(r[k])
             out[f"s{s}_a"], out[f"s{s}_log_p"], out[f"s{s}_tgt"] = r["a"], r["log_p"], r["tgt"]
@@ -181,6 +197,10 @@ def make_sac():
             for i in range(nc):
                 out[f"s{s}_q{i}_grads"], out[f"s{s}_q{i}_params"] = r["q_grads"][i], r["q_params"][i]
                 out[f"s{s}_q{i}_tgt_params"] = r["q_tgt_params"][i]
+        if "adamw_critic" in kw:   # the second moment and its running maximum after the last step
+            for i in range(nc):
+                out[f"q{i}_exp_avg_sq"] = T.flatten(agent.opt[f"q{i}"]["v"])
+                out[f"q{i}_max_exp_avg_sq"] = T.flatten(agent.opt[f"q{i}"]["vmax"])
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
@@ -188,7 +208,20 @@ IQN_CASES = {
     # name: (psi_kind, feature_dim, embed_dim, f_units, n_actions, psi_in, psi_units, B, n_pred, n_tgt, steps, lr)
     "iqn_mlp_small": ("mlp", 64, 16, [32], 3, 5, [48], 8, 8, 8, 3, 1e-3),
     "iqn_cnn_b2": ("cnn", 3136, 64, [512], 6, None, [], 2, 8, 8, 2, 1e-4),
+    "iqn_mlp_small_adamw": ("mlp", 64, 16, [32], 3, 5, [48], 8, 8, 8, 4, 2e-3),
 }
+# IqnModelConfig.opt_config = OptimizerConfig::AdamW (opt.rs:20-27, 38-55) of the cases that have one
+IQN_ADAMW = {"iqn_mlp_small_adamw": dict(beta1=0.8, beta2=0.9, wd=0.05, eps=1e-6, amsgrad=True)}
+
+
+def iqn_case_batch(name, s):
+    """minibatch + percent points of step s (the AdamW case scales rewards so that amsgrad is not a no-op, as sac_case_batch)"""
+    from oracle import torch_ref as T
+    kind, F_, E, fu, A, pin, pu, B, n_p, n_t, steps, lr = IQN_CASES[name]
+    b = list(T.iqn_batch(B, kind, A, n_p, n_t, sum(map(ord, name)) + 50 + s, in_dim=pin))
+    if name in IQN_ADAMW:
+        b[3] = (b[3] * (10.0 if s < 2 else 0.1)).astype(np.float32)
+    return tuple(b)
 
 
 def iqn_case(name):
@@ -207,11 +240,11 @@ def make_iqn():
     torch.set_num_threads(1)
     for name in IQN_CASES:
         kind, F_, E, fu, A, pin, pu, B, n_p, n_t, steps, lr, sh, p0, seed = iqn_case(name)
-        agent = T.TorchIqn(kind, sh, p0, lr=lr, feature_dim=F_, embed_dim=E, tau=0.01, soft_update_interval=2)
+        agent = T.TorchIqn(kind, sh, p0, lr=lr, feature_dim=F_, embed_dim=E, tau=0.01, soft_update_interval=2, adamw=IQN_ADAMW.get(name))
         st = sample_stride(p0.size)
         out = {}
         for s in range(steps):
-            r = agent.update(*T.iqn_batch(B, kind, A, n_p, n_t, seed + 50 + s, in_dim=pin))
+            r = agent.update(*iqn_case_batch(name, s))
             out[f"s{s}_loss"] = np.float32(r["loss"])
             out[f"s{s}_z_pred"], out[f"s{s}_z_tgt"], out[f"s{s}_tgt"] = r["z_pred"], r["z_tgt"], r["tgt"]
             out[f"s{s}_grads_sample"], out[f"s{s}_params_sample"] = r["grads"][::st], r["params"][::st]
@@ -222,6 +255,8 @@ def make_iqn():
                 gn.append(np.linalg.norm(r["grads"][o:o + n].astype(np.float64)))
                 o += n
             out[f"s{s}_grad_norms"] = np.array(gn)
+        if name in IQN_ADAMW:
+            out["exp_avg_sq"], out["max_exp_avg_sq"] = T.flatten(agent.v), T.flatten(agent.vmax)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 

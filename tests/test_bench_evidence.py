@@ -130,3 +130,27 @@ def test_the_window_protocol_is_frozen_with_its_version():
     # the legs run in the order the string names: cold window, steady-state loop, the timed window
     i_cold, i_ss, i_val = src.index("dt_c = window(0)"), src.index("run(n_ss,"), src.index("dt = window(0 if cold is None")
     assert i_cold < i_ss < i_val
+
+
+def test_c4_step_work_counts_every_layer_once(tmp_path, monkeypatch):
+    """Round 5's C4 lines printed step.gflop 936.7 (the four `*_3xbf16` aliases were summed with their layers) and a step fraction of
+    1.23 "of the FP32 peak" for the exact-f32 run.  The step's work is the sum over DISTINCT layers (489.5 GFLOP at batch 512, 64
+    quantiles), and a step whose kernels all sit on the FP32 pipe cannot exceed its peak."""
+    _tree(tmp_path, True, monkeypatch)
+    fl = bench.iqn_kernel_flops(512, 64)
+    step_flops = sum(fl.values())
+    assert abs(step_flops / 1e9 - 489.5) < 0.1
+    aliased = dict(fl)
+    aliased.update({k + "_3xbf16": fl[k] for k in bench.C4_SPLIT_LAYERS})
+    assert bench.distinct_layer_flops(aliased) == step_flops and sum(aliased.values()) > 1.9 * step_flops   # (what round 5 summed)
+    # an exact-f32 run: every label of the work model on the FP32 pipe, each launch AT the pipe's peak, serial schedule
+    saved = dict(bench.BF16_ISSUE)
+    try:
+        bench.BF16_ISSUE.clear()
+        prof = {k: v / (bench.PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3 for k, v in fl.items()}
+        conf = {"flops": aliased, "bytes": {"sample": 1}, "step_flops": step_flops, "batch": 512, "name": "c4"}
+        r = bench.roofline(conf, prof, {k: 1 for k in prof}, 0.0, sum(prof.values()))
+    finally:
+        bench.BF16_ISSUE.update(saved)
+    assert abs(r["step"]["gflop"] - step_flops / 1e9) < 1e-2
+    assert r["step"]["frac"] <= 1.0 + 1e-3 and abs(r["step"]["fp32_mfma"]["gflop"] - r["step"]["gflop"]) < 1e-2

@@ -38,11 +38,13 @@ def _run(B, name, golden_dir):
     from oracle import torch_ref as T
     kind, F_, E, fu, A, pin, pu, Bsz, n_p, n_t, steps, lr, sh, p0, seed = MG.iqn_case(name)
     g = np.load(os.path.join(golden_dir, name + ".npz"))
-    a = _agent(B, kind, F_, E, fu, A, pin, pu, Bsz, lr, p0, tau=0.01, soft_update_interval=2)
+    adamw = MG.IQN_ADAMW.get(name)
+    opt = {} if adamw is None else dict(opt_config=B.OptimizerConfig.AdamW(lr, **adamw))
+    a = _agent(B, kind, F_, E, fu, A, pin, pu, Bsz, lr, p0, tau=0.01, soft_update_interval=2, **opt)
     assert (a.get_params("iqn") == p0).all() and a.param_count() == p0.size
     st = MG.sample_stride(p0.size)
     for s in range(steps):
-        batch = T.iqn_batch(Bsz, kind, A, n_p, n_t, seed + 50 + s, in_dim=pin)
+        batch = MG.iqn_case_batch(name, s)
         assert rel(a.forward(batch[0], batch[5], "iqn"), g[f"s{s}_z_pred"]) < QTOL, s
         assert rel(a.forward(batch[2], batch[6], "iqn_tgt"), g[f"s{s}_z_tgt"]) < QTOL, s
         rec = a.update_on_batch(*batch)
@@ -57,11 +59,22 @@ def _run(B, name, golden_dir):
             o += n
         assert np.abs(a.get_params("iqn")[::st].astype(np.float64) - g[f"s{s}_params_sample"]).max() < 0.1 * lr
         assert rel(a.get_params("iqn_tgt")[::st], g[f"s{s}_tgt_params_sample"]) < 1e-5
+    if adamw is not None and adamw.get("amsgrad"):   # max_exp_avg_sq (arena 5) after the last step
+        v, vmax = a.get_params("exp_avg_sq"), a.get_params("max_exp_avg_sq")
+        assert (vmax >= v).all() and (vmax > v * 1.1).mean() > 0.3
+        assert np.abs(vmax - g["max_exp_avg_sq"]).max() <= 2e-3 * np.abs(g["max_exp_avg_sq"]).max()
+        assert np.abs(v - g["exp_avg_sq"]).max() <= 2e-3 * np.abs(g["exp_avg_sq"]).max()
     a.close()
 
 
 def test_iqn_golden_mlp_small(B, golden_dir):
     _run(B, "iqn_mlp_small", golden_dir)
+
+
+def test_iqn_golden_mlp_small_adamw_amsgrad(B, golden_dir):
+    """OptimizerConfig::AdamW{amsgrad: true} through bdr_iqn_config::opt (iqn/model/config.rs:50 -> opt.rs:20-27, 38-55), 4 steps with
+    rewards scaled 10x then 0.1x so that the running maximum of exp_avg_sq is ahead of it (make_golden.iqn_case_batch)."""
+    _run(B, "iqn_mlp_small_adamw", golden_dir)
 
 
 def test_iqn_golden_cnn_b2(B, golden_dir):

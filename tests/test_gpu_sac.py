@@ -24,8 +24,14 @@ def B():
     return border_amd
 
 
+def _opt(B, lr, adamw):
+    """OptimizerConfig of one model: Adam{lr} or AdamW{lr, ..} (opt.rs:13-28)"""
+    return None if adamw is None else B.OptimizerConfig.AdamW(lr, **adamw)
+
+
 def _agent(B, od, ad, pu, qu, nc, Bsz, kw, pi0, q0):
     cfg = B.SacConfig(obs_dim=od, act_dim=ad, pi_units=tuple(pu), q_units=tuple(qu), lr_actor=kw["lr_actor"], lr_critic=kw["lr_critic"],
+                      opt_actor=_opt(B, kw["lr_actor"], kw.get("adamw_actor")), opt_critic=_opt(B, kw["lr_critic"], kw.get("adamw_critic")),
                       ent_coef_mode=kw["ent_coef"], critic_loss=kw["critic_loss"], reward_scale=kw.get("reward_scale", 1.0),
                       n_critics=nc, batch_size=Bsz, device=0)
     a = B.Sac.build(cfg)
@@ -42,7 +48,7 @@ def _run(B, name, golden_dir):
     a = _agent(B, od, ad, pu, qu, nc, Bsz, kw, pi0, q0)
     assert (a.get_params("pi") == pi0).all() and (a.get_params("qnet_0") == q0[0]).all()
     for s in range(steps):
-        rec = a.update_on_batch(*T.sac_batch(Bsz, od, ad, seed + 100 + s))
+        rec = a.update_on_batch(*MG.sac_case_batch(name, s))
         # log_p is ill-conditioned near |a| -> 1 (see tests/test_oracle_sac.py): 5e-4 on the scalars
         for k in ("loss_critic", "loss_actor", "ent_coef"):
             assert abs(rec[k] - g[f"s{s}_{k}"]) <= 5e-4 * abs(g[f"s{s}_{k}"]) + 1e-6, (s, k, rec[k], g[f"s{s}_{k}"])
@@ -54,11 +60,26 @@ def _run(B, name, golden_dir):
         assert np.abs(a.get_params("pi") - g[f"s{s}_pi_params"]).max() < 0.3 * kw["lr_actor"]
         assert abs(float(a.get_params("log_alpha")[0]) - g[f"s{s}_log_alpha"]) < 1e-6
     assert a.n_opts == steps
+    if kw.get("adamw_critic", {}).get("amsgrad"):   # AdamW{amsgrad: true}: max_exp_avg_sq (parameter model +400) and exp_avg_sq after the last step
+        for i in range(nc):
+            v, vmax = a.get_params(f"qnet_{i}", "exp_avg_sq"), a.get_params(f"qnet_{i}", "max_exp_avg_sq")
+            assert (vmax >= v).all() and (vmax > v * 1.1).mean() > 0.1          # the maximum really is ahead of the decayed second moment
+            assert np.abs(vmax - g[f"q{i}_max_exp_avg_sq"]).max() <= 2e-3 * np.abs(g[f"q{i}_max_exp_avg_sq"]).max()
+            assert np.abs(v - g[f"q{i}_exp_avg_sq"]).max() <= 2e-3 * np.abs(g[f"q{i}_exp_avg_sq"]).max()
+        with pytest.raises(Exception):
+            a.get_params("pi", "max_exp_avg_sq")                                   # the actor's AdamW has amsgrad off: no such arena
     a.close()
 
 
 def test_sac_twin_q_auto_alpha(B, golden_dir):
     _run(B, "sac_17_6_twinq_auto", golden_dir)
+
+
+def test_sac_twin_q_adamw_actor_and_amsgrad_critics(B, golden_dir):
+    """OptimizerConfig::AdamW through bdr_sac_config::opt_actor / opt_critic (opt.rs:20-27, 38-55): decoupled decay, custom betas / eps
+    on the actor; the twin critics with amsgrad.  Rewards are scaled 10x then 0.1x (make_golden.sac_case_batch), so the running
+    maximum is ahead of exp_avg_sq and a plain-AdamW step would miss the golden parameters."""
+    _run(B, "sac_17_6_twinq_adamw", golden_dir)
 
 
 def test_sac_pendulum_fix_alpha_huber(B, golden_dir):

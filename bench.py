@@ -773,13 +773,15 @@ def main():
             result["warmup_note"] = (f"`warmup` = the W = {args.warmup} untimed steps directly in front of the K timed ones (the contract's window); "
                                      f"{untimed_before} untimed steps ran in this process before the timed ones in total (cold window + steady-state leg + W)")
         result["protocol_version"] = PROTOCOL_VERSION
+    agent.close()
     # The exact-f32 twin (round 6): the default agent of c2 / c4 computes split-operand bf16 products in its large forward layers
     # (bdr_{dqn,iqn}_config::arithmetic = BDR_ARITH_BF16X3_6).  A second agent built with BDR_ARITH_F32_EXACT on the same ring runs
     # the same protocol in this process - half a second of the loop, then W untimed + K timed steps - so that every line carries both
-    # arithmetics' rates from one box.  N = 1 only; after the headline's legs, so `value` is untouched (protocol version unchanged).
+    # arithmetics' rates from one box.  N = 1 only; after the headline's legs, so `value` is untouched (protocol version unchanged); after
+    # the headline agent is CLOSED: one DQN agent per process orders its two queues with device flags, a second one alive beside it falls
+    # back to event ordering (~10 % slower) and would not be the same schedule.
     if (rank == 0 and world == 1 and args.config in ("c2", "c4") and not args.no_exact_leg and cold is not None
             and not arithmetic_is_exact(args.arithmetic, {"c2": "BDR_DQN_F32_EXACT", "c4": "BDR_IQN_F32_EXACT"}[args.config])):
-        agent.sync()
         saved_issue = dict(BF16_ISSUE)
         conf_x = build_config(B, args.config, args, rank, local_rank, arithmetic="f32_exact", rb=rb)
         conf_x["name"] = args.config
@@ -809,7 +811,6 @@ def main():
         BF16_ISSUE.clear(); BF16_ISSUE.update(saved_issue)
         result["value_exact_f32"] = ex["value"]
         result["exact_f32"] = ex
-    agent.close()
     rb.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

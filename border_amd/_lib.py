@@ -162,7 +162,7 @@ ABI_SYMBOLS = [
     "bdr_agent_opt", "bdr_agent_opt_with_record", "bdr_agent_opt_with_scalars", "bdr_agent_record_keys", "bdr_agent_draw_noise", "bdr_agent_param_count_of", "bdr_dqn_update_on_batch", "bdr_agent_qvalues",
     "bdr_explorer_config_default", "bdr_agent_set_explorer", "bdr_agent_get_explorer", "bdr_agent_sample", "bdr_agent_sample_device", "bdr_agent_qvalues_device",
     "bdr_agent_sync", "bdr_agent_n_opts", "bdr_agent_param_count", "bdr_agent_get_params",
-    "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_agent_set_checkpoint_format",
+    "bdr_agent_set_params", "bdr_agent_arena_device_ptr", "bdr_agent_arena_release", "bdr_agent_save_params", "bdr_agent_load_params", "bdr_agent_set_checkpoint_format",
     "bdr_checkpoint_write", "bdr_checkpoint_read", "bdr_dqn_probe",
     "bdr_agent_profile_enable", "bdr_agent_profile_read",
     "bdr_iqn_config_default", "bdr_iqn_create", "bdr_iqn_update_on_batch", "bdr_iqn_forward", "bdr_iqn_qvalues",
@@ -249,6 +249,7 @@ def lib() -> C.CDLL:
     L.bdr_agent_get_params.argtypes = [vp, i32, vp, u64]
     L.bdr_agent_set_params.argtypes = [vp, i32, vp, u64]
     L.bdr_agent_arena_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u64)]
+    L.bdr_agent_arena_release.argtypes = [vp, i32]
     L.bdr_agent_save_params.argtypes = [vp, C.c_char_p]
     L.bdr_agent_load_params.argtypes = [vp, C.c_char_p]
     L.bdr_dqn_probe.argtypes = [vp, i32, vp, u64]

@@ -128,7 +128,8 @@ class ModelMailbox:
 
     def __init__(self, agent, n_readers: int, which: str = None, device: int = 0):
         which = which or next(iter(agent.WHICH))
-        _, n = agent.arena_device_ptr(which)
+        _, n = agent.arena_device_ptr(which)      # only the size is wanted: hand the arena straight back, or the learner would re-split
+        _lib.check(_lib.lib().bdr_agent_arena_release(agent.handle, agent.WHICH[which]))   # its weight planes before every forward from here on
         h = C.c_void_p()
         _lib.check(_bind().bdr_model_mailbox_create(device, n, n_readers, C.byref(h)))
         self._h, self.which = h, agent.WHICH[which]

@@ -68,7 +68,8 @@ def build_examples() -> str:
     for name in EXAMPLES:
         src = os.path.join(root, "examples", name + ".cpp")
         exe = os.path.join(root, "examples", name)
-        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        hdr = os.path.join(root, "include", "border_amd.h")   # (a config struct that grows changes the examples' stack frames)
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB), os.path.getmtime(hdr)):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", src, "-I" + os.path.join(root, "include"), "-L" + HERE, "-lborder_amd",
                                    "-Wl,-rpath,$ORIGIN/../border_amd", "-o", exe])
         exes.append(exe)

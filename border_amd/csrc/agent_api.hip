@@ -283,6 +283,15 @@ static int32_t create_dir_all(const char* dir)
     return BDR_OK;
 }
 
+// the error words after a step that THIS call enqueued and synchronised: a device-side report is then about this very step, which has
+// run - bdr_last_error_is_deferred() says 2, not 1, so that a caller keeps the record and does not run the step a second time
+static int32_t err_check_after_step(bdr_agent* a)
+{
+    const int32_t st = a->err_check();
+    if (st != BDR_OK && bdr::g_err_deferred) bdr::g_err_deferred = 2;
+    return st;
+}
+
 static bool is_dqn(const bdr_agent* a) { return a && (!strcmp(a->kind(), "dqn_cnn") || !strcmp(a->kind(), "dqn_mlp")); }
 
 extern "C" {
@@ -366,10 +375,9 @@ int32_t bdr_agent_opt_with_record(bdr_agent* a, bdr_replay* r, bdr_dqn_record* r
     const int32_t st = a->record(v, 128, &n);
     a->rec_opt = false;
     BDR_TRY(st);
-    BDR_TRY(a->err_check());
-    rec->loss = v[0]; rec->has_verbose = n >= 5;
+    rec->loss = v[0]; rec->has_verbose = n >= 5;   // the record is complete whatever the error words say about the step that produced it
     if (n >= 5) { rec->pred_mean = v[1]; rec->reward_mean = v[2]; rec->tgt_mean = v[3]; rec->tgt_minus_pred_mean = v[4]; }
-    return BDR_OK;
+    return err_check_after_step(a);
 }
 
 int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* r, float* out, int32_t cap, int32_t* n_out)
@@ -385,9 +393,8 @@ int32_t bdr_agent_opt_with_scalars(bdr_agent* a, bdr_replay* r, float* out, int3
     const int32_t st = a->record(out, cap, &n);
     a->rec_opt = false;
     BDR_TRY(st);
-    BDR_TRY(a->err_check());
-    *n_out = n;
-    return BDR_OK;
+    *n_out = n;   // the record is complete whatever the error words say about the step that produced it
+    return err_check_after_step(a);
 }
 
 // names of the scalars bdr_agent_opt_with_scalars returns, '\n'-separated, in order
@@ -554,9 +561,16 @@ int32_t bdr_agent_sample(bdr_agent* a, uint64_t n, const void* obs, int64_t* act
     BDR_REQUIRE(a && obs && act_out, "null argument");
     std::vector<float> q;
     int A = 0;
+    a->err_fresh = false;   // (set again only by THIS call's own pinned read-back: a flag left by an earlier qvalues call must not send this one down the poll on old words)
     BDR_TRY(action_values(a, n, obs, q, &A));
-    if (a->err_fresh) { a->err_fresh = false; BDR_TRY(a->err_poll()); }   // the forward pass brought the device's error words along (dqn_cnn_qvalues)
-    else BDR_TRY(a->err_check());
+    if (a->err_fresh) {   // the forward pass brought the device's error words along (rows_wait): report from them, no second copy;
+        a->err_fresh = false;   // the buffer's priority flag (a NaN handed to update_priority) is a host-side word and is looked at either way
+        BDR_TRY(a->err_poll());
+        bool alive = false;
+        const int32_t st = replay_per_check(a->last_replay_uid, &alive);
+        if (!alive) a->last_replay_uid = 0;
+        BDR_TRY(st);
+    } else BDR_TRY(a->err_check());
     Explorer& x = a->explorer;
     double eps = 0.0;
     bool is_random = false;
@@ -674,6 +688,15 @@ int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint
     BDR_REQUIRE(p, "unknown arena %d", which);
     a->arena_escaped(which);   // the caller may write through it whenever they like: derived copies of these parameters are never trusted again
     *ptr = p; *n_floats = n;
+    return BDR_OK;
+}
+
+int32_t bdr_agent_arena_release(bdr_agent* a, int32_t which)
+{
+    BDR_REQUIRE(a, "null argument");
+    size_t n = 0;
+    BDR_REQUIRE(a->arena(which, &n), "unknown arena %d", which);   // (joins a pending exchange and marks derived copies stale: the last write may be recent)
+    a->arena_released(which);
     return BDR_OK;
 }
 

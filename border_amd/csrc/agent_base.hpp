@@ -298,6 +298,7 @@ struct bdr_agent {
     virtual int32_t get_params(int which, float* out, uint64_t n) = 0;
     virtual int32_t set_params(int which, const float* in, uint64_t n) = 0;
     virtual float* arena(int which, size_t* n) = 0;               // flat device arena (kernel layout)
+    virtual void arena_released(int) {}                           // ... and the caller handed it back (bdr_agent_arena_release)
     virtual void arena_escaped(int) {}                            // the raw pointer of arena `which` left the library (bdr_agent_arena_device_ptr)
     virtual int32_t save(const char* dir) = 0;
     virtual int32_t load(const char* dir) = 0;
@@ -528,10 +529,11 @@ __device__ __forceinline__ float track_element(float src, float dst, float tau, 
 }
 
 __global__ __launch_bounds__(256) void k_track(float* __restrict__ dst, const float* __restrict__ src, size_t n4, float tau,
-                                               float omt)
+                                               float omt, const unsigned* poison = nullptr)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    if (poison && *poison) return;   // a cross-queue gate timed out: the update this soft update belongs to was skipped, and so is it
     f32x4 d = reinterpret_cast<f32x4*>(dst)[i], s = reinterpret_cast<const f32x4*>(src)[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) d[j] = track_element(s[j], d[j], tau, omt);
@@ -577,7 +579,7 @@ inline int32_t launch_adam_amsgrad(hipStream_t st, float* p, const float* g, flo
 inline int32_t launch_track(hipStream_t st, float* dst, const float* src, size_t n_floats, double tau)
 {
     const size_t n4 = n_floats / 4;
-    BDR_HIP(step_launch(st, false, k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), dst, src, n4, (float)tau, (float)(1.0 - tau)));
+    BDR_HIP(step_launch(st, false, k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), dst, src, n4, (float)tau, (float)(1.0 - tau), (const unsigned*)nullptr));
     return BDR_OK;
 }
 inline int32_t launch_scale(hipStream_t st, float* p, size_t n_floats, float sc)

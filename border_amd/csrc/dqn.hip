@@ -75,14 +75,11 @@ __device__ __forceinline__ size_t cpl_index(int k, int n) { return ((size_t)(k >
 // element e = k * 64 + n of W2 (layer 0) or W3 (layer 1) -> its three bf16 terms
 __device__ __forceinline__ void conv_plane_store(uint16_t* __restrict__ pl, int layer, int e, float x)
 {
-    const uint32_t hi = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(hi);                   // exact
-    const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mid);                 // exact, <= 8 significant bits
-    const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
+    uint16_t v[3];
+    split3_rn(x, v);                                            // (igemm_b3.hpp: round-to-nearest terms, exact sum)
     const size_t n = (size_t)(layer ? 576 : 512) * 64, o = cpl_index(e >> 6, e & 63);
     uint16_t* d = pl + (layer ? CPL_W3 : CPL_W2);
-    d[o] = (uint16_t)(hi >> 16); d[n + o] = (uint16_t)(mid >> 16); d[2 * n + o] = (uint16_t)(lo >> 16);
+    d[o] = v[0]; d[n + o] = v[1]; d[2 * n + o] = v[2];
 }
 
 // the planes of one parameter set from its f32 weights (every writer of conv parameters other than k_reduce_adam leaves them stale:
@@ -429,6 +426,7 @@ struct DqnCnn : bdr_agent {
     const float* last_reward = nullptr; int last_B = 0;
     // bookkeeping (dqn/base.rs:26-48)
     uint64_t adam_step = 0, soft_update_counter = 0;
+    int64_t conv_step_lag = 0;   // the conv segment's optimizer step number is adam_step - conv_step_lag: 0 unless a gate time-out fell between the step's two optimizer passes (on_gate_timeout)
     // conv2 / conv3 on the bf16 matrix cores with split f32 operands (igemm_b3.hpp): bf16 planes of W2 / W3 beside each parameter set
     // ([0] online, [1] target).  k_reduce_adam writes the online set's planes with the parameters; every other writer of conv
     // parameters marks the set stale (planes_stale) and the next forward re-splits it on its own queue, behind whatever orders
@@ -439,8 +437,9 @@ struct DqnCnn : bdr_agent {
     bool conv_b3 = true;
     void planes_stale(int set) { if (set == 0 || set == 1) cpl_fresh[set] = false; }
     void arena_escaped(int which) override { if (which == 0 || which == 1) cpl_escaped[which] = true; }
+    void arena_released(int which) override { if (which == 0 || which == 1) { cpl_escaped[which] = false; cpl_fresh[which] = false; } }
     float* act_part = nullptr; unsigned* act_tickets = nullptr;   // scratch of the acting kernels (act_small.hpp)
-    unsigned long long* applied_step = nullptr;   // device word: the Adam step number of the last l1 / l2 pass that was not skipped (on_gate_timeout)
+    unsigned long long* applied_step = nullptr;   // device words: the Adam step number of the last pass that was not skipped - [0] l1 / l2 (k_adam, or the whole arena), [1] the conv segment (k_reduce_adam)
 
     ~DqnCnn() override;
     const char* kind() const override { return "dqn_cnn"; }
@@ -533,6 +532,7 @@ struct ConvReduceAdamArgs {
     int reduce_blocks;
     const unsigned* poison;  // sig + SIG_ERR: a gate timed out, leave the parameters alone
     int reduce_only;         // gradients only (the optimizer step follows an all-reduce: synchronous data-parallel mode)
+    unsigned long long* applied; unsigned long long step;   // *applied = step by a launch that was not skipped (on_gate_timeout rolls the conv segment's step number back to it)
     uint16_t* cpl;           // the parameter set's bf16 planes of W2 / W3 (segments 1, 2), written with the parameters; null: none
 };
 // Schedule 3 cross-queue ordering without barrier packets (igemm.hpp start_signal).
@@ -581,9 +581,12 @@ __global__ __launch_bounds__(64) void k_signal(unsigned* sig, int which, unsigne
     if (threadIdx.x == 0) __hip_atomic_store(sig + which, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__global__ void k_copy_word_unless(unsigned long long* dst, const unsigned long long* src, const unsigned* poison) { if (!(poison && *poison)) *dst = *src; }
+
 __global__ __launch_bounds__(256) void k_reduce_adam(ConvReduceAdamArgs a)
 {
     const bool poisoned = a.reduce_only || (a.poison && *a.poison != 0);
+    if (a.applied && !poisoned && blockIdx.x == 0 && threadIdx.x == 0) *a.applied = a.step;
     if ((int)blockIdx.x >= a.reduce_blocks) {
         if (poisoned) return;
         const size_t i = a.rest0_4 + (size_t)(blockIdx.x - a.reduce_blocks) * 256 + threadIdx.x;
@@ -987,7 +990,9 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
         // the conv layers' Adam step rides on their partial reduction (k_reduce_adam); l1 / l2: adam_l1_l2 above
         ConvReduceAdamArgs ra{};
         ra.r = r; ra.p = a->q; ra.g = a->grad; ra.m = a->m; ra.v = a->v; ra.gbase = a->grad;
-        ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = adam_s; ra.reduce_blocks = wg; ra.poison = a->sig + SIG_ERR; ra.reduce_only = defer ? 1 : 0;
+        ra.rest0_4 = ra.n4 = ar.w4 / 4; ra.s = a->conv_step_lag ? adam_scalars(c, (uint64_t)std::max<int64_t>((int64_t)a->adam_step - a->conv_step_lag, 1)) : adam_s;
+        ra.applied = defer ? nullptr : a->applied_step + 1; ra.step = (unsigned long long)((int64_t)a->adam_step - a->conv_step_lag);
+        ra.reduce_blocks = wg; ra.poison = a->sig + SIG_ERR; ra.reduce_only = defer ? 1 : 0;
         ra.cpl = a->conv_b3 && !defer ? a->cpl[0] : nullptr;
         Bracket br(a, "reduce_adam");
         hipLaunchKernelGGL(k_reduce_adam, dim3(wg), dim3(256), 0, a->stream, ra);
@@ -1003,7 +1008,7 @@ int32_t soft_update(DqnCnn* a)
     const float tau = (float)a->cfg.tau, omt = (float)(1.0 - a->cfg.tau);
     Bracket br(a, "track");
     a->planes_stale(1);
-    hipLaunchKernelGGL(k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q_tgt, a->q, n4, tau, omt);
+    hipLaunchKernelGGL(k_track, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q_tgt, a->q, n4, tau, omt, (const unsigned*)(a->sig + SIG_ERR));
     BDR_HIP(hipGetLastError());
     if (a->sig_epoch != 0 && a->split_fwd && !a->prof) {   // the other queue's next target forward must see the new target parameters
         a->track_epoch = a->sig_epoch;
@@ -1033,11 +1038,28 @@ int32_t adam_all(DqnCnn* a)
     a->planes_stale(0);
     Bracket br(a, "adam_all");
     const size_t n4 = a->ar.total / 4;
-    if (a->amsgrad)
-        return launch_adam_amsgrad(a->stream, a->q, a->grad, a->m, a->v, a->vmax, a->ar.total, adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR), a->applied_step, (unsigned long long)a->adam_step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, a->stream, a->q, (const float*)a->grad, a->m, a->v, n4,
-                       adam_scalars(a->cfg, a->adam_step), (const unsigned*)(a->sig + SIG_ERR), a->applied_step, (unsigned long long)a->adam_step);
-    BDR_HIP(hipGetLastError());
+    const unsigned* poison = (const unsigned*)(a->sig + SIG_ERR);
+    // ranges of the arena with their own optimizer step number: one (the whole arena) unless a gate time-out once fell between the fused
+    // path's two passes - then the conv segment [0, w4) continues from the step number ITS moments are at
+    struct Range { size_t off, n; uint64_t step; int slot; } rg[2] = {{0, a->ar.total, a->adam_step, 0}, {0, 0, 0, 1}};
+    int nr = 1;
+    if (a->conv_step_lag) {
+        const uint64_t cs = (uint64_t)std::max<int64_t>((int64_t)a->adam_step - a->conv_step_lag, 1);
+        rg[0] = Range{a->ar.w4, a->ar.total - a->ar.w4, a->adam_step, 0}; rg[1] = Range{0, a->ar.w4, cs, 1}; nr = 2;
+    }
+    for (int k = 0; k < nr; ++k) {
+        const Range& g = rg[k];
+        const AdamScalars sc = adam_scalars(a->cfg, g.step);
+        if (a->amsgrad) { BDR_TRY(launch_adam_amsgrad(a->stream, a->q + g.off, a->grad + g.off, a->m + g.off, a->v + g.off, a->vmax + g.off, g.n, sc, poison, a->applied_step + g.slot, (unsigned long long)g.step)); continue; }
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((g.n / 4 + 255) / 256)), dim3(256), 0, a->stream, a->q + g.off, (const float*)(a->grad + g.off), a->m + g.off, a->v + g.off, g.n / 4,
+                           sc, poison, a->applied_step + g.slot, (unsigned long long)g.step);
+        BDR_HIP(hipGetLastError());
+    }
+    if (nr == 1) {   // the whole-arena pass stands for both segments
+        hipLaunchKernelGGL(k_copy_word_unless, dim3(1), dim3(1), 0, a->stream, a->applied_step + 1, (const unsigned long long*)a->applied_step, poison);
+        BDR_HIP(hipGetLastError());
+    }
+    (void)n4;
     return BDR_OK;
 }
 
@@ -1225,12 +1247,24 @@ void DqnCnn::on_gate_timeout()
         // Updates whose parameter-writing kernels ran while the poison word was up were skipped on the device: the host's step numbers go
         // back to the last update that was applied, so Adam's bias corrections continue from the state the parameters are in
         // (the l1 / l2 pass, 95 % of the arena, records the step number it applied; opt.rs:74-83).
-        unsigned long long applied = 0;
-        if (hipMemcpy(&applied, applied_step, sizeof applied, hipMemcpyDeviceToHost) == hipSuccess && applied < adam_step) {
-            const uint64_t skipped = adam_step - applied;
-            adam_step = applied;
-            n_opts -= std::min(n_opts, skipped / std::max<uint64_t>(1, cfg.n_updates_per_opt));
-            fprintf(stderr, "border_amd: %llu update(s) behind the failed gate were skipped on the device; the step counters were rolled back with them\n", (unsigned long long)skipped);
+        // The two optimizer passes of the fused path (l1 / l2 on the weight-gradient queue, the conv segment at the end of the dX queue)
+        // each record the step number they applied; a time-out that fell BETWEEN them leaves the conv segment one step behind: it keeps
+        // its own step number from then on (conv_step_lag), so every segment's bias corrections match the moments it holds.
+        unsigned long long applied[2] = {0, 0};
+        if (hipMemcpy(applied, applied_step, sizeof applied, hipMemcpyDeviceToHost) == hipSuccess) {
+            const int64_t conv_now = (int64_t)adam_step - conv_step_lag;
+            if (applied[0] < adam_step || (int64_t)applied[1] < conv_now) {
+                const uint64_t skipped = adam_step - std::min<uint64_t>(applied[0], adam_step);
+                adam_step -= skipped;
+                conv_step_lag = (int64_t)adam_step - (int64_t)std::min<uint64_t>(applied[1], (uint64_t)std::max<int64_t>(conv_now, 0));
+                const uint64_t opts_back = std::min(n_opts, skipped / std::max<uint64_t>(1, cfg.n_updates_per_opt));
+                n_opts -= opts_back;
+                // the soft updates of the skipped opts were skipped on the device with them (k_track is poison-gated): their counter goes back too
+                const uint64_t iv = std::max<uint64_t>(1, cfg.soft_update_interval);
+                soft_update_counter = (soft_update_counter + iv - opts_back % iv) % iv;
+                fprintf(stderr, "border_amd: %llu update(s) behind the failed gate were skipped on the device; the step counters were rolled back with them%s\n",
+                        (unsigned long long)skipped, conv_step_lag ? " (the conv segment is one optimizer step behind l1 / l2 and keeps its own step number)" : "");
+            }
         }
     }
     sig_epoch = 0; head_gate_enqueued = false;
@@ -1444,8 +1478,8 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     BDR_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* e = getenv("BDR_SCHED")) a->sched = std::max(0, std::min(3, atoi(e)));
     BDR_HIP(hipMalloc((void**)&a->sig, 16 * sizeof(unsigned)));
-    BDR_HIP(hipMalloc((void**)&a->applied_step, sizeof(unsigned long long)));
-    BDR_HIP(hipMemsetAsync(a->applied_step, 0, sizeof(unsigned long long), a->stream));
+    BDR_HIP(hipMalloc((void**)&a->applied_step, 2 * sizeof(unsigned long long)));
+    BDR_HIP(hipMemsetAsync(a->applied_step, 0, 2 * sizeof(unsigned long long), a->stream));
     BDR_HIP(hipMemsetAsync(a->sig, 0, 16 * sizeof(unsigned), a->stream));   // synchronised with the parameter upload below
     if (getenv("BDR_GATE_TRACE")) {
         BDR_HIP(hipMalloc((void**)&a->gate_trace, 32 * sizeof(unsigned long long)));
@@ -1619,8 +1653,12 @@ int32_t dqn_cnn_probe(bdr_agent* base, int32_t what, float* out, uint64_t n)
         case 2: src = a->pred; break;
         case 3: src = a->tgt; break;
         case 4: src = a->loss; break;
+        case 5: src = a->a1[0]; break;   // the online network's activations on `obs`, position-major: [B][20*20][32], [B][9*9][64], [B][7*7][64]
+        case 6: src = a->a2[0]; break;
+        case 7: src = a->a3[0]; break;
         default: return fail(BDR_ERR_INVALID, "unknown probe %d", what);
     }
+    BDR_REQUIRE(src, "nothing to probe yet (no update has run)");
     BDR_HIP(hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToHost, a->stream));
     BDR_HIP(hipStreamSynchronize(a->stream));
     return BDR_OK;

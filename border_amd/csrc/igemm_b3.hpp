@@ -3,8 +3,8 @@
 // peak with the exact kernel: csrc/iqn.hip).  The B = 256 conv layers of the DQN step are operand-delivery bound and gain nothing
 // from it (tools/probes/bp_probe.hip); they stay on the FP32 MFMA.
 //
-// Every f32 operand x is split exactly into three bf16 terms x = hi + mid + lo (8 + 8 + 8 significant bits, truncation
-// split), so a product a*b is the sum of nine exact bf16 x bf16 products.  TERMS = 9 keeps all of them: the MFMA then
+// Every f32 operand x is split exactly into three bf16 terms x = t0 + t1 + t2 (8 + 8 + 8 significant bits, round-to-nearest
+// split: split3_rn below), so a product a*b is the sum of nine exact bf16 x bf16 products.  TERMS = 9 keeps all of them: the MFMA then
 // only rounds in its f32 accumulation, the error class of the FP32 MFMA / an fmaf chain.  TERMS = 6 drops the three
 // products below 2^-24 |a||b| (mid*lo, lo*mid, lo*lo): measured 4e-6 relative on the C4 layer against the exact kernel
 // (the parity bar is 1e-4 on quantile values; tests/test_gpu_iqn.py holds both kernels to it and to each other).  v_mfma_f32_32x32x16_bf16 retires 16 k in 32 cycles, the FP32
@@ -39,21 +39,43 @@ constexpr int B3_ROW = 32;   // u16 per row
 constexpr bool b3_xcd_map = BDR_B3_XCD_MAP != 0;
 __device__ __forceinline__ int b3_off(int row, int chunk) { return row * B3_ROW + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
-// exact 3-way split of four floats into packed bf16 pairs: p[plane] = {pair(x0,x1), pair(x2,x3)}
+// ---- the operand split.  x = t0 + t1 + t2 EXACTLY, every term a bf16, every term the ROUND-TO-NEAREST-EVEN bf16 of what the terms before
+// it left over (v_cvt_pk_bf16_f32).  Exactness: an f32 has 24 significant bits; after an 8-bit term rounded to nearest the residual is at most
+// half an ulp of that term, so it spans <= 16 bit positions, the next residual <= 8, which the third term holds exactly; each subtraction
+// is exact (the result is representable).  Rounds 4-5 split by TRUNCATION (mask the low 16 bits): also exact, but every residual then
+// carries the sign of x, so the three products a 6-term kernel drops (t1*u2, t2*u1, t2*u2) all push the same way; with the nearest split the
+// residuals are half the size and of either sign - the dropped part is ~10x smaller at the maximum and zero-mean (What's
+// weak 2; tests/test_gpu_dqn.py states the resulting per-layer budget).  The nearest split is also the cheaper one here: one packed
+// conversion per pair instead of two masks and a pack.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pair_rn(float a, float b)   // {bf16(a) in bits 0-15, bf16(b) in bits 16-31}
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// one float -> its three terms (bf16 bit patterns)
+__device__ __forceinline__ void split3_rn(float x, uint16_t (&v)[3])
+{
+    const uint32_t h = bf16_pair_rn(x, 0.f) & 0xffffu;
+    const float r1 = x - __uint_as_float(h << 16);               // exact
+    const uint32_t m = bf16_pair_rn(r1, 0.f) & 0xffffu;
+    const float r2 = r1 - __uint_as_float(m << 16);              // exact, <= 8 significant bits
+    const uint32_t l = bf16_pair_rn(r2, 0.f) & 0xffffu;          // exact
+    v[0] = (uint16_t)h; v[1] = (uint16_t)m; v[2] = (uint16_t)l;
+}
+// four floats -> packed bf16 pairs: p[plane] = {pair(x0,x1), pair(x2,x3)}
 __device__ __forceinline__ void split3_f32x4(const f32x4& x, u32x2_t (&p)[3])
 {
-    uint32_t hi[4], mid[4], lo[4];
+    float r[4] = {x[0], x[1], x[2], x[3]};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        hi[j] = __float_as_uint(x[j]) & 0xffff0000u;
-        const float r1 = x[j] - __uint_as_float(hi[j]);            // exact
-        mid[j] = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(mid[j]);             // exact, <= 8 significant bits
-        lo[j] = __float_as_uint(r2) & 0xffff0000u;
+    for (int pl = 0; pl < 3; ++pl) {
+        const uint32_t a = bf16_pair_rn(r[0], r[1]), b = bf16_pair_rn(r[2], r[3]);
+        p[pl] = u32x2_t{a, b};
+        if (pl < 2) {
+            r[0] -= __uint_as_float(a << 16); r[1] -= __uint_as_float(a & 0xffff0000u);
+            r[2] -= __uint_as_float(b << 16); r[3] -= __uint_as_float(b & 0xffff0000u);
+        }
     }
-    p[0] = u32x2_t{(hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]};
-    p[1] = u32x2_t{(mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]};
-    p[2] = u32x2_t{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]};
 }
 
 // weights -> three bf16 planes in BOTH orders from one read of the f32 matrix src[R][C] (row stride ld): nat[plane][R][C] and
@@ -68,12 +90,8 @@ static __global__ __launch_bounds__(256) void k_split_planes2(const float* __res
     for (int j = 0; j < 4; ++j) {
         const int r = r0 + ty + 8 * j, c = c0 + tx;
         const float x = (r < R && c < C) ? src[(size_t)r * ld + c] : 0.f;
-        const uint32_t hi = __float_as_uint(x) & 0xffff0000u;
-        const float r1 = x - __uint_as_float(hi);
-        const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(mid);
-        const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
-        const uint16_t v[3] = {(uint16_t)(hi >> 16), (uint16_t)(mid >> 16), (uint16_t)(lo >> 16)};
+        uint16_t v[3];
+        split3_rn(x, v);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             t[pl][ty + 8 * j][tx] = v[pl];
@@ -99,13 +117,10 @@ static __global__ __launch_bounds__(256) void k_split_planes(const float* __rest
     if (i >= n) return;
     const int r = (int)(i / C), c = (int)(i % C);
     const float x = src[i];
-    const uint32_t hi = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(hi);
-    const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mid);
-    const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
+    uint16_t v[3];
+    split3_rn(x, v);
     const size_t o = T ? (size_t)c * R + r : i;
-    dst[o] = (uint16_t)(hi >> 16); dst[n + o] = (uint16_t)(mid >> 16); dst[2 * n + o] = (uint16_t)(lo >> 16);
+    dst[o] = v[0]; dst[n + o] = v[1]; dst[2 * n + o] = v[2];
 }
 
 // P: as for k_igemm, plus

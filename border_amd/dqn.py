@@ -353,6 +353,10 @@ class Dqn:
         _lib.check(_lib.lib().bdr_agent_arena_device_ptr(self._h, self.WHICH[which], C.byref(ptr), C.byref(n)))
         return ptr.value, n.value
 
+    def arena_release(self, which="qnet") -> None:
+        """hands an arena back after arena_device_ptr: the library's derived copies (bf16 weight planes) are trusted again"""
+        _lib.check(_lib.lib().bdr_agent_arena_release(self._h, self.WHICH[which]))
+
     def param_count(self) -> int:
         n = C.c_uint64()
         _lib.check(_lib.lib().bdr_agent_param_count(self._h, C.byref(n)))
@@ -377,7 +381,7 @@ class Dqn:
 
     # probes / profiling ----------------------------------------------------------------------
     def probe(self, what: str, n: int) -> np.ndarray:
-        idx = {"q_pred_all": 0, "q_next_all": 1, "pred": 2, "tgt": 3, "loss": 4}[what]
+        idx = {"q_pred_all": 0, "q_next_all": 1, "pred": 2, "tgt": 3, "loss": 4, "act_conv1": 5, "act_conv2": 6, "act_conv3": 7}[what]
         out = np.empty(n, np.float32)
         _lib.check(_lib.lib().bdr_dqn_probe(self._h, idx, _p(out), n))
         return out

@@ -50,7 +50,12 @@ BDR_API const char* bdr_last_error(void);
  * fail on its own arguments, the condition has been cleared and the agent's state is that of the last good update.  Agent::opt returns
  * () in the reference (border-core/src/base/agent.rs:24-136): a caller of bdr_agent_opt may log such a report and go on, and must
  * treat every other failure (BDR_ERR_EMPTY, a buffer that does not match the agent, a HIP error of the call itself) as the reference's
- * panic.  0 otherwise. */
+ * panic.  0 otherwise.
+ * 2 is the same kind of report raised by the step THE FAILING CALL ITSELF ran: bdr_agent_opt_with_record / _with_scalars enqueue the
+ * step, synchronise and read the error words once more - when those flag this very step (its own TD kernel met an out-of-range action,
+ * its own tree update a NaN priority) the step HAS run (n_opts and the optimizer step advanced once) and the record it produced is
+ * complete in the caller's buffers (rec / out, *n_out).  A caller logs the report and keeps the record; it must NOT run the call
+ * again to "retry" - that would be a second optimisation step.  After 1 the step of the failing call was never enqueued. */
 BDR_API int32_t bdr_last_error_is_deferred(void);
 BDR_API int32_t bdr_device_count(int32_t* count);
 BDR_API const char* bdr_version(void);
@@ -384,8 +389,13 @@ BDR_API int32_t bdr_agent_get_params(bdr_agent* a, int32_t which, float* out, ui
 BDR_API int32_t bdr_agent_set_params(bdr_agent* a, int32_t which, const float* in, uint64_t n);
 
 /* Device address of a flat parameter arena (internal kernel layout, identical on every rank) so a
- * host that already owns a communicator (e.g. torch.distributed) can reduce it in place. */
+ * host that already owns a communicator (e.g. torch.distributed) can reduce it in place.
+ * Cost: from this call on the library cannot know when arena `which` is written, so every copy it derives from those parameters
+ * (AtariCnn DQN: the bf16 planes of W2 / W3 the split-operand forward reads) is rebuilt before EVERY forward of that parameter set
+ * (one ~4 us launch per forward) - until bdr_agent_arena_release(a, which) hands the arena back. */
 BDR_API int32_t bdr_agent_arena_device_ptr(bdr_agent* a, int32_t which, void** ptr, uint64_t* n_floats);
+/* "I no longer write through the pointer bdr_agent_arena_device_ptr gave me": derived copies are rebuilt once more and trusted again. */
+BDR_API int32_t bdr_agent_arena_release(bdr_agent* a, int32_t which);
 
 /* Agent::save_params / load_params (dqn/base.rs:345-371; iqn/base.rs:303-317; sac/base.rs:313-345): writes / reads
  * `qnet.pt.tch`, `qnet_tgt.pt.tch` (IQN: iqn, iqn_tgt; SAC: pi, qnet_{i}, qnet_tgt_{i}, ent_coef) under dir - the
@@ -602,7 +612,8 @@ BDR_API int32_t bdr_checkpoint_write(const char* path, const bdr_named_tensor* m
 BDR_API int32_t bdr_checkpoint_read(const char* path, const bdr_named_tensor* meta, uint32_t n_tensors, float* data, uint64_t n);
 
 /* Parity probes: copy intermediates of the LAST update to the host.
- * what: 0 q_pred_all [B][A], 1 q_next_all [B][A], 2 pred [B], 3 tgt [B], 4 loss [1]. */
+ * what: 0 q_pred_all [B][A], 1 q_next_all [B][A], 2 pred [B], 3 tgt [B], 4 loss [1];
+ * AtariCnn only, the online network's activations on `obs`, position-major (NHWC): 5 conv1 [B][400][32], 6 conv2 [B][81][64], 7 conv3 [B][49][64]. */
 BDR_API int32_t bdr_dqn_probe(bdr_agent* a, int32_t what, float* out, uint64_t n);
 
 /* Per-kernel device timing of the opt step (bench.py roofline leg): when enabled the step is

@@ -305,6 +305,8 @@ where
     let mut n_floats = 0u64;
     let mut dev_ptr = std::ptr::null_mut();
     check(unsafe { ffi::bdr_agent_arena_device_ptr(learner.raw(), 0, &mut dev_ptr, &mut n_floats) })?;
+    // only the size was wanted: hand the arena back, or the learner rebuilds its derived weight copies before every forward from here on
+    check(unsafe { ffi::bdr_agent_arena_release(learner.raw(), 0) })?;
     let mut mailbox = std::ptr::null_mut();
     check(unsafe { ffi::bdr_model_mailbox_create(device, n_floats, n_actors as u32, &mut mailbox) })?;
     mailbox_guard.0 = mailbox;

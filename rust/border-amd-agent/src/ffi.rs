@@ -551,6 +551,7 @@ extern "C" {
     pub fn bdr_agent_get_params(a: *mut bdr_agent, which: i32, out: *mut f32, n: u64) -> i32;
     pub fn bdr_agent_set_params(a: *mut bdr_agent, which: i32, inp: *const f32, n: u64) -> i32;
     pub fn bdr_agent_arena_device_ptr(a: *mut bdr_agent, which: i32, ptr: *mut *mut c_void, n_floats: *mut u64) -> i32;
+    pub fn bdr_agent_arena_release(a: *mut bdr_agent, which: i32) -> i32;
     pub fn bdr_agent_set_checkpoint_format(a: *mut bdr_agent, format: i32) -> i32;
     pub fn bdr_agent_save_params(a: *mut bdr_agent, dir: *const c_char) -> i32;
     pub fn bdr_agent_load_params(a: *mut bdr_agent, dir: *const c_char) -> i32;

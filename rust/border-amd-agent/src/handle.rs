@@ -105,10 +105,23 @@ impl AgentHandle {
     pub(crate) fn opt_with_record(&mut self, buffer: *mut ffi::bdr_replay) -> Record {
         let mut vals = vec![0f32; 256];
         let mut n = 0i32;
-        // the same policy as `opt`: an earlier step's device-side report is logged and kept, then the step runs
+        // the same policy as `opt`: an earlier step's device-side report is logged and kept, then the step runs.  The library tells the
+        // two kinds of report apart (bdr_last_error_is_deferred): 1 = raised by the poll in front of the step, which was therefore never
+        // enqueued - run it now; 2 = raised by the check behind the step this call ran - the step is done (n_opts advanced once) and its
+        // record is in `vals` / `n`: keep both, do NOT run a second step.
         let mut rc = unsafe { ffi::bdr_agent_opt_with_scalars(self.h, buffer, vals.as_mut_ptr(), vals.len() as i32, &mut n) };
-        if rc != ffi::BDR_OK && self.defer_if_async(rc, "Agent::opt_with_record") {
-            rc = unsafe { ffi::bdr_agent_opt_with_scalars(self.h, buffer, vals.as_mut_ptr(), vals.len() as i32, &mut n) };
+        if rc != ffi::BDR_OK {
+            let kind = unsafe { ffi::bdr_last_error_is_deferred() };
+            if self.defer_if_async(rc, "Agent::opt_with_record") {
+                rc = if kind == 2 {
+                    ffi::BDR_OK
+                } else {
+                    unsafe { ffi::bdr_agent_opt_with_scalars(self.h, buffer, vals.as_mut_ptr(), vals.len() as i32, &mut n) }
+                };
+                if rc != ffi::BDR_OK && unsafe { ffi::bdr_last_error_is_deferred() } == 2 && self.defer_if_async(rc, "Agent::opt_with_record") {
+                    rc = ffi::BDR_OK; // the retried step ran and reported on itself: same rule
+                }
+            }
         }
         expect(rc, "Agent::opt_with_record");
         let keys = self.record_keys().to_vec();

@@ -89,7 +89,11 @@ def _run_golden(B, fix, batch_fn, n_steps, param_seed, Bsz, **kw):
         assert abs(rec["loss"] - g[f"s{s}_loss"]) <= QTOL * abs(g[f"s{s}_loss"]) + 1e-9
         grads = a.get_params("grad")
         st = max(1, grads.size // 4096) | 1
-        assert rel(grads[::st], g[f"s{s}_grads_sample"]) < 2e-4, (s, rel(grads[::st], g[f"s{s}_grads_sample"]))
+        # every sampled gradient entry to 2e-4 of the largest; ONE entry may sit at a ReLU boundary (a unit whose pre-activation is within f32
+        # round-off of zero is masked differently by two correct implementations; measured with tools/diag/golden_b8_modes.py: step 0 3e-7 /
+        # 8e-8, step 1 2.8e-7 with exact products and ONE conv3 entry at 2.4e-4 with the split forward, all others below 1e-4) - bounded at 1e-3
+        dg = np.abs(grads[::st].astype(np.float64) - g[f"s{s}_grads_sample"]) / np.abs(g[f"s{s}_grads_sample"]).max()
+        assert (dg > 2e-4).sum() <= 1 and dg.max() < 1e-3, (s, int((dg > 2e-4).sum()), dg.max())
         o = 0
         for i, sh in enumerate(shapes):
             n = int(np.prod(sh))
@@ -483,13 +487,22 @@ def test_adamw_amsgrad_matches_aten(B, kind):
     a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
     t = T.TorchDqn(kind, shapes, p0, lr=lr, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, adamw=kw)
     plain = T.TorchDqn(kind, shapes, p0, lr=lr, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, adamw=dict(kw, amsgrad=False))
+    # Adam normalises every element by its own second moment: an element whose gradient is rounding noise (|g| below ~1e-5 of the largest
+    # gradient: its SIGN is not determined in f32) still moves by up to lr per step, in a direction two correct implementations need not
+    # share.  Those elements are bounded by what Adam can move them (2 lr per step); every element whose reference gradient has been above
+    # the noise floor in every step so far must agree to a small fraction of one step.
+    determined = None
     for s, batch in enumerate(batches):
         r = t.update(*batch)
         plain.update(*batch)
         rec = a.update_on_batch(*batch)
         assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-9, (s, rec["loss"], r["loss"])
         d = np.abs(a.get_params("qnet").astype(np.float64) - t.params())
-        assert d.max() < 0.1 * lr, (s, d.max())
+        gabs = np.abs(r["grads"].astype(np.float64))
+        ok = gabs > 1e-5 * gabs.max()
+        determined = ok if determined is None else (determined & ok)
+        assert d[determined].max() < 0.1 * lr and d.max() < 2.2 * lr * (s + 1), (s, d[determined].max(), d.max())
+        assert determined.mean() > 0.5, (s, determined.mean())
     assert a.n_opts == len(batches)
     vmax, v = a.get_params("max_exp_avg_sq"), a.get_params("exp_avg_sq")
     assert (vmax >= v).all() and (vmax > v * 1.5).mean() > 0.1            # the maximum really is ahead of the decayed second moment
@@ -1045,6 +1058,17 @@ def test_a_deferred_report_is_told_apart_from_a_failure_of_the_call_itself(B):
         a.sync()
     assert e.value.code == 1 and "action index" in str(e.value) and L.bdr_last_error_is_deferred() == 1
     a.sync()                                           # reported once, cleared
+    # ... and the same condition raised by the step the failing call ITSELF ran (Agent::opt_with_record: enqueue, synchronise, check): kind 2.
+    # The step has run exactly once and its record is in the caller's buffer - a caller that "retried" would take a second optimizer step
+    # (the Rust shim did).
+    import ctypes as C
+    n0 = a.n_opts
+    vals, n_out = (C.c_float * 64)(*([float("nan")] * 64)), C.c_int32(-1)
+    rc = L.bdr_agent_opt_with_scalars(a.handle, rb.handle, vals, 64, C.byref(n_out))
+    assert rc == 1 and L.bdr_last_error_is_deferred() == 2 and b"action index" in L.bdr_last_error()
+    assert a.n_opts == n0 + 1 and n_out.value >= 1 and np.isfinite(vals[0])          # one step, and its loss is there
+    a.sync()
+    assert a.n_opts == n0 + 1
     a.close(); rb.close()
 
 
@@ -1054,7 +1078,7 @@ def test_split_operand_conv_planes_follow_every_parameter_writer(B, monkeypatch,
     (csrc/dqn.hip: cpl, k_reduce_adam writes the online planes with the parameters; soft updates, set_params, load, the all-reduce
     and a gate time-out leave a set stale and the next forward re-splits it).  A stale plane would be a whole Adam step / soft update
     behind: at lr = 3e-3, tau = 0.5 that is tens of percent on the loss.  A twin agent on the exact FP32-MFMA kernels
-    (BDR_DQN_F32_EXACT=1) over the same ring and the same parameters must agree at every step within the split's own error class
+    (bdr_dqn_config::arithmetic = BDR_ARITH_F32_EXACT) over the same ring and the same parameters must agree at every step within the split's own error class
     (six of nine partial products: ~2e-6 per layer) plus Adam's amplification of it; and the acting kernels (exact f32, n <= 8)
     must agree with the training forward (planes) on the same rows after the run."""
     from oracle import torch_ref as T
@@ -1063,9 +1087,8 @@ def test_split_operand_conv_planes_follow_every_parameter_writer(B, monkeypatch,
     kw = dict(batch_size=Bsz, lr=3e-3, critic_loss="SmoothL1", tau=0.5, soft_update_interval=3)
     agents, bufs = [], []
     for exact in (False, True):
-        if exact: monkeypatch.setenv("BDR_DQN_F32_EXACT", "1")
-        else: monkeypatch.delenv("BDR_DQN_F32_EXACT", raising=False)
-        a = make_agent(B, **kw)
+        monkeypatch.delenv("BDR_DQN_F32_EXACT", raising=False)
+        a = make_agent(B, arithmetic="f32_exact" if exact else "bf16x3_6", **kw)   # bdr_dqn_config::arithmetic, not the A/B variable
         a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
         rb = B.SimpleReplayBuffer(B.SimpleReplayBufferConfig(capacity=cap, seed=42), (4, 1, 84, 84), np.uint8)
         rb.fill_synthetic(cap, seed=3, kind=0, n_actions=6)
@@ -1098,3 +1121,64 @@ def test_split_operand_conv_planes_follow_every_parameter_writer(B, monkeypatch,
     for step in range(13, 17): both(step)
     acting_agrees(agents[0])
     for a, rb in zip(agents, bufs): a.close(); rb.close()
+
+
+def test_split_forward_error_budget_per_layer_at_c2_shapes(B, monkeypatch):
+    """The split-operand forward's OWN error budget, layer by layer, at the headline shapes (B = 256: conv2 = [20736][512] x [512][64],
+    conv3 = [12544][576] x [576][64]).  Each layer's output is compared with an f64 evaluation of that layer on the device's own
+    input activations (probes 5-7), so only the layer's arithmetic shows: products (exact f32 on the FP32 MFMA, or six of the nine bf16
+    partial products of round-to-nearest split operands) and the f32 accumulation order.  Budget, relative to the layer's largest
+    output: 1e-6 for either arithmetic (an f32 dot product of K = 512 / 576 terms in any order is ~4e-7; the three dropped
+    products add <= 3 * 2^-26 per product before cancellation; measured on MI355X: 8.5e-7 / 7.9e-7 split, 8.0e-7 / 4.9e-7 exact, mean signed
+    -5e-9 / -6e-9 split, 7e-10 / -3e-10 exact), the two arithmetics within 2e-6 of each other (measured 1.2e-6), and the split path's
+    MEAN signed error against f64 below 2e-8: the nearest split leaves no bias (the truncation split of rounds 4-5 pushed
+    every dropped product the same way).  The env override is also covered: BDR_DQN_F32_EXACT=0 forces the split kernels onto an
+    agent configured exact, and the labels / results say so."""
+    import torch
+    from oracle import torch_ref as T
+    monkeypatch.delenv("BDR_DQN_F32_EXACT", raising=False)
+    Bsz, A = 256, 6
+    p0 = T.init_params(T.cnn_shapes(A), 12)
+    obs, act, nobs, rew, term = T.synthetic_atari_batch(Bsz, A, 77)
+    w = T.unflatten(p0, T.cnn_shapes(A))     # c1.w c1.b c2.w c2.b c3.w c3.b l1.w l1.b l2.w l2.b
+    out = {}
+    for mode in ("bf16x3_6", "f32_exact"):
+        a = make_agent(B, A, batch_size=Bsz, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, arithmetic=mode)
+        a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+        a.update_on_batch(obs, act, nobs, rew, term)
+        a1 = a.probe("act_conv1", Bsz * 400 * 32).reshape(Bsz, 20, 20, 32)
+        a2 = a.probe("act_conv2", Bsz * 81 * 64).reshape(Bsz, 9, 9, 64)
+        a3 = a.probe("act_conv3", Bsz * 49 * 64).reshape(Bsz, 7, 7, 64)
+        out[mode] = (a1, a2, a3)
+        a.close()
+
+    def layer64(x_nhwc, wt, bias, stride):
+        x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2).double()
+        y = torch.nn.functional.conv2d(x, wt.detach().double(), bias.detach().double(), stride=stride).relu()
+        return y.permute(0, 2, 3, 1).numpy()
+
+    assert (out["bf16x3_6"][0] == out["f32_exact"][0]).all()            # conv1 is the same kernel in both
+    errs = {}
+    for mode, (a1, a2, a3) in out.items():
+        r2, r3 = layer64(a1, w[2], w[3], 2), layer64(a2, w[4], w[5], 1)
+        e2, e3 = (a2.astype(np.float64) - r2) / np.abs(r2).max(), (a3.astype(np.float64) - r3) / np.abs(r3).max()
+        errs[mode] = (np.abs(e2).max(), np.abs(e3).max(), e2[r2 > 0].mean(), e3[r3 > 0].mean())
+        assert np.abs(e2).max() < 1e-6 and np.abs(e3).max() < 1e-6, (mode, errs[mode])
+    print("per-layer error vs f64 (max conv2, max conv3, mean signed conv2, mean signed conv3):", errs)
+    assert abs(errs["bf16x3_6"][2]) < 2e-8 and abs(errs["bf16x3_6"][3]) < 2e-8, errs
+    for i in (1, 2):
+        d = np.abs(out["bf16x3_6"][i].astype(np.float64) - out["f32_exact"][i]).max() / np.abs(out["f32_exact"][i]).max()
+        assert d < 2e-6, (i, d)
+    # the A/B variable overrides the field in both directions
+    monkeypatch.setenv("BDR_DQN_F32_EXACT", "0")
+    a = make_agent(B, A, batch_size=Bsz, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, arithmetic="f32_exact")
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    a.update_on_batch(obs, act, nobs, rew, term)
+    assert (a.probe("act_conv2", Bsz * 81 * 64).reshape(Bsz, 9, 9, 64) == out["bf16x3_6"][1]).all()
+    a.close()
+    monkeypatch.setenv("BDR_DQN_F32_EXACT", "1")
+    a = make_agent(B, A, batch_size=Bsz, critic_loss="SmoothL1", tau=1.0, soft_update_interval=10000, arithmetic="bf16x3_6")
+    a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
+    a.update_on_batch(obs, act, nobs, rew, term)
+    assert (a.probe("act_conv2", Bsz * 81 * 64).reshape(Bsz, 9, 9, 64) == out["f32_exact"][1]).all()
+    a.close()

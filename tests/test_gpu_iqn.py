@@ -184,7 +184,7 @@ def test_iqn_baseline_config4_full_size_vs_oracle(B):
 @pytest.mark.parametrize("Bsz,NQ", [(64, 64), (128, 32)])
 def test_split_operand_merge_layer_equals_the_exact_kernels(B, monkeypatch, Bsz, NQ):
     """The merge layer f.L[1] at a matrix-bound size (M = B * N = 4096 rows x 3136 x 512) on the bf16 matrix cores with split operands
-    (igemm_b3.hpp: six of the nine exact bf16 partial products) against the exact FP32-MFMA kernels (BDR_IQN_F32_EXACT=1) on the same
+    (igemm_b3.hpp: six of the nine exact bf16 partial products) against the exact FP32-MFMA kernels (arithmetic = f32_exact) on the same
     update: quantile values 1e-5, loss 1e-5, every gradient 1e-4 of its variable's scale - an order tighter than the 1e-4 bar both
     hold against the oracle - and the profile labels name the arithmetic that ran."""
     from oracle import torch_ref as T
@@ -195,11 +195,11 @@ def test_split_operand_merge_layer_equals_the_exact_kernels(B, monkeypatch, Bsz,
     out = {}
     for mode in ("exact", "split", "split_separate_merge_bwd"):
         monkeypatch.delenv("BDR_IQN_F32_EXACT", raising=False); monkeypatch.delenv("BDR_IQN_NO_MERGE_EPILOGUE", raising=False)
-        if mode == "exact":
-            monkeypatch.setenv("BDR_IQN_F32_EXACT", "1")
-        elif mode != "split":      # with 64 percent points per sample the merge's backward is the input-gradient kernel's epilogue; this is the separate pass
+        if mode not in ("exact", "split"):      # with 64 percent points per sample the merge's backward is the input-gradient kernel's epilogue; this is the separate pass
             monkeypatch.setenv("BDR_IQN_NO_MERGE_EPILOGUE", "1")
-        a = _agent(B, "cnn", 3136, 64, [512], A, None, [], Bsz, 1e-4, p0, tau=1.0, soft_update_interval=10000)
+        # the arithmetic is stated through the boundary (bdr_iqn_config::arithmetic), not through the A/B variable
+        a = _agent(B, "cnn", 3136, 64, [512], A, None, [], Bsz, 1e-4, p0, tau=1.0, soft_update_interval=10000,
+                   arithmetic="f32_exact" if mode == "exact" else "bf16x3_6")
         z = a.forward(batch[0], batch[5], "iqn")
         a.profile_enable(True)
         rec = a.update_on_batch(*batch)
@@ -240,10 +240,9 @@ def test_split_operand_merge_layer_behind_an_mlp_feature_extractor(B, monkeypatc
     out = {}
     for mode in ("exact", "split"):
         monkeypatch.delenv("BDR_IQN_F32_EXACT", raising=False)
-        if mode == "exact":
-            monkeypatch.setenv("BDR_IQN_F32_EXACT", "1")
         f_cfg = B.MlpConfig(in_dim=8, units=(64,), out_dim=F_, activation_out=act_out)
-        cfg = B.IqnConfig(f_config=f_cfg, feature_dim=F_, embed_dim=64, m_units=(512,), n_actions=A, lr=1e-4, batch_size=Bsz, device=0, tau=1.0, soft_update_interval=10000)
+        cfg = B.IqnConfig(f_config=f_cfg, feature_dim=F_, embed_dim=64, m_units=(512,), n_actions=A, lr=1e-4, batch_size=Bsz, device=0, tau=1.0, soft_update_interval=10000,
+                          arithmetic="f32_exact" if mode == "exact" else "bf16x3_6")
         a = B.Iqn.build(cfg)
         a.set_params(p0, "iqn"); a.set_params(p0, "iqn_tgt")
         a.profile_enable(True)

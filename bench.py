@@ -590,6 +590,10 @@ def main():
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         if not args.overlap_exchange:
             os.environ["BDR_NO_XCHG_OVERLAP"] = "1"
+    if world > 1 and os.environ.get("BDR_BENCH_SHARE_GPU") == "1":
+        # flow test of the N>1 path on a 1-GPU box: the ranks share device 0, which RCCL refuses - they load the communicator's
+        # host-transport TEST build (same comm.hip, librccl's entry points over host shared memory); the line says so and carries no rccl_ranks
+        os.environ.setdefault("BORDER_AMD_LIB", os.path.join(ROOT, "border_amd", "libborder_amd_hostcomm.so"))
     import torch  # noqa: F401  (first: one HIP runtime per process, see border_amd/_lib.py)
     import border_amd as B
 
@@ -650,14 +654,12 @@ def main():
     if world > 1:
         # RCCL or nothing: a failure to bring the communicator up on ANY rank ends the run on every rank (MIN-reduce of
         # a success flag over the control plane), with a non-zero exit status - never a silently slower data plane.
-        if share:   # explicit opt-in (tests of the control flow on a 1-GPU box): RCCL refuses duplicate devices
-            exch = B.ParamExchange(world, rank, args.sync_interval, "torch", local_rank, None, conf["which"])
-        else:
-            try:
-                exch = B.ParamExchange.rccl_or_raise(world, rank, args.sync_interval, local_rank, bcast_bytes, conf["which"])
-            except RuntimeError as e:
-                sys.stderr.write(f"bench.py: {e}; an N>1 run has no other data plane\n")
-                sys.exit(3)
+        # (BDR_BENCH_SHARE_GPU=1, the flow test on a 1-GPU box: the same calls, on the communicator's host-transport test build - see below)
+        try:
+            exch = B.ParamExchange.rccl_or_raise(world, rank, args.sync_interval, local_rank, bcast_bytes, conf["which"])
+        except RuntimeError as e:
+            sys.stderr.write(f"bench.py: {e}; an N>1 run has no other data plane\n")
+            sys.exit(3)
         rccl_ranks = 0 if share else world
         # Setup, before the warm-up: every replica starts from the learner's parameters (the reference's first sync,
         # async_trainer/base.rs:268-272) and the communicator runs the measured collective once - RCCL builds its channels and
@@ -746,7 +748,7 @@ def main():
             roof = roofline(conf, prof, cnt, null_ms, ms)
         par = f"dp{world} (replica + replay shard per GPU"
         if world > 1:
-            par += f", parameter all-reduce every {args.sync_interval} opts over " + ("RCCL" if rccl_ranks else "host staging (BDR_BENCH_SHARE_GPU test mode)")
+            par += f", parameter all-reduce every {args.sync_interval} opts over " + ("RCCL" if rccl_ranks else "the communicator's host-transport TEST build (BDR_BENCH_SHARE_GPU=1)")
             par += ", overlapped per-segment exchange" if args.overlap_exchange else ", exchange in the agent's stream"
         par += ")"
         cfgd = {"workload": conf["workload"], "name": args.config, "batch_size": conf["batch"], "replay_capacity": conf["capacity"]}
@@ -759,7 +761,7 @@ def main():
                   "config": cfgd, "roofline": roof}
         if per_gpu is not None:
             result["per_gpu"] = {"unit": "opt-steps/s", "values": per_gpu, "aggregate": round(value, 2),
-                                 "sync_interval": args.sync_interval, "data_plane": "rccl" if rccl_ranks else "host staging (BDR_BENCH_SHARE_GPU=1: ranks share one device, which RCCL refuses)"}
+                                 "sync_interval": args.sync_interval, "data_plane": "rccl" if rccl_ranks else "host-transport test build of csrc/comm.hip (BDR_BENCH_SHARE_GPU=1: ranks share one device, which RCCL refuses)"}
         if steady is not None:
             result["steady_state"] = steady
         if cold is not None:

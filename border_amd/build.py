@@ -56,6 +56,31 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOSTCOMM_LIB = os.path.join(HERE, "libborder_amd_hostcomm.so")
+
+
+def build_hostcomm_library(verbose: bool = False) -> str:
+    """libborder_amd_hostcomm.so: the SAME objects with csrc/comm.hip compiled under -DBDR_COMM_HOST_TRANSPORT - the six librccl entry
+    points replaced by a host shared-memory transport (csrc/comm_host_transport.hpp) so that the N > 1 call sequences of comm.hip can run
+    with several ranks on ONE GPU (tests/test_gpu_multi.py on a 1-GPU box, bench.py's BDR_BENCH_SHARE_GPU flow test).  A test vehicle:
+    loaded only when BORDER_AMD_LIB names it."""
+    build_library()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(CSRC, "comm.hip")
+    obj = os.path.join(CSRC, "comm_hostcomm.o")
+    deps = [src, os.path.join(CSRC, "comm_host_transport.hpp"), os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "border_amd.h")]
+    if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps):
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+               "-DBDR_COMM_HOST_TRANSPORT", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    if not os.path.exists(HOSTCOMM_LIB) or os.path.getmtime(HOSTCOMM_LIB) < max(os.path.getmtime(obj), os.path.getmtime(LIB)):
+        objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES if s != "comm.hip" and os.path.exists(os.path.join(CSRC, s))]
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HOSTCOMM_LIB] + objs + [obj, "-ldl", "-lrt"])
+    return HOSTCOMM_LIB
+
+
 EXAMPLES = ("train_dqn_synthetic", "online_loop_atari")
 
 
@@ -79,3 +104,4 @@ def build_examples() -> str:
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
     print(build_examples())
+    print(build_hostcomm_library(verbose=True))

@@ -358,6 +358,73 @@ struct DxC2MP {
 #endif
 using DxC2M = DxC2MP<BDR_DXC2M_SHAPE>;
 
+// The merged-class GEMM with POSITION-CLASS tiles (round 6; conv3's DxC3PosP idea on the stride-2 layer): workgroup (x, y) = 64 images at the
+// half-resolution position pos(y) = (ihh, iwh), all four parity classes (128 columns).  Its k loop walks only the taps that reach a valid
+// output from that position: 4 in the interior (64 positions), 2 on the border rows / columns (32), 1 at the corners (4) - 2 592 k-tile
+// units of 64 x 128 x 32 per 256 images instead of 3 200, and the longest workgroups (8 k-tiles) are exactly 256 = one per CU at B = 256;
+// the 144 short ones (4 and 2 k-tiles) run beside them.  The flat row tiling had 400 equal workgroups of 8 k-tiles: 144 CUs held two,
+// 112 idled through half of the k loop.  y enumerates the positions by decreasing tap count so that the long tiles are dispatched first.
+// Per output element the products are those of DxC2MP minus the ones with a zero-padding operand, in the same order: bit-identical results.
+// grid: (ceil(B / 64), 100, 1).
+static __device__ __constant__ unsigned char c2_pos_by_taps[100] = {
+    11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36, 37, 38, 41, 42, 43, 44, 45, 46, 47, 48, 51, 52, 53, 54, 55,
+    56, 57, 58, 61, 62, 63, 64, 65, 66, 67, 68, 71, 72, 73, 74, 75, 76, 77, 78, 81, 82, 83, 84, 85, 86, 87, 88, 1, 2, 3, 4, 5, 6, 7, 8, 10, 19, 20, 29,
+    30, 39, 40, 49, 50, 59, 60, 69, 70, 79, 80, 89, 91, 92, 93, 94, 95, 96, 97, 98, 0, 9, 90, 99};
+template <int WM_, int WN_, int TM_, int TN_>
+struct DxC2MPosP {
+    using G = GeomC2;
+    using A = ADxS2Pos<G>;
+    using Args = DxArgs;          // M = B * 100 (rows of ONE class)
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int RPI = 1, RPIP = 0;
+    static constexpr int NC = 4 * G::CIN;          // columns n = class * 32 + cin
+    static constexpr bool B_TR = true;
+    static constexpr int NPOS = A::HH * A::WH;
+    __device__ static bool vrow(const Args& a, int mv, int& mr) { return vrow_flat(a.M, mv, mr); }   // (unused: vrow_y)
+    __device__ static bool vrow_y(const Args& a, int y, int mv, int& mr)
+    {
+        mr = mv * NPOS + c2_pos_by_taps[y];     // image mv at this workgroup's position
+        return mr < a.M;
+    }
+    __device__ static constexpr int N(const Args&) { return NC; }
+    __device__ static constexpr int KP(const Args&) { return G::COUT; }
+    __device__ static int M(const Args& a) { return a.M; }
+    __device__ static const float* a_src(const Args& a, int) { return a.dy; }
+    __device__ static const float* w(const Args& a, int, int) { return a.w; }
+    __device__ static void pos_taps(int y, int& a0, int& na, int& b0, int& nb)
+    {
+        const int pos = c2_pos_by_taps[y];
+        A::taps(pos / A::WH, G::OH, a0, na);
+        A::taps(pos % A::WH, G::OW, b0, nb);
+    }
+    __device__ static int tap_index(int, int t) { return t; }   // (unused: b_row)
+    // weight row of column n = (class, cin) for the t-th VALID tap of position y: W2 is [(kh,kw,cin)][cout], kh = ph + 2a, kw = pw + 2*b2
+    __device__ static int b_row(int y, int t, int n)
+    {
+        int a0, na, b0, nb;
+        pos_taps(y, a0, na, b0, nb);
+        const int tc = min(t, na * nb - 1);
+        const int th = nb == 2 ? tc >> 1 : tc;
+        const int a = a0 + th, b2 = b0 + (tc - th * nb), cls = n >> 5;
+        return (((cls >> 1) + 2 * a) * 4 + (cls & 1) + 2 * b2) * G::CIN + (n & 31);
+    }
+    __device__ static void kt_range(const Args&, int y, int& k0, int& k1)
+    {
+        int a0, na, b0, nb;
+        pos_taps(y, a0, na, b0, nb);
+        k0 = 0; k1 = na * nb * (G::COUT / BK);
+    }
+    struct Epi { gptr<const float> mask; gptr<float> out; };
+    __device__ static Epi epi(const Args& a, int, int) { return Epi{pin_sgpr(a.mask), pin_sgpr(a.out)}; }
+    __device__ static float epi_load(const Epi& e, int m, int n) { return e.mask[DxC2MP<WM_, WN_, TM_, TN_>::out_index(m, n)]; }
+    __device__ static void store(const Epi& e, int m, int n, float v, float mask) { e.out[DxC2MP<WM_, WN_, TM_, TN_>::out_index(m, n)] = mask > 0.f ? v : 0.f; }
+};
+#ifndef BDR_DXC2MPOS_SHAPE
+#define BDR_DXC2MPOS_SHAPE 2, 2, 1, 1  // 64 images x 64 columns: 800 workgroups at B = 256 (512 of 8 k-tiles, 256 of 4, 32 of 2); same box, 3 interleaved runs: 5 176-5 189 opt-steps/s against 5 093-5 095 for 64 x 128, 5 182-5 184 for 32 x 128, 5 054-5 061 for 128 x 64 and 5 025-5 037 for the flat row tiles of rounds 4-5
+#endif
+using DxC2MPos = DxC2MPosP<BDR_DXC2MPOS_SHAPE>;
+template <class P> inline dim3 dxc2_pos_grid(int B) { return dim3((unsigned)((B + P::WM * P::TM * 32 - 1) / (P::WM * P::TM * 32)) * n_tiles<P>(), P::NPOS, 1); }
+
 // ================================================================================================
 // weight-gradient policies
 // ================================================================================================

@@ -37,10 +37,25 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
+}  // namespace
+#ifdef BDR_COMM_HOST_TRANSPORT
+#include "comm_host_transport.hpp"   // (test build only: see the file's header)
+#endif
+namespace {
 
 int32_t load_rccl()
 {
     if (g_rccl.h) return BDR_OK;
+#ifdef BDR_COMM_HOST_TRANSPORT
+    {   // the test library: the same six entry points over host shared memory, so that N ranks may share one GPU
+        Rccl r; r.h = (void*)&g_rccl;
+        r.GetUniqueId = host_transport::get_unique_id; r.CommInitRank = host_transport::comm_init_rank; r.CommDestroy = host_transport::comm_destroy;
+        r.AllReduce = host_transport::all_reduce; r.Broadcast = host_transport::broadcast; r.GetErrorString = host_transport::error_string;
+        g_rccl = r;
+        fprintf(stderr, "border_amd: this is the HOST-TRANSPORT TEST BUILD of the communicator (libborder_amd_hostcomm.so): collectives are staged through host shared memory\n");
+        return BDR_OK;
+    }
+#endif
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }

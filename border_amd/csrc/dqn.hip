@@ -57,7 +57,7 @@ namespace {
 #define BDR_TEAMS_DX_C2 1
 #endif
 #ifndef BDR_DXC2_MERGED
-#define BDR_DXC2_MERGED 1   // conv2 input gradient: the four parity classes as one GEMM (DxC2M); 0: one launch slice per class (DxC2)
+#define BDR_DXC2_MERGED 2   // conv2 input gradient: 2 = the four parity classes as one GEMM over position-class tiles (DxC2MPos, valid taps only); 1 = the same GEMM over flat row tiles (DxC2M); 0 = one launch slice per class (DxC2)
 #endif
 // conv3 forward of the DQN step: 32x64 tiles, two k-split teams (392 workgroups per instance instead of 196: with the split forward every
 // launch is ONE instance, and 196 tiles left a quarter of the CUs idle; round 4, same box: 4 700 vs 4 647 opt-steps/s)
@@ -901,7 +901,9 @@ int32_t update_critic(DqnCnn* a, int B, const uint8_t* obs, const uint8_t* next_
     auto c2_dx = [&]() -> int32_t {
         DxArgs d{a->dy2, a->q + ar.w2, a->a1[0], a->dy1, B * 100, sigf(SIG_DXC3), epoch};
         Bracket br(a, "bwd_conv2_dx");
-#if BDR_DXC2_MERGED
+#if BDR_DXC2_MERGED == 2
+        BDR_HIP((launch_igemm<DxC2MPos, TEAMS_DX_C2>(a->stream, dxc2_pos_grid<DxC2MPos>(B), d)));
+#elif BDR_DXC2_MERGED
         BDR_HIP((launch_igemm<DxC2M, TEAMS_DX_C2>(a->stream, dim3(m_tiles<DxC2M>(d.M) * n_tiles<DxC2M>(), 1, 1), d)));
 #else
         BDR_HIP((launch_igemm<DxC2, TEAMS_DX_C2>(a->stream, dim3((d.M + 127) / 128, 4, 1), d)));

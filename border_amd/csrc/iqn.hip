@@ -425,7 +425,11 @@ struct Iqn : bdr_agent {
                 hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, stream, part_conv + pl.off_c3, pl.stride_c3, chunks, grad + conv.w3, n, 576 * 64, 1.0f);
                 BDR_HIP(hipGetLastError());
             }
-            { DxArgs d{dy3, p + conv.w3, a2, dy2, Bn * 81}; Bracket br(a, "psi_conv3_dx"); LAUNCH(k_igemm<DxC3>, dim3((d.M + 63) / 64, 1, 1), d); }
+            {   // position-class tiles (cnn_layers.hpp DxC3PosP: only the taps that reach a valid output; bit-identical to the flat row tiles)
+                DxArgs d{dy3, p + conv.w3, a2, dy2, Bn * 81, nullptr, 0};
+                Bracket br(a, "psi_conv3_dx");
+                BDR_HIP((launch_igemm<DxC3Pos, 2>(stream, dim3(((Bn + DxC3Pos::WM * DxC3Pos::TM * 32 - 1) / (DxC3Pos::WM * DxC3Pos::TM * 32)) * n_tiles<DxC3Pos>(), 81, 1), d)));
+            }
             {
                 const int Mr = Bn * 81, chunks = std::min(pl.chunks_c2, (Mr + 31) / 32);
                 DwArgs d{a1, dy2, part_conv + pl.off_c2, pl.stride_c2, Mr};
@@ -434,7 +438,11 @@ struct Iqn : bdr_agent {
                 hipLaunchKernelGGL(k_reduce_partials, dim3((n + 63) / 64), dim3(256), 0, stream, part_conv + pl.off_c2, pl.stride_c2, chunks, grad + conv.w2, n, 512 * 64, 1.0f);
                 BDR_HIP(hipGetLastError());
             }
-            { DxArgs d{dy2, p + conv.w2, a1, dy1, Bn * 100}; Bracket br(a, "psi_conv2_dx"); LAUNCH(k_igemm<DxC2>, dim3((d.M + 127) / 128, 4, 1), d); }
+            {   // the four parity classes as one GEMM over position-class tiles (DxC2MPosP), as the DQN step
+                DxArgs d{dy2, p + conv.w2, a1, dy1, Bn * 100, nullptr, 0};
+                Bracket br(a, "psi_conv2_dx");
+                BDR_HIP((launch_igemm<DxC2MPos, 1>(stream, dxc2_pos_grid<DxC2MPos>(Bn), d)));
+            }
             {
                 const int chunks = std::min(pl.chunks_c1, Bn);
                 Conv1DwArgs d{obs, dy1, part_conv + pl.off_c1, pl.stride_c1, Bn};

@@ -254,35 +254,31 @@ class NativeTrainer:
 
 
 class ParamExchange:
-    """Parameter averaging across one-replica-per-GPU ranks.
+    """Parameter averaging across one-replica-per-GPU ranks over the library's own communicator (csrc/comm.hip): ncclAllReduce on the
+    flat f32 arena + 1/N scale, enqueued on the agent's stream (or, per segment, on its communication queue); no host sync.  The
+    unique id is created on rank 0 and handed to the other ranks by `bcast_bytes` (a callable(bytes|None) -> bytes, e.g. a
+    torch.distributed broadcast on the control plane).  There is no other data plane here: rounds 1-5 carried a host-vector
+    "torch" backend for the CPU tests; those now subclass this class (tests/test_param_exchange_gloo.py) and the N ranks-on-one-GPU
+    flow tests load the communicator's host-transport test build instead (libborder_amd_hostcomm.so, build.build_hostcomm_library)."""
 
-    backend "rccl": the library's own communicator (ncclAllReduce on the flat f32 arena + 1/N
-    scale, enqueued on the agent's stream; no host sync).  The unique id is created on rank 0
-    and handed to the other ranks by `bcast_bytes` (a callable(bytes|None) -> bytes, e.g. a
-    torch.distributed broadcast).
-    backend "torch": torch.distributed all_reduce on a tensor (CPU gloo path used by the
-    world_size-2 tests; params cross the C ABI as host vectors).
-    """
-
-    def __init__(self, world_size: int, rank: int, sync_interval: int, backend: str = "rccl", device: int = 0,
-                 bcast_bytes=None, which=("qnet",)):
-        if backend not in ("rccl", "torch"):
-            raise ValueError(f"ParamExchange backend {backend!r}: 'rccl' (the library's communicator, the GPU data plane) or 'torch' (host vectors over gloo, CPU tests)")
-        self.world_size, self.rank, self.sync_interval, self.backend = world_size, rank, sync_interval, backend
+    def __init__(self, world_size: int, rank: int, sync_interval: int, device: int = 0, bcast_bytes=None, which=("qnet",)):
+        self.world_size, self.rank, self.sync_interval = world_size, rank, sync_interval
         self.which = tuple(which)
         self.device = device
         self._comm = None
-        self.fallback_reason = None
-        if world_size > 1 and backend == "rccl":
-            L = _lib.lib()
-            uid = (C.c_uint8 * _lib.BDR_UNIQUE_ID_BYTES)()
-            if rank == 0:
-                _lib.check(L.bdr_comm_get_unique_id(uid))
-            raw = bcast_bytes(bytes(uid) if rank == 0 else None)
-            uid = (C.c_uint8 * _lib.BDR_UNIQUE_ID_BYTES)(*raw)
-            h = C.c_void_p()
-            _lib.check(L.bdr_comm_init_rank(uid, world_size, rank, device, C.byref(h)))
-            self._comm = h
+        if world_size > 1:
+            self._comm = self._connect(bcast_bytes)
+
+    def _connect(self, bcast_bytes):
+        L = _lib.lib()
+        uid = (C.c_uint8 * _lib.BDR_UNIQUE_ID_BYTES)()
+        if self.rank == 0:
+            _lib.check(L.bdr_comm_get_unique_id(uid))
+        raw = bcast_bytes(bytes(uid) if self.rank == 0 else None)
+        uid = (C.c_uint8 * _lib.BDR_UNIQUE_ID_BYTES)(*raw)
+        h = C.c_void_p()
+        _lib.check(L.bdr_comm_init_rank(uid, self.world_size, self.rank, self.device, C.byref(h)))
+        return h
 
     @classmethod
     def rccl_or_raise(cls, world_size: int, rank: int, sync_interval: int, device: int, bcast_bytes, which=("qnet",)):
@@ -294,7 +290,7 @@ class ParamExchange:
         import torch.distributed as dist
         ex, err = None, None
         try:
-            ex = cls(world_size, rank, sync_interval, "rccl", device, bcast_bytes, which)
+            ex = cls(world_size, rank, sync_interval, device, bcast_bytes, which)
         except Exception as e:  # noqa: BLE001  (reported below, on every rank)
             err = e
         ok = torch.tensor([0 if ex is None else 1], dtype=torch.int32)
@@ -320,47 +316,24 @@ class ParamExchange:
     def average(self, agent) -> None:
         if self.world_size == 1:
             return
-        if self.backend == "rccl":
-            for w in self.which:
-                _lib.check(_lib.lib().bdr_agent_allreduce_params(agent.handle, self._comm, agent.WHICH[w]))
-        else:
-            import torch
-            import torch.distributed as dist
-            for w in self.which:
-                t = torch.from_numpy(np.array(agent.get_params(w), copy=True))
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                t /= self.world_size
-                agent.set_params(t.numpy(), w)
+        for w in self.which:
+            _lib.check(_lib.lib().bdr_agent_allreduce_params(agent.handle, self._comm, agent.WHICH[w]))
 
     def agree(self, local_ok: bool = True) -> bool:
         """MIN over ranks of local_ok: every rank calls it before a collective (bdr_learner_ops::agree); a rank that failed
         passes False once and every rank learns it instead of blocking in the next all-reduce."""
         if self.world_size == 1:
             return bool(local_ok)
-        if self.backend == "rccl":
-            out = C.c_int32(0)
-            _lib.check(_lib.lib().bdr_comm_agree(self._comm, 1 if local_ok else 0, C.byref(out)))
-            return bool(out.value)
-        import torch
-        import torch.distributed as dist
-        t = torch.tensor([1 if local_ok else 0], dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(int(t[0]))
+        out = C.c_int32(0)
+        _lib.check(_lib.lib().bdr_comm_agree(self._comm, 1 if local_ok else 0, C.byref(out)))
+        return bool(out.value)
 
     def broadcast(self, agent, root: int = 0) -> None:
         """The faithful learner->actors sync (SyncModel::sync_model on every actor)."""
         if self.world_size == 1:
             return
-        if self.backend == "rccl":
-            for w in self.which:
-                _lib.check(_lib.lib().bdr_agent_broadcast_params(agent.handle, self._comm, agent.WHICH[w], root))
-        else:
-            import torch
-            import torch.distributed as dist
-            for w in self.which:
-                t = torch.from_numpy(np.array(agent.get_params(w), copy=True))
-                dist.broadcast(t, src=root)
-                agent.set_params(t.numpy(), w)
+        for w in self.which:
+            _lib.check(_lib.lib().bdr_agent_broadcast_params(agent.handle, self._comm, agent.WHICH[w], root))
 
 
 def shard_seed(base_seed: int, rank: int) -> int:

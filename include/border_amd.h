@@ -354,7 +354,15 @@ BDR_API int32_t bdr_agent_get_explorer(const bdr_agent* a, bdr_explorer_config* 
 /* Policy::sample (dqn/base.rs:211-242, iqn/base.rs:204-228) for n_procs observations (host rows as in the
  * replay buffer): device forward, exploration as configured, act_out[n_procs] (int64).
  * train: n_samples_act += 1 (and n_samples_best_act += 1 when every row took its greedy action, the
- * reference's `record_verbose_level >= 2` bookkeeping).  info may be NULL. */
+ * reference's `record_verbose_level >= 2` bookkeeping).  info may be NULL.
+ * ONE network, two kernel families (AtariCnn DQN / IQN): calls with n_procs <= 8 run the acting kernels (csrc/act_small.hpp: exact f32
+ * products from the f32 weights, k-sliced 32 x 32 tiles), larger calls the training forward (conv2 / conv3 with the agent's
+ * `arithmetic`).  The two evaluate the same function to f32 round-off - Q-values within 5e-6 of the largest |Q| with BDR_ARITH_BF16X3_6,
+ * 1e-6 with BDR_ARITH_F32_EXACT (tests/test_gpu_sample.py) - but not bit for bit: the greedy action of a row is the same on both
+ * whenever its two leading Q-values differ by more than 2e-5 of the largest |Q|; below that distance it may depend on how many
+ * environments share the call (8 vs 9).  Exact ties (equal rows of the output layer) resolve to the first maximum on both.  The
+ * reference has the same property across batch sizes (ATen picks its GEMM blocking by shape); a caller that needs one family for
+ * every n sets BDR_NO_ACT_SMALL=1 (training forward always, ~2x the one-observation latency). */
 typedef struct {
     double eps;            /* eps used by this call (eps-greedy), else 0 */
     int32_t is_random;     /* the call took the random branch */

@@ -1,9 +1,11 @@
-"""Two REAL ranks over RCCL (csrc/comm.hip with nranks = 2): the N>1 data planes of SURVEY.md 8(e) on hardware.
+"""Two REAL ranks through csrc/comm.hip with nranks = 2: the N>1 data planes of SURVEY.md 8(e) on hardware.
 
-Needs >= 2 MI355X in one box: RCCL refuses two ranks on one device, so on the 1-GPU lease these tests SKIP (the single-rank
-forms live in tests/test_gpu_sync_dp.py, the control flow over gloo in tests/test_param_exchange_gloo.py and
-tests/test_async_trainer_host.py).  One process per GPU, spawned here; torch.distributed (gloo) is only the control plane
-(unique-id hand-off, barriers), exactly as in bench.py.
+On a box with >= 2 MI355X: one process per GPU over RCCL.  On the 1-GPU lease RCCL refuses two ranks on one device, so the two ranks
+SHARE device 0 and load libborder_amd_hostcomm.so - the same objects with comm.hip compiled under -DBDR_COMM_HOST_TRANSPORT, i.e. the six
+librccl entry points replaced by a host shared-memory transport (csrc/comm_host_transport.hpp) and every line ABOVE them unchanged:
+bdr_comm_agree, bdr_agent_allreduce_params with its per-segment overlapped exchange, the 1/N scale, bdr_agent_set_grad_comm,
+bdr_agent_broadcast_params, the async trainer's exchange / agree hooks.  (Rounds 1-5 skipped all of this at one GPU: comm.hip had never seen
+a second rank.)  torch.distributed (gloo) is only the control plane (unique-id hand-off, barriers), exactly as in bench.py.
 
 Parity statements (8(e) "Parity at G>1"), each against something that IS parity-checked on one GPU:
  (i)   synchronous data-parallel, 2 x 128 rows: grads_on_batch -> ncclAllReduce(grad)/2 -> apply_grads on both ranks == the C
@@ -42,7 +44,11 @@ def _n_gpus():
         return 0
 
 
-needs_two = pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 MI355X in one box (RCCL refuses two ranks on one device)")
+HOSTCOMM = os.path.join(ROOT, "border_amd", "libborder_amd_hostcomm.so")
+# two ranks: RCCL over two GPUs when the box has them, else the host-transport build of the communicator with both ranks on device 0
+SHARE_ONE_GPU = _n_gpus() < 2
+needs_two = pytest.mark.skipif(_n_gpus() < 1 or (SHARE_ONE_GPU and not os.path.exists(HOSTCOMM)),
+                               reason="needs an MI355X and, with fewer than two of them, border_amd/libborder_amd_hostcomm.so (build.build_hostcomm_library)")
 
 
 def _cnn(B, bs, dev, **kw):
@@ -67,7 +73,7 @@ def _rank_main(rank, world, port, out):
     from oracle import torch_ref as T
     dist.init_process_group("gloo", rank=rank, world_size=world)
     L = B._lib.lib()
-    dev = rank
+    dev = 0 if os.environ.get("BDR_TEST_SHARE_GPU") == "1" else rank
 
     def bcast_bytes(b):
         t = torch.zeros(B._lib.BDR_UNIQUE_ID_BYTES, dtype=torch.uint8)
@@ -224,8 +230,18 @@ def _spawn(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
+    saved = {k: os.environ.get(k) for k in ("BORDER_AMD_LIB", "BDR_TEST_SHARE_GPU")}
+    if world > 1 and SHARE_ONE_GPU:   # (spawned children inherit the environment at start())
+        os.environ["BORDER_AMD_LIB"], os.environ["BDR_TEST_SHARE_GPU"] = HOSTCOMM, "1"
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda r: r["rank"])
     for p in procs:
         p.join(timeout=120)

@@ -161,7 +161,28 @@ def test_acting_kernels_agree_with_the_training_forward(B, A):
         top2 = np.sort(q_train, axis=1)[:, -2:]
         clear = (top2[:, 1] - top2[:, 0]) > 2e-5 * scale
         assert (q_act.argmax(1)[clear] == q_train.argmax(1)[clear]).all()
-    # device-resident rows take the same kernels: same bits as host rows
+    # The boundary between the two families is n = 8 / 9 (include/border_amd.h at bdr_agent_sample): the SAME 8 rows alone and with a ninth.
+    # Near-ties are engineered in the output layer: action 1's row = action 0's row (an exact tie: the first maximum on both paths), action
+    # 2's = action 0's with the bias raised by 1e-4 of |Q| (a gap well above the 2e-5 band: action 2 wherever the three lead).
+    p = a.get_params("qnet").copy()
+    shapes = T.cnn_shapes(A)
+    off = np.cumsum([0] + [int(np.prod(sh)) for sh in shapes])
+    w5, b5 = p[off[8]:off[9]].reshape(A, 512), p[off[9]:off[10]]
+    obs8 = rng.integers(0, 256, (8, 4, 1, 84, 84), dtype=np.uint8)
+    scale = np.abs(a.qvalues(obs8)).max()
+    w5[0] *= 3.0; b5[0] = abs(b5[0]) + scale          # action 0 leads everywhere ...
+    w5[1] = w5[0]; b5[1] = b5[0]                       # ... action 1 ties with it exactly ...
+    w5[2] = w5[0]; b5[2] = b5[0] + np.float32(1e-4) * scale   # ... and action 2 is ahead by a clear margin
+    a.set_params(p, "qnet")
+    q8 = a.qvalues(obs8)                                                             # acting kernels
+    q9 = a.qvalues(np.concatenate([obs8, rng.integers(0, 256, (1, 4, 1, 84, 84), dtype=np.uint8)]))[:8]   # training forward
+    assert (q8[:, 0] == q8[:, 1]).all() and (q9[:, 0] == q9[:, 1]).all()             # the tie is exact on both paths
+    assert (q8.argmax(1) == 2).all() and (q9.argmax(1) == 2).all()                   # the clear leader wins on both
+    assert np.abs(q8 - q9).max() <= 5e-6 * np.abs(q9).max()
+    b5[2] = b5[0] - 1.0                                                              # without the leader: the exact tie -> first maximum, on both
+    a.set_params(p, "qnet")
+    assert (a.sample_greedy(obs8) == 0).all()
+    assert (a.sample_greedy(np.concatenate([obs8, obs8[:1]]))[:8] == 0).all()
     a.close()
 
 

@@ -1,5 +1,8 @@
-"""N>1 path on CPU: world_size-2 gloo processes drive border_amd.ParamExchange (backend "torch")
-and the shard/seed logic with an oracle-backed stand-in agent (no GPU in this container).
+"""N>1 path on CPU: world_size-2 gloo processes drive border_amd.ParamExchange's schedule (after_opt intervals, the RCCL-or-nothing
+ladder agreed on by every rank) and the shard/seed logic (no GPU in this container).  The product class has ONE data plane, the
+library's communicator, which needs a GPU: here a TEST-SIDE subclass (GlooExchange, below) moves the vectors over gloo instead.  The
+real call sequences of csrc/comm.hip with two ranks run in tests/test_gpu_multi.py (-m gpu; on a 1-GPU box over the communicator's
+host-transport test build).
 Properties: averaging identical replicas is the identity; the average is
 the arithmetic mean of the ranks' parameters; broadcast makes every rank equal to the root;
 shards draw from distinct StdRng streams."""
@@ -28,6 +31,38 @@ class FakeAgent:
         self.p[which] = np.array(v, np.float32)
 
 
+def _gloo_exchange_class():
+    """ParamExchange with its three collectives on torch.distributed / gloo host vectors: the test's own data plane (the product has none
+    but the library's communicator)."""
+    import torch
+    import torch.distributed as dist
+    from border_amd.trainer import ParamExchange
+
+    class GlooExchange(ParamExchange):
+        def _connect(self, bcast_bytes):
+            return None
+
+        def average(self, agent):
+            for w in self.which:
+                t = torch.from_numpy(np.array(agent.get_params(w), copy=True))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t /= self.world_size
+                agent.set_params(t.numpy(), w)
+
+        def agree(self, local_ok=True):
+            t = torch.tensor([1 if local_ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t[0]))
+
+        def broadcast(self, agent, root=0):
+            for w in self.which:
+                t = torch.from_numpy(np.array(agent.get_params(w), copy=True))
+                dist.broadcast(t, src=root)
+                agent.set_params(t.numpy(), w)
+
+    return GlooExchange
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -35,7 +70,8 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from border_amd.trainer import ParamExchange, shard_seed
     from oracle import oracle as O
-    ex = ParamExchange(world, rank, sync_interval=3, backend="torch")
+    ex = _gloo_exchange_class()(world, rank, sync_interval=3)
+    ok_agree = ex.agree(True) is True and ex.agree(rank != 1) is False
     base = np.linspace(-1, 1, 1000).astype(np.float32)
     # (i) identical replicas: averaging is the identity
     a = FakeAgent(base)
@@ -59,7 +95,7 @@ def _worker(rank, world, port, out):
         ok_ladder = "RCCL communicator could not be initialised" in str(e)
     # (iv) distinct replay streams per shard
     ix = O.StdRng.seed_from_u64(shard_seed(42, rank)).sample_indices(1_000_000, 8).tolist()
-    out.put((rank, ok_identity, ok_mean, ok_bcast and ok_ladder, ix))
+    out.put((rank, ok_identity, ok_mean, ok_bcast and ok_ladder and ok_agree, ix))
     dist.barrier()
     dist.destroy_process_group()
 

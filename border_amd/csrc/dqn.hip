@@ -45,7 +45,7 @@ namespace {
 #define BDR_TEAMS_DX_L1 BDR_TEAMS
 #endif
 #ifndef BDR_TEAMS_DX_C3
-#define BDR_TEAMS_DX_C3 BDR_TEAMS
+#define BDR_TEAMS_DX_C3 1   // round 6, with conv2's dX on position-class tiles: one team 5 218-5 222 opt-steps/s, two teams 5 158-5 163 (same box, interleaved)
 #endif
 #ifndef BDR_TEAMS_FWD_L1
 #define BDR_TEAMS_FWD_L1 1

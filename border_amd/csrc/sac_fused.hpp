@@ -76,6 +76,44 @@ __device__ __forceinline__ void sac_heads_row(const SacHeadsActionArgs& p, const
     for (int off = 32; off > 0; off >>= 1) { nl += __shfl_xor(nl, off); sl += __shfl_xor(sl, off); }
     if (lane == 0) p.logp[row] = nl - sl;
 }
+// The same arithmetic for the wave's FOUR rows at once, 16 lanes per row (round 6; A <= 16): lane = (row group g, column c).  One pass of
+// exponentials / tanh / log and one 4-step butterfly per wave instead of four passes with 6-step butterflies.  Same bits: the butterfly
+// tree over the A real columns is the one sac_heads_row walks (its upper steps add exact zeros), and the padded columns 16 .. 31 of
+// mean / e, which sac_heads_row rewrites with the zeros they hold from allocation (zero weights, zero bias), are simply left alone.
+__device__ __forceinline__ void sac_heads_rows16(const SacHeadsActionArgs& p, const float (*red_m)[32][33], const float (*red_s)[32][33], int r0, int m0, int lane,
+                                                 float bias_m, float bias_s, float zv)
+{
+    const int g = lane >> 4, c = lane & 15;
+    const int r = r0 + g, row = m0 + r;
+    const bool ok = row < p.B;
+    float nl = 0.f, sl = 0.f;
+    float mv = dense_small_sum(red_m, r, c) + bias_m;
+    float ev = dense_small_sum(red_s, r, c) + bias_s;
+    if (p.hm.relu) mv = mv > 0.f ? mv : 0.f;
+    if (p.hs.relu) ev = ev > 0.f ? ev : 0.f;
+    const size_t q = (size_t)(ok ? row : 0) * p.ld + c;
+    float a = 0.f, s = 0.f, sd = 0.f;
+    if (c < p.A) {
+        const float z = zv;
+        s = expf(ev);
+        const float cl = fminf(fmaxf(s, p.lo), p.hi);
+        sd = expf(cl);
+        a = tanhf(sd * z + mv);
+        nl = -0.91893853320467274178f - 0.5f * (z * z);
+        sl = logf((1.0f - a * a) + p.eps);
+    }
+    if (ok) {
+        p.mean[q] = mv; p.e[q] = ev;
+        if (c < p.A) {
+            p.xq[(size_t)row * p.ldq + p.col0 + c] = a;
+            if (p.a_out) { p.a_out[q] = a; p.s_out[q] = s; p.sd_out[q] = sd; }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { nl += __shfl_xor(nl, off); sl += __shfl_xor(sl, off); }
+    if (ok && c == 0) p.logp[row] = nl - sl;
+}
+
 __global__ __launch_bounds__(512) void k_sac_heads_action(SacHeadsActionArgs p)
 {
     __shared__ float red[2][4][32][33];
@@ -85,13 +123,22 @@ __global__ __launch_bounds__(512) void k_sac_heads_action(SacHeadsActionArgs p)
     const float* arow = p.h + (size_t)min(m0 + (lane & 31), p.B - 1) * p.ldh;
     const HeadRef& hd = team ? p.hs : p.hm;
     // operands of the row arithmetic that do not depend on the tiles: loaded beside the tile operands, not behind the barrier
-    const float bias_m = p.hm.bias[lane & 31], bias_s = p.hs.bias[lane & 31];
+    const bool grouped = p.A <= 16;   // (uniform) four rows per wave side by side, 16 lanes each
+    const int bcol = grouped ? (lane & 15) : (lane & 31);
+    const float bias_m = p.hm.bias[bcol], bias_s = p.hs.bias[bcol];
     float zrow[4];
+    if (grouped) {
+        const int row = min(m0 + wave * 4 + (lane >> 4), p.B - 1);
+        zrow[0] = (lane & 15) < p.A ? p.z[(size_t)row * p.A + (lane & 15)] : 0.f;
+        zrow[1] = zrow[2] = zrow[3] = 0.f;
+    } else {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) zrow[rr] = lane < p.A ? p.z[(size_t)min(m0 + wave * 4 + rr, p.B - 1) * p.A + lane] : 0.f;
+        for (int rr = 0; rr < 4; ++rr) zrow[rr] = lane < p.A ? p.z[(size_t)min(m0 + wave * 4 + rr, p.B - 1) * p.A + lane] : 0.f;
+    }
     dense_small_tile<false>([&](int k) { return *reinterpret_cast<const f32x4*>(arow + k); }, hd.w, p.w_ld, 0, p.kred, w4, lane, red[team]);
     asm volatile("" ::"v"(zrow[0]), "v"(zrow[1]), "v"(zrow[2]), "v"(zrow[3]), "v"(bias_m), "v"(bias_s));   // landed before the first store (last_layer_dx_land)
     __syncthreads();
+    if (grouped) { sac_heads_rows16(p, red[0], red[1], wave * 4, m0, lane, bias_m, bias_s, zrow[0]); return; }
     // one wave per row, lanes over the action dimension: k_sac_action's arithmetic and its butterfly sums
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {

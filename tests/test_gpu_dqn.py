@@ -482,38 +482,22 @@ def test_adamw_amsgrad_matches_aten(B, kind):
     # rewards x10 on the first two steps: large gradients first, small ones after -> exp_avg_sq decays below its maximum
     batches = [(o, a_, n, (r * (10.0 if s < 2 else 0.1)).astype(np.float32), t) for s, (o, a_, n, r, t) in enumerate(batches)]
     cfg = B.DqnConfig(model_config=B.DqnModelConfig(q_config=qc, opt_config=B.OptimizerConfig.AdamW(lr, **kw)),
-                      device=0, batch_size=len(batches[0][3]), critic_loss="SmoothL1", tau=0.01, soft_update_interval=1)
+                      device=0, batch_size=len(batches[0][3]), critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, arithmetic="f32_exact")
     a = B.Dqn.build(cfg)
     a.set_params(p0, "qnet"); a.set_params(p0, "qnet_tgt")
     t = T.TorchDqn(kind, shapes, p0, lr=lr, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, adamw=kw)
     plain = T.TorchDqn(kind, shapes, p0, lr=lr, critic_loss="SmoothL1", tau=0.01, soft_update_interval=1, adamw=dict(kw, amsgrad=False))
-    # Adam normalises every element by its own second moment: an element whose gradient is at the level the gradients themselves agree to
-    # (2e-4 of its variable's largest entry, assert_grads_close: a ReLU unit at its boundary, f32 summation order) has no determined SIGN,
-    # yet moves by up to lr per step - in a direction two correct implementations need not share.  Those elements are bounded by what Adam
-    # can move them (2 lr per step); every element whose reference gradient has been 5x above that level in every step so far must agree to
-    # a small fraction of one step.
-    determined = None
-    var_of = np.concatenate([np.full(int(np.prod(sh)), k) for k, sh in enumerate(shapes)])
+    # (the Nature-CNN case runs with arithmetic = f32_exact: at B = 8 ONE ReLU unit at its boundary - which the 1e-6 of the split-operand
+    #  forward moves across it now and then, here with the nearest split and not with round 5's truncation split - perturbs every conv
+    #  gradient by ~1 % (tools/diag/amsgrad_cnn.py: 2e-5 .. 1e-4 absolute with the split forward, 1e-9 with exact products), and Adam turns a
+    #  sign change of a near-zero gradient entry into 2 lr; this test is about the optimizer, which does not depend on the forward's arithmetic)
     for s, batch in enumerate(batches):
         r = t.update(*batch)
         plain.update(*batch)
         rec = a.update_on_batch(*batch)
         assert abs(rec["loss"] - r["loss"]) <= 3e-4 * abs(r["loss"]) + 1e-9, (s, rec["loss"], r["loss"])
         d = np.abs(a.get_params("qnet").astype(np.float64) - t.params())
-        gabs = np.abs(r["grads"].astype(np.float64))
-        vmax_of = np.array([gabs[var_of == k].max() for k in range(len(shapes))])
-        ok = gabs > 1e-3 * vmax_of[var_of]
-        determined = ok if determined is None else (determined & ok)
-        assert d.max() < 2.2 * lr * (s + 1), (s, d.max())
-        assert determined.mean() > 0.1, (s, determined.mean())
-        # ... except in at most two output channels per variable (a ReLU unit at its boundary perturbs ONE output channel of a layer's
-        # gradient: assert_grads_close allows the same), which only have to stay inside what Adam can move them
-        o = 0
-        for sh in shapes:
-            n = int(np.prod(sh))
-            over = ((d[o:o + n] > 0.1 * lr) & determined[o:o + n]).reshape(sh[0], -1).any(1)
-            assert over.sum() <= 2, (s, sh, int(over.sum()), d[o:o + n][determined[o:o + n]].max())
-            o += n
+        assert d.max() < 0.1 * lr, (s, d.max())
     assert a.n_opts == len(batches)
     vmax, v = a.get_params("max_exp_avg_sq"), a.get_params("exp_avg_sq")
     assert (vmax >= v).all() and (vmax > v * 1.5).mean() > 0.1            # the maximum really is ahead of the decayed second moment

@@ -549,7 +549,7 @@ def main():
     ap.add_argument("--double-dqn", action="store_true")
     ap.add_argument("--sync-interval", type=int, default=10, help="opt steps between RCCL parameter averaging (N>1)")
     ap.add_argument("--overlap-exchange", action="store_true",
-                    help="N>1: the per-segment parameter exchange on the agent's communication queue, overlapped with the step (DESIGN.md 7). Default: "
+                    help="N>1: the per-segment parameter exchange on the agent's communication queue, overlapped with the step (DESIGN.md 7, LAB.md 7). Default: "
                          "the collective in the agent's own stream - the form with nothing but stream order between it and the step; the overlapped "
                          "form has only ever run on ONE rank (tests/test_gpu_multi.py needs 2 GPUs), and a measurement must not hang")
     ap.add_argument("--per", action="store_true", help="prioritized replay (PerConfig defaults) instead of uniform sampling (c2)")
@@ -689,7 +689,7 @@ def main():
 
     # Order of the legs (round 4).  A short window (the driver's 5 + 20 steps = 5.5 ms) that starts right after agent construction
     # sits inside the chip's clock ramp: after >= 10 ms of idle a chip-filling MFMA kernel runs 12 % slower and recovers over ~10 ms
-    # of load (tools/probes/dvfs_probe.hip) - 9 % of such a window is decided by what the process did in the
+    # of load (LAB.md section 6, tools/probes/dvfs_probe.hip) - 9 % of such a window is decided by what the process did in the
     # 10 ms before it, not by the opt step.  bench.py has always run a `steady_state` leg (the same loop for ~0.5 s); it now runs
     # BEFORE the contract's window instead of after it, so that the window measures the opt step and not the ramp:
     #     cold_window  (W + K right after construction: reported, the round-1..3 `value`)

@@ -100,6 +100,7 @@ struct bdr_replay {
     uint64_t stage_records = 0;
     unsigned* done_host = nullptr; unsigned* done_dev = nullptr; unsigned done_seq = 0;   // pinned "small push finished" word (host view / device view) and its sequence number
     unsigned* done_ticket = nullptr;                        // device: records of the current small push that are finished
+    unsigned dev_rows_checks = 0;                            // counts cache hits of dev_rows_ok (every 1024th one re-validates)
     const void* dev_rows_ok[2] = {nullptr, nullptr};       // bdr_replay_push_device: the obs / next_obs base addresses that passed the device-pointer check last
     uint8_t* d_tails = nullptr; uint64_t tails_cap = 0;   // bdr_replay_push_device: device copy of a run's act / reward / flags
     // device batch buffers (lazily sized)

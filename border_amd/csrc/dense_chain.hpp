@@ -26,7 +26,7 @@ struct Chain2Args {
     int M, n1, relu0, relu1;                  // layer 0: [C2_K0][C2_N0], layer 1: [C2_N0][n1]; n1 % (32 TPW) == 0
     unsigned* sig_flag; unsigned sig_epoch;   // optional: start_signal (igemm.hpp)
     // optional: the inputs x are written by another queue, which publishes wait_epoch in *wait_flag when they are complete (queue_flags.hpp).  The wait
-    // is the kernel's first act - one cached load's round trip - instead of a one-wave k_flag_wait packet in front of the launch (+0.9 % of the SAC step)
+    // is the kernel's first act - one cached load's round trip - instead of a one-wave k_flag_wait packet in front of the launch (+0.9 % of the SAC step, LAB.md 5)
     const unsigned* wait_flag; unsigned wait_epoch; unsigned long long wait_limit; unsigned* wait_err; unsigned wait_code;
 #ifdef C2_STAMPS
     long long* stamps;

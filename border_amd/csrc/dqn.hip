@@ -45,7 +45,9 @@ namespace {
 #define BDR_TEAMS_DX_L1 BDR_TEAMS
 #endif
 #ifndef BDR_TEAMS_DX_C3
-#define BDR_TEAMS_DX_C3 1   // round 6, with conv2's dX on position-class tiles: one team 5 218-5 222 opt-steps/s, two teams 5 158-5 163 (same box, interleaved)
+#define BDR_TEAMS_DX_C3 BDR_TEAMS   // round 6, with conv2's dX on position-class tiles: one team is +1.1 % IN THE STEP (5 218-5 222 against 5 158-5 163 opt-steps/s, same box,
+                                   // interleaved: fewer waves leave the other queue more room) but 23.4 us instead of 18.1 on its own (18 k-tiles in sequence at the
+                                   // interior positions); two teams stay: the kernel's own time is what the roofline is read on (LAB.md "Round 6")
 #endif
 #ifndef BDR_TEAMS_FWD_L1
 #define BDR_TEAMS_FWD_L1 1
@@ -676,7 +678,7 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         static_cast<FwdArgs&>(fb) = f;
         for (int z = 0; z < nz; ++z) fb.wpl[z] = a->cpl[inst[z].params == a->q ? 0 : 1] + CPL_W2;
         Bracket br(a, "fwd_conv2");
-        BDR_HIP((launch_igemm_b3<FwdC2B3, 6>(st, dim3(m_tiles<FwdC2B3>(f.M), 1, nz), fb)));
+        BDR_HIP((launch_igemm_b3<FwdC2B3, 6>(st, dim3(m_tiles<FwdC2B3>(f.M) * n_tiles<FwdC2B3>(), 1, nz), fb)));
     } else { Bracket br(a, "fwd_conv2"); BDR_HIP((launch_igemm<FwdC2, TEAMS_FWD_C2>(st, dim3(m_tiles<FwdC2>(f.M) * n_tiles<FwdC2>(), 1, nz), f))); }
     f.M = B * 49;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a2[inst[z].slot]; f.w[z] = inst[z].params + ar.w3; f.bias[z] = inst[z].params + ar.b3; f.out[z] = a->a3[inst[z].slot]; }
@@ -684,7 +686,7 @@ int32_t forward(DqnCnn* a, const NetInst* inst, int nz, int B, const TdArgs* td 
         static_cast<FwdArgs&>(fb) = f;
         for (int z = 0; z < nz; ++z) fb.wpl[z] = a->cpl[inst[z].params == a->q ? 0 : 1] + CPL_W3;
         Bracket br(a, "fwd_conv3");
-        BDR_HIP((launch_igemm_b3<FwdC3B3, 6>(st, dim3(m_tiles<FwdC3B3>(f.M), 1, nz), fb)));
+        BDR_HIP((launch_igemm_b3<FwdC3B3, 6>(st, dim3(m_tiles<FwdC3B3>(f.M) * n_tiles<FwdC3B3>(), 1, nz), fb)));
     } else { Bracket br(a, "fwd_conv3"); BDR_HIP((launch_igemm<FwdC3D, TEAMS_FWD_C3>(st, dim3(m_tiles<FwdC3D>(f.M) * n_tiles<FwdC3D>(), 1, nz), f))); }
     f.M = B; f.nkt_per_split = (98 + L1_SPLIT - 1) / L1_SPLIT;
     for (int z = 0; z < nz; ++z) { f.x[z] = a->a3[inst[z].slot]; f.w[z] = inst[z].params + ar.w4; f.bias[z] = nullptr; f.out[z] = a->p1[inst[z].slot]; }

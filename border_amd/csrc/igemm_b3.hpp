@@ -1,7 +1,7 @@
 // GEMM on the bf16 matrix cores with SPLIT f32 operands ("3 x bf16"), for the layers that ARE matrix-bound: IQN's
 // [B * N quantiles][3136] x [3136][512] forward and its input gradient at config C4 (M = 32 768 rows, 0.74-0.79 of the FP32-MFMA
 // peak with the exact kernel: csrc/iqn.hip).  The B = 256 conv layers of the DQN step are operand-delivery bound and gain nothing
-// from it (tools/probes/bp_probe.hip); they stay on the FP32 MFMA.
+// from it (tools/probes/bp_probe.hip, LAB.md 5); they stay on the FP32 MFMA.
 //
 // Every f32 operand x is split exactly into three bf16 terms x = t0 + t1 + t2 (8 + 8 + 8 significant bits, round-to-nearest
 // split: split3_rn below), so a product a*b is the sum of nine exact bf16 x bf16 products.  TERMS = 9 keeps all of them: the MFMA then

@@ -1,7 +1,7 @@
 // Ordering two HIP streams of ONE agent by device flags instead of events (the SAC step's side queue, sac.hip).
 //
 // hipEventRecord / hipStreamWaitEvent put a barrier packet into both queues; on this platform each costs its queue a 5-7 us
-// bubble, which is a whole stage of a launch-bound step.  Here the producer queue runs a one-wave kernel
+// bubble (LAB.md section 5), which is a whole stage of a launch-bound step.  Here the producer queue runs a one-wave kernel
 // that stores the step's epoch to a flag word, and the consumer queue runs a one-wave kernel that returns once the flag has
 // reached the epoch:
 //   k_flag_set   a normal dispatch (barrier bit set): it starts after everything queued before it on its stream has completed

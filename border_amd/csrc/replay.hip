@@ -734,8 +734,10 @@ int32_t bdr_replay_push_device(bdr_replay* r, uint64_t n, const void* obs_dev, u
                                  "buffer with frame_stack > 0");
     BDR_HIP(hipSetDevice(r->device));
     for (const void* p : {obs_dev, next_obs_dev}) {
-        // (the check is a driver call of ~2 us: an address that passed it last time - the environment's stacks, push after push - is not asked again)
-        if (p == r->dev_rows_ok[0] || p == r->dev_rows_ok[1]) continue;
+        // (the check is a driver call of ~2 us: an address that passed it last time - the environment's stacks, push after push - is not asked
+        //  again; every 1024th push asks anyway, so an allocation that was freed and whose address came back as host or another GPU's memory
+        //  is noticed within a bounded number of pushes instead of never)
+        if ((p == r->dev_rows_ok[0] || p == r->dev_rows_ok[1]) && (r->dev_rows_checks++ & 1023u) != 1023u) continue;
         hipPointerAttribute_t at{};
         BDR_REQUIRE(hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice && at.device == r->device,
                     "observation rows must be device memory of the buffer's GPU (host rows go through bdr_replay_push)");
@@ -772,6 +774,7 @@ int32_t bdr_replay_push_device(bdr_replay* r, uint64_t n, const void* obs_dev, u
             for (unsigned spins = 0; (int)(*done - sa.seq) < 0; ++spins) {
                 if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {   // (a lost kernel: fall back to the stream's own report)
                     BDR_HIP(hipStreamSynchronize(r->stream));
+                    if ((int)(*done - sa.seq) < 0) return fail(BDR_ERR_HIP, "a small device push never reported completion (sequence %u)", sa.seq);
                     break;
                 }
             }

@@ -336,7 +336,7 @@ struct Sac : bdr_agent, SacBatch {
     StepGraph graph; StepGraphPolicy graph_policy;   // step_graph.hpp
     bool gather_in_pack = true;               // BDR_NO_STEP_GATHER=1: separate gather launch
     bool fuse_rows = true;                    // BDR_NO_SAC_FUSE=1: the narrow layers as launches of their own (sac_fused.hpp)
-    bool heads_in_chain = false;              // BDR_SAC_HEADS_FUSE=1: k_sac_heads_action's part by the last workgroup of each row block of the trunk launch (measured: -3 %)
+    bool heads_in_chain = false;              // BDR_SAC_HEADS_FUSE=1: k_sac_heads_action's part by the last workgroup of each row block of the trunk launch (measured: -3 %, LAB.md 5)
     static constexpr int HEAD_TICKETS = 2048;
     unsigned* head_tickets = nullptr;         // [2][HEAD_TICKETS] row-block tickets of k_sac_pi_chain_heads (prologue pass / critic-phase pass)
     bool wait_in_kernel = true;               // BDR_SAC_WAIT_PACKET=1: the main queue's wait for the prologue as a one-wave packet instead of inside the first critic launch

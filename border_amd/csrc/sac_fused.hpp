@@ -1,6 +1,6 @@
 // Row-block kernels of the SAC step (included by sac.hip): the narrow layers of the step - the actor's two heads (256 -> A), the
 // critics' last layer (256 -> 1) and first-layer input gradient (only the A action columns are needed) - are not worth a launch
-// of their own (a dependent kernel costs >= 2.4 us whatever it does) and neither are the row-wise kernels between
+// of their own (a dependent kernel costs >= 2.4 us whatever it does, LAB.md 5) and neither are the row-wise kernels between
 // them.  A workgroup here takes 32 batch rows, forms the narrow layers' 32x32 tiles with the SAME tile function as the
 // layer-by-layer path (dense_small_tile / dense_small_sum: same k-slices, same MFMA order, same four-way sum) and does the row-wise
 // math of the step on them in registers / LDS:
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512) void k_sac_td_last(SacTdLastArgs p)
 // The batch-wide parts of k_sac_q_last (EntCoef::update + the actor loss) and k_sac_td_last (the critics' loss sums) as ONE MORE WORKGROUP of the
 // launch that follows them on the queue - the critics' layer-1 input gradient, which reads nothing they write.  Inside their own kernels these parts
 // are a ticket (agent-scope partials acknowledged, an atomic's round trip) and then one workgroup's 2-3 dependent round trips while the queue waits for
-// the kernel to end: 3.2 of k_sac_q_last's 13.9 us (DESIGN.md 5, round 3 stamps).  Behind a kernel boundary the partials are ordinary memory, and the
+// the kernel to end: 3.2 of k_sac_q_last's 13.9 us (LAB.md 5, round 3 stamps).  Behind a kernel boundary the partials are ordinary memory, and the
 // sums run in the shadow of 512 tile workgroups.  Same partials, same order (block partials one by one in block order), same scalar arithmetic.
 struct SacTailArgs {
     int kind;                             // 0: none; 1: k_sac_q_last's part; 2: k_sac_td_last's part

@@ -1,7 +1,7 @@
 // Replaying a launch-bound opt step from a hipGraph.
 //
 // The SAC and Mlp-DQN steps are chains of 20-70 kernels of 2-8 us: the host needs 4-5 us per launch (hipLaunchKernel + argument
-// marshalling), which is what bounds those configurations.  The step's launch sequence is the same every time - only
+// marshalling), which is what bounds those configurations (LAB.md 6).  The step's launch sequence is the same every time - only
 // a handful of by-value arguments change (Adam's bias corrections, the RNG counters, the replay stream position) - so it is
 // captured once into a hipGraph and replayed with ONE hipGraphLaunch; the varying arguments are patched into their kernel nodes
 // (hipGraphExecKernelNodeSetParams) right before the launch.

@@ -1,7 +1,7 @@
 // Direct-to-LDS variant of k_igemm (global_load_lds_dwordx4 staging, XOR-swizzled tiles, mid-tile barrier
 // with cross-tile fragment prefetch).  EXPERIMENTAL: bit-identical results to k_igemm but not faster on
 // gfx950 at these shapes (the k loop is bound by LDS instruction issue and the per-k-tile barrier, not by
-// the register staging it removes), so the product does not use it.  Only
+// the register staging it removes; see LAB.md section 6), so the product does not use it.  Only
 // tools/probes/ includes this header.
 #pragma once
 #include "igemm.hpp"

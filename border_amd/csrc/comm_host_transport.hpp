@@ -41,17 +41,35 @@ inline const char* error_string(int e)
                  case ERR_TIMEOUT: return "host transport: a rank did not reach the barrier within 120 s"; default: return "host transport: bad argument"; }
 }
 
+// the segment behind `name`: POSIX shared memory, or - where /dev/shm is missing or too small for it - a file under /tmp mapped MAP_SHARED
+inline int seg_open(const char* name, bool create)
+{
+    int fd = create ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
+    if (fd >= 0 && create && ftruncate(fd, (off_t)SEG_BYTES) != 0) { close(fd); shm_unlink(name); fd = -1; }
+    if (fd >= 0) return fd;
+    char path[192];
+    snprintf(path, sizeof path, "/tmp%s", name);
+    fd = create ? open(path, O_CREAT | O_EXCL | O_RDWR, 0600) : open(path, O_RDWR);
+    if (fd >= 0 && create && ftruncate(fd, (off_t)SEG_BYTES) != 0) { close(fd); unlink(path); fd = -1; }
+    return fd;
+}
+inline void seg_unlink(const char* name)
+{
+    char path[192];
+    snprintf(path, sizeof path, "/tmp%s", name);
+    if (shm_unlink(name) != 0) (void)unlink(path);
+}
+
 inline int get_unique_id(rcclUniqueId* id)
 {
     static std::atomic<unsigned> serial{0};
     memset(id->internal, 0, sizeof id->internal);
     const auto t = std::chrono::steady_clock::now().time_since_epoch().count();
     snprintf(id->internal, sizeof id->internal, "/bdr_comm_%d_%u_%llx", (int)getpid(), serial.fetch_add(1), (unsigned long long)t);
-    const int fd = shm_open(id->internal, O_CREAT | O_EXCL | O_RDWR, 0600);
+    const int fd = seg_open(id->internal, true);   // (sparse: pages exist once they are touched)
     if (fd < 0) return ERR_SYS;
-    const int rc = ftruncate(fd, (off_t)SEG_BYTES);   // (sparse: pages exist once they are touched)
     close(fd);
-    return rc == 0 ? OK : ERR_SYS;
+    return OK;
 }
 
 inline int barrier(Comm* c)
@@ -77,7 +95,7 @@ inline int comm_init_rank(rcclComm_t* out, int nranks, rcclUniqueId id, int rank
 {
     if (nranks < 1 || nranks > MAX_RANKS || rank < 0 || rank >= nranks) return ERR_ARG;
     id.internal[sizeof id.internal - 1] = 0;
-    const int fd = shm_open(id.internal, O_RDWR, 0600);
+    const int fd = seg_open(id.internal, false);
     if (fd < 0) return ERR_SYS;
     void* m = mmap(nullptr, SEG_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
@@ -86,7 +104,7 @@ inline int comm_init_rank(rcclComm_t* out, int nranks, rcclUniqueId id, int rank
     c->hdr = (Header*)m; c->slots = (uint8_t*)m + 4096; c->nranks = nranks; c->rank = rank;
     c->hdr->nranks = (uint32_t)nranks;
     if (hipHostMalloc(&c->pinned, SLOT_BYTES, hipHostMallocDefault) != hipSuccess) { munmap(m, SEG_BYTES); delete c; return ERR_SYS; }
-    if (c->hdr->attached.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)nranks) shm_unlink(id.internal);   // every rank holds a mapping: the name can go
+    if (c->hdr->attached.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)nranks) seg_unlink(id.internal);   // every rank holds a mapping: the name can go
     *out = c;
     return barrier(c);   // like ncclCommInitRank: returns once every rank has joined
 }

@@ -401,7 +401,7 @@ struct DqnCnn : bdr_agent {
     bool defer_adam = false;                         // update_critic stops after backward (synchronous-DP mode, grads_on_batch)
     bool split_fwd = true;                           // schedule 3: target network forward on the other queue (BDR_NO_SPLIT_FWD=1: off)
     bool noted_event_fallback = false;               // the one-line note of effective_sched() has been printed
-    bool three_queues = false;                       // BDR_TQ=1: gather + target forward on the third stream when it is free (measured SLOWER)
+    bool three_queues = true;                        // gather + target forward on the third stream when it is free (no prioritized replay); BDR_TQ=0: on the weight-gradient queue
     bool tgt_enqueued = false;                       // opt_inner has put this update's target forward on the other queue
     unsigned track_epoch = 0;                        // epoch of the last update that was followed by a soft update (SIG_TRACK)
     bool track_wait_pending = false;                 // the other queue must see SIG_TRACK == track_epoch before it reads q_tgt again
@@ -1086,11 +1086,12 @@ int32_t opt_inner(DqnCnn* a, bdr_replay* r)
             // the dX queue waits for it with its own gate in front of conv1.
             const unsigned epoch = a->sig_epoch + 1;     // the epoch update_critic is about to take
             BDR_TRY(replay_flip_batch(r, a->cfg.batch_size));
-            // Third queue (opt-in, BDR_TQ=1): without prioritized replay the agent's third stream (its tree-update queue) is
-            // free, and the gather + target forward of update n can go there.  They depend on nothing but "head(n-1) is done",
-            // so they would run beside update n-1's backward instead of waiting behind this update's weight-gradient work.
-            // Measured on the same box: 4 420 vs 4 545 opt-steps/s - with two queues the chip is already throughput-bound
-            // (it clocks to its power budget), a third stream of GEMMs only slows the dX chain down.  Kept for experiments.
+            // Third queue (default since round 6; BDR_TQ=0: off): without prioritized replay the agent's third stream (its tree-update
+            // queue) is free, and the gather + target forward of update n go there.  They depend on nothing but "head(n-1) is done",
+            // so they run beside update n-1's backward instead of waiting behind this update's weight-gradient work.  Round 2 measured
+            // this SLOWER (4 420 vs 4 545: the dX chain lost more than the queue gained); with round 6's kernels it is never slower and
+            // up to 2 % faster - same box, interleaved: 5 296 / 5 289 vs 5 178 / 5 186, 5 097 / 5 093 vs 5 048 / 5 025, 4 972 / 4 974 vs
+            // 4 972 / 4 954.  Same bits (tests/test_gpu_dqn.py::test_opt_stream_is_deterministic_and_overlap_invariant).
             const bool tq3 = a->split_fwd && a->three_queues && !r->per && a->aux_gated;
             hipStream_t tq = tq3 ? a->aux : a->side;
             if (tq3) BDR_TRY(launch_gate(a, tq, SIG_HEAD, epoch - 1, -1));
@@ -1497,7 +1498,7 @@ int32_t dqn_cnn_create(const bdr_dqn_config* cfg, bdr_agent** out)
     a->split_fwd = getenv("BDR_NO_SPLIT_FWD") == nullptr;
     a->conv_b3 = arith_is_split(cfg->arithmetic, "BDR_DQN_F32_EXACT");   // bdr_dqn_config::arithmetic; the variable overrides it for A/B runs only
     if (a->conv_b3) for (auto& pl : a->cpl) BDR_HIP(hipMalloc((void**)&pl, CPL_U16 * 2));
-    a->three_queues = getenv("BDR_TQ") != nullptr;
+    { const char* e = getenv("BDR_TQ"); a->three_queues = !(e && e[0] == '0'); }
     float** arenas[5] = {&a->q, &a->q_tgt, &a->grad, &a->m, &a->v};
     for (auto p : arenas) {
         BDR_TRY(alloc_f(p, a->ar.total));

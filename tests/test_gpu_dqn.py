@@ -770,6 +770,13 @@ def test_opt_stream_is_deterministic_and_overlap_invariant(B):
     for sched in (None, 0, 1, 2, 3):
         p, t = run(sched)
         assert (p1 == p).all() and (t1 == t).all(), sched
+    # the default puts the gather + target forward on the agent's third queue; BDR_TQ=0 keeps them on the weight-gradient queue
+    os.environ["BDR_TQ"] = "0"
+    try:
+        p, t = run(None)
+    finally:
+        os.environ.pop("BDR_TQ", None)
+    assert (p1 == p).all() and (t1 == t).all(), "BDR_TQ=0"
 
 
 def test_mixed_api_sequences_on_the_flag_ordered_schedule(B, tmp_path):
